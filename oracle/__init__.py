@@ -1,0 +1,176 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end of the CPU oracle (oracle/illico_oracle.c).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package; nothing under ``illico_amd/`` does.  The oracle restates the reference's algorithm
+(remydubois/illico v0.2.0); its parity is pinned by ``tests/golden`` (outputs of the reference
+itself) and by scipy.stats.mannwhitneyu, the reference's own test oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from collections import namedtuple
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "_build" / "libillico_oracle.so"
+
+ALTERNATIVES = {"two-sided": 0, "less": 1, "greater": 2}
+FORMATS = {"dense": 0, "csc": 1, "csr": 2}
+
+# illico/utils/groups.py:6-15
+GroupContainer = namedtuple(
+    "GroupContainer", ["encoded_groups", "counts", "indices", "indptr", "encoded_ref_group"]
+)
+
+
+def build(force: bool = False) -> Path:
+    """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
+    if force or not _SO.exists() or any(
+        (_HERE / f).stat().st_mtime > _SO.stat().st_mtime for f in ("illico_oracle.c", "oracle_impl.inc")
+    ):
+        subprocess.run(["make", "-C", str(_HERE), "-B"], check=True, capture_output=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(str(_SO))
+        i64, dbl, p = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+        _lib.oracle_run.restype = ctypes.c_int
+        _lib.oracle_run.argtypes = [ctypes.c_int, ctypes.c_int, p, p, p, i64, i64, i64, i64, i64,
+                                    p, p, p, p, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, i64, ctypes.c_int, p, p, p]
+        _lib.oracle_compute_pval.restype = dbl
+        _lib.oracle_compute_pval.argtypes = [i64, i64, i64, dbl, dbl, dbl, dbl, ctypes.c_int]
+        for sfx in ("f32", "f64"):
+            f = getattr(_lib, f"oracle_rank_sum_and_ties_from_sorted_{sfx}")
+            f.restype = None
+            f.argtypes = [p, i64, p, i64, p, p]
+            f = getattr(_lib, f"oracle_accumulate_group_ranksums_from_argsort_{sfx}")
+            f.restype = dbl
+            f.argtypes = [p, p, i64, p, p, i64]
+        _lib.oracle_check_indices_sorted_per_parcel.restype = ctypes.c_int
+        _lib.oracle_check_indices_sorted_per_parcel.argtypes = [p, p, i64]
+        _lib.oracle_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def encode_and_count_groups(groups, ref_group):
+    """Restates illico/utils/groups.py:18-58 (np.unique ordering, argsort indices, cumsum indptr)."""
+    groups = np.asarray(groups)
+    if ref_group is not None and ref_group not in groups:
+        raise ValueError(f"Reference group `{ref_group}` is not present in the group labels.")
+    unique_groups, encoded, counts = np.unique(groups, return_inverse=True, return_counts=True)
+    encoded = encoded.astype(np.int64)
+    indices = np.argsort(encoded, kind="stable").astype(np.int64)
+    indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    if ref_group is None:
+        ref = -1
+    else:
+        ref = int(np.searchsorted(unique_groups, ref_group))
+    return unique_groups, GroupContainer(encoded, counts.astype(np.int64), indices, indptr, ref)
+
+
+def rank_sum_and_ties_from_sorted(A, B):
+    """ranking.py:52-158."""
+    A = np.ascontiguousarray(A)
+    B = np.ascontiguousarray(B)
+    dt = np.float32 if (A.dtype == np.float32 and B.dtype == np.float32) else np.float64
+    A = A.astype(dt, copy=False)
+    B = B.astype(dt, copy=False)
+    rs, ts = ctypes.c_double(), ctypes.c_double()
+    f = getattr(lib(), f"oracle_rank_sum_and_ties_from_sorted_{'f32' if dt == np.float32 else 'f64'}")
+    f(_ptr(A), A.size, _ptr(B), B.size, ctypes.byref(rs), ctypes.byref(ts))
+    return rs.value, ts.value
+
+
+def accumulate_group_ranksums_from_argsort(arr, idx, groups, n_groups):
+    """ranking.py:7-49; returns (ranksums[n_groups], tie_sum)."""
+    arr = np.ascontiguousarray(arr)
+    dt = np.float32 if arr.dtype == np.float32 else np.float64
+    arr = arr.astype(dt, copy=False)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    groups = np.ascontiguousarray(groups, dtype=np.int64)
+    ranksums = np.zeros(n_groups, dtype=np.float64)
+    f = getattr(lib(), f"oracle_accumulate_group_ranksums_from_argsort_{'f32' if dt == np.float32 else 'f64'}")
+    ts = f(_ptr(arr), _ptr(idx), arr.size, _ptr(groups), _ptr(ranksums), 1)
+    return ranksums, ts
+
+
+def compute_pval(n_ref, n_tgt, n, tie_sum, U, mu, contin_corr=0.0, alternative="two-sided"):
+    """math.py:64-118."""
+    if alternative not in ALTERNATIVES:
+        raise ValueError(f"Unsupported alternative hypothesis: {alternative}")
+    return lib().oracle_compute_pval(int(n_ref), int(n_tgt), int(n), float(tie_sum), float(U), float(mu),
+                                     float(contin_corr), ALTERNATIVES[alternative])
+
+
+def check_indices_sorted_per_parcel(indices, indptr) -> bool:
+    indices = np.ascontiguousarray(indices, dtype=np.int64)
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    return bool(lib().oracle_check_indices_sorted_per_parcel(_ptr(indices), _ptr(indptr), indptr.size - 1))
+
+
+def run(X, grpc: GroupContainer, *, is_log1p=False, use_continuity=True, tie_correct=True,
+        alternative="two-sided", col_lb=0, col_ub=None, batch_size=256, n_threads=1):
+    """Whole-call CPU path: returns (pvalues, statistics, fold_change), each float64 [G, col_ub-col_lb].
+
+    ``X`` is a C-contiguous 2-D ndarray (dense), or a scipy.sparse csc/csr matrix.
+    """
+    from scipy import sparse
+
+    if alternative not in ALTERNATIVES:
+        raise ValueError(f"Unsupported alternative hypothesis: {alternative}")
+    if sparse.issparse(X):
+        fmt = "csc" if sparse.isspmatrix_csc(X) or X.format == "csc" else "csr"
+        if X.format not in ("csc", "csr"):
+            raise KeyError(f"Support for data type {type(X)} is not implemented.")
+        dt = np.float32 if X.data.dtype == np.float32 else np.float64
+        data = np.ascontiguousarray(X.data, dtype=dt)
+        indices = np.ascontiguousarray(X.indices, dtype=np.int64)
+        indptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        n_rows, n_cols = X.shape
+        ld = 0
+    else:
+        fmt = "dense"
+        dt = np.float32 if X.dtype == np.float32 else np.float64
+        data = np.ascontiguousarray(X, dtype=dt)
+        indices = indptr = None
+        n_rows, n_cols = data.shape
+        ld = n_cols
+    if col_ub is None:
+        col_ub = n_cols
+    G = int(grpc.counts.size)
+    W = max(col_ub - col_lb, 0)
+    out = [np.empty((G, W), dtype=np.float64) for _ in range(3)]
+    enc = np.ascontiguousarray(grpc.encoded_groups, dtype=np.int64)
+    cnt = np.ascontiguousarray(grpc.counts, dtype=np.int64)
+    gi = np.ascontiguousarray(grpc.indices, dtype=np.int64)
+    gp = np.ascontiguousarray(grpc.indptr, dtype=np.int64)
+    rc = lib().oracle_run(FORMATS[fmt], 0 if dt == np.float32 else 1, _ptr(data), _ptr(indices), _ptr(indptr),
+                          n_rows, n_cols, ld, col_lb, col_ub, _ptr(enc), _ptr(cnt), _ptr(gi), _ptr(gp), G,
+                          int(grpc.encoded_ref_group), int(is_log1p), int(use_continuity), int(tie_correct),
+                          ALTERNATIVES[alternative], int(batch_size), int(n_threads), _ptr(out[0]), _ptr(out[1]),
+                          _ptr(out[2]))
+    if rc == -2:
+        raise ValueError(f"Invalid chunk bounds: {(col_lb, col_ub)} for data with {n_cols} columns.")
+    if rc != 0:
+        raise RuntimeError(f"oracle_run failed with code {rc}")
+    return tuple(out)
+
+
+def max_threads() -> int:
+    return int(lib().oracle_max_threads())
