@@ -1,0 +1,335 @@
+"""ctypes binding of libillico_hip.so (include/illico_hip.h) and the Engine that owns one context.
+
+The product path has no CPU fallback: if the HIP library is missing or no MI355X is visible the
+calls below raise -- nothing here imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from pathlib import Path
+
+import numpy as np
+
+_SO = Path(__file__).resolve().parent / "csrc" / "libillico_hip.so"
+
+OK = 0
+ERR_ARG, ERR_BOUNDS, ERR_ALTERNATIVE, ERR_DTYPE, ERR_NO_GROUPS, ERR_UNSORTED = -1, -2, -3, -4, -5, -6
+ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = -10, -11, -12
+
+F32, F64, I32, I64 = 0, 1, 2, 3
+IDX_I32, IDX_I64 = 0, 1
+ALTERNATIVES = {"two-sided": 0, "less": 1, "greater": 2}
+FLAG_LOG1P, FLAG_CONTINUITY, FLAG_TIE_CORRECT, FLAG_INPUT_DEVICE, FLAG_OUTPUT_DEVICE = 1, 2, 4, 8, 16
+
+_DTYPES = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.int32): I32, np.dtype(np.int64): I64}
+
+# every symbol include/illico_hip.h declares
+SYMBOLS = [
+    "illico_ctx_create", "illico_ctx_destroy", "illico_ctx_set_stream", "illico_ctx_set_option",
+    "illico_last_error", "illico_ctx_synchronize", "illico_set_groups", "illico_run_dense", "illico_run_csc",
+    "illico_run_csr", "illico_csr_indices_sorted", "illico_profile_num_kernels", "illico_profile_kernel_name",
+    "illico_profile_get", "illico_profile_reset", "illico_version",
+]
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> ctypes.CDLL:
+    """Load libillico_hip.so; raises if it has not been built (python -m illico_amd.csrc.build)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not _SO.exists():
+            raise ImportError(
+                f"{_SO} is missing: the HIP engine has not been built. Run `python __graft_entry__.py` or "
+                "`python illico_amd/csrc/build.py`. There is no CPU fallback.")
+        lib = ctypes.CDLL(str(_SO))
+        vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        lib.illico_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
+        lib.illico_ctx_destroy.argtypes = [vp]
+        lib.illico_ctx_set_stream.argtypes = [vp, vp]
+        lib.illico_ctx_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+        lib.illico_last_error.argtypes = [vp]
+        lib.illico_last_error.restype = ctypes.c_char_p
+        lib.illico_ctx_synchronize.argtypes = [vp]
+        lib.illico_set_groups.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64]
+        lib.illico_run_dense.argtypes = [vp, vp, ci, i64, i64, i64, i64, i64, ci, ci, vp, vp, vp, i64]
+        for f in (lib.illico_run_csc, lib.illico_run_csr):
+            f.argtypes = [vp, vp, ci, vp, vp, ci, i64, i64, i64, i64, ci, ci, vp, vp, vp, i64]
+        lib.illico_csr_indices_sorted.argtypes = [vp, vp, vp, ci, i64, ci, ctypes.POINTER(ci)]
+        lib.illico_profile_num_kernels.argtypes = []
+        lib.illico_profile_kernel_name.argtypes = [ci]
+        lib.illico_profile_kernel_name.restype = ctypes.c_char_p
+        lib.illico_profile_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
+        lib.illico_profile_reset.argtypes = [vp]
+        lib.illico_version.restype = ctypes.c_char_p
+        for name in SYMBOLS:
+            f = getattr(lib, name)
+            if f.restype is ctypes.c_int and name not in ("illico_profile_num_kernels",):
+                pass
+        _lib = lib
+        return lib
+
+
+def _raise(code: int, msg: str):
+    if code in (ERR_ARG, ERR_BOUNDS, ERR_ALTERNATIVE, ERR_NO_GROUPS, ERR_UNSORTED):
+        raise ValueError(msg)
+    if code == ERR_DTYPE:
+        raise KeyError(msg)
+    if code == ERR_OOM:
+        raise MemoryError(msg)
+    if code == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(f"illico_hip error {code}: {msg}")
+
+
+def _is_torch_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class _Buf:
+    """A host ndarray or a device torch.Tensor seen as (pointer, on_device, keepalive)."""
+
+    def __init__(self, x, dtype=None):
+        if _is_torch_tensor(x):
+            if not x.is_contiguous():
+                raise ValueError("device tensors must be contiguous")
+            self.on_device = x.is_cuda
+            self.ptr = x.data_ptr()
+            self.keep = x
+            self.np_dtype = np.dtype(str(x.dtype).replace("torch.", ""))
+        else:
+            a = np.ascontiguousarray(x, dtype=dtype)
+            self.on_device = False
+            self.ptr = a.ctypes.data
+            self.keep = a
+            self.np_dtype = a.dtype
+
+
+def dtype_code(np_dtype) -> int:
+    try:
+        return _DTYPES[np.dtype(np_dtype)]
+    except KeyError as e:
+        raise KeyError(f"Support for element dtype {np_dtype} is not implemented.") from e
+
+
+def normalize_values(a: np.ndarray) -> np.ndarray:
+    """Host arrays of dtypes the engine has no kernel for are widened losslessly (order and equality kept)."""
+    dt = a.dtype
+    if dt in _DTYPES:
+        return a
+    if dt == np.float16:
+        return a.astype(np.float32)
+    if dt.kind == "b" or (dt.kind in "iu" and dt.itemsize < 4):
+        return a.astype(np.int32)
+    if dt == np.uint32:
+        return a.astype(np.int64)
+    if dt == np.uint64:
+        if a.size and a.max() > np.iinfo(np.int64).max:
+            raise KeyError("uint64 values above 2**63-1 are not supported.")
+        return a.astype(np.int64)
+    raise KeyError(f"Support for element dtype {dt} is not implemented.")
+
+
+class Engine:
+    """One illico_ctx: one device, one stream, device scratch, the current GroupContainer."""
+
+    def __init__(self, device: int | None = None):
+        self.lib = load()
+        if device is None:
+            device = _current_device()
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        rc = self.lib.illico_ctx_create(self.device, ctypes.byref(h))
+        if rc != OK or not h.value:
+            raise RuntimeError(
+                f"illico_ctx_create(device={self.device}) failed with code {rc}: no usable MI355X/HIP device. "
+                "The engine has no CPU fallback.")
+        self.h = h
+        self._groups_key = None
+        self._groups_keep = None
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.illico_ctx_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != OK:
+            _raise(rc, (self.lib.illico_last_error(self.h) or b"").decode())
+
+    def set_option(self, key: str, value: int):
+        self._check(self.lib.illico_ctx_set_option(self.h, key.encode(), int(value)))
+
+    def set_stream(self, stream_ptr: int):
+        self._check(self.lib.illico_ctx_set_stream(self.h, ctypes.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._check(self.lib.illico_ctx_synchronize(self.h))
+
+    # ---- groups (GroupContainer of illico/utils/groups.py:6-15) ----
+    def set_groups(self, grpc):
+        key = id(grpc)
+        if self._groups_key == key and self._groups_keep is grpc:
+            return
+        enc = np.ascontiguousarray(grpc.encoded_groups, dtype=np.int64)
+        cnt = np.ascontiguousarray(grpc.counts, dtype=np.int64)
+        idx = np.ascontiguousarray(grpc.indices, dtype=np.int64)
+        ptr = np.ascontiguousarray(grpc.indptr, dtype=np.int64)
+        self._check(self.lib.illico_set_groups(self.h, enc.ctypes.data, cnt.ctypes.data, idx.ctypes.data,
+                                               ptr.ctypes.data, enc.size, cnt.size, int(grpc.encoded_ref_group)))
+        self._groups_key, self._groups_keep = key, grpc
+        self.n_groups = int(cnt.size)
+
+    @staticmethod
+    def _flags(is_log1p, use_continuity, tie_correct):
+        return (FLAG_LOG1P if is_log1p else 0) | (FLAG_CONTINUITY if use_continuity else 0) | \
+               (FLAG_TIE_CORRECT if tie_correct else 0)
+
+    @staticmethod
+    def _alt(alternative):
+        try:
+            return ALTERNATIVES[alternative]
+        except KeyError:
+            raise ValueError(f"Unsupported alternative hypothesis: {alternative}") from None
+
+    def _outputs(self, out, G, W, want_device):
+        """out: None (allocate host planes), a tuple of three host ndarrays (views with a common row stride are
+        fine) or three device tensors."""
+        if out is None:
+            if want_device:
+                import torch
+                planes = tuple(torch.empty((G, W), dtype=torch.float64, device=f"cuda:{self.device}") for _ in range(3))
+            else:
+                planes = tuple(np.empty((G, W), dtype=np.float64) for _ in range(3))
+        else:
+            planes = tuple(out)
+        ptrs, flag, ld = [], 0, None
+        for p in planes:
+            if _is_torch_tensor(p):
+                if p.dtype != __import__("torch").float64 or p.dim() != 2 or p.stride(1) != 1:
+                    raise ValueError("device output planes must be float64 [G, W] with unit column stride")
+                l = p.stride(0)
+                ptrs.append(p.data_ptr())
+                flag = FLAG_OUTPUT_DEVICE if p.is_cuda else 0
+            else:
+                if p.dtype != np.float64 or p.ndim != 2 or p.strides[1] != 8 or p.shape != (G, W):
+                    raise ValueError("output planes must be float64 [G, W] with unit column stride")
+                l = p.strides[0] // 8 if G > 1 else max(W, p.strides[0] // 8)
+                ptrs.append(p.ctypes.data)
+            if ld is None:
+                ld = l
+            elif ld != l:
+                raise ValueError("output planes must share one row stride")
+        return planes, ptrs, flag, int(ld if ld else max(W, 1))
+
+    def run_dense(self, X, col_lb, col_ub, *, is_log1p=False, use_continuity=True, tie_correct=True,
+                  alternative="two-sided", out=None, device_out=False):
+        alt = self._alt(alternative)
+        if _is_torch_tensor(X):
+            if X.dim() != 2 or X.stride(1) != 1:
+                raise ValueError("X must be row-major 2-D")
+            buf_ptr, on_dev, keep = X.data_ptr(), X.is_cuda, X
+            n_rows, n_cols, ld = X.shape[0], X.shape[1], X.stride(0)
+            dt = dtype_code(str(X.dtype).replace("torch.", ""))
+        else:
+            X = normalize_values(np.asarray(X))
+            if X.ndim != 2 or (X.shape[1] > 1 and X.strides[1] != X.itemsize):
+                X = np.ascontiguousarray(X)
+            buf_ptr, on_dev, keep = X.ctypes.data, False, X
+            n_rows, n_cols = X.shape
+            ld = X.strides[0] // X.itemsize if n_rows > 1 else n_cols
+            dt = dtype_code(X.dtype)
+        if col_lb < 0 or col_ub > n_cols or col_lb > col_ub:
+            raise ValueError(f"Invalid chunk bounds: {(col_lb, col_ub)} for data with {n_cols} columns.")
+        G, W = self.n_groups, col_ub - col_lb
+        planes, ptrs, oflag, out_ld = self._outputs(out, G, W, device_out)
+        flags = self._flags(is_log1p, use_continuity, tie_correct) | (FLAG_INPUT_DEVICE if on_dev else 0) | oflag
+        self._check(self.lib.illico_run_dense(self.h, buf_ptr, dt, n_rows, n_cols, ld, col_lb, col_ub, flags, alt,
+                                              ptrs[0], ptrs[1], ptrs[2], out_ld))
+        del keep
+        return planes
+
+    def run_sparse(self, fmt, data, indices, indptr, shape, col_lb, col_ub, *, is_log1p=False, use_continuity=True,
+                   tie_correct=True, alternative="two-sided", out=None, device_out=False):
+        alt = self._alt(alternative)
+        n_rows, n_cols = int(shape[0]), int(shape[1])
+        if _is_torch_tensor(data):
+            d, i, p = _Buf(data), _Buf(indices), _Buf(indptr)
+        else:
+            d = _Buf(normalize_values(np.asarray(data)))
+            idt = np.int32 if (np.asarray(indices).dtype == np.int32 and np.asarray(indptr).dtype == np.int32) else np.int64
+            i, p = _Buf(indices, idt), _Buf(indptr, idt)
+        if i.np_dtype != p.np_dtype or i.np_dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
+            raise KeyError(f"Support for index dtypes {i.np_dtype}/{p.np_dtype} is not implemented.")
+        if not (d.on_device == i.on_device == p.on_device):
+            raise ValueError("data, indices and indptr must live on the same side (host or device)")
+        if col_lb < 0 or col_ub > n_cols or col_lb > col_ub:
+            raise ValueError(f"Invalid chunk bounds: {(col_lb, col_ub)} for data with {n_cols} columns.")
+        G, W = self.n_groups, col_ub - col_lb
+        planes, ptrs, oflag, out_ld = self._outputs(out, G, W, device_out)
+        flags = self._flags(is_log1p, use_continuity, tie_correct) | (FLAG_INPUT_DEVICE if d.on_device else 0) | oflag
+        fn = self.lib.illico_run_csc if fmt == "csc" else self.lib.illico_run_csr
+        self._check(fn(self.h, d.ptr, dtype_code(d.np_dtype), i.ptr, p.ptr, IDX_I32 if i.np_dtype == np.int32 else IDX_I64,
+                       n_rows, n_cols, col_lb, col_ub, flags, alt, ptrs[0], ptrs[1], ptrs[2], out_ld))
+        return planes
+
+    def csr_indices_sorted(self, indices, indptr, n_rows) -> bool:
+        i, p = _Buf(indices), _Buf(indptr)
+        if i.np_dtype != p.np_dtype:
+            i, p = _Buf(np.asarray(indices), np.int64), _Buf(np.asarray(indptr), np.int64)
+        res = ctypes.c_int(0)
+        self._check(self.lib.illico_csr_indices_sorted(self.h, i.ptr, p.ptr, IDX_I32 if i.np_dtype == np.int32 else IDX_I64,
+                                                       int(n_rows), FLAG_INPUT_DEVICE if i.on_device else 0,
+                                                       ctypes.byref(res)))
+        return bool(res.value)
+
+    # ---- measurement hooks ----
+    def profile(self, on: bool = True):
+        self.set_option("profile", 1 if on else 0)
+
+    def profile_reset(self):
+        self._check(self.lib.illico_profile_reset(self.h))
+
+    def profile_get(self) -> dict:
+        out = {}
+        for k in range(self.lib.illico_profile_num_kernels()):
+            ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+            self._check(self.lib.illico_profile_get(self.h, k, ctypes.byref(ms), ctypes.byref(n)))
+            if n.value:
+                out[self.lib.illico_profile_kernel_name(k).decode()] = {"ms": ms.value, "launches": n.value}
+        return out
+
+
+def _current_device() -> int:
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.current_device()
+    except Exception:
+        pass
+    return 0
+
+
+_engines = threading.local()
+
+
+def get_engine(device: int | None = None) -> Engine:
+    """Per-thread, per-device engine (a context is single-threaded, include/illico_hip.h)."""
+    if device is None:
+        device = _current_device()
+    cache = getattr(_engines, "cache", None)
+    if cache is None:
+        cache = _engines.cache = {}
+    if device not in cache:
+        cache[device] = Engine(device)
+    return cache[device]

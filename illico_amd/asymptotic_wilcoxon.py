@@ -1,0 +1,113 @@
+"""Drop-in for ``illico.asymptotic_wilcoxon`` (reference illico/asymptotic_wilcoxon.py:71-258).
+
+Same signature, same DataFrame (MultiIndex (pert, feature); float64 columns p_value, statistic,
+fold_change; group-major rows).  The body is a ctypes driver of the MI355X engine: the gene-chunk
+loop of the reference (asymptotic_wilcoxon.py:213-249) becomes calls of the registered dispatcher,
+which writes its [G, w] planes straight into the result arrays.
+"""
+from __future__ import annotations
+
+import math
+from typing import Literal
+
+import numpy as np
+import pandas as pd
+from scipy import sparse
+
+from illico_amd.utils.groups import GroupContainer, encode_and_count_groups
+from illico_amd.utils.registry import DataHandler, Test, data_handler_registry, dispatcher_registry
+
+__all__ = ["asymptotic_wilcoxon", "operator"]
+
+
+def operator(data_handler: DataHandler, lb: int, ub: int, group_container: GroupContainer, is_log1p: bool,
+             use_continuity: bool, alternative: str, tie_correct: bool, out=None):
+    """One gene chunk -- the reference's ``operator`` (asymptotic_wilcoxon.py:29-68), not delayed."""
+    test = Test.OVR if group_container.encoded_ref_group == -1 else Test.OVO
+    dispatcher = dispatcher_registry.get(test, data_handler.kernel_data_format())
+    if lb < 0 or ub > data_handler.data.shape[1] or lb > ub:
+        raise ValueError(f"Invalid chunk bounds: {(lb, ub)} for data with {data_handler.data.shape[1]} columns.")
+    fetched_data, bounds = data_handler.fetch(lb, ub)
+    X = data_handler.to_nb(fetched_data)
+    kw = {} if out is None else {"out": out}
+    pvalues, statistics, fold_change = dispatcher(X, *bounds, group_container, is_log1p, use_continuity, tie_correct,
+                                                  alternative, **kw)
+    return (pvalues, statistics, fold_change), (lb, ub)
+
+
+def asymptotic_wilcoxon(
+    adata,
+    is_log1p: bool,
+    group_keys: str,
+    reference: str | None = None,
+    n_threads: int = 1,
+    batch_size: int | Literal["auto"] = "auto",
+    alternative: str = "two-sided",
+    use_continuity: bool = True,
+    tie_correct: bool = True,
+    layer: str | None = None,
+    precompile: bool = True,
+) -> pd.DataFrame:
+    """Asymptotic Mann-Whitney / Wilcoxon rank-sum tests per (group, gene) on one MI355X.
+
+    Parameters are those of the reference (asymptotic_wilcoxon.py:84-116).  ``adata`` is an
+    ``anndata.AnnData`` or any object with ``.X``, ``.layers``, ``.obs[group_keys]`` and
+    ``.var_names`` (``illico_amd.AnnDataLite``).  ``reference=None`` runs one-versus-rest.
+    ``n_threads`` is accepted and ignored (one GPU context does the work); ``precompile`` is a
+    no-op (HIP code objects are built ahead of time).  ``batch_size="auto"`` hands the whole gene
+    range to the engine, which batches by HBM budget and computes every column (the reference's
+    "auto" splitter leaves one column per chunk boundary uncomputed); an integer
+    ``batch_size`` issues one dispatcher call per chunk like the reference.
+
+    In an OVO call the reference-group row is (p=1.0, statistic=-1.0) in every format (the
+    reference writes that in its sparse path, sparse_ovo.py:140-143, and leaves the row
+    uninitialised in its dense path).
+
+    Raises ``ValueError`` (unsorted CSR indices, unknown reference label, bad ``batch_size`` or
+    ``alternative``) and ``KeyError`` (unsupported container) like the reference.
+    """
+    X = adata.layers[layer] if layer is not None else adata.X
+    data_handler = data_handler_registry.get(X)
+
+    if isinstance(X, sparse.csr_matrix) or (hasattr(sparse, "csr_array") and isinstance(X, sparse.csr_array)):
+        from illico_amd.utils.ranking import check_indices_sorted_per_parcel
+        if not check_indices_sorted_per_parcel(X.indices, X.indptr):
+            raise ValueError(
+                "Input data matrix indices are not sorted. This is very unusual and may lead to incorrect results. "
+                "This can be the result of operations like `adata[:, np.random.choice(…)]` that do not preserve sorting."
+                "Please make sure that indices used to chunk the adata or the expression matrix have been sorted "
+                "prior to computing DE genes.")
+    if alternative not in ("two-sided", "less", "greater"):
+        raise ValueError(f"Unsupported alternative hypothesis: {alternative}")
+
+    raw_groups = np.asarray(adata.obs[group_keys])
+    unique_raw_groups, group_container = encode_and_count_groups(groups=raw_groups, ref_group=reference)
+    n_genes = X.shape[1]
+    n_groups = int(group_container.counts.size)
+
+    if n_genes < 256 or batch_size == "auto":
+        iterator = [(0, n_genes)]
+    elif isinstance(batch_size, (int, np.integer)) and not isinstance(batch_size, bool):
+        bs = min(int(batch_size), math.ceil(n_genes / max(int(n_threads), 1)))
+        if bs <= 0:
+            raise ValueError(f"Invalid batch_size value: {batch_size}. Must be 'auto' or an integer.")
+        bounds = np.append(np.arange(0, n_genes, bs), n_genes)
+        iterator = list(zip(bounds[:-1].tolist(), bounds[1:].tolist()))
+    else:
+        raise ValueError(f"Invalid batch_size value: {batch_size}. Must be 'auto' or an integer.")
+
+    # three [G, n_genes] planes; each chunk writes its [:, lb:ub] window in place
+    planes = np.empty((3, n_groups, n_genes), dtype=np.float64)
+    for lb, ub in iterator:
+        if ub == lb:
+            continue
+        out = tuple(planes[k][:, lb:ub] for k in range(3))
+        operator(data_handler, lb, ub, group_container, is_log1p, use_continuity, alternative, tie_correct, out=out)
+
+    cols = pd.Series(np.asarray(adata.var_names), name="feature", dtype=str)
+    rows = pd.Series(unique_raw_groups, name="pert", dtype=str)
+    return pd.DataFrame(
+        {"p_value": planes[0].reshape(-1), "statistic": planes[1].reshape(-1), "fold_change": planes[2].reshape(-1)},
+        index=pd.MultiIndex.from_product([rows, cols], names=["pert", "feature"]),
+        copy=False,
+    )

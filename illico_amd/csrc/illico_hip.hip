@@ -1,0 +1,471 @@
+// libillico_hip: MI355X (gfx950) engine behind include/illico_hip.h.
+// Host side: context, device scratch, gene batching, kernel launches, measurement hooks.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/illico_hip.h"
+#include "common.h"
+#include "kernels_finalize.h"
+#include "kernels_ovo.h"
+#include "kernels_ovr.h"
+#include "kernels_sparse.h"
+
+// ---- profiled kernel ids ---------------------------------------------------------------------
+enum {
+    KID_TRANSPOSE = 0,
+    KID_OVO_RANK,
+    KID_FINALIZE,
+    KID_RADIX_SORT,
+    KID_OVR_SCAN,
+    KID_SPARSE_SEG,
+    KID_GENE_TOTALS,
+    KID_MISC,
+    KID_COUNT
+};
+static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank",    "k_finalize",   "k_radix_sort",
+                                              "k_ovr_scan",          "k_sparse_seg", "k_gene_totals", "misc"};
+
+struct ProfEvent {
+    int kid;
+    hipEvent_t a, b;
+};
+
+struct illico_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // groups
+    bool has_groups = false;
+    int64_t n_cells = 0, n_groups = 0, ref = -1;
+    std::vector<int> h_counts;
+    int64_t max_nonref = 0;
+    int *d_codes = nullptr;       // [N] group code of each cell
+    int *d_perm = nullptr;        // [N] cell index at group-contiguous position p
+    int *d_posptr = nullptr;      // [G+1]
+    int *d_counts = nullptr;      // [G]
+    int *d_code_by_pos = nullptr; // [N] group code at position p
+    // options
+    int64_t gene_batch = 0;
+    int64_t scratch_bytes = 24ll << 30;
+    bool profile = false;
+    std::vector<ProfEvent> events;
+    double prof_ms[KID_COUNT] = {0};
+    int64_t prof_n[KID_COUNT] = {0};
+    // grow-only scratch
+    std::map<std::string, std::pair<void *, size_t>> scratch;
+};
+
+static int fail(illico_ctx *c, int code, const char *fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? ILLICO_ERR_OOM : ILLICO_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #call, hipGetErrorString(e__), __FILE__, __LINE__);                            \
+    } while (0)
+
+static int get_scratch(illico_ctx *c, const char *name, size_t bytes, void **out) {
+    auto &s = c->scratch[name];
+    if (s.second < bytes) {
+        if (s.first) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipFree(s.first));
+            s.first = nullptr;
+            s.second = 0;
+        }
+        size_t want = bytes + (bytes >> 4) + 256;
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(c, ILLICO_ERR_OOM, "hipMalloc(%zu bytes) for scratch '%s' failed: %s", want, name, hipGetErrorString(e));
+        s.first = p;
+        s.second = want;
+    }
+    *out = s.first;
+    return ILLICO_OK;
+}
+
+struct ProfScope {
+    illico_ctx *c;
+    int kid;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(illico_ctx *c_, int kid_) : c(c_), kid(kid_) {
+        if (c->profile) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, c->stream);
+        }
+    }
+    ~ProfScope() {
+        if (c->profile) {
+            hipEventRecord(b, c->stream);
+            c->events.push_back({kid, a, b});
+        }
+    }
+};
+
+static void drain_events(illico_ctx *c) {
+    if (c->events.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto &e : c->events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->prof_ms[e.kid] += ms;
+            c->prof_n[e.kid] += 1;
+        }
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    c->events.clear();
+}
+
+// ============================================================================================
+extern "C" {
+
+const char *illico_version(void) { return "illico_hip 0.1 (gfx950)"; }
+
+int illico_ctx_create(int device_id, illico_ctx **out_ctx) {
+    if (!out_ctx) return ILLICO_ERR_ARG;
+    *out_ctx = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ILLICO_ERR_HIP;
+    if (device_id < 0 || device_id >= ndev) return ILLICO_ERR_ARG;
+    illico_ctx *c = new illico_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return ILLICO_ERR_HIP;
+    }
+    c->own_stream = true;
+    *out_ctx = c;
+    return ILLICO_OK;
+}
+
+static void free_groups(illico_ctx *c) {
+    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos}) {
+        if (*p) hipFree(*p);
+        *p = nullptr;
+    }
+    c->has_groups = false;
+}
+
+int illico_ctx_destroy(illico_ctx *c) {
+    if (!c) return ILLICO_ERR_ARG;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    drain_events(c);
+    free_groups(c);
+    for (auto &kv : c->scratch)
+        if (kv.second.first) hipFree(kv.second.first);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return ILLICO_OK;
+}
+
+int illico_ctx_set_stream(illico_ctx *c, void *hip_stream) {
+    if (!c) return ILLICO_ERR_ARG;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    drain_events(c);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return ILLICO_OK;
+}
+
+int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
+    if (!c || !key) return ILLICO_ERR_ARG;
+    if (!strcmp(key, "gene_batch")) c->gene_batch = value;
+    else if (!strcmp(key, "scratch_bytes")) c->scratch_bytes = value;
+    else if (!strcmp(key, "profile")) c->profile = value != 0;
+    else return fail(c, ILLICO_ERR_ARG, "unknown option '%s'", key);
+    return ILLICO_OK;
+}
+
+const char *illico_last_error(const illico_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int illico_ctx_synchronize(illico_ctx *c) {
+    if (!c) return ILLICO_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ILLICO_OK;
+}
+
+int illico_profile_num_kernels(void) { return KID_COUNT; }
+const char *illico_profile_kernel_name(int k) { return (k >= 0 && k < KID_COUNT) ? kKernelNames[k] : ""; }
+int illico_profile_get(illico_ctx *c, int k, double *total_ms, int64_t *launches) {
+    if (!c || k < 0 || k >= KID_COUNT) return ILLICO_ERR_ARG;
+    hipSetDevice(c->device);
+    drain_events(c);
+    if (total_ms) *total_ms = c->prof_ms[k];
+    if (launches) *launches = c->prof_n[k];
+    return ILLICO_OK;
+}
+int illico_profile_reset(illico_ctx *c) {
+    if (!c) return ILLICO_ERR_ARG;
+    hipSetDevice(c->device);
+    drain_events(c);
+    for (int k = 0; k < KID_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    return ILLICO_OK;
+}
+
+// ---- groups ---------------------------------------------------------------------------------
+int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_t *counts, const int64_t *indices,
+                      const int64_t *indptr, int64_t n_cells, int64_t n_groups, int64_t ref) {
+    if (!c || !encoded_groups || !counts || !indices || !indptr) return fail(c, ILLICO_ERR_ARG, "null group array");
+    if (n_cells <= 0 || n_groups <= 0 || n_cells > 0x7FFFFFF0ll) return fail(c, ILLICO_ERR_ARG, "bad n_cells/n_groups");
+    if (ref < -1 || ref >= n_groups) return fail(c, ILLICO_ERR_ARG, "encoded_ref_group out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_groups(c);
+    std::vector<int> codes(n_cells), perm(n_cells), cbp(n_cells), posptr(n_groups + 1), cnt(n_groups);
+    int64_t tot = 0, max_nonref = 0;
+    for (int64_t g = 0; g < n_groups; ++g) {
+        if (counts[g] < 0 || indptr[g] != tot) return fail(c, ILLICO_ERR_ARG, "indptr/counts inconsistent at group %lld", (long long)g);
+        cnt[g] = (int)counts[g];
+        posptr[g] = (int)tot;
+        tot += counts[g];
+        if (g != ref) max_nonref = std::max<int64_t>(max_nonref, counts[g]);
+    }
+    if (tot != n_cells || indptr[n_groups] != n_cells) return fail(c, ILLICO_ERR_ARG, "counts do not sum to n_cells");
+    posptr[n_groups] = (int)n_cells;
+    for (int64_t i = 0; i < n_cells; ++i) {
+        int64_t g = encoded_groups[i];
+        if (g < 0 || g >= n_groups) return fail(c, ILLICO_ERR_ARG, "encoded group out of range at cell %lld", (long long)i);
+        codes[i] = (int)g;
+    }
+    for (int64_t g = 0; g < n_groups; ++g)
+        for (int64_t p = indptr[g]; p < indptr[g + 1]; ++p) {
+            int64_t cell = indices[p];
+            if (cell < 0 || cell >= n_cells || codes[cell] != g) return fail(c, ILLICO_ERR_ARG, "indices[%lld] is not a cell of group %lld", (long long)p, (long long)g);
+            perm[p] = (int)cell;
+            cbp[p] = (int)g;
+        }
+    auto up = [&](int **d, const std::vector<int> &h) -> int {
+        HIPCHK(c, hipMalloc((void **)d, h.size() * sizeof(int)));
+        HIPCHK(c, hipMemcpy(*d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+        return ILLICO_OK;
+    };
+    int rc;
+    if ((rc = up(&c->d_codes, codes)) || (rc = up(&c->d_perm, perm)) || (rc = up(&c->d_posptr, posptr)) ||
+        (rc = up(&c->d_counts, cnt)) || (rc = up(&c->d_code_by_pos, cbp)))
+        return rc;
+    c->h_counts = cnt;
+    c->n_cells = n_cells;
+    c->n_groups = n_groups;
+    c->ref = ref;
+    c->max_nonref = max_nonref;
+    c->has_groups = true;
+    return ILLICO_OK;
+}
+
+} // extern "C"
+
+// ============================================================================================
+// dense driver
+// ============================================================================================
+static const size_t kMaxLds = 160 * 1024;
+static const int kOvoThreads = 512;
+#include "ovr_driver.h"
+
+template <typename KeyT> static size_t ovo_lds_bytes(int ref_cap, bool runend, int nt) {
+    size_t nw = nt / 64;
+    size_t b = (((size_t)ref_cap * sizeof(KeyT)) + 15) & ~(size_t)15;
+    if (runend) b += (((size_t)ref_cap * 2) + 15) & ~(size_t)15;
+    b += nw * 256 * sizeof(KeyT) + nw * 256 * 4;
+    b += nw * 8 * 2 + 16;
+    return b;
+}
+
+template <typename KeyT, int KMAX, bool RUNEND>
+static int launch_ovo_t(illico_ctx *c, const OvoParams &P, size_t lds) {
+    auto kern = k_ovo_rank<KeyT, KMAX, RUNEND, kOvoThreads>;
+    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps(c, KID_OVO_RANK);
+    hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(kOvoThreads), lds, c->stream, P);
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+
+template <typename KeyT> static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz) {
+    if (max_grp_nnz > 1024)
+        return fail(c, ILLICO_ERR_UNSUPPORTED, "OVO with a non-reference group of %lld cells (> 1024) is not supported by this build yet", (long long)max_grp_nnz);
+    int ref_cap = (int)std::max<int64_t>(max_ref_nnz, 1);
+    bool runend = ref_cap <= 65535 && ovo_lds_bytes<KeyT>(ref_cap, true, kOvoThreads) <= kMaxLds;
+    size_t lds = ovo_lds_bytes<KeyT>(ref_cap, runend, kOvoThreads);
+    if (lds > kMaxLds)
+        return fail(c, ILLICO_ERR_UNSUPPORTED, "reference group of %lld cells does not fit the 160 KiB LDS of a CU in this build", (long long)max_ref_nnz);
+    P.ref_cap = ref_cap;
+    bool big = max_grp_nnz > 256;
+    if (big) return runend ? launch_ovo_t<KeyT, 16, true>(c, P, lds) : launch_ovo_t<KeyT, 16, false>(c, P, lds);
+    return runend ? launch_ovo_t<KeyT, 4, true>(c, P, lds) : launch_ovo_t<KeyT, 4, false>(c, P, lds);
+}
+
+template <typename InT, typename KeyT>
+static int launch_transpose(illico_ctx *c, const void *X, int64_t ld, int64_t col0, int ncols, int N, KeyT *Xt, int64_t stride) {
+    ProfScope ps(c, KID_TRANSPOSE);
+    dim3 grid((N + 63) / 64, (ncols + 63) / 64);
+    hipLaunchKernelGGL((k_transpose_permute<InT, KeyT>), grid, dim3(256), 0, c->stream, (const InT *)X, (long long)ld,
+                       (long long)col0, ncols, (const int *)c->d_perm, N, Xt, (long long)stride);
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+
+static int launch_finalize(illico_ctx *c, const long long *s2u, const u64 *stie, const double *ssum, const double *gene_total,
+                           int nb, int flags, int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld,
+                           int64_t col_off) {
+    FinalizeParams F;
+    F.in_2u = s2u; F.in_tie = stie; F.in_sum = ssum; F.gene_total = gene_total;
+    F.counts = c->d_counts; F.G = (int)c->n_groups; F.ref = (int)c->ref; F.nb = nb; F.n_cells = c->n_cells;
+    F.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;
+    F.tie_correct = (flags & ILLICO_FLAG_TIE_CORRECT) ? 1 : 0;
+    F.alternative = alternative;
+    F.out_p = out_p + col_off; F.out_u = out_u + col_off; F.out_fc = out_fc + col_off; F.out_ld = out_ld;
+    ProfScope ps(c, KID_FINALIZE);
+    dim3 grid((nb + 31) / 32, ((int)c->n_groups + 31) / 32);
+    hipLaunchKernelGGL(k_finalize, grid, dim3(256), 0, c->stream, F);
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+
+static size_t dtype_size(int dt) { return (dt == ILLICO_F32 || dt == ILLICO_I32) ? 4 : 8; }
+
+struct OutPlanes {
+    double *p, *u, *fc; // device
+    int64_t ld;
+    bool staged;
+};
+
+static int begin_outputs(illico_ctx *c, int flags, int64_t W, double *out_p, double *out_u, double *out_fc, int64_t out_ld, OutPlanes *o) {
+    if (flags & ILLICO_FLAG_OUTPUT_DEVICE) {
+        *o = {out_p, out_u, out_fc, out_ld, false};
+        return ILLICO_OK;
+    }
+    void *buf;
+    size_t plane = (size_t)c->n_groups * (size_t)W;
+    int rc = get_scratch(c, "out_planes", plane * 3 * sizeof(double), &buf);
+    if (rc) return rc;
+    double *b = (double *)buf;
+    *o = {b, b + plane, b + 2 * plane, W, true};
+    return ILLICO_OK;
+}
+
+static int end_outputs(illico_ctx *c, const OutPlanes &o, int64_t W, double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
+    if (!o.staged) return ILLICO_OK;
+    size_t G = (size_t)c->n_groups;
+    HIPCHK(c, hipMemcpy2DAsync(out_p, out_ld * 8, o.p, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(out_u, out_ld * 8, o.u, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(out_fc, out_ld * 8, o.fc, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ILLICO_OK;
+}
+
+static int check_common(illico_ctx *c, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int alternative,
+                        const void *o1, const void *o2, const void *o3, int64_t out_ld) {
+    if (!c) return ILLICO_ERR_ARG;
+    if (!c->has_groups) return fail(c, ILLICO_ERR_NO_GROUPS, "illico_set_groups has not been called");
+    if (n_rows != c->n_cells) return fail(c, ILLICO_ERR_NO_GROUPS, "X has %lld rows but the groups describe %lld cells", (long long)n_rows, (long long)c->n_cells);
+    if (col_lb < 0 || col_ub > n_cols || col_lb > col_ub) return fail(c, ILLICO_ERR_BOUNDS, "Invalid chunk bounds: (%lld, %lld) for data with %lld columns.", (long long)col_lb, (long long)col_ub, (long long)n_cols);
+    if (alternative < 0 || alternative > 2) return fail(c, ILLICO_ERR_ALTERNATIVE, "Unsupported alternative hypothesis code %d", alternative);
+    if (!o1 || !o2 || !o3) return fail(c, ILLICO_ERR_ARG, "null output plane");
+    if (out_ld < col_ub - col_lb) return fail(c, ILLICO_ERR_ARG, "out_ld smaller than the chunk width");
+    return ILLICO_OK;
+}
+
+template <typename InT, typename KeyT>
+static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
+                       int alternative, const OutPlanes &o) {
+    const int64_t W = col_ub - col_lb;
+    const int G = (int)c->n_groups;
+    const bool ovr = c->ref < 0;
+    const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
+    const int64_t stride = (N + 63) & ~63ll;
+    // genes per pass: bounded by the scratch cap (keys + sort ping-pong for OVR + host staging)
+    size_t per_gene = (size_t)stride * sizeof(KeyT) * (ovr ? 2 : 1) + (ovr ? (size_t)stride * 4 * 2 : 0) +
+                      (in_dev ? 0 : (size_t)N * sizeof(InT)) + (size_t)G * 24 + 64;
+    int64_t nb_max = c->gene_batch > 0 ? c->gene_batch : std::max<int64_t>(64, (int64_t)(c->scratch_bytes / per_gene));
+    nb_max = std::min<int64_t>(nb_max, W);
+    if (nb_max > 64) nb_max &= ~63ll;
+    nb_max = std::max<int64_t>(nb_max, 1);
+
+    void *v;
+    int rc;
+    if ((rc = get_scratch(c, "xt", (size_t)nb_max * stride * sizeof(KeyT), &v))) return rc;
+    KeyT *Xt = (KeyT *)v;
+    if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
+    long long *s2u = (long long *)v;
+    u64 *stie = (u64 *)(s2u + (size_t)nb_max * G);
+    double *ssum = (double *)(stie + (size_t)nb_max * G);
+    double *gtot = ssum + (size_t)nb_max * G;
+    InT *xin = nullptr;
+    if (!in_dev) {
+        if ((rc = get_scratch(c, "xin", (size_t)nb_max * N * sizeof(InT), &v))) return rc;
+        xin = (InT *)v;
+    }
+    for (int64_t b0 = col_lb; b0 < col_ub; b0 += nb_max) {
+        const int nb = (int)std::min<int64_t>(nb_max, col_ub - b0);
+        const void *src = X;
+        int64_t src_ld = ld, src_col0 = b0;
+        if (!in_dev) {
+            HIPCHK(c, hipMemcpy2DAsync(xin, (size_t)nb * sizeof(InT), (const InT *)X + b0, (size_t)ld * sizeof(InT),
+                                       (size_t)nb * sizeof(InT), (size_t)N, hipMemcpyHostToDevice, c->stream));
+            src = xin; src_ld = nb; src_col0 = 0;
+        }
+        if ((rc = launch_transpose<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride))) return rc;
+        if (!ovr) {
+            OvoParams P;
+            P.Xs = Xt; P.gene_stride = stride; P.pos_ptr = c->d_posptr; P.seg_ptr = nullptr; P.counts = c->d_counts;
+            P.G = G; P.ref = (int)c->ref; P.n_genes = nb; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
+            P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
+            if ((rc = launch_ovo<KeyT>(c, P, c->h_counts[c->ref], c->max_nonref))) return rc;
+            if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
+        } else {
+            if ((rc = run_ovr_dense_batch<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot))) return rc;
+            if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
+        }
+    }
+    return ILLICO_OK;
+}
+
+extern "C" int illico_run_dense(illico_ctx *c, const void *X, int dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                                int64_t col_lb, int64_t col_ub, int flags, int alternative, double *out_p, double *out_u,
+                                double *out_fc, int64_t out_ld) {
+    int rc = check_common(c, n_rows, n_cols, col_lb, col_ub, alternative, out_p, out_u, out_fc, out_ld);
+    if (rc) return rc;
+    if (!X) return fail(c, ILLICO_ERR_ARG, "null X");
+    if (ld < n_cols) return fail(c, ILLICO_ERR_ARG, "ld smaller than n_cols");
+    if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t W = col_ub - col_lb;
+    if (W == 0) return ILLICO_OK;
+    OutPlanes o;
+    if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) return rc;
+    switch (dtype) {
+    case ILLICO_F32: rc = run_dense_t<float, u32>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o); break;
+    case ILLICO_F64: rc = run_dense_t<double, u64>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o); break;
+    case ILLICO_I32: rc = run_dense_t<int32_t, u32>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o); break;
+    default: rc = run_dense_t<int64_t, u64>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o); break;
+    }
+    if (rc) return rc;
+    return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
+}
+
+#include "sparse_driver.h"

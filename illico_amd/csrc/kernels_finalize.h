@@ -1,0 +1,98 @@
+// K3  integer rank statistics -> (p-value, U statistic, fold change), transposed to [group][gene].
+//
+// Restates compute_pval (illico/utils/math.py:64-118, fastmath=False) operation by operation in
+// IEEE float64 (this translation unit is built with -ffp-contract=off), and
+// fold_change_from_summed_expr (utils/math.py:168-193).
+#pragma once
+#include "common.h"
+
+struct FinalizeParams {
+    const long long *in_2u;   // [nb][G]  2*U
+    const u64 *in_tie;        // [nb][G]  tie sum
+    const double *in_sum;     // [nb][G]  per-group sum of (expm1'd) values
+    const double *gene_total; // [nb] sum over groups, OVR only (utils/math.py:185)
+    const int *counts;        // [G]
+    int G, ref, nb;           // ref == -1 => OVR
+    long long n_cells;
+    int use_continuity, tie_correct, alternative;
+    double *out_p, *out_u, *out_fc; // [G][out_ld], column offset already applied
+    long long out_ld;
+};
+
+__device__ __forceinline__ double pval_device(long long n_ref, long long n_tgt, long long n, double tie_sum, double U,
+                                              double mu, double cc, int alternative) {
+    double tie_corr = 1.0 - tie_sum / (double)(n * (n - 1) * (n + 1));            // math.py:95
+    if (tie_corr > 1.0e-9) {                                                       // :96
+        double sigma = sqrt((double)(n_ref * n_tgt * (n_ref + n_tgt + 1)) / 12.0 * tie_corr); // :97
+        if (alternative == 0) {                                                    // :99-104
+            double other = (double)(n_ref * n_tgt) - U;
+            U = (U < other) ? U : other;
+            double delta = U - mu;
+            double sgn = (delta > 0.0) ? 1.0 : ((delta < 0.0) ? -1.0 : 0.0);
+            double z = (fabs(delta) + sgn * cc) / sigma;
+            return erfc(z / sqrt(2.0));
+        } else if (alternative == 2) {                                             // greater :105-109
+            double z = ((U - mu) - cc) / sigma;
+            return 0.5 * erfc(z / sqrt(2.0));
+        } else {                                                                   // less :110-114
+            double z = ((U - mu) + cc) / sigma;
+            return 0.5 * erfc(-z / sqrt(2.0));
+        }
+    }
+    return 1.0;                                                                    // :117-118
+}
+
+// 32 genes x 32 groups per block; stats are read coalesced along groups, results written coalesced
+// along genes.
+__global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
+    __shared__ double tp[32][33], tu[32][33], tf[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // ty 0..7
+    const int gene0 = blockIdx.x * 32, grp0 = blockIdx.y * 32;
+    const bool ovr = P.ref < 0;
+    const double cc = P.use_continuity ? 0.5 : 0.0;
+    long long total_cells = P.n_cells;
+    for (int gy = ty; gy < 32; gy += 8) {
+        int gene = gene0 + gy, g = grp0 + tx;
+        if (gene < P.nb && g < P.G) {
+            size_t o = (size_t)gene * P.G + g;
+            long long n_tgt = P.counts[g];
+            long long n_ref = ovr ? (total_cells - n_tgt) : (long long)P.counts[P.ref];
+            long long n = ovr ? total_cells : (n_ref + n_tgt);
+            double U = 0.5 * (double)P.in_2u[o];
+            double tie = P.tie_correct ? (double)P.in_tie[o] : 0.0;
+            double mu = (double)(n_ref * n_tgt) / 2.0;
+            double p;
+            if (!ovr && g == P.ref) { p = 1.0; U = -1.0; }                         // sparse_ovo.py:140-143
+            else p = pval_device(n_ref, n_tgt, n, tie, U, mu, cc, P.alternative);
+            // fold change, math.py:181-192
+            double sum_g = P.in_sum[o];
+            double mu_tgt = sum_g / (double)n_tgt;
+            double mu_ref;
+            if (ovr) mu_ref = (P.gene_total[gene] - sum_g) / (double)(total_cells - n_tgt);
+            else mu_ref = P.in_sum[(size_t)gene * P.G + P.ref] / (double)P.counts[P.ref];
+            double fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+            tp[gy][tx] = p;
+            tu[gy][tx] = U;
+            tf[gy][tx] = fc;
+        }
+    }
+    __syncthreads();
+    for (int gy = ty; gy < 32; gy += 8) {
+        int g = grp0 + gy, gene = gene0 + tx;
+        if (gene < P.nb && g < P.G) {
+            size_t o = (size_t)g * P.out_ld + gene;
+            P.out_p[o] = tp[tx][gy];
+            P.out_u[o] = tu[tx][gy];
+            P.out_fc[o] = tf[tx][gy];
+        }
+    }
+}
+
+// per-gene sum over groups, rows added in group order like group_agg_counts.sum(axis=0) (math.py:185)
+__global__ void k_gene_totals(const double *in_sum, int G, int nb, double *gene_total) {
+    int gene = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gene >= nb) return;
+    double t = 0.0;
+    for (int g = 0; g < G; ++g) t += in_sum[(size_t)gene * G + g];
+    gene_total[gene] = t;
+}

@@ -1,0 +1,291 @@
+// One-versus-rest (OVR) kernels.
+//
+// Replaces, on device, dense_ovr_mwu_kernel_over_contiguous_col_chunk (illico/ovr/dense_ovr.py:15-80)
+// and sparse_ovr_mwu_kernel (illico/ovr/sparse_ovr.py:23-97): np.argsort of a whole gene column and
+// _accumulate_group_ranksums_from_argsort (utils/ranking.py:7-49).
+//
+// One workgroup per gene: stable LSD radix sort of (key, group code) pairs through HBM ping-pong
+// buffers (8-bit digits, passes whose digit is constant over the column are skipped), then two
+// streaming sweeps over the sorted column.  For a run of equal keys occupying sorted slots [s, e)
+// every member has 2*avg_rank = s + e + 1 (ranking.py:38: avg_rank = 0.5*(i+1+j)); the forward sweep
+// adds s+1 and the backward sweep adds e into the member's group accumulator (LDS, 64-bit integer
+// atomics), so rank sums are exact integers.  Implicit zeros (sparse inputs) form one analytic tie
+// block between the negative and the positive keys (sparse_ovr.py:70-83).
+#pragma once
+#include "common.h"
+
+struct OvrParams {
+    void *keys_a;             // [n_genes rows]  in: unsorted keys (destroyed)
+    void *keys_b;             // ping-pong
+    u32 *vals_a;              // group code per key; may hold garbage when code_by_pos is given
+    u32 *vals_b;
+    const int *code_by_pos;   // dense layout: group code of position i (payload generated on the fly); else null
+    const long long *row_ptr; // sparse layout: [n_genes+1] offsets of each gene's keys; null => dense (gene*stride, n = N)
+    long long stride;         // dense layout
+    const int *pos_ptr;       // dense layout: [G+1] group positions, for the per-group sums
+    const int *counts;        // [G]
+    int G, n_genes, dt, is_log1p;
+    long long n_cells;
+    long long *out_2u;        // [n_genes][G]
+    u64 *out_tie;             // [n_genes][G]
+    double *out_sum;          // [n_genes][G]
+};
+
+#define OVR_NT 1024
+#define OVR_E 4
+
+template <int NT> __device__ __forceinline__ int block_incl_scan_max(int x, int carry, int *wtot, int tid, int &prev_out) {
+    // inclusive max-scan over the workgroup in thread order; prev_out = scan value of the previous thread (carry for tid 0)
+    const int lane = tid & 63, wave = tid >> 6;
+    int wi = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(wi, d);
+        if (lane >= d) wi = max(wi, o);
+    }
+    if (lane == 63) wtot[wave] = wi;
+    __syncthreads();
+    int wp = carry;
+    for (int w = 0; w < wave; ++w) wp = max(wp, wtot[w]);
+    int up = __shfl_up(wi, 1);
+    prev_out = lane > 0 ? max(up, wp) : wp;
+    __syncthreads();
+    return max(wi, wp);
+}
+
+template <int NT> __device__ __forceinline__ int block_incl_scan_min_rev(int x, int carry, int *wtot, int tid) {
+    // inclusive min-scan from the last thread towards the first
+    constexpr int NW = NT / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    int wi = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_down(wi, d);
+        if (lane + d < 64) wi = min(wi, o);
+    }
+    if (lane == 0) wtot[wave] = wi;
+    __syncthreads();
+    int wp = carry;
+    for (int w = NW - 1; w > wave; --w) wp = min(wp, wtot[w]);
+    __syncthreads();
+    return min(wi, wp);
+}
+
+template <typename KeyT, bool SPARSE>
+__global__ __launch_bounds__(OVR_NT) void k_ovr_gene(OvrParams P) {
+    constexpr int NT = OVR_NT, NW = NT / 64, E = OVR_E;
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
+    extern __shared__ __align__(16) unsigned char smem[];
+    u32 *wcnt = (u32 *)smem;                 // [NW][256]
+    u32 *hist = wcnt + NW * 256;             // [256]
+    u32 *dbase = hist + 256;                 // [256]
+    int *wtot = (int *)(dbase + 256);        // [NW]
+    u64 *red = (u64 *)(wtot + NW + (NW & 1)); // [NW]
+    int *flag = (int *)(red + NW);           // [4]
+    u64 *R2 = (u64 *)(flag + 4);             // [G]
+    u32 *gcnt = (u32 *)(R2 + P.G);           // [G] (SPARSE only)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = P.G;
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    for (int gene = blockIdx.x; gene < P.n_genes; gene += gridDim.x) {
+        long long start;
+        int n;
+        if (SPARSE) { start = P.row_ptr[gene]; n = (int)(P.row_ptr[gene + 1] - start); }
+        else { start = (long long)gene * P.stride; n = (int)P.n_cells; }
+        KeyT *ka = (KeyT *)P.keys_a + start, *kb = (KeyT *)P.keys_b + start;
+        u32 *va = P.vals_a + start, *vb = P.vals_b + start;
+        const long long n0 = P.n_cells - n; // implicit zeros
+
+        // ---- per-group sums of values for the fold change (deterministic order) ----
+        if (!SPARSE) {
+            for (int g = wave; g < G; g += NW) {
+                int p0 = P.pos_ptr[g], p1 = P.pos_ptr[g + 1];
+                double s = 0.0;
+                for (int i = p0 + lane; i < p1; i += 64) s += P.is_log1p ? key_to_expm1(ka[i], P.dt) : key_to_double(ka[i], P.dt);
+                s = wave_sum(s);
+                if (lane == 0) P.out_sum[(size_t)gene * G + g] = s;
+            }
+        } else {
+            double *fsum = (double *)R2; // reuse the accumulator array before the sweeps
+            for (int g = tid; g < G; g += NT) fsum[g] = 0.0;
+            __syncthreads();
+            for (int i = tid; i < n; i += NT) {
+                double x = P.is_log1p ? key_to_expm1(ka[i], P.dt) : key_to_double(ka[i], P.dt);
+                atomicAdd(&fsum[va[i]], x);
+            }
+            __syncthreads();
+            for (int g = tid; g < G; g += NT) P.out_sum[(size_t)gene * G + g] = fsum[g];
+        }
+        __syncthreads();
+
+        // ---- stable LSD radix sort of (key, group) ----
+        KeyT *ksrc = ka, *kdst = kb;
+        u32 *vsrc = va, *vdst = vb;
+        bool have_vals = SPARSE;
+        for (int shift = 0; shift < (int)sizeof(KeyT) * 8; shift += 8) {
+            for (int i = tid; i < 256; i += NT) hist[i] = 0;
+            if (tid == 0) flag[0] = 0;
+            __syncthreads();
+            for (int i0 = 0; i0 < n; i0 += NT) {
+                int i = i0 + tid;
+                bool valid = i < n;
+                u32 d = valid ? (u32)((ksrc[i] >> shift) & 0xFF) : 0u;
+                u64 peers = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    u64 bal = __ballot((d >> b) & 1u);
+                    peers &= ((d >> b) & 1u) ? bal : ~bal;
+                }
+                if (valid && (peers & lt_mask) == 0) atomicAdd(&hist[d], (u32)__popcll(peers));
+            }
+            __syncthreads();
+            if (tid < 256 && hist[tid] == (u32)n) flag[0] = 1;
+            __syncthreads();
+            if (flag[0]) { __syncthreads(); continue; } // digit constant over the column: nothing to move
+            if (tid < 256) {
+                u32 acc = 0;
+                for (int k = 0; k < tid; ++k) acc += hist[k];
+                dbase[tid] = acc;
+            }
+            __syncthreads();
+            for (int cbase = 0; cbase < n; cbase += NT * E) {
+                for (int k = lane; k < 256; k += 64) wcnt[wave * 256 + k] = 0;
+                wave_lds_fence();
+                KeyT key[E];
+                u32 val[E], off[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    int i = cbase + (wave * E + e) * 64 + lane;
+                    bool valid = i < n;
+                    key[e] = valid ? ksrc[i] : (KeyT)0;
+                    val[e] = valid ? (have_vals ? vsrc[i] : (u32)P.code_by_pos[i]) : 0u;
+                    u32 d = (u32)((key[e] >> shift) & 0xFF);
+                    u64 peers = __ballot(valid);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        u64 bal = __ballot((d >> b) & 1u);
+                        peers &= ((d >> b) & 1u) ? bal : ~bal;
+                    }
+                    u32 before = valid ? wcnt[wave * 256 + d] : 0u;
+                    off[e] = before + (u32)__popcll(peers & lt_mask);
+                    wave_lds_fence();
+                    if (valid && (peers & lt_mask) == 0) wcnt[wave * 256 + d] = before + (u32)__popcll(peers);
+                    wave_lds_fence();
+                }
+                __syncthreads();
+                if (tid < 256) {
+                    u32 run = dbase[tid];
+                    for (int w = 0; w < NW; ++w) {
+                        u32 cnt = wcnt[w * 256 + tid];
+                        wcnt[w * 256 + tid] = run;
+                        run += cnt;
+                    }
+                    dbase[tid] = run;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    int i = cbase + (wave * E + e) * 64 + lane;
+                    if (i < n) {
+                        u32 d = (u32)((key[e] >> shift) & 0xFF);
+                        u32 dst = wcnt[wave * 256 + d] + off[e];
+                        kdst[dst] = key[e];
+                        vdst[dst] = val[e];
+                    }
+                }
+                __syncthreads();
+            }
+            // make this pass's global writes visible to the whole workgroup before they are re-read
+            __threadfence_block();
+            __syncthreads();
+            { KeyT *t = ksrc; ksrc = kdst; kdst = t; }
+            { u32 *t = vsrc; vsrc = vdst; vdst = t; }
+            have_vals = true;
+        }
+        if (!have_vals) { // every pass skipped (column constant): materialise the payload
+            for (int i = tid; i < n; i += NT) vsrc[i] = (u32)P.code_by_pos[i];
+            __threadfence_block();
+            __syncthreads();
+        }
+        const KeyT *K = ksrc;
+        const u32 *V = vsrc;
+
+        // ---- sweeps over the sorted column ----
+        for (int g = tid; g < G; g += NT) { R2[g] = 0; if (SPARSE) gcnt[g] = 0; }
+        __syncthreads();
+        u64 tie = 0;
+        int carry = 0;
+        for (int cbase = 0; cbase < n; cbase += NT) { // forward: s(i)+1, run lengths
+            int i = cbase + tid;
+            bool valid = i < n;
+            KeyT k = valid ? K[i] : (KeyT)0;
+            bool head = valid && (i == 0 || K[i - 1] != k);
+            int sprev;
+            int s = block_incl_scan_max<NT>(head ? i : -1, carry, wtot, tid, sprev);
+            if (head && i > 0) { u64 t = (u64)(i - sprev); tie += t * t * t - t; }
+            if (valid) {
+                u64 add = (u64)s + 1ull + ((SPARSE && k > ZEROK) ? 2ull * (u64)n0 : 0ull);
+                atomicAdd(&R2[V[i]], add);
+                if (SPARSE) atomicAdd(&gcnt[V[i]], 1u);
+            }
+            int last = min(n - 1 - cbase, NT - 1);
+            if (tid == last) flag[1] = s;
+            __syncthreads();
+            carry = flag[1];
+            __syncthreads();
+        }
+        if (tid == 0 && n > 0) { u64 t = (u64)(n - carry); tie += t * t * t - t; }
+        int carry_e = n;
+        const int nchunks = (n + NT - 1) / NT;
+        for (int c = nchunks - 1; c >= 0; --c) { // backward: e(i)
+            int i = c * NT + tid;
+            bool valid = i < n;
+            KeyT k = valid ? K[i] : (KeyT)0;
+            bool tail = valid && (i == n - 1 || K[i + 1] != k);
+            int e = block_incl_scan_min_rev<NT>(tail ? i + 1 : 0x7FFFFFFF, carry_e, wtot, tid);
+            if (valid) atomicAdd(&R2[V[i]], (u64)e);
+            if (tid == 0) flag[1] = e;
+            __syncthreads();
+            carry_e = flag[1];
+            __syncthreads();
+        }
+        // tie sum: block reduce
+        tie = wave_sum(tie);
+        if (lane == 0) red[wave] = tie;
+        if (tid == 0) { // number of negative keys (sparse layout only)
+            int P0 = 0;
+            if (SPARSE && n > 0) {
+                int lo = 0, hi = n;
+                while (lo < hi) { int mid = (lo + hi) >> 1; if (K[mid] < ZEROK) lo = mid + 1; else hi = mid; }
+                P0 = lo;
+            }
+            flag[2] = P0;
+        }
+        __syncthreads();
+        u64 tie_total = 0;
+        for (int w = 0; w < NW; ++w) tie_total += red[w];
+        tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
+        const long long nneg = flag[2];
+        for (int g = tid; g < G; g += NT) {
+            long long n_g = P.counts[g];
+            u64 r2 = R2[g];
+            if (SPARSE) {
+                long long z = n_g - (long long)gcnt[g];
+                r2 += (u64)z * (u64)(2 * nneg + n0 + 1);
+            }
+            long long two_u = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;
+            P.out_2u[(size_t)gene * G + g] = two_u;
+            P.out_tie[(size_t)gene * G + g] = tie_total;
+        }
+        __syncthreads();
+    }
+}
+
+static inline size_t ovr_lds_bytes(int G, bool sparse) {
+    const int NW = OVR_NT / 64;
+    size_t b = (size_t)NW * 256 * 4 + 256 * 4 + 256 * 4 + (NW + (NW & 1)) * 4 + NW * 8 + 16;
+    b += (size_t)G * 8 + (sparse ? (size_t)G * 4 : 0);
+    return b;
+}

@@ -1,0 +1,42 @@
+"""Group encoding -- same GroupContainer as the reference (illico/utils/groups.py:6-15, :18-58)."""
+from __future__ import annotations
+
+from collections import namedtuple
+from typing import Any
+
+import numpy as np
+
+GroupContainer = namedtuple(
+    "GroupContainer",
+    ["encoded_groups", "counts", "indices", "indptr", "encoded_ref_group"],
+)
+
+
+def encode_and_count_groups(groups, ref_group: Any):
+    """Build the GroupContainer.
+
+    Same outputs as the reference (labels ordered as ``np.unique`` orders them, int64 arrays,
+    ``encoded_ref_group == -1`` for one-versus-rest), computed without the per-cell Python loop
+    of groups.py:42-44: ``np.unique(return_inverse=True)`` gives the codes directly and a stable
+    argsort of the codes gives ``indices`` sorted inside each group (the order the reference's
+    own TODO at groups.py:46 asks for).
+    """
+    groups = np.asarray(groups)
+    if ref_group is not None and not np.any(groups == ref_group):
+        raise ValueError(f"Reference group `{ref_group}` is not present in the group labels.")
+    unique_groups, encoded_groups, group_counts = np.unique(groups, return_inverse=True, return_counts=True)
+    encoded_groups = np.ascontiguousarray(encoded_groups.reshape(-1), dtype=np.int64)
+    group_counts = group_counts.astype(np.int64)
+    group_indices = np.argsort(encoded_groups, kind="stable").astype(np.int64)
+    group_indptr = np.concatenate([[0], np.cumsum(group_counts)]).astype(np.int64)
+    if ref_group is None:
+        encoded_ref = -1
+    else:
+        encoded_ref = int(np.flatnonzero(unique_groups == ref_group)[0])
+    return unique_groups, GroupContainer(
+        encoded_groups=encoded_groups,
+        counts=group_counts,
+        indices=group_indices,
+        indptr=group_indptr,
+        encoded_ref_group=encoded_ref,
+    )

@@ -1,0 +1,118 @@
+/*
+ * illico_hip.h -- C-ABI of libillico_hip.so, the MI355X (gfx950) engine for illico's asymptotic
+ * Wilcoxon rank-sum hot path.
+ *
+ * The reference (remydubois/illico v0.2.0) has no FFI: its seam is the Python operator
+ *   dispatcher(X, chunk_lb, chunk_ub, grpc, is_log1p, use_continuity, tie_correct, alternative)
+ *       -> (pvalues, statistics, fold_change)          each float64 [n_groups, chunk_ub-chunk_lb]
+ * (illico/asymptotic_wilcoxon.py:59-67; Numba signature illico/utils/compile.py:35-47), one
+ * implementation per (Test, KernelDataFormat) key (illico/utils/registry.py:15-43).  The entry
+ * points below are what a binding for that seam binds: plain pointers and sizes, `int` status
+ * returns (0 = ok, negative = error mapped by the host onto the reference's exception types),
+ * nothing thrown across the boundary.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Ownership: the caller owns X, the group arrays and the three output planes; the library owns
+ * only device scratch inside the context and never writes to X (the reference's tests assert the
+ * input is not mutated, tests/test_asymptotic_wilcoxon.py:187-194).
+ * Threading: one context = one HIP stream = one host thread at a time; different contexts may be
+ * driven from different host threads (the reference's "threads, never processes" model,
+ * illico/asymptotic_wilcoxon.py:236-241).
+ */
+#ifndef ILLICO_HIP_H
+#define ILLICO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct illico_ctx illico_ctx;
+
+/* status codes; the Python host maps them onto the reference's exceptions */
+enum {
+    ILLICO_OK = 0,
+    ILLICO_ERR_ARG = -1,          /* null pointer / nonsensical size                          -> ValueError */
+    ILLICO_ERR_BOUNDS = -2,       /* bad chunk bounds (asymptotic_wilcoxon.py:49-50, csc.py:158-159, csr.py:161-162) -> ValueError */
+    ILLICO_ERR_ALTERNATIVE = -3,  /* unknown alternative (utils/math.py:116)                  -> ValueError */
+    ILLICO_ERR_DTYPE = -4,        /* unsupported element / index dtype (registry.py:54-58)    -> KeyError   */
+    ILLICO_ERR_NO_GROUPS = -5,    /* illico_set_groups not called / inconsistent with n_rows  -> ValueError */
+    ILLICO_ERR_UNSORTED = -6,     /* CSR indices not sorted (asymptotic_wilcoxon.py:186-193)  -> ValueError */
+    ILLICO_ERR_HIP = -10,         /* a HIP runtime call failed (see illico_last_error)        -> RuntimeError */
+    ILLICO_ERR_OOM = -11,         /* device allocation failed                                 -> MemoryError */
+    ILLICO_ERR_UNSUPPORTED = -12  /* shape outside what this build handles (see last_error)   -> NotImplementedError */
+};
+
+/* element dtypes of X / data */
+enum { ILLICO_F32 = 0, ILLICO_F64 = 1, ILLICO_I32 = 2, ILLICO_I64 = 3 };
+/* index dtypes of sparse indices/indptr (scipy uses one dtype for both) */
+enum { ILLICO_IDX_I32 = 0, ILLICO_IDX_I64 = 1 };
+/* alternative hypothesis (utils/math.py:99-116) */
+enum { ILLICO_ALT_TWO_SIDED = 0, ILLICO_ALT_LESS = 1, ILLICO_ALT_GREATER = 2 };
+/* flags */
+enum {
+    ILLICO_FLAG_LOG1P = 1,          /* is_log1p        (utils/math.py:212)        */
+    ILLICO_FLAG_CONTINUITY = 2,     /* use_continuity  (ovo/dense_ovo.py:58)      */
+    ILLICO_FLAG_TIE_CORRECT = 4,    /* tie_correct     (ovo/dense_ovo.py:54)      */
+    ILLICO_FLAG_INPUT_DEVICE = 8,   /* X / data / indices / indptr are device pointers on ctx's device */
+    ILLICO_FLAG_OUTPUT_DEVICE = 16  /* out_p / out_u / out_fc are device pointers                       */
+};
+
+/* ---- context ---------------------------------------------------------------------------- */
+int illico_ctx_create(int device_id, illico_ctx **out_ctx);
+int illico_ctx_destroy(illico_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int illico_ctx_set_stream(illico_ctx *ctx, void *hip_stream);
+/* Tunables: "gene_batch" (genes per device pass, 0 = auto), "scratch_bytes" (cap of device scratch),
+ * "profile" (1 = bracket every kernel launch with HIP events on the context's stream). */
+int illico_ctx_set_option(illico_ctx *ctx, const char *key, int64_t value);
+const char *illico_last_error(const illico_ctx *ctx);
+int illico_ctx_synchronize(illico_ctx *ctx);
+
+/* ---- groups: GroupContainer of illico/utils/groups.py:6-15, all int64 host arrays ------- */
+/* encoded_groups[n_cells], counts[n_groups], indices[n_cells] (cells ordered by group),
+ * indptr[n_groups+1]; encoded_ref_group == -1 selects OVR (asymptotic_wilcoxon.py:41-44). */
+int illico_set_groups(illico_ctx *ctx, const int64_t *encoded_groups, const int64_t *counts,
+                      const int64_t *indices, const int64_t *indptr, int64_t n_cells, int64_t n_groups,
+                      int64_t encoded_ref_group);
+
+/* ---- the six (Test x KernelDataFormat) dispatchers of registry.py:26-43 -------------------
+ * Each computes columns [col_lb, col_ub) and writes three row-major float64 planes
+ * out_*[g * out_ld + (j - col_lb)], g < n_groups.  The reference-group row of an OVO call is
+ * written as (p = 1.0, U = -1.0) in every format (sparse_ovo.py:140-143).
+ */
+/* replaces dense_ovo_mwu_kernel_over_contiguous_col_chunk (ovo/dense_ovo.py:65-137) and
+ * dense_ovr_mwu_kernel_over_contiguous_col_chunk (ovr/dense_ovr.py:15-80); X is row-major
+ * [n_rows, >=n_cols] with leading dimension ld elements (registry.py:105-108). */
+int illico_run_dense(illico_ctx *ctx, const void *X, int dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                     int64_t col_lb, int64_t col_ub, int flags, int alternative, double *out_p, double *out_u,
+                     double *out_fc, int64_t out_ld);
+/* replaces csc_ovo_mwu_kernel_over_contiguous_col_chunk (ovo/sparse_ovo.py:163-210) and
+ * csc_ovr_mwu_kernel_over_contiguous_col_chunk (ovr/sparse_ovr.py:100-155); CSCMatrix(data, indices,
+ * indptr, shape) of utils/sparse/csc.py:10. */
+int illico_run_csc(illico_ctx *ctx, const void *data, int dtype, const void *indices, const void *indptr,
+                   int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags,
+                   int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld);
+/* replaces csr_ovo_mwu_kernel_over_contiguous_col_chunk (ovo/sparse_ovo.py:214-260) and
+ * csr_ovr_mwu_kernel_over_contiguous_col_chunk (ovr/sparse_ovr.py:158-208); CSRMatrix of
+ * utils/sparse/csr.py:16.  Indices must be sorted per row (checked by illico_csr_indices_sorted). */
+int illico_run_csr(illico_ctx *ctx, const void *data, int dtype, const void *indices, const void *indptr,
+                   int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags,
+                   int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld);
+/* replaces check_indices_sorted_per_parcel (utils/ranking.py:245-273); *out_sorted = 1/0. */
+int illico_csr_indices_sorted(illico_ctx *ctx, const void *indices, const void *indptr, int idx_dtype,
+                              int64_t n_rows, int flags, int *out_sorted);
+
+/* ---- measurement hooks (bench.py roofline leg) ------------------------------------------- */
+int illico_profile_num_kernels(void);
+const char *illico_profile_kernel_name(int kernel_id);
+/* Sums HIP-event durations of kernel `kernel_id` since the last reset (synchronises the stream). */
+int illico_profile_get(illico_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+int illico_profile_reset(illico_ctx *ctx);
+
+const char *illico_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ILLICO_HIP_H */

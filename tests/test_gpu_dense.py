@@ -1,0 +1,179 @@
+"""GPU parity tests (dense input): HIP engine through the C-ABI vs the CPU oracle and the golden vectors.
+
+Bar (north star / reference tests/test_asymptotic_wilcoxon.py:166-185): statistic bit-exact,
+p-value rtol 1e-12 atol 0, fold change rtol 1e-12 (is_log1p=False).
+"""
+import numpy as np
+import pandas as pd
+import pytest
+
+import oracle
+from conftest import assert_planes_match, load_golden, make_counts, make_labels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from illico_amd._lib import get_engine
+    return get_engine()
+
+
+def _run(engine, X, grpc, **kw):
+    engine.set_groups(grpc)
+    return engine.run_dense(X, kw.pop("col_lb", 0), kw.pop("col_ub", X.shape[1]), **kw)
+
+
+@pytest.mark.parametrize("name", ["c1_1k_200_10", "small_ragged", "sparse90", "continuous"])
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_dense_matches_reference_goldens(engine, name, test):
+    z = load_golden(name)
+    X, labels, ref = z["X"], z["labels"], str(z["reference"])
+    from illico_amd.utils.groups import encode_and_count_groups
+    for key in [k for k in z.files if k.startswith(f"dense|{test}|")]:
+        _, _, alt, cc, tc = key.split("|")
+        _, g = encode_and_count_groups(labels, ref if test == "ovo" else None)
+        got = _run(engine, X, g, use_continuity=bool(int(cc)), tie_correct=bool(int(tc)), alternative=alt)
+        gold = z[key]
+        assert_planes_match(got, (gold[:, :, 0], gold[:, :, 1], gold[:, :, 2]), ref_row=g.encoded_ref_group,
+                            what=f"{name} {key}")
+        if test == "ovo":
+            assert np.all(got[0][g.encoded_ref_group] == 1.0) and np.all(got[1][g.encoded_ref_group] == -1.0)
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
+def test_dense_dtypes_vs_oracle(engine, test, dtype):
+    X, rng = make_counts(11, 3000, 70, 0.5)
+    labels = make_labels(rng, 3000, 9, n_ref=300)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    Xd = X.astype(dtype)
+    got = _run(engine, Xd, g)
+    want = oracle.run(X.astype(np.float64), g)
+    assert_planes_match(got, want, what=f"{test} {dtype}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_dense_negative_and_continuous_values(engine, test):
+    rng = np.random.RandomState(5)
+    X = rng.randn(2500, 33).astype(np.float32)
+    X[rng.rand(*X.shape) < 0.3] = 0.0
+    X[rng.rand(*X.shape) < 0.01] = -0.0
+    labels = make_labels(rng, 2500, 8, n_ref=200)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    got = _run(engine, X, g)
+    want = oracle.run(X, g)
+    # mixed-sign sums cancel: fold change is compared at 1e-9 here, U and p at the usual bar
+    assert_planes_match(got, want, fc_rtol=1e-9, what=test)
+
+
+def test_ovo_ragged_group_sizes(engine):
+    """Group sizes straddling every wave-sort width (1, 63..65, 127..129, 255..257, 511..513, 1023, 1024)."""
+    sizes = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 700]
+    rng = np.random.RandomState(3)
+    codes = np.concatenate([np.full(s, i) for i, s in enumerate(sizes)])
+    rng.shuffle(codes)
+    labels = np.array([f"g{c:02d}" for c in codes])
+    n = codes.size
+    X = rng.poisson(rng.uniform(0.1, 8, size=21), size=(n, 21)).astype(np.float32)
+    X[rng.rand(n, 21) < 0.4] = 0
+    X[:, 3] = 0.0           # constant gene: tie_corr == 0 -> p = 1 (math.py:96,117-118)
+    X[:, 4] = rng.rand(n)   # no ties at all
+    for ref in ("g16", "g00", "g09"):
+        _, g = oracle.encode_and_count_groups(labels, ref)
+        got = _run(engine, X, g)
+        want = oracle.run(X, g)
+        assert_planes_match(got, want, what=f"ref={ref}")
+
+
+def test_ovr_ragged(engine):
+    rng = np.random.RandomState(4)
+    sizes = [1, 5, 64, 1000, 3000, 129]
+    codes = np.concatenate([np.full(s, i) for i, s in enumerate(sizes)])
+    rng.shuffle(codes)
+    labels = np.array([f"g{c:02d}" for c in codes])
+    n = codes.size
+    X = rng.poisson(2.0, size=(n, 19)).astype(np.float32)
+    X[:, 0] = 0.0
+    X[:, 1] = rng.rand(n)
+    X[:, 2] = 7.0
+    _, g = oracle.encode_and_count_groups(labels, None)
+    got = _run(engine, X, g)
+    want = oracle.run(X, g)
+    assert_planes_match(got, want, what="ovr ragged")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_column_window_batching_and_strides(engine, test):
+    X, rng = make_counts(21, 2000, 301, 0.5)
+    labels = make_labels(rng, 2000, 6, n_ref=150)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    want = oracle.run(X, g, col_lb=37, col_ub=290)
+    engine.set_option("gene_batch", 64)
+    try:
+        got = _run(engine, X, g, col_lb=37, col_ub=290)
+    finally:
+        engine.set_option("gene_batch", 0)
+    assert_planes_match(got, want, what="window")
+    # output planes that are column windows of larger arrays (row stride != width)
+    big = np.full((3, g.counts.size, 400), np.nan)
+    out = tuple(big[k][:, 100:353] for k in range(3))
+    _run(engine, X, g, col_lb=37, col_ub=290, out=out)
+    assert_planes_match(out, want, what="strided out")
+    assert np.isnan(big[:, :, :100]).all() and np.isnan(big[:, :, 353:]).all()
+    with pytest.raises(ValueError):
+        _run(engine, X, g, col_lb=5, col_ub=302)
+    with pytest.raises(ValueError):
+        _run(engine, X, g, alternative="bigger")
+
+
+def test_device_resident_input_and_output(engine):
+    import torch
+    X, rng = make_counts(8, 4000, 130, 0.5)
+    labels = make_labels(rng, 4000, 12, n_ref=300)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    want = oracle.run(X, g)
+    Xd = torch.from_numpy(X).cuda()
+    engine.set_groups(g)
+    outs = engine.run_dense(Xd, 0, X.shape[1], device_out=True)
+    engine.synchronize()
+    got = tuple(o.cpu().numpy() for o in outs)
+    assert_planes_match(got, want, what="device io")
+    np.testing.assert_array_equal(Xd.cpu().numpy(), X)  # input not mutated
+
+
+def test_log1p_fold_change(engine):
+    X, rng = make_counts(9, 1500, 40, 0.5)
+    labels = make_labels(rng, 1500, 6, n_ref=120)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    Xl = np.log1p(X)
+    got = _run(engine, Xl, g, is_log1p=True)
+    want = oracle.run(Xl, g, is_log1p=True)
+    # expm1 is evaluated in float32 (utils/math.py:212): device and libm expm1f may differ by an f32 ulp
+    assert_planes_match(got, want, fc_rtol=1e-6, what="log1p")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_drop_in_call_dataframe(test):
+    from illico_amd import AnnDataLite, asymptotic_wilcoxon
+    z = load_golden("c1_1k_200_10")
+    X, labels, ref = z["X"], z["labels"], str(z["reference"])
+    adata = AnnDataLite(X.copy(), obs=pd.DataFrame({"pert": labels}))
+    df = asymptotic_wilcoxon(adata, is_log1p=False, group_keys="pert", reference=ref if test == "ovo" else None,
+                             batch_size=64 if test == "ovo" else "auto")
+    assert list(df.columns) == ["p_value", "statistic", "fold_change"]
+    assert df.index.names == ["pert", "feature"]
+    gold = z[f"dense|{test}|two-sided|1|1"]
+    G = gold.shape[0]
+    got = df.values.reshape(G, X.shape[1], 3)
+    ref_row = int(np.flatnonzero(z["groups"] == ref)[0]) if test == "ovo" else None
+    assert_planes_match((got[:, :, 0], got[:, :, 1], got[:, :, 2]), (gold[:, :, 0], gold[:, :, 1], gold[:, :, 2]),
+                        ref_row=ref_row, what="dataframe")
+    assert list(df.index.get_level_values(0).unique()) == list(z["groups"])
+    np.testing.assert_array_equal(adata.X, X)  # input not mutated (reference tests :187-194)
+    with pytest.raises(ValueError):
+        asymptotic_wilcoxon(adata, is_log1p=False, group_keys="pert", reference="nope")
+    with pytest.raises(KeyError):
+        asymptotic_wilcoxon(AnnDataLite([[1.0]], obs=pd.DataFrame({"pert": ["a"]})) if False else
+                            type("A", (), {"X": object(), "layers": {}, "obs": {"pert": ["a"]}, "var_names": ["g"]})(),
+                            is_log1p=False, group_keys="pert")
