@@ -20,7 +20,7 @@ struct OvrParams {
     u32 *vals_a;              // group code per key; may hold garbage when code_by_pos is given
     u32 *vals_b;
     const int *code_by_pos;   // dense layout: group code of position i (payload generated on the fly); else null
-    const long long *row_ptr; // sparse layout: [n_genes+1] offsets of each gene's keys; null => dense (gene*stride, n = N)
+    const u32 *seg_ptr;       // sparse layout: [n_genes][G+1] offsets of each (gene, group) run; null => dense (gene*stride, n = N)
     long long stride;         // dense layout
     const int *pos_ptr;       // dense layout: [G+1] group positions, for the per-group sums
     const int *counts;        // [G]
@@ -92,31 +92,22 @@ __global__ __launch_bounds__(OVR_NT) void k_ovr_gene(OvrParams P) {
     for (int gene = blockIdx.x; gene < P.n_genes; gene += gridDim.x) {
         long long start;
         int n;
-        if (SPARSE) { start = P.row_ptr[gene]; n = (int)(P.row_ptr[gene + 1] - start); }
+        const u32 *sp = nullptr;
+        if (SPARSE) { sp = P.seg_ptr + (size_t)gene * (G + 1); start = sp[0]; n = (int)(sp[G] - sp[0]); }
         else { start = (long long)gene * P.stride; n = (int)P.n_cells; }
         KeyT *ka = (KeyT *)P.keys_a + start, *kb = (KeyT *)P.keys_b + start;
         u32 *va = P.vals_a + start, *vb = P.vals_b + start;
         const long long n0 = P.n_cells - n; // implicit zeros
 
-        // ---- per-group sums of values for the fold change (deterministic order) ----
-        if (!SPARSE) {
-            for (int g = wave; g < G; g += NW) {
-                int p0 = P.pos_ptr[g], p1 = P.pos_ptr[g + 1];
-                double s = 0.0;
-                for (int i = p0 + lane; i < p1; i += 64) s += P.is_log1p ? key_to_expm1(ka[i], P.dt) : key_to_double(ka[i], P.dt);
-                s = wave_sum(s);
-                if (lane == 0) P.out_sum[(size_t)gene * G + g] = s;
-            }
-        } else {
-            double *fsum = (double *)R2; // reuse the accumulator array before the sweeps
-            for (int g = tid; g < G; g += NT) fsum[g] = 0.0;
-            __syncthreads();
-            for (int i = tid; i < n; i += NT) {
-                double x = P.is_log1p ? key_to_expm1(ka[i], P.dt) : key_to_double(ka[i], P.dt);
-                atomicAdd(&fsum[va[i]], x);
-            }
-            __syncthreads();
-            for (int g = tid; g < G; g += NT) P.out_sum[(size_t)gene * G + g] = fsum[g];
+        // ---- per-group sums of values for the fold change (deterministic order; runs are group-contiguous) ----
+        for (int g = wave; g < G; g += NW) {
+            int p0, p1;
+            if (SPARSE) { p0 = (int)(sp[g] - sp[0]); p1 = (int)(sp[g + 1] - sp[0]); }
+            else { p0 = P.pos_ptr[g]; p1 = P.pos_ptr[g + 1]; }
+            double s = 0.0;
+            for (int i = p0 + lane; i < p1; i += 64) s += P.is_log1p ? key_to_expm1(ka[i], P.dt) : key_to_double(ka[i], P.dt);
+            s = wave_sum(s);
+            if (lane == 0) P.out_sum[(size_t)gene * G + g] = s;
         }
         __syncthreads();
 

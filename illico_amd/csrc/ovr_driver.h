@@ -36,7 +36,7 @@ static int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     u32 *vb = (u32 *)v;
     OvrParams P;
     P.keys_a = Xt; P.keys_b = kb; P.vals_a = va; P.vals_b = vb;
-    P.code_by_pos = c->d_code_by_pos; P.row_ptr = nullptr; P.stride = stride; P.pos_ptr = c->d_posptr;
+    P.code_by_pos = c->d_code_by_pos; P.seg_ptr = nullptr; P.stride = stride; P.pos_ptr = c->d_posptr;
     P.counts = c->d_counts; P.G = (int)c->n_groups; P.n_genes = nb; P.dt = dtype;
     P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = N;
     P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;

@@ -1,20 +1,260 @@
-// Host-side drivers of the CSC / CSR entry points.
+// Host-side drivers of the CSC / CSR entry points (included at the end of illico_hip.hip).
 #pragma once
+
+static size_t seg_lds_bytes(int G) { return (size_t)((G + 3) & ~3) * 4 + SEG_NT * 4; }
+
+struct SparseBatch {
+    int64_t g0, g1;   // gene range (absolute column indices)
+    int64_t nnz;      // stored entries in the range
+    int64_t max_gene; // largest per-gene nnz in the range
+};
+
+// split [col_lb, col_ub) so that each batch's scratch stays under the cap and its nnz below 2^31
+static std::vector<SparseBatch> plan_batches(const std::vector<int64_t> &gene_nnz, int64_t col_lb, size_t per_nnz,
+                                             size_t per_gene, int64_t gene_batch, size_t cap) {
+    std::vector<SparseBatch> out;
+    const int64_t W = (int64_t)gene_nnz.size();
+    int64_t i = 0;
+    while (i < W) {
+        SparseBatch b{col_lb + i, col_lb + i, 0, 0};
+        size_t bytes = 0;
+        while (i < W) {
+            int64_t c = gene_nnz[i];
+            size_t add = (size_t)c * per_nnz + per_gene;
+            bool full = (b.g1 > b.g0) && (bytes + add > cap || b.nnz + c > 0x7FFF0000ll || (gene_batch > 0 && b.g1 - b.g0 >= gene_batch));
+            if (full) break;
+            bytes += add;
+            b.nnz += c;
+            b.max_gene = std::max(b.max_gene, c);
+            b.g1 += 1;
+            ++i;
+        }
+        out.push_back(b);
+    }
+    return out;
+}
+
+template <typename InT, typename IdxT, typename KeyT>
+static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indices, const void *indptr, int dtype,
+                        int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                        const OutPlanes &o) {
+    const int G = (int)c->n_groups;
+    const bool ovr = c->ref < 0;
+    const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
+    const int64_t W = col_ub - col_lb;
+    const int64_t n_ptr = (is_csr ? n_rows : n_cols) + 1;
+    if (seg_lds_bytes(G) > kMaxLds) return fail(c, ILLICO_ERR_UNSUPPORTED, "sparse input with %d groups exceeds the LDS histogram of this build", G);
+    int rc;
+    void *v;
+
+    // host copy of indptr (batch planning for CSC; total nnz for CSR)
+    std::vector<IdxT> h_indptr(n_ptr);
+    if (in_dev) HIPCHK(c, hipMemcpy(h_indptr.data(), indptr, n_ptr * sizeof(IdxT), hipMemcpyDeviceToHost));
+    else memcpy(h_indptr.data(), indptr, n_ptr * sizeof(IdxT));
+    const int64_t total_nnz = (int64_t)h_indptr[n_ptr - 1];
+    if (h_indptr[0] != 0) return fail(c, ILLICO_ERR_ARG, "indptr[0] must be 0");
+
+    // device views of the matrix
+    const InT *d_data = (const InT *)data;
+    const IdxT *d_indices = (const IdxT *)indices, *d_indptr = (const IdxT *)indptr;
+    int64_t kshift = 0; // d_data[k - kshift] holds stored entry k
+    if (!in_dev) {
+        if ((rc = get_scratch(c, "sp_indptr", n_ptr * sizeof(IdxT), &v))) return rc;
+        HIPCHK(c, hipMemcpyAsync(v, indptr, n_ptr * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
+        d_indptr = (const IdxT *)v;
+        if (is_csr) { // rows span every column: the whole matrix goes to the device once
+            if ((rc = get_scratch(c, "sp_data", std::max<size_t>(total_nnz, 1) * sizeof(InT), &v))) return rc;
+            HIPCHK(c, hipMemcpyAsync(v, data, total_nnz * sizeof(InT), hipMemcpyHostToDevice, c->stream));
+            d_data = (const InT *)v;
+            if ((rc = get_scratch(c, "sp_indices", std::max<size_t>(total_nnz, 1) * sizeof(IdxT), &v))) return rc;
+            HIPCHK(c, hipMemcpyAsync(v, indices, total_nnz * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
+            d_indices = (const IdxT *)v;
+        }
+    }
+
+    // per-gene stored-entry counts of the requested window
+    std::vector<int64_t> gene_nnz(W);
+    if (!is_csr) {
+        for (int64_t j = 0; j < W; ++j) gene_nnz[j] = (int64_t)h_indptr[col_lb + j + 1] - (int64_t)h_indptr[col_lb + j];
+    } else {
+        if ((rc = get_scratch(c, "sp_colcnt", std::max<size_t>(W, 1) * 4, &v))) return rc;
+        u32 *d_cc = (u32 *)v;
+        HIPCHK(c, hipMemsetAsync(d_cc, 0, W * 4, c->stream));
+        {
+            ProfScope ps(c, KID_SPARSE_SEG);
+            hipLaunchKernelGGL((k_csr_col_nnz<IdxT>), dim3(2048), dim3(256), 0, c->stream, d_indices, (long long)total_nnz,
+                               (long long)col_lb, (long long)col_ub, d_cc);
+            HIPCHK(c, hipGetLastError());
+        }
+        std::vector<u32> h_cc(W);
+        HIPCHK(c, hipMemcpyAsync(h_cc.data(), d_cc, W * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int64_t j = 0; j < W; ++j) gene_nnz[j] = h_cc[j];
+    }
+
+    const size_t per_nnz = sizeof(KeyT) * (ovr ? 2 : 1) + (ovr ? 8 : 0) + ((!in_dev && !is_csr) ? sizeof(InT) + sizeof(IdxT) : 0);
+    const size_t per_gene = (size_t)(G + 1) * 4 * (is_csr ? 2 : 1) + (size_t)G * 24 + 64;
+    auto batches = plan_batches(gene_nnz, col_lb, per_nnz, per_gene, c->gene_batch, (size_t)c->scratch_bytes);
+
+    for (const SparseBatch &b : batches) {
+        const int nb = (int)(b.g1 - b.g0);
+        const size_t nnz = (size_t)std::max<int64_t>(b.nnz, 1);
+        if ((rc = get_scratch(c, "xt", nnz * sizeof(KeyT), &v))) return rc;
+        KeyT *Xs = (KeyT *)v;
+        if ((rc = get_scratch(c, "sp_seg", (size_t)nb * (G + 1) * 4, &v))) return rc;
+        u32 *seg = (u32 *)v;
+        u32 *va = nullptr, *vb = nullptr;
+        void *kb = nullptr;
+        if (ovr) {
+            if ((rc = get_scratch(c, "ovr_kb", nnz * sizeof(KeyT), &v))) return rc;
+            kb = v;
+            if ((rc = get_scratch(c, "ovr_va", nnz * 4, &v))) return rc;
+            va = (u32 *)v;
+            if ((rc = get_scratch(c, "ovr_vb", nnz * 4, &v))) return rc;
+            vb = (u32 *)v;
+        }
+        if ((rc = get_scratch(c, "stats", (size_t)nb * G * 24 + (size_t)nb * 8, &v))) return rc;
+        long long *s2u = (long long *)v;
+        u64 *stie = (u64 *)(s2u + (size_t)nb * G);
+        double *ssum = (double *)(stie + (size_t)nb * G);
+        double *gtot = ssum + (size_t)nb * G;
+
+        if (!is_csr) {
+            const int64_t k0 = (int64_t)h_indptr[b.g0];
+            const InT *bd = d_data;
+            const IdxT *bi = d_indices;
+            if (!in_dev) { // upload this batch's slice of data / indices
+                if ((rc = get_scratch(c, "sp_data", nnz * sizeof(InT), &v))) return rc;
+                HIPCHK(c, hipMemcpyAsync(v, (const InT *)data + k0, b.nnz * sizeof(InT), hipMemcpyHostToDevice, c->stream));
+                bd = (const InT *)v - k0;
+                if ((rc = get_scratch(c, "sp_indices", nnz * sizeof(IdxT), &v))) return rc;
+                HIPCHK(c, hipMemcpyAsync(v, (const IdxT *)indices + k0, b.nnz * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
+                bi = (const IdxT *)v - k0;
+            }
+            ProfScope ps(c, KID_SPARSE_SEG);
+            auto kern = k_csc_segment<InT, IdxT, KeyT>;
+            size_t lds = seg_lds_bytes(G);
+            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(SEG_NT), lds, c->stream, bd, bi, d_indptr, (long long)b.g0, nb,
+                               (const int *)c->d_codes, G, Xs, va, seg);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            if ((rc = get_scratch(c, "sp_cursor", (size_t)nb * (G + 1) * 4 + (size_t)nb * 8, &v))) return rc;
+            u32 *cursor = (u32 *)v;
+            u32 *gene_tot = cursor + (size_t)nb * (G + 1);
+            u32 *gene_base = gene_tot + nb;
+            HIPCHK(c, hipMemsetAsync(seg, 0, (size_t)nb * (G + 1) * 4, c->stream));
+            ProfScope ps(c, KID_SPARSE_SEG);
+            const int rows_grid = (int)std::min<int64_t>((n_rows + 3) / 4, 8192);
+            hipLaunchKernelGGL((k_csr_count<InT, IdxT>), dim3(rows_grid), dim3(256), 0, c->stream, d_data, d_indices, d_indptr,
+                               (int)n_rows, (long long)b.g0, (long long)b.g1, (const int *)c->d_codes, G, seg);
+            size_t lds = seg_lds_bytes(G);
+            HIPCHK(c, hipFuncSetAttribute((const void *)k_seg_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_seg_scan, dim3(nb), dim3(SEG_NT), lds, c->stream, seg, G, nb, gene_tot);
+            hipLaunchKernelGGL(k_gene_base_scan, dim3(1), dim3(1024), 0, c->stream, (const u32 *)gene_tot, nb, gene_base);
+            long long tot = (long long)nb * (G + 1);
+            hipLaunchKernelGGL(k_seg_add_base, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, seg, cursor,
+                               (const u32 *)gene_base, G, nb);
+            hipLaunchKernelGGL((k_csr_scatter<InT, IdxT, KeyT>), dim3(rows_grid), dim3(256), 0, c->stream, d_data, d_indices,
+                               d_indptr, (int)n_rows, (long long)b.g0, (long long)b.g1, (const int *)c->d_codes, G, cursor, Xs, va);
+            HIPCHK(c, hipGetLastError());
+        }
+
+        if (!ovr) {
+            OvoParams P;
+            P.Xs = Xs; P.gene_stride = 0; P.pos_ptr = c->d_posptr; P.seg_ptr = seg; P.counts = c->d_counts;
+            P.G = G; P.ref = (int)c->ref; P.n_genes = nb; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
+            P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
+            int64_t ref_cap = std::min<int64_t>(c->h_counts[c->ref], b.max_gene);
+            int64_t grp_cap = std::min<int64_t>(c->max_nonref, b.max_gene);
+            if ((rc = launch_ovo<KeyT>(c, P, ref_cap, grp_cap))) return rc;
+            if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b.g0 - col_lb))) return rc;
+        } else {
+            OvrParams P;
+            P.keys_a = Xs; P.keys_b = kb; P.vals_a = va; P.vals_b = vb; P.code_by_pos = nullptr; P.seg_ptr = seg;
+            P.stride = 0; P.pos_ptr = nullptr; P.counts = c->d_counts; P.G = G; P.n_genes = nb; P.dt = dtype;
+            P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows;
+            P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
+            if ((rc = launch_ovr_gene<KeyT, true>(c, P))) return rc;
+            if ((rc = launch_gene_totals(c, ssum, G, nb, gtot))) return rc;
+            if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b.g0 - col_lb))) return rc;
+        }
+    }
+    return ILLICO_OK;
+}
+
+static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr,
+                      int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                      double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
+    int rc = check_common(c, n_rows, n_cols, col_lb, col_ub, alternative, out_p, out_u, out_fc, out_ld);
+    if (rc) return rc;
+    if (!data || !indices || !indptr) return fail(c, ILLICO_ERR_ARG, "null sparse array");
+    if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    if (idx_dtype != ILLICO_IDX_I32 && idx_dtype != ILLICO_IDX_I64) return fail(c, ILLICO_ERR_DTYPE, "unsupported index dtype code %d", idx_dtype);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t W = col_ub - col_lb;
+    if (W == 0) return ILLICO_OK;
+    OutPlanes o;
+    if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) return rc;
+#define SP_CALL(InT, KeyT)                                                                                                 \
+    (idx_dtype == ILLICO_IDX_I32                                                                                           \
+         ? run_sparse_t<InT, int32_t, KeyT>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o) \
+         : run_sparse_t<InT, int64_t, KeyT>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o))
+    switch (dtype) {
+    case ILLICO_F32: rc = SP_CALL(float, u32); break;
+    case ILLICO_F64: rc = SP_CALL(double, u64); break;
+    case ILLICO_I32: rc = SP_CALL(int32_t, u32); break;
+    default: rc = SP_CALL(int64_t, u64); break;
+    }
+#undef SP_CALL
+    if (rc) return rc;
+    return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
+}
+
 extern "C" int illico_run_csc(illico_ctx *c, const void *data, int dtype, const void *indices, const void *indptr,
                               int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags,
                               int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
-    int rc = check_common(c, n_rows, n_cols, col_lb, col_ub, alternative, out_p, out_u, out_fc, out_ld);
-    if (rc) return rc;
-    return fail(c, ILLICO_ERR_UNSUPPORTED, "CSC path not built yet");
+    return run_sparse(c, false, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative,
+                      out_p, out_u, out_fc, out_ld);
 }
 extern "C" int illico_run_csr(illico_ctx *c, const void *data, int dtype, const void *indices, const void *indptr,
                               int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags,
                               int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
-    int rc = check_common(c, n_rows, n_cols, col_lb, col_ub, alternative, out_p, out_u, out_fc, out_ld);
-    if (rc) return rc;
-    return fail(c, ILLICO_ERR_UNSUPPORTED, "CSR path not built yet");
+    return run_sparse(c, true, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative,
+                      out_p, out_u, out_fc, out_ld);
 }
+
+template <typename IdxT> static int csr_sorted_host(const IdxT *indices, const IdxT *indptr, int64_t n_rows) {
+    for (int64_t r = 0; r < n_rows; ++r)
+        for (int64_t k = (int64_t)indptr[r] + 1; k < (int64_t)indptr[r + 1]; ++k)
+            if (indices[k] < indices[k - 1]) return 0;
+    return 1;
+}
+
 extern "C" int illico_csr_indices_sorted(illico_ctx *c, const void *indices, const void *indptr, int idx_dtype,
                                          int64_t n_rows, int flags, int *out_sorted) {
-    return fail(c, ILLICO_ERR_UNSUPPORTED, "not built yet");
+    if (!c || !indices || !indptr || !out_sorted || n_rows < 0) return fail(c, ILLICO_ERR_ARG, "bad argument");
+    if (idx_dtype != ILLICO_IDX_I32 && idx_dtype != ILLICO_IDX_I64) return fail(c, ILLICO_ERR_DTYPE, "unsupported index dtype code %d", idx_dtype);
+    if (!(flags & ILLICO_FLAG_INPUT_DEVICE)) {
+        *out_sorted = idx_dtype == ILLICO_IDX_I32 ? csr_sorted_host((const int32_t *)indices, (const int32_t *)indptr, n_rows)
+                                                  : csr_sorted_host((const int64_t *)indices, (const int64_t *)indptr, n_rows);
+        return ILLICO_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    void *v;
+    int rc = get_scratch(c, "flag", 16, &v);
+    if (rc) return rc;
+    int *d_bad = (int *)v;
+    HIPCHK(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
+    const int grid = (int)std::min<int64_t>((n_rows + 3) / 4 + 1, 8192);
+    if (idx_dtype == ILLICO_IDX_I32)
+        hipLaunchKernelGGL((k_csr_sorted_check<int32_t>), dim3(grid), dim3(256), 0, c->stream, (const int32_t *)indices, (const int32_t *)indptr, (int)n_rows, d_bad);
+    else
+        hipLaunchKernelGGL((k_csr_sorted_check<int64_t>), dim3(grid), dim3(256), 0, c->stream, (const int64_t *)indices, (const int64_t *)indptr, (int)n_rows, d_bad);
+    HIPCHK(c, hipGetLastError());
+    int bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out_sorted = bad ? 0 : 1;
+    return ILLICO_OK;
 }

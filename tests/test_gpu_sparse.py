@@ -1,0 +1,123 @@
+"""GPU parity tests (CSC / CSR input) through the C-ABI vs the CPU oracle and the golden vectors."""
+import numpy as np
+import pandas as pd
+import pytest
+from scipy import sparse
+
+import oracle
+from conftest import assert_planes_match, load_golden, make_counts, make_labels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from illico_amd._lib import get_engine
+    return get_engine()
+
+
+def _run(engine, M, grpc, **kw):
+    engine.set_groups(grpc)
+    lb, ub = kw.pop("col_lb", 0), kw.pop("col_ub", M.shape[1])
+    return engine.run_sparse(M.format, M.data, M.indices, M.indptr, M.shape, lb, ub, **kw)
+
+
+@pytest.mark.parametrize("name", ["c1_1k_200_10", "small_ragged", "sparse90", "continuous"])
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_sparse_matches_reference_goldens(engine, name, fmt, test):
+    z = load_golden(name)
+    X, labels, ref = z["X"], z["labels"], str(z["reference"])
+    M = sparse.csc_matrix(X) if fmt == "csc" else sparse.csr_matrix(X)
+    from illico_amd.utils.groups import encode_and_count_groups
+    keys = [k for k in z.files if k.startswith(f"{fmt}|{test}|") and k.count("|") == 4]
+    assert keys
+    for key in keys:
+        _, _, alt, cc, tc = key.split("|")
+        _, g = encode_and_count_groups(labels, ref if test == "ovo" else None)
+        got = _run(engine, M, g, use_continuity=bool(int(cc)), tie_correct=bool(int(tc)), alternative=alt)
+        gold = z[key]
+        assert_planes_match(got, (gold[:, :, 0], gold[:, :, 1], gold[:, :, 2]), ref_row=g.encoded_ref_group,
+                            what=f"{name} {key}")
+
+
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("dtype,idx", [(np.float32, np.int32), (np.float64, np.int64), (np.int32, np.int32)])
+def test_sparse_dtypes_windows_batches(engine, fmt, test, dtype, idx):
+    X, rng = make_counts(31, 2500, 150, 0.85)
+    labels = make_labels(rng, 2500, 11, n_ref=250)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    M = (sparse.csc_matrix if fmt == "csc" else sparse.csr_matrix)(X.astype(dtype))
+    M.indices = M.indices.astype(idx)
+    M.indptr = M.indptr.astype(idx)
+    want = oracle.run(X.astype(np.float64), g, col_lb=13, col_ub=141)
+    engine.set_option("gene_batch", 50)
+    try:
+        got = _run(engine, M, g, col_lb=13, col_ub=141)
+    finally:
+        engine.set_option("gene_batch", 0)
+    assert_planes_match(got, want, what=f"{fmt} {test} {dtype}")
+
+
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_sparse_edge_cases(engine, fmt, test):
+    """Empty columns, empty rows, an all-dense column, explicit stored zeros (dropped: they are zeros)."""
+    rng = np.random.RandomState(7)
+    n, m = 1200, 24
+    X = rng.poisson(1.0, size=(n, m)).astype(np.float32)
+    X[rng.rand(n, m) < 0.7] = 0
+    X[:, 0] = 0.0
+    X[:, 1] = 1.0 + rng.poisson(3.0, size=n)
+    X[5, :] = 0.0
+    labels = make_labels(rng, n, 7, n_ref=100)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    M = (sparse.csc_matrix if fmt == "csc" else sparse.csr_matrix)(X)
+    # plant explicit zeros in the structure
+    M = M.tolil()
+    M = (sparse.csc_matrix if fmt == "csc" else sparse.csr_matrix)(M)
+    M.data[::17] = 0.0
+    Xz = M.toarray()
+    want = oracle.run(Xz, g)  # dense semantics: a stored zero is a zero
+    got = _run(engine, M, g)
+    assert_planes_match(got, want, what=f"{fmt} {test} edge")
+
+
+def test_sparse_device_resident(engine):
+    import torch
+    X, rng = make_counts(41, 3000, 90, 0.9)
+    labels = make_labels(rng, 3000, 10, n_ref=300)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    want = oracle.run(X, g)
+    M = sparse.csc_matrix(X)
+    engine.set_groups(g)
+    d, i, p = (torch.from_numpy(a).cuda() for a in (M.data, M.indices, M.indptr))
+    got = engine.run_sparse("csc", d, i, p, M.shape, 0, M.shape[1])
+    assert_planes_match(got, want, what="csc device")
+
+
+def test_csr_sorted_check_and_drop_in(engine):
+    from illico_amd import AnnDataLite, asymptotic_wilcoxon
+    X, rng = make_counts(51, 800, 20, 0.6)
+    labels = make_labels(rng, 800, 5)
+    M = sparse.csr_matrix(X)
+    assert engine.csr_indices_sorted(M.indices, M.indptr, M.shape[0])
+    import torch
+    assert engine.csr_indices_sorted(torch.from_numpy(M.indices).cuda(), torch.from_numpy(M.indptr).cuda(), M.shape[0])
+    bad = M.copy()
+    s, e = bad.indptr[3], bad.indptr[4]
+    assert e - s >= 2
+    bad.indices[s:e] = bad.indices[s:e][::-1].copy()
+    assert not engine.csr_indices_sorted(bad.indices, bad.indptr, bad.shape[0])
+    assert not engine.csr_indices_sorted(torch.from_numpy(bad.indices).cuda(), torch.from_numpy(bad.indptr).cuda(), bad.shape[0])
+    adata = AnnDataLite(bad, obs=pd.DataFrame({"pert": labels}))
+    with pytest.raises(ValueError, match="not sorted"):  # reference tests/test_asymptotic_wilcoxon.py:259-273
+        asymptotic_wilcoxon(adata, is_log1p=False, group_keys="pert", reference=labels[0])
+    for fmt in ("csc", "csr"):
+        A = AnnDataLite((sparse.csc_matrix if fmt == "csc" else sparse.csr_matrix)(X), obs=pd.DataFrame({"pert": labels}))
+        df = asymptotic_wilcoxon(A, is_log1p=False, group_keys="pert", reference=labels[0])
+        uniq, g = oracle.encode_and_count_groups(labels, labels[0])
+        want = oracle.run(X, g)
+        got = df.values.reshape(len(uniq), X.shape[1], 3)
+        assert_planes_match((got[:, :, 0], got[:, :, 1], got[:, :, 2]), want, ref_row=g.encoded_ref_group, what=fmt)
