@@ -1,0 +1,150 @@
+"""CPU-only tests of the host side: C-ABI surface, group encoding, registries, argument errors."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+from scipy import sparse
+
+import oracle
+from conftest import ROOT, load_golden, make_counts, make_labels
+
+
+def test_cabi_exports_every_declared_symbol():
+    """libillico_hip.so loads without a GPU and exports every entry point include/illico_hip.h declares."""
+    from illico_amd import _lib
+    header = (ROOT / "include" / "illico_hip.h").read_text()
+    declared = sorted(set(re.findall(r"\b(illico_[a-z_0-9]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in illico_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == declared
+    assert lib.illico_version().startswith(b"illico_hip")
+    assert lib.illico_profile_num_kernels() > 0
+    assert lib.illico_profile_kernel_name(0)
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a device the product path fails loudly; it never routes through the oracle."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from illico_amd import AnnDataLite, asymptotic_wilcoxon
+    X, rng = make_counts(0, 50, 4, 0.5)
+    adata = AnnDataLite(X, obs=pd.DataFrame({"pert": make_labels(rng, 50, 3)}))
+    with pytest.raises(RuntimeError, match="no CPU fallback|illico_ctx_create"):
+        asymptotic_wilcoxon(adata, is_log1p=False, group_keys="pert")
+    import illico_amd, sys
+    src = "".join(p.read_text() for p in (ROOT / "illico_amd").rglob("*.py"))
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_encode_and_count_groups_matches_reference_semantics():
+    from illico_amd.utils.groups import encode_and_count_groups
+    labels = np.array(["pert_10", "pert_2", "ctrl", "pert_10", "ctrl", "pert_2", "pert_2"])
+    uniq, g = encode_and_count_groups(labels, "ctrl")
+    assert list(uniq) == ["ctrl", "pert_10", "pert_2"]  # lexicographic, as np.unique (groups.py:42)
+    assert g.encoded_ref_group == 0
+    np.testing.assert_array_equal(g.encoded_groups, [1, 2, 0, 1, 0, 2, 2])
+    np.testing.assert_array_equal(g.counts, [2, 2, 3])
+    np.testing.assert_array_equal(g.indptr, [0, 2, 4, 7])
+    for k in range(3):
+        assert set(g.indices[g.indptr[k]:g.indptr[k + 1]]) == set(np.flatnonzero(g.encoded_groups == k))
+    assert all(a.dtype == np.int64 for a in (g.encoded_groups, g.counts, g.indices, g.indptr))
+    _, g2 = encode_and_count_groups(labels, None)
+    assert g2.encoded_ref_group == -1
+    with pytest.raises(ValueError, match="not present"):
+        encode_and_count_groups(labels, "nope")
+    # same container as the oracle's restatement of groups.py
+    z = load_golden("c1_1k_200_10")
+    u1, a = encode_and_count_groups(z["labels"], str(z["reference"]))
+    u2, b = oracle.encode_and_count_groups(z["labels"], str(z["reference"]))
+    np.testing.assert_array_equal(u1, z["groups"])
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_registries_and_handlers():
+    from illico_amd.utils.registry import (CSCMatrix, CSRMatrix, KernelDataFormat, Test, data_handler_registry,
+                                           dispatcher_registry)
+    for t in Test:
+        for f in KernelDataFormat:
+            assert callable(dispatcher_registry.get(t, f))
+            assert callable(dispatcher_registry.get(t.value, f.value))
+    with pytest.raises(KeyError, match="No dispatcher registered"):
+        dispatcher_registry.pop((Test.OVO, KernelDataFormat.CSR)) and dispatcher_registry.get("ovo", "csr")
+    import illico_amd.ovo as ovo
+    dispatcher_registry[(Test.OVO, KernelDataFormat.CSR)] = ovo.csr_ovo_mwu_kernel_over_contiguous_col_chunk
+    X = np.zeros((4, 3), dtype=np.float32)
+    h = data_handler_registry.get(X)
+    assert h.kernel_data_format() == KernelDataFormat.DENSE and h.footprint() == X.nbytes
+    assert h.fetch(1, 2) == (X, (1, 2)) or h.fetch(1, 2)[1] == (1, 2)
+    hc = data_handler_registry.get(sparse.csc_matrix(X))
+    assert hc.kernel_data_format() == KernelDataFormat.CSC and isinstance(hc.to_nb(hc.data), CSCMatrix)
+    hr = data_handler_registry.get(sparse.csr_matrix(X))
+    assert hr.kernel_data_format() == KernelDataFormat.CSR and isinstance(hr.to_nb(hr.data), CSRMatrix)
+    with pytest.raises(KeyError, match="is not implemented"):
+        data_handler_registry.get(sparse.coo_matrix(X))
+    with pytest.raises(KeyError, match="is not implemented"):
+        data_handler_registry.get([[1.0]])
+
+
+def test_sorted_check_vectorised_vs_oracle():
+    from illico_amd.utils.ranking import check_indices_sorted_per_parcel
+    rng = np.random.RandomState(0)
+    for t in range(50):
+        M = sparse.random(30, 20, density=0.3, format="csr", random_state=rng)
+        if t % 2:
+            r = rng.randint(0, 30)
+            s, e = M.indptr[r], M.indptr[r + 1]
+            M.indices[s:e] = rng.permutation(M.indices[s:e])
+        assert check_indices_sorted_per_parcel(M.indices, M.indptr) == oracle.check_indices_sorted_per_parcel(M.indices, M.indptr)
+    assert check_indices_sorted_per_parcel(np.array([], dtype=np.int32), np.array([0, 0, 0]))
+
+
+def test_value_dtype_widening():
+    from illico_amd._lib import normalize_values
+    assert normalize_values(np.zeros(3, np.uint8)).dtype == np.int32
+    assert normalize_values(np.zeros(3, np.int16)).dtype == np.int32
+    assert normalize_values(np.zeros(3, np.float16)).dtype == np.float32
+    assert normalize_values(np.zeros(3, np.uint32)).dtype == np.int64
+    assert normalize_values(np.zeros(3, np.float64)).dtype == np.float64
+    with pytest.raises(KeyError):
+        normalize_values(np.zeros(3, np.complex64))
+
+
+def test_argument_errors_before_any_device_work():
+    from illico_amd import AnnDataLite, asymptotic_wilcoxon
+    X, rng = make_counts(0, 60, 300, 0.5)
+    labels = make_labels(rng, 60, 3)
+    adata = AnnDataLite(X, obs=pd.DataFrame({"pert": labels}))
+    with pytest.raises(ValueError, match="not present"):
+        asymptotic_wilcoxon(adata, is_log1p=False, group_keys="pert", reference="nope")
+    with pytest.raises(ValueError, match="Invalid batch_size"):
+        asymptotic_wilcoxon(adata, is_log1p=False, group_keys="pert", batch_size="big")
+    with pytest.raises(ValueError, match="Unsupported alternative"):
+        asymptotic_wilcoxon(adata, is_log1p=False, group_keys="pert", alternative="bigger")
+    with pytest.raises(KeyError, match="is not implemented"):
+        asymptotic_wilcoxon(AnnDataLite(sparse.coo_matrix(X), obs=pd.DataFrame({"pert": labels})), is_log1p=False,
+                            group_keys="pert")
+    bad = sparse.csr_matrix(X)
+    s, e = bad.indptr[0], bad.indptr[1]
+    bad.indices[s:e] = bad.indices[s:e][::-1].copy()
+    with pytest.raises(ValueError, match="not sorted"):
+        asymptotic_wilcoxon(AnnDataLite(bad, obs=pd.DataFrame({"pert": labels})), is_log1p=False, group_keys="pert")
+
+
+def test_shard_bounds():
+    from illico_amd.distributed import rank_gene_range, shard_bounds
+    for n in (0, 1, 7, 8000, 30000):
+        for parts in (1, 2, 3, 8):
+            b = shard_bounds(n, parts)
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+            w = [u - l for l, u in b]
+            assert max(w) - min(w) <= 1
+        r = [rank_gene_range(n, k, 8) for k in range(8)]
+        assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(7))
