@@ -94,9 +94,126 @@ template <typename KeyT> __device__ __forceinline__ void compex(KeyT &lo, KeyT &
     hi = b;
 }
 
+// ---------------------------------------------------------------------------------------------
+// VALU-only lane exchanges (DPP row permutes + v_permlane16/32_swap): none of these touch the LDS
+// crossbar, which ds_bpermute / __shfl do.  dpp_ctrl encodings: quad_perm = a|b<<2|c<<4|d<<6,
+// row_shl:n = 0x100+n, row_shr:n = 0x110+n, row_ror:n = 0x120+n, wave_shl:1 = 0x130,
+// wave_shr:1 = 0x138, row_mirror = 0x140, row_half_mirror = 0x141, row_bcast:15 = 0x142,
+// row_bcast:31 = 0x143.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = false>
+__device__ __forceinline__ u32 dpp_u32(u32 old, u32 src) {
+    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, BANK_MASK, BOUND);
+}
+// full permutation inside a row: every lane has a source, so no `old` value is needed (lets the
+// compiler fold the move into the consuming VALU instruction's DPP operand)
+template <int CTRL> __device__ __forceinline__ u32 dpp_perm(u32 src) {
+    return (u32)__builtin_amdgcn_mov_dpp((int)src, CTRL, 0xF, 0xF, true);
+}
+
+// value of lane (lane ^ M) for the masks the sort network uses: 1,2,4,8,16,32 and 3,7,15,31,63
+template <int M> __device__ __forceinline__ u32 xor_lanes(u32 v, int lane) {
+    constexpr int L = M & 15;
+    static_assert(L == 0 || L == 1 || L == 2 || L == 3 || L == 4 || L == 7 || L == 8 || L == 15, "unsupported lane mask");
+    u32 t = v;
+    if constexpr (L == 1) t = dpp_perm<0xB1>(v);        // quad_perm [1,0,3,2]
+    else if constexpr (L == 2) t = dpp_perm<0x4E>(v);   // quad_perm [2,3,0,1]
+    else if constexpr (L == 3) t = dpp_perm<0x1B>(v);   // quad_perm [3,2,1,0]
+    else if constexpr (L == 7) t = dpp_perm<0x141>(v);  // row_half_mirror
+    else if constexpr (L == 15) t = dpp_perm<0x140>(v); // row_mirror
+    else if constexpr (L == 8) t = dpp_perm<0x128>(v);  // row_ror:8
+    else if constexpr (L == 4) {
+        t = dpp_u32<0x104, 0xF, 0x5>(v, v);               // banks 0,2 <- lane+4
+        t = dpp_u32<0x114, 0xF, 0xA>(t, v);               // banks 1,3 <- lane-4
+    }
+    if constexpr ((M & 16) != 0) {
+        auto r = __builtin_amdgcn_permlane16_swap(t, t, false, false);
+        t = (lane & 16) ? (u32)r[0] : (u32)r[1];
+    }
+    if constexpr ((M & 32) != 0) {
+        auto r = __builtin_amdgcn_permlane32_swap(t, t, false, false);
+        t = (lane & 32) ? (u32)r[0] : (u32)r[1];
+    }
+    return t;
+}
+template <int M> __device__ __forceinline__ u64 xor_lanes(u64 v, int lane) {
+    u32 lo = xor_lanes<M>((u32)v, lane), hi = xor_lanes<M>((u32)(v >> 32), lane);
+    return ((u64)hi << 32) | lo;
+}
+template <int M> __device__ __forceinline__ int xor_lanes(int v, int lane) { return (int)xor_lanes<M>((u32)v, lane); }
+template <int M> __device__ __forceinline__ double xor_lanes(double v, int lane) {
+    return __longlong_as_double((long long)xor_lanes<M>((u64)__double_as_longlong(v), lane));
+}
+
+// lane l <- lane l-1 (lane 0 keeps `fill`), lane l <- lane l+1 (lane 63 keeps `fill`)
+__device__ __forceinline__ u32 wave_shr1(u32 v, u32 fill) { return dpp_u32<0x138>(fill, v); }
+__device__ __forceinline__ u32 wave_shl1(u32 v, u32 fill) { return dpp_u32<0x130>(fill, v); }
+__device__ __forceinline__ u64 wave_shr1(u64 v, u64 fill) {
+    return ((u64)wave_shr1((u32)(v >> 32), (u32)(fill >> 32)) << 32) | wave_shr1((u32)v, (u32)fill);
+}
+__device__ __forceinline__ u64 wave_shl1(u64 v, u64 fill) {
+    return ((u64)wave_shl1((u32)(v >> 32), (u32)(fill >> 32)) << 32) | wave_shl1((u32)v, (u32)fill);
+}
+
+// inclusive scans over the 64 lanes (row_shr 1,2,4,8 then row_bcast 15 / 31)
+__device__ __forceinline__ int wave_incl_scan_add(int x) {
+    x += (int)dpp_u32<0x111>(0u, (u32)x);
+    x += (int)dpp_u32<0x112>(0u, (u32)x);
+    x += (int)dpp_u32<0x114>(0u, (u32)x);
+    x += (int)dpp_u32<0x118>(0u, (u32)x);
+    x += (int)dpp_u32<0x142, 0xA>(0u, (u32)x);
+    x += (int)dpp_u32<0x143, 0xC>(0u, (u32)x);
+    return x;
+}
+__device__ __forceinline__ int wave_incl_scan_max(int x) { // identity: INT_MIN
+    const u32 id = 0x80000000u;
+    x = max(x, (int)dpp_u32<0x111>(id, (u32)x));
+    x = max(x, (int)dpp_u32<0x112>(id, (u32)x));
+    x = max(x, (int)dpp_u32<0x114>(id, (u32)x));
+    x = max(x, (int)dpp_u32<0x118>(id, (u32)x));
+    x = max(x, (int)dpp_u32<0x142, 0xA>(id, (u32)x));
+    x = max(x, (int)dpp_u32<0x143, 0xC>(id, (u32)x));
+    return x;
+}
+
 // Sort 64*K keys held K per lane; sorted position of (lane, r) is lane*K + r.  All-ascending
 // ("flip") bitonic network: intra-lane stages are plain register compare-exchanges, cross-lane
-// stages exchange with lane^mask.  21*K cross-lane exchanges for 64*K keys.
+// stages exchange with lane^mask through DPP / permlane swaps.  21*K cross-lane exchanges.
+template <typename KeyT, int K, int SIZE> __device__ __forceinline__ void wave_bitonic_merge(KeyT (&v)[K], int lane) {
+    constexpr int lm = SIZE / K - 1;
+    const bool keep_min = (lane & (SIZE / K / 2)) == 0;
+    KeyT pv[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) pv[r] = xor_lanes<lm>(v[K - 1 - r], lane);
+#pragma unroll
+    for (int r = 0; r < K; ++r) v[r] = keep_min ? umin_t(v[r], pv[r]) : umax_t(v[r], pv[r]);
+    if constexpr (SIZE / K / 4 >= 1) {
+        constexpr int ls0 = SIZE / K / 4;
+#define ILLICO_HALF_CLEAN(LS)                                                   \
+    if constexpr (ls0 >= (LS)) {                                                \
+        const bool km = (lane & (LS)) == 0;                                     \
+        _Pragma("unroll") for (int r = 0; r < K; ++r) {                         \
+            KeyT q = xor_lanes<(LS)>(v[r], lane);                               \
+            v[r] = km ? umin_t(v[r], q) : umax_t(v[r], q);                      \
+        }                                                                       \
+    }
+        ILLICO_HALF_CLEAN(16)
+        ILLICO_HALF_CLEAN(8)
+        ILLICO_HALF_CLEAN(4)
+        ILLICO_HALF_CLEAN(2)
+        ILLICO_HALF_CLEAN(1)
+#undef ILLICO_HALF_CLEAN
+    }
+#pragma unroll
+    for (int stride = K >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            int p = r ^ stride;
+            if (p > r) compex(v[r], v[p]);
+        }
+    }
+}
+
 template <typename KeyT, int K> __device__ __forceinline__ void wave_bitonic_sort(KeyT (&v)[K], int lane) {
 #pragma unroll
     for (int size = 2; size <= K; size <<= 1) {
@@ -114,34 +231,35 @@ template <typename KeyT, int K> __device__ __forceinline__ void wave_bitonic_sor
             }
         }
     }
-#pragma unroll
-    for (int size = 2 * K; size <= 64 * K; size <<= 1) {
-        const int lm = size / K - 1;
-        const bool keep_min = (lane & (size / K / 2)) == 0;
-        KeyT pv[K];
-#pragma unroll
-        for (int r = 0; r < K; ++r) pv[r] = __shfl_xor(v[K - 1 - r], lm);
-#pragma unroll
-        for (int r = 0; r < K; ++r) v[r] = keep_min ? umin_t(v[r], pv[r]) : umax_t(v[r], pv[r]);
-#pragma unroll
-        for (int ls = size / K / 4; ls > 0; ls >>= 1) {
-            const bool km = (lane & ls) == 0;
-#pragma unroll
-            for (int r = 0; r < K; ++r) {
-                KeyT q = __shfl_xor(v[r], ls);
-                v[r] = km ? umin_t(v[r], q) : umax_t(v[r], q);
-            }
-        }
-#pragma unroll
-        for (int stride = K >> 1; stride > 0; stride >>= 1) {
-#pragma unroll
-            for (int r = 0; r < K; ++r) {
-                int p = r ^ stride;
-                if (p > r) compex(v[r], v[p]);
-            }
+    wave_bitonic_merge<KeyT, K, 2 * K>(v, lane);
+    wave_bitonic_merge<KeyT, K, 4 * K>(v, lane);
+    wave_bitonic_merge<KeyT, K, 8 * K>(v, lane);
+    wave_bitonic_merge<KeyT, K, 16 * K>(v, lane);
+    wave_bitonic_merge<KeyT, K, 32 * K>(v, lane);
+    wave_bitonic_merge<KeyT, K, 64 * K>(v, lane);
+}
+
+// Transpose-reduce: 64 per-lane partial vectors x_0..x_63 (pushed one at a time, x_j's lanes are the
+// partials of item j) -> lane j ends up holding sum_l x_j[l].  A binary counter of half-combined
+// registers: 63 combines in total instead of 64 six-step butterflies.
+template <typename T, int LVL> __device__ __forceinline__ T tr_combine(T a, T b, int lane) {
+    // a: earlier items, b: later items; lanes with bit LVL clear keep a's side
+    const bool hi = (lane >> LVL) & 1;
+    T keep = hi ? b : a, send = hi ? a : b;
+    return keep + xor_lanes<(1 << LVL)>(send, lane);
+}
+template <typename T> struct TrReduce {
+    T acc[6];
+    T result;
+    template <int LVL> __device__ __forceinline__ void push_lvl(T x, int j, int lane) {
+        if constexpr (LVL == 6) { result = x; }
+        else {
+            if (j & (1 << LVL)) push_lvl<LVL + 1>(tr_combine<T, LVL>(acc[LVL], x, lane), j, lane);
+            else acc[LVL] = x;
         }
     }
-}
+    __device__ __forceinline__ void push(T x, int j, int lane) { push_lvl<0>(x, j, lane); }
+};
 
 // Sort n keys in LDS with the whole workgroup (NT threads).  Same all-ascending network; slots
 // >= n are virtual +inf, so compare-exchanges whose upper index is >= n are no-ops and n need not

@@ -14,6 +14,7 @@
 #include "common.h"
 #include "kernels_finalize.h"
 #include "kernels_ovo.h"
+#include "kernels_ovo_counts.h"
 #include "kernels_ovr.h"
 #include "kernels_sparse.h"
 
@@ -21,6 +22,7 @@
 enum {
     KID_TRANSPOSE = 0,
     KID_OVO_RANK,
+    KID_OVO_COUNTS,
     KID_FINALIZE,
     KID_RADIX_SORT,
     KID_OVR_SCAN,
@@ -29,7 +31,7 @@ enum {
     KID_MISC,
     KID_COUNT
 };
-static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank",    "k_finalize",   "k_radix_sort",
+static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_finalize",   "k_radix_sort",
                                               "k_ovr_scan",          "k_sparse_seg", "k_gene_totals", "misc"};
 
 struct ProfEvent {
@@ -55,6 +57,7 @@ struct illico_ctx {
     // options
     int64_t gene_batch = 0;
     int64_t scratch_bytes = 24ll << 30;
+    bool no_counts_path = false;
     bool profile = false;
     std::vector<ProfEvent> events;
     double prof_ms[KID_COUNT] = {0};
@@ -196,6 +199,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "gene_batch")) c->gene_batch = value;
     else if (!strcmp(key, "scratch_bytes")) c->scratch_bytes = value;
     else if (!strcmp(key, "profile")) c->profile = value != 0;
+    else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else return fail(c, ILLICO_ERR_ARG, "unknown option '%s'", key);
     return ILLICO_OK;
 }
@@ -296,37 +300,65 @@ template <typename KeyT> static size_t ovo_lds_bytes(int ref_cap, bool runend, i
 }
 
 template <typename KeyT, int KMAX, bool RUNEND>
-static int launch_ovo_t(illico_ctx *c, const OvoParams &P, size_t lds) {
+static int launch_ovo_t(illico_ctx *c, const OvoParams &P, size_t lds, const u32 *flags) {
     auto kern = k_ovo_rank<KeyT, KMAX, RUNEND, kOvoThreads>;
     HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(c, KID_OVO_RANK);
-    hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(kOvoThreads), lds, c->stream, P);
+    hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(kOvoThreads), lds, c->stream, P, flags);
     HIPCHK(c, hipGetLastError());
     return ILLICO_OK;
 }
 
-template <typename KeyT> static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz) {
-    if (max_grp_nnz > 1024)
-        return fail(c, ILLICO_ERR_UNSUPPORTED, "OVO with a non-reference group of %lld cells (> 1024) is not supported by this build yet", (long long)max_grp_nnz);
+// flags: per-gene routing word written by the ingest kernels (0 = count-valued gene -> k_ovo_counts,
+// non-zero -> k_ovo_rank); nullptr routes every gene through the general sort path.
+template <typename KeyT> static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz, const u32 *flags) {
+    if (flags) {
+        ProfScope ps(c, KID_OVO_COUNTS);
+        hipLaunchKernelGGL((k_ovo_counts<KeyT>), dim3(P.n_genes), dim3(COUNTS_NT), 0, c->stream, P, flags);
+        HIPCHK(c, hipGetLastError());
+    }
     int ref_cap = (int)std::max<int64_t>(max_ref_nnz, 1);
     bool runend = ref_cap <= 65535 && ovo_lds_bytes<KeyT>(ref_cap, true, kOvoThreads) <= kMaxLds;
     size_t lds = ovo_lds_bytes<KeyT>(ref_cap, runend, kOvoThreads);
-    if (lds > kMaxLds)
-        return fail(c, ILLICO_ERR_UNSUPPORTED, "reference group of %lld cells does not fit the 160 KiB LDS of a CU in this build", (long long)max_ref_nnz);
+    const bool fits = max_grp_nnz <= 1024 && lds <= kMaxLds;
+    if (!fits) {
+        bool any_general = true;
+        if (flags) { // only genes the histogram path could not take need the sort path: are there any?
+            std::vector<u32> h(P.n_genes);
+            HIPCHK(c, hipMemcpyAsync(h.data(), flags, (size_t)P.n_genes * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            any_general = std::any_of(h.begin(), h.end(), [](u32 f) { return f != 0; });
+        }
+        if (!any_general) return ILLICO_OK;
+        if (max_grp_nnz > 1024)
+            return fail(c, ILLICO_ERR_UNSUPPORTED, "OVO on non-count data with a non-reference group of %lld cells (> 1024) is not supported by this build yet", (long long)max_grp_nnz);
+        return fail(c, ILLICO_ERR_UNSUPPORTED, "OVO on non-count data with a reference group of %lld cells does not fit the 160 KiB LDS of a CU in this build", (long long)max_ref_nnz);
+    }
     P.ref_cap = ref_cap;
     bool big = max_grp_nnz > 256;
-    if (big) return runend ? launch_ovo_t<KeyT, 16, true>(c, P, lds) : launch_ovo_t<KeyT, 16, false>(c, P, lds);
-    return runend ? launch_ovo_t<KeyT, 4, true>(c, P, lds) : launch_ovo_t<KeyT, 4, false>(c, P, lds);
+    if (big) return runend ? launch_ovo_t<KeyT, 16, true>(c, P, lds, flags) : launch_ovo_t<KeyT, 16, false>(c, P, lds, flags);
+    return runend ? launch_ovo_t<KeyT, 4, true>(c, P, lds, flags) : launch_ovo_t<KeyT, 4, false>(c, P, lds, flags);
 }
 
 template <typename InT, typename KeyT>
-static int launch_transpose(illico_ctx *c, const void *X, int64_t ld, int64_t col0, int ncols, int N, KeyT *Xt, int64_t stride) {
+static int launch_transpose(illico_ctx *c, const void *X, int64_t ld, int64_t col0, int ncols, int N, KeyT *Xt, int64_t stride, u32 *flags) {
     ProfScope ps(c, KID_TRANSPOSE);
     dim3 grid((N + 63) / 64, (ncols + 63) / 64);
-    hipLaunchKernelGGL((k_transpose_permute<InT, KeyT>), grid, dim3(256), 0, c->stream, (const InT *)X, (long long)ld,
-                       (long long)col0, ncols, (const int *)c->d_perm, N, Xt, (long long)stride);
+    constexpr int VEC = 16 / (int)sizeof(InT);
+    const bool aligned = ((uintptr_t)X % 16 == 0) && (ld % VEC == 0) && (col0 % VEC == 0) && ((uintptr_t)Xt % 16 == 0) && (stride % 64 == 0);
+    if (aligned)
+        hipLaunchKernelGGL((k_transpose_permute_vec<InT, KeyT, VEC>), grid, dim3(256), 0, c->stream, (const InT *)X, (long long)ld,
+                           (long long)col0, ncols, (const int *)c->d_perm, N, Xt, (long long)stride, flags, COUNTS_R);
+    else
+        hipLaunchKernelGGL((k_transpose_permute<InT, KeyT>), grid, dim3(256), 0, c->stream, (const InT *)X, (long long)ld,
+                           (long long)col0, ncols, (const int *)c->d_perm, N, Xt, (long long)stride, flags, COUNTS_R);
     HIPCHK(c, hipGetLastError());
     return ILLICO_OK;
+}
+
+// the histogram path needs integer value sums (no expm1) and 16-bit group bins
+static bool counts_path_allowed(const illico_ctx *c, int flags) {
+    return !(flags & ILLICO_FLAG_LOG1P) && c->ref >= 0 && c->max_nonref <= 65535 && !c->no_counts_path;
 }
 
 static int launch_finalize(illico_ctx *c, const long long *s2u, const u64 *stie, const double *ssum, const double *gene_total,
@@ -415,6 +447,11 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
     u64 *stie = (u64 *)(s2u + (size_t)nb_max * G);
     double *ssum = (double *)(stie + (size_t)nb_max * G);
     double *gtot = ssum + (size_t)nb_max * G;
+    u32 *gflags = nullptr;
+    if (counts_path_allowed(c, flags)) {
+        if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
+        gflags = (u32 *)v;
+    }
     InT *xin = nullptr;
     if (!in_dev) {
         if ((rc = get_scratch(c, "xin", (size_t)nb_max * N * sizeof(InT), &v))) return rc;
@@ -429,13 +466,14 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
                                        (size_t)nb * sizeof(InT), (size_t)N, hipMemcpyHostToDevice, c->stream));
             src = xin; src_ld = nb; src_col0 = 0;
         }
-        if ((rc = launch_transpose<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride))) return rc;
+        if (gflags) HIPCHK(c, hipMemsetAsync(gflags, 0, (size_t)nb * 4, c->stream));
+        if ((rc = launch_transpose<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, gflags))) return rc;
         if (!ovr) {
             OvoParams P;
             P.Xs = Xt; P.gene_stride = stride; P.pos_ptr = c->d_posptr; P.seg_ptr = nullptr; P.counts = c->d_counts;
             P.G = G; P.ref = (int)c->ref; P.n_genes = nb; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
             P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
-            if ((rc = launch_ovo<KeyT>(c, P, c->h_counts[c->ref], c->max_nonref))) return rc;
+            if ((rc = launch_ovo<KeyT>(c, P, c->h_counts[c->ref], c->max_nonref, gflags))) return rc;
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
         } else {
             if ((rc = run_ovr_dense_batch<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot))) return rc;

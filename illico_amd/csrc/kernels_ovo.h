@@ -23,10 +23,17 @@
 //   64x64 tile through LDS: reads 64 consecutive genes of one row (256 B for f32), writes 64
 //   consecutive positions of one gene.
 // ---------------------------------------------------------------------------------------------
+// true iff v is an integer in [0, limit): the gene can take the histogram path (kernels_ovo_counts.h)
+__device__ __forceinline__ bool count_ok(float v, int limit) { return v >= 0.0f && v < (float)limit && v == truncf(v); }
+__device__ __forceinline__ bool count_ok(double v, int limit) { return v >= 0.0 && v < (double)limit && v == trunc(v); }
+__device__ __forceinline__ bool count_ok(int32_t v, int limit) { return v >= 0 && v < limit; }
+__device__ __forceinline__ bool count_ok(int64_t v, int limit) { return v >= 0 && v < (int64_t)limit; }
+
 template <typename InT, typename KeyT>
 __global__ __launch_bounds__(256) void k_transpose_permute(const InT *__restrict__ X, long long ld, long long col0,
                                                            int ncols, const int *__restrict__ perm, int N,
-                                                           KeyT *__restrict__ Xt, long long xt_stride) {
+                                                           KeyT *__restrict__ Xt, long long xt_stride,
+                                                           u32 *__restrict__ gene_flags, int count_limit) {
     __shared__ KeyT tile[64][65];
     const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -36,7 +43,9 @@ __global__ __launch_bounds__(256) void k_transpose_permute(const InT *__restrict
         KeyT k = KeyInfo<KeyT>::MAXK;
         if (p < N && c < ncols) {
             long long row = perm[p];
-            k = key_of(X[row * ld + col0 + c]);
+            InT val = X[row * ld + col0 + c];
+            k = key_of(val);
+            if (gene_flags && !count_ok(val, count_limit) && gene_flags[c] == 0) gene_flags[c] = 1u;
         }
         tile[r][tx] = k;
     }
@@ -45,6 +54,65 @@ __global__ __launch_bounds__(256) void k_transpose_permute(const InT *__restrict
     for (int cc = ty; cc < 64; cc += 4) {
         int c = c0 + cc, p = p0 + tx;
         if (c < ncols && p < N) Xt[(long long)c * xt_stride + p] = tile[tx][cc];
+    }
+}
+
+// Vectorised variant: 16 B per lane on both sides (VEC = 16 / sizeof(InT) elements).  Requires X + row*ld
+// + col0 to be 16-B aligned (checked by the host: pointer, ld and col0 multiples of VEC).  LDS tile is
+// gene-major [64 genes][65]: both phases are at most 2-way bank conflicts.
+template <typename InT, typename KeyT, int VEC>
+__global__ __launch_bounds__(256) void k_transpose_permute_vec(const InT *__restrict__ X, long long ld, long long col0,
+                                                               int ncols, const int *__restrict__ perm, int N,
+                                                               KeyT *__restrict__ Xt, long long xt_stride,
+                                                               u32 *__restrict__ gene_flags, int count_limit) {
+    typedef InT __attribute__((ext_vector_type(VEC))) InV;
+    typedef KeyT __attribute__((ext_vector_type(VEC))) KeyV;
+    __shared__ KeyT tile[64][65];
+    constexpr int LPR = 64 / VEC;      // lanes per 64-wide row / column
+    constexpr int RPI = 256 / LPR;     // rows (or genes) per iteration
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int q = threadIdx.x % LPR, r0 = threadIdx.x / LPR;
+    bool viol[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) viol[e] = false;
+#pragma unroll
+    for (int r = r0; r < 64; r += RPI) {
+        const int p = p0 + r, c = c0 + q * VEC;
+        KeyT k[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) k[e] = KeyInfo<KeyT>::MAXK;
+        if (p < N) {
+            const InT *src = X + (long long)perm[p] * ld + col0 + c;
+            if (c + VEC <= ncols) {
+                InV v = *reinterpret_cast<const InV *>(src);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { k[e] = key_of(v[e]); viol[e] |= !count_ok(v[e], count_limit); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (c + e < ncols) { k[e] = key_of(src[e]); viol[e] |= !count_ok(src[e], count_limit); }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) tile[q * VEC + e][r] = k[e];
+    }
+    if (gene_flags) { // at most one (checked) store per gene per thread; a stale-L1 miss only repeats the store
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = c0 + q * VEC + e;
+            if (viol[e] && c < ncols && gene_flags[c] == 0) gene_flags[c] = 1u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cc = r0; cc < 64; cc += RPI) {
+        const int c = c0 + cc, p = p0 + q * VEC;
+        if (c < ncols && p < N) { // rows are padded to a multiple of 64 keys, so the 16-B store stays inside the row
+            KeyV o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = tile[cc][q * VEC + e];
+            *reinterpret_cast<KeyV *>(Xt + (long long)c * xt_stride + p) = o;
+        }
     }
 }
 
@@ -64,8 +132,10 @@ struct OvoParams {
     double *out_sum;         // [n_genes][G]  sum of values (expm1'd if is_log1p)
 };
 
-template <typename KeyT, int K, bool RUNEND>
-__device__ __forceinline__ void ovo_wave_group(const KeyT *__restrict__ seg, int nB, const KeyT *A,
+// One group's values (nB <= 64*K keys) handled by one wavefront.  Returns PER-LANE partial sums
+// (S2, tie, value sum); the caller folds 64 groups' partials with a transpose-reduce.
+template <typename KeyT, int K, int KIN, bool RUNEND>
+__device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, const KeyT *A,
                                                const u16 *runend, u32 nA, u32 topA, u32 zA, KeyT *sk, u32 *sb,
                                                int lane, int dt, int is_log1p, u64 &S2out, u64 &tieout,
                                                double &sumout) {
@@ -74,63 +144,50 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT *__restrict__ seg, int
     KeyT v[K];
     double s = 0.0;
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-        int idx = r * 64 + lane;
-        bool ok = idx < nB;
-        v[r] = ok ? seg[idx] : MAXK;
-        if (ok) s += is_log1p ? key_to_expm1(v[r], dt) : key_to_double(v[r], dt);
+    for (int r = 0; r < K; ++r) { // vin[r] holds element r*64 + lane of the group (MAXK beyond nB)
+        v[r] = vin[r];
+        if (r * 64 + lane < nB) s += is_log1p ? key_to_expm1(v[r], dt) : key_to_double(v[r], dt);
     }
     wave_bitonic_sort<KeyT, K>(v, lane);
 
-    // run heads (first element of each run of equal keys), in sorted order i = lane*K + r
-    KeyT prev_last = __shfl_up(v[K - 1], 1);
-    bool head[K];
-    const int BIG = 0x7FFFFFFF;
-    int fh = BIG, hc = 0;
+    // Runs of equal keys in sorted order i = lane*K + r.  The LAST element of a run (its tail) represents
+    // it: the run length is i - (position of the run's head) + 1, and the head position of every element is
+    // an inclusive prefix-max of head positions -- prefix scans are native DPP (row_shr / row_bcast).
+    const KeyT prev_last = wave_shr1(v[K - 1], (KeyT)0);
+    const KeyT next_first = wave_shl1(v[0], MAXK);
+    int lh = -1;          // position of the last head seen in this lane
+    int shead[K];         // head position of element r if it lies in this lane, else -1
+    bool tail[K];
+    int tc = 0;
 #pragma unroll
-    for (int r = K - 1; r >= 0; --r) {
-        int idx = lane * K + r;
-        KeyT prev = (r == 0) ? prev_last : v[r - 1];
-        head[r] = (idx < nB) && (idx == 0 || v[r] != prev);
-        if (head[r]) { fh = idx; ++hc; }
+    for (int r = 0; r < K; ++r) {
+        const int idx = lane * K + r;
+        const KeyT prev = (r == 0) ? prev_last : v[r - 1];
+        const KeyT next = (r == K - 1) ? next_first : v[r + 1];
+        const bool valid = idx < nB;
+        if (valid && (idx == 0 || v[r] != prev)) lh = idx;
+        shead[r] = lh;
+        tail[r] = valid && (idx == nB - 1 || v[r] != next);
+        tc += tail[r] ? 1 : 0;
     }
-    // first head strictly after this lane (exclusive suffix-min over lanes), clipped to nB
-    int m = fh;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int o = __shfl_down(m, d);
-        if (lane + d < 64) m = min(m, o);
-    }
-    int carry = __shfl_down(m, 1);
-    if (lane == 63) carry = BIG;
-    carry = min(carry, nB);
-    u32 tB[K];
-    {
-        int nxt = carry;
-#pragma unroll
-        for (int r = K - 1; r >= 0; --r) {
-            int idx = lane * K + r;
-            tB[r] = (u32)(nxt - idx);
-            if (head[r]) nxt = idx;
-        }
-    }
-    // rank of each head among the heads (exclusive scan over lanes)
-    int incl = hc;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    const int H = __shfl(incl, 63);
-    const int excl = incl - hc;
+    const int incl_h = wave_incl_scan_max(lh);
+    const int carry_h = (int)wave_shr1((u32)incl_h, 0xFFFFFFFFu); // head position inherited from earlier lanes
+    const int incl_t = wave_incl_scan_add(tc);
+    const int H = __builtin_amdgcn_readlane(incl_t, 63);
+    const int excl_t = incl_t - tc;
 
     u64 S2 = 0, tie = 0;
     for (int base = 0; base < H; base += 256) {
-        int hr = excl - base;
+        int hr = excl_t - base;
 #pragma unroll
         for (int r = 0; r < K; ++r) {
-            if (head[r]) {
-                if (hr >= 0 && hr < 256) { sk[hr] = v[r]; sb[hr] = tB[r]; }
+            if (tail[r]) {
+                if (hr >= 0 && hr < 256) {
+                    const int idx = lane * K + r;
+                    const int hp = shead[r] >= 0 ? shead[r] : carry_h;
+                    sk[hr] = v[r];
+                    sb[hr] = (u32)(idx - hp + 1);
+                }
                 ++hr;
             }
         }
@@ -154,13 +211,13 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT *__restrict__ seg, int
         }
         wave_lds_fence();
     }
-    S2out = wave_sum(S2);
-    tieout = wave_sum(tie);
-    sumout = wave_sum(s);
+    S2out = S2;
+    tieout = tie;
+    sumout = s;
 }
 
 template <typename KeyT, int KMAX, bool RUNEND, int NT>
-__global__ __launch_bounds__(NT) void k_ovo_rank(OvoParams P) {
+__global__ __launch_bounds__(NT, (KMAX <= 4 ? 1024 : 512) / NT * (NT / 256)) void k_ovo_rank(OvoParams P, const u32 *__restrict__ gene_flags) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NW = NT / 64;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
@@ -184,6 +241,7 @@ __global__ __launch_bounds__(NT) void k_ovo_rank(OvoParams P) {
     const int n_ref = P.counts[ref];
 
     for (int gene = blockIdx.x; gene < P.n_genes; gene += gridDim.x) {
+        if (gene_flags && gene_flags[gene] == 0) continue; // count-valued gene: handled by k_ovo_counts
         // ---- reference column -> LDS, sorted ----
         long long rstart;
         u32 nA;
@@ -238,45 +296,70 @@ __global__ __launch_bounds__(NT) void k_ovo_rank(OvoParams P) {
         KeyT *sk = sk_all + wave * 256;
         u32 *sb = sb_all + wave * 256;
         for (int g0 = wave * 64; g0 < G; g0 += NW * 64) {
-            long long r2u = 0;
-            u64 rtie = 0;
-            double rsum = 0.0;
-            const int jn = min(64, G - g0);
-            for (int j = 0; j < jn; ++j) {
-                const int g = g0 + j;
-                if (g == ref) {
-                    if (lane == j) { r2u = -2; rtie = 0; rsum = refsum; }
-                    continue;
+            TrReduce<u64> rS2, rTie;
+            TrReduce<double> rSum;
+            // The next group's keys are fetched into registers while the current group is processed: one
+            // wavefront walks ~G/NW groups back to back and would otherwise expose a full HBM round trip each.
+            KeyT nxt[KMAX];
+            int nB_n = 0, zB_n = 0;
+            auto fetch = [&](int g) {
+                nB_n = 0; zB_n = 0;
+#pragma unroll
+                for (int r = 0; r < KMAX; ++r) nxt[r] = KeyInfo<KeyT>::MAXK;
+                if (g < G && g != ref) {
+                    const int n_g = P.counts[g];
+                    long long bstart;
+                    if (sp) { bstart = sp[g]; nB_n = (int)(sp[g + 1] - sp[g]); }
+                    else { bstart = (long long)gene * P.gene_stride + P.pos_ptr[g]; nB_n = n_g; }
+                    zB_n = n_g - nB_n;
+                    const KeyT *seg = Xs + bstart;
+#pragma unroll
+                    for (int r = 0; r < KMAX; ++r) {
+                        const int idx = r * 64 + lane;
+                        if (idx < nB_n) nxt[r] = seg[idx];
+                    }
                 }
-                const int n_g = P.counts[g];
-                long long bstart;
-                int nB;
-                if (sp) { bstart = sp[g]; nB = (int)(sp[g + 1] - sp[g]); }
-                else { bstart = (long long)gene * P.gene_stride + P.pos_ptr[g]; nB = n_g; }
-                const u32 zB = (u32)(n_g - nB);
+            };
+            fetch(g0);
+            for (int j = 0; j < 64; ++j) { // always 64 pushes so that the transpose-reduce completes
+                const int g = g0 + j;
+                KeyT cur[KMAX];
+#pragma unroll
+                for (int r = 0; r < KMAX; ++r) cur[r] = nxt[r];
+                const int nB = nB_n;
+                const u32 zB = (u32)zB_n;
+                fetch(g + 1 < g0 + 64 ? g + 1 : G);
                 u64 S2 = 0, tie = 0;
                 double sum = 0.0;
-                const KeyT *seg = Xs + bstart;
-                if (nB <= 64) ovo_wave_group<KeyT, 1, RUNEND>(seg, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                else if (nB <= 128) ovo_wave_group<KeyT, 2, RUNEND>(seg, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                else if (nB <= 256) ovo_wave_group<KeyT, 4, RUNEND>(seg, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                else if (KMAX >= 8 && nB <= 512) ovo_wave_group<KeyT, (KMAX >= 8 ? 8 : 4), RUNEND>(seg, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                else if (KMAX >= 16 && nB <= 1024) ovo_wave_group<KeyT, (KMAX >= 16 ? 16 : 4), RUNEND>(seg, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                // implicit zeros of B (sparse layout): each ranks above A's negatives and ties with A's zeros
-                S2 += (u64)zB * (2ull * nnegA + zA);
-                const u64 t0 = (u64)zA + zB;
-                const u64 tie_total = T_A + tie + (t0 * t0 * t0 - t0);
-                if (lane == j) {
-                    r2u = 2ll * (long long)n_ref * (long long)n_g - (long long)S2;
-                    rtie = tie_total;
-                    rsum = sum;
+                if (g < G && g != ref) {
+                    if (nB <= 64) ovo_wave_group<KeyT, 1, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    else if (nB <= 128) ovo_wave_group<KeyT, 2, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    else if (nB <= 256) ovo_wave_group<KeyT, 4, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    else if (KMAX >= 8 && nB <= 512) ovo_wave_group<KeyT, (KMAX >= 8 ? 8 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    else if (KMAX >= 16 && nB <= 1024) ovo_wave_group<KeyT, (KMAX >= 16 ? 16 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    if (lane == 0) {
+                        // implicit zeros of B (sparse layout): each ranks above A's negatives and ties with A's zeros
+                        S2 += (u64)zB * (2ull * nnegA + zA);
+                        const u64 t0 = (u64)zA + zB;
+                        tie += T_A + (t0 * t0 * t0 - t0);
+                    }
                 }
+                rS2.push(S2, j, lane);
+                rTie.push(tie, j, lane);
+                rSum.push(sum, j, lane);
             }
-            if (lane < jn) {
-                size_t o = (size_t)gene * G + g0 + lane;
-                P.out_2u[o] = r2u;
-                P.out_tie[o] = rtie;
-                P.out_sum[o] = rsum;
+            const int g = g0 + lane; // lane j now holds the totals of group g0 + j
+            if (g < G) {
+                size_t o = (size_t)gene * G + g;
+                if (g == ref) {
+                    P.out_2u[o] = -2;
+                    P.out_tie[o] = 0;
+                    P.out_sum[o] = refsum;
+                } else {
+                    P.out_2u[o] = 2ll * (long long)n_ref * (long long)P.counts[g] - (long long)rS2.result;
+                    P.out_tie[o] = rTie.result;
+                    P.out_sum[o] = rSum.result;
+                }
             }
         }
         __syncthreads();

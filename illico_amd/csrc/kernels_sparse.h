@@ -12,6 +12,7 @@
 // Explicitly stored zeros are dropped (they are zeros), so results equal the dense path's.
 #pragma once
 #include "common.h"
+#include "kernels_ovo.h"
 
 // exclusive scan of arr[0..n) in place by the whole workgroup; returns the total.  tmp: [NT] words of LDS.
 template <int NT> __device__ __forceinline__ u32 block_excl_scan_inplace(u32 *arr, int n, u32 *tmp, int tid) {
@@ -42,7 +43,8 @@ template <typename InT, typename IdxT, typename KeyT>
 __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ data, const IdxT *__restrict__ indices,
                                                         const IdxT *__restrict__ indptr, long long col0, int nb,
                                                         const int *__restrict__ codes, int G, KeyT *__restrict__ Xs,
-                                                        u32 *__restrict__ vals, u32 *__restrict__ seg_ptr) {
+                                                        u32 *__restrict__ vals, u32 *__restrict__ seg_ptr,
+                                                        u32 *__restrict__ gene_flags, int count_limit) {
     extern __shared__ __align__(16) unsigned char smem[];
     u32 *hist = (u32 *)smem;
     u32 *tmp = hist + ((G + 3) & ~3);
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
         for (int g = tid; g < G; g += SEG_NT) sp[g] = gbase + hist[g];
         if (tid == 0) sp[G] = gbase + total;
         __syncthreads();
+        bool viol = false;
         for (long long k = k0 + tid; k < k1; k += SEG_NT) {
             InT v = data[k];
             if (v != (InT)0) {
@@ -68,8 +71,10 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
                 u32 pos = gbase + atomicAdd(&hist[c], 1u);
                 Xs[pos] = key_of(v);
                 if (vals) vals[pos] = (u32)c;
+                viol |= !count_ok(v, count_limit);
             }
         }
+        if (gene_flags && viol) gene_flags[gene] = 1u;
         __syncthreads();
     }
 }
@@ -153,7 +158,8 @@ template <typename InT, typename IdxT, typename KeyT>
 __global__ __launch_bounds__(256) void k_csr_scatter(const InT *__restrict__ data, const IdxT *__restrict__ indices,
                                                      const IdxT *__restrict__ indptr, int n_rows, long long c0, long long c1,
                                                      const int *__restrict__ codes, int G, u32 *__restrict__ cursor,
-                                                     KeyT *__restrict__ Xs, u32 *__restrict__ vals) {
+                                                     KeyT *__restrict__ Xs, u32 *__restrict__ vals,
+                                                     u32 *__restrict__ gene_flags, int count_limit) {
     const int lane = threadIdx.x & 63;
     const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -169,9 +175,11 @@ __global__ __launch_bounds__(256) void k_csr_scatter(const InT *__restrict__ dat
         for (long long k = a + lane; k < b; k += 64) {
             InT v = data[k];
             if (v != (InT)0) {
-                u32 pos = atomicAdd(&cursor[((long long)indices[k] - c0) * (G + 1) + c], 1u);
+                const long long gcol = (long long)indices[k] - c0;
+                u32 pos = atomicAdd(&cursor[gcol * (G + 1) + c], 1u);
                 Xs[pos] = key_of(v);
                 if (vals) vals[pos] = (u32)c;
+                if (gene_flags && !count_ok(v, count_limit) && gene_flags[gcol] == 0) gene_flags[gcol] = 1u;
             }
         }
     }

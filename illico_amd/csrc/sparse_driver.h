@@ -118,6 +118,12 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         u64 *stie = (u64 *)(s2u + (size_t)nb * G);
         double *ssum = (double *)(stie + (size_t)nb * G);
         double *gtot = ssum + (size_t)nb * G;
+        u32 *gflags = nullptr;
+        if (counts_path_allowed(c, flags)) {
+            if ((rc = get_scratch(c, "gene_flags", (size_t)nb * 4, &v))) return rc;
+            gflags = (u32 *)v;
+            HIPCHK(c, hipMemsetAsync(gflags, 0, (size_t)nb * 4, c->stream));
+        }
 
         if (!is_csr) {
             const int64_t k0 = (int64_t)h_indptr[b.g0];
@@ -136,7 +142,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             size_t lds = seg_lds_bytes(G);
             HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(nb), dim3(SEG_NT), lds, c->stream, bd, bi, d_indptr, (long long)b.g0, nb,
-                               (const int *)c->d_codes, G, Xs, va, seg);
+                               (const int *)c->d_codes, G, Xs, va, seg, gflags, COUNTS_R);
             HIPCHK(c, hipGetLastError());
         } else {
             if ((rc = get_scratch(c, "sp_cursor", (size_t)nb * (G + 1) * 4 + (size_t)nb * 8, &v))) return rc;
@@ -156,7 +162,8 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             hipLaunchKernelGGL(k_seg_add_base, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, seg, cursor,
                                (const u32 *)gene_base, G, nb);
             hipLaunchKernelGGL((k_csr_scatter<InT, IdxT, KeyT>), dim3(rows_grid), dim3(256), 0, c->stream, d_data, d_indices,
-                               d_indptr, (int)n_rows, (long long)b.g0, (long long)b.g1, (const int *)c->d_codes, G, cursor, Xs, va);
+                               d_indptr, (int)n_rows, (long long)b.g0, (long long)b.g1, (const int *)c->d_codes, G, cursor, Xs, va,
+                               gflags, COUNTS_R);
             HIPCHK(c, hipGetLastError());
         }
 
@@ -167,7 +174,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
             int64_t ref_cap = std::min<int64_t>(c->h_counts[c->ref], b.max_gene);
             int64_t grp_cap = std::min<int64_t>(c->max_nonref, b.max_gene);
-            if ((rc = launch_ovo<KeyT>(c, P, ref_cap, grp_cap))) return rc;
+            if ((rc = launch_ovo<KeyT>(c, P, ref_cap, grp_cap, gflags))) return rc;
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b.g0 - col_lb))) return rc;
         } else {
             OvrParams P;

@@ -24,9 +24,18 @@ def _run(engine, X, grpc, **kw):
     return engine.run_dense(X, kw.pop("col_lb", 0), kw.pop("col_ub", X.shape[1]), **kw)
 
 
+@pytest.fixture(params=["counts+sort", "sort-only"])
+def route(request, engine):
+    """OVO has two device routes per gene: the histogram path for count-valued genes and the general sort
+    path.  'sort-only' forces every gene through the sort path so that both are covered on count data."""
+    engine.set_option("no_counts_path", 1 if request.param == "sort-only" else 0)
+    yield request.param
+    engine.set_option("no_counts_path", 0)
+
+
 @pytest.mark.parametrize("name", ["c1_1k_200_10", "small_ragged", "sparse90", "continuous"])
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
-def test_dense_matches_reference_goldens(engine, name, test):
+def test_dense_matches_reference_goldens(engine, name, test, route):
     z = load_golden(name)
     X, labels, ref = z["X"], z["labels"], str(z["reference"])
     from illico_amd.utils.groups import encode_and_count_groups
@@ -67,7 +76,7 @@ def test_dense_negative_and_continuous_values(engine, test):
     assert_planes_match(got, want, fc_rtol=1e-9, what=test)
 
 
-def test_ovo_ragged_group_sizes(engine):
+def test_ovo_ragged_group_sizes(engine, route):
     """Group sizes straddling every wave-sort width (1, 63..65, 127..129, 255..257, 511..513, 1023, 1024)."""
     sizes = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 700]
     rng = np.random.RandomState(3)
@@ -84,6 +93,45 @@ def test_ovo_ragged_group_sizes(engine):
         got = _run(engine, X, g)
         want = oracle.run(X, g)
         assert_planes_match(got, want, what=f"ref={ref}")
+
+
+def test_ovo_counts_route_big_groups_and_mixed_genes(engine):
+    """Histogram route: group and reference sizes beyond what the sort route holds in registers / LDS, genes
+    that must fall back to the sort route (fractional, negative, >= 2048) next to count-valued ones."""
+    rng = np.random.RandomState(13)
+    sizes = [45000, 3000, 1500, 700, 64, 1]  # reference 45000 cells (> 160 KiB of LDS keys), groups > 1024
+    codes = np.concatenate([np.full(s, i) for i, s in enumerate(sizes)])
+    rng.shuffle(codes)
+    labels = np.array([f"g{c:02d}" for c in codes])
+    n = codes.size
+    X = rng.poisson(rng.uniform(0.1, 30, size=9), size=(n, 9)).astype(np.float32)
+    X[rng.rand(n, 9) < 0.5] = 0
+    X[:, 5] = rng.randint(0, 2048, size=n)   # widest value range the table holds
+    X[:, 6] = 0.0
+    _, g = oracle.encode_and_count_groups(labels, "g00")
+    want = oracle.run(X, g)
+    got = _run(engine, X, g)
+    assert_planes_match(got, want, what="counts route, big groups")
+    for dt in (np.int32, np.float64, np.int64):
+        assert_planes_match(_run(engine, X.astype(dt), g), want, what=f"counts route {dt}")
+    # a gene outside the table needs the sort route, which cannot hold these group sizes: loud failure
+    Xbad = X.copy()
+    Xbad[0, 2] = 0.5
+    with pytest.raises(NotImplementedError):
+        _run(engine, Xbad, g)
+    # moderate sizes: mixed routes in one call
+    sizes = [900, 700, 300, 64, 1]
+    codes = np.concatenate([np.full(s, i) for i, s in enumerate(sizes)])
+    rng.shuffle(codes)
+    labels = np.array([f"g{c:02d}" for c in codes])
+    n = codes.size
+    X = rng.poisson(3.0, size=(n, 12)).astype(np.float32)
+    X[:, 1] += 0.25 * (rng.rand(n) < 0.1)   # fractional values
+    X[:, 2] -= 1.0                          # negative values
+    X[:, 3] = rng.randint(0, 5000, size=n)  # above the table
+    X[3, 4] = 2048.0                        # exactly one value at the table limit
+    _, g = oracle.encode_and_count_groups(labels, "g01")
+    assert_planes_match(_run(engine, X, g), oracle.run(X, g), what="mixed routes")
 
 
 def test_ovr_ragged(engine):

@@ -22,10 +22,17 @@ def _run(engine, M, grpc, **kw):
     return engine.run_sparse(M.format, M.data, M.indices, M.indptr, M.shape, lb, ub, **kw)
 
 
+@pytest.fixture(params=["counts+sort", "sort-only"])
+def route(request, engine):
+    engine.set_option("no_counts_path", 1 if request.param == "sort-only" else 0)
+    yield request.param
+    engine.set_option("no_counts_path", 0)
+
+
 @pytest.mark.parametrize("name", ["c1_1k_200_10", "small_ragged", "sparse90", "continuous"])
 @pytest.mark.parametrize("fmt", ["csc", "csr"])
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
-def test_sparse_matches_reference_goldens(engine, name, fmt, test):
+def test_sparse_matches_reference_goldens(engine, name, fmt, test, route):
     z = load_golden(name)
     X, labels, ref = z["X"], z["labels"], str(z["reference"])
     M = sparse.csc_matrix(X) if fmt == "csc" else sparse.csr_matrix(X)
@@ -62,7 +69,7 @@ def test_sparse_dtypes_windows_batches(engine, fmt, test, dtype, idx):
 
 @pytest.mark.parametrize("fmt", ["csc", "csr"])
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
-def test_sparse_edge_cases(engine, fmt, test):
+def test_sparse_edge_cases(engine, fmt, test, route):
     """Empty columns, empty rows, an all-dense column, explicit stored zeros (dropped: they are zeros)."""
     rng = np.random.RandomState(7)
     n, m = 1200, 24
