@@ -15,6 +15,7 @@
 #include "kernels_finalize.h"
 #include "kernels_ovo.h"
 #include "kernels_ovo_counts.h"
+#include "kernels_ovo_fused.h"
 #include "kernels_ovr.h"
 #include "kernels_sparse.h"
 
@@ -23,6 +24,8 @@ enum {
     KID_TRANSPOSE = 0,
     KID_OVO_RANK,
     KID_OVO_COUNTS,
+    KID_OVO_FUSED,
+    KID_FUSED_REF,
     KID_FINALIZE,
     KID_RADIX_SORT,
     KID_OVR_SCAN,
@@ -31,7 +34,7 @@ enum {
     KID_MISC,
     KID_COUNT
 };
-static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_finalize",   "k_radix_sort",
+static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_fused_ref", "k_finalize",   "k_radix_sort",
                                               "k_ovr_scan",          "k_sparse_seg", "k_gene_totals", "misc"};
 
 struct ProfEvent {
@@ -58,6 +61,7 @@ struct illico_ctx {
     int64_t gene_batch = 0;
     int64_t scratch_bytes = 24ll << 30;
     bool no_counts_path = false;
+    bool no_fused_path = false;
     bool profile = false;
     std::vector<ProfEvent> events;
     double prof_ms[KID_COUNT] = {0};
@@ -200,6 +204,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "scratch_bytes")) c->scratch_bytes = value;
     else if (!strcmp(key, "profile")) c->profile = value != 0;
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
+    else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else return fail(c, ILLICO_ERR_ARG, "unknown option '%s'", key);
     return ILLICO_OK;
 }
@@ -422,6 +427,55 @@ static int check_common(illico_ctx *c, int64_t n_rows, int64_t n_cols, int64_t c
     return ILLICO_OK;
 }
 
+#define FUSED_RT 64
+
+// Fused single-pass route over genes [b0, b0+nb): writes final planes for every gene it can take and sets
+// h_flags[j] != 0 for the others.
+template <typename InT>
+static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, int flags, int alternative,
+                         const OutPlanes &o, int64_t col_off, std::vector<u32> &h_flags) {
+    constexpr int RT = FUSED_RT;
+    void *v;
+    int rc;
+    size_t bytes = (size_t)nb * RT * 4 + (size_t)nb * (RT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * 4 + 64;
+    if ((rc = get_scratch(c, "fused_tables", bytes, &v))) return rc;
+    FusedParams P;
+    P.X = X; P.ld = ld; P.col0 = b0; P.ncols = nb; P.perm = c->d_perm; P.pos_ptr = c->d_posptr; P.counts = c->d_counts;
+    P.G = (int)c->n_groups; P.ref = (int)c->ref;
+    P.ref_TA = (u64 *)v;
+    P.ref_sum = P.ref_TA + nb;
+    P.ref_hist = (u32 *)(P.ref_sum + nb);
+    P.ref_cum = P.ref_hist + (size_t)nb * RT;
+    P.gene_flags = P.ref_cum + (size_t)nb * (RT + 1);
+    P.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;
+    P.tie_correct = (flags & ILLICO_FLAG_TIE_CORRECT) ? 1 : 0;
+    P.alternative = alternative;
+    P.out_p = o.p + col_off; P.out_u = o.u + col_off; P.out_fc = o.fc + col_off; P.out_ld = o.ld;
+    const int n_ref = c->h_counts[c->ref];
+    P.ref_rows_per_wg = 1024;
+    P.groups_per_wg = 8;
+    const int tiles = (nb + 63) / 64;
+    HIPCHK(c, hipMemsetAsync(P.ref_hist, 0, (size_t)nb * RT * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(P.gene_flags, 0, (size_t)nb * 4, c->stream));
+    {
+        ProfScope ps(c, KID_FUSED_REF);
+        hipLaunchKernelGGL((k_fused_ref_hist<InT, RT>), dim3(tiles, (n_ref + P.ref_rows_per_wg - 1) / P.ref_rows_per_wg), dim3(FUSED_NT), 0,
+                           c->stream, P);
+        hipLaunchKernelGGL((k_fused_ref_scan<RT>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, P);
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        ProfScope ps(c, KID_OVO_FUSED);
+        hipLaunchKernelGGL((k_ovo_fused<InT, RT>), dim3(tiles, ((int)c->n_groups + P.groups_per_wg - 1) / P.groups_per_wg), dim3(FUSED_NT), 0,
+                           c->stream, P);
+        HIPCHK(c, hipGetLastError());
+    }
+    h_flags.resize(nb);
+    HIPCHK(c, hipMemcpyAsync(h_flags.data(), P.gene_flags, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ILLICO_OK;
+}
+
 template <typename InT, typename KeyT>
 static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
                        int alternative, const OutPlanes &o) {
@@ -430,16 +484,36 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
     const bool ovr = c->ref < 0;
     const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
     const int64_t stride = (N + 63) & ~63ll;
-    // genes per pass: bounded by the scratch cap (keys + sort ping-pong for OVR + host staging)
+    int rc;
+    void *v;
+
+    // ---- route 1 (device-resident dense OVO): fused single pass; it reports the genes it could not take ----
+    std::vector<std::pair<int64_t, int64_t>> runs; // column ranges still to be computed by the two-pass routes
+    if (!ovr && in_dev && counts_path_allowed(c, flags) && !c->no_fused_path) {
+        std::vector<u32> hf;
+        if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf))) return rc;
+        for (int64_t j = 0; j < W;) {
+            if (!hf[j]) { ++j; continue; }
+            int64_t e = j;
+            while (e < W && hf[e]) ++e;
+            runs.push_back({col_lb + j, col_lb + e});
+            j = e;
+        }
+        if (runs.empty()) return ILLICO_OK;
+    } else {
+        runs.push_back({col_lb, col_ub});
+    }
+    int64_t widest = 0;
+    for (auto &r : runs) widest = std::max(widest, r.second - r.first);
+
+    // ---- routes 2/3: transpose pass + per-gene rank kernels, in gene batches bounded by the scratch cap ----
     size_t per_gene = (size_t)stride * sizeof(KeyT) * (ovr ? 2 : 1) + (ovr ? (size_t)stride * 4 * 2 : 0) +
                       (in_dev ? 0 : (size_t)N * sizeof(InT)) + (size_t)G * 24 + 64;
     int64_t nb_max = c->gene_batch > 0 ? c->gene_batch : std::max<int64_t>(64, (int64_t)(c->scratch_bytes / per_gene));
-    nb_max = std::min<int64_t>(nb_max, W);
+    nb_max = std::min<int64_t>(nb_max, widest);
     if (nb_max > 64) nb_max &= ~63ll;
     nb_max = std::max<int64_t>(nb_max, 1);
 
-    void *v;
-    int rc;
     if ((rc = get_scratch(c, "xt", (size_t)nb_max * stride * sizeof(KeyT), &v))) return rc;
     KeyT *Xt = (KeyT *)v;
     if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
@@ -457,8 +531,9 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
         if ((rc = get_scratch(c, "xin", (size_t)nb_max * N * sizeof(InT), &v))) return rc;
         xin = (InT *)v;
     }
-    for (int64_t b0 = col_lb; b0 < col_ub; b0 += nb_max) {
-        const int nb = (int)std::min<int64_t>(nb_max, col_ub - b0);
+    for (auto &run : runs)
+    for (int64_t b0 = run.first; b0 < run.second; b0 += nb_max) {
+        const int nb = (int)std::min<int64_t>(nb_max, run.second - b0);
         const void *src = X;
         int64_t src_ld = ld, src_col0 = b0;
         if (!in_dev) {

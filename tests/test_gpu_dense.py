@@ -19,18 +19,32 @@ def engine():
     return get_engine()
 
 
+_DEVICE_INPUT = False  # set by the `route` fixture: device-resident X takes the fused single-pass OVO route
+
+
 def _run(engine, X, grpc, **kw):
     engine.set_groups(grpc)
+    if _DEVICE_INPUT and isinstance(X, np.ndarray) and X.dtype in (np.float32, np.float64, np.int32, np.int64):
+        import torch
+        Xd = torch.from_numpy(np.ascontiguousarray(X)).cuda()
+        out = engine.run_dense(Xd, kw.pop("col_lb", 0), kw.pop("col_ub", X.shape[1]), **kw)
+        engine.synchronize()
+        np.testing.assert_array_equal(Xd.cpu().numpy(), X)  # input never mutated
+        return out
     return engine.run_dense(X, kw.pop("col_lb", 0), kw.pop("col_ub", X.shape[1]), **kw)
 
 
-@pytest.fixture(params=["counts+sort", "sort-only"])
+@pytest.fixture(params=["fused+counts+sort", "counts+sort", "sort-only"])
 def route(request, engine):
-    """OVO has two device routes per gene: the histogram path for count-valued genes and the general sort
-    path.  'sort-only' forces every gene through the sort path so that both are covered on count data."""
+    """Dense OVO has three device routes per gene: the fused single-pass histogram kernel (device-resident X,
+    integer values < 64), the two-pass histogram kernel (integer values < 2048) and the general sort route.
+    The params switch routes off so that each one is exercised on the same data."""
+    global _DEVICE_INPUT
+    _DEVICE_INPUT = request.param.startswith("fused")
     engine.set_option("no_counts_path", 1 if request.param == "sort-only" else 0)
     yield request.param
     engine.set_option("no_counts_path", 0)
+    _DEVICE_INPUT = False
 
 
 @pytest.mark.parametrize("name", ["c1_1k_200_10", "small_ragged", "sparse90", "continuous"])
@@ -52,7 +66,7 @@ def test_dense_matches_reference_goldens(engine, name, test, route):
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
-def test_dense_dtypes_vs_oracle(engine, test, dtype):
+def test_dense_dtypes_vs_oracle(engine, test, dtype, route):
     X, rng = make_counts(11, 3000, 70, 0.5)
     labels = make_labels(rng, 3000, 9, n_ref=300)
     _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
@@ -63,7 +77,7 @@ def test_dense_dtypes_vs_oracle(engine, test, dtype):
 
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
-def test_dense_negative_and_continuous_values(engine, test):
+def test_dense_negative_and_continuous_values(engine, test, route):
     rng = np.random.RandomState(5)
     X = rng.randn(2500, 33).astype(np.float32)
     X[rng.rand(*X.shape) < 0.3] = 0.0
@@ -95,7 +109,17 @@ def test_ovo_ragged_group_sizes(engine, route):
         assert_planes_match(got, want, what=f"ref={ref}")
 
 
-def test_ovo_counts_route_big_groups_and_mixed_genes(engine):
+@pytest.mark.parametrize("device_input", [False, True])
+def test_ovo_counts_route_big_groups_and_mixed_genes(engine, device_input):
+    global _DEVICE_INPUT
+    _DEVICE_INPUT = device_input
+    try:
+        _counts_route_body(engine)
+    finally:
+        _DEVICE_INPUT = False
+
+
+def _counts_route_body(engine):
     """Histogram route: group and reference sizes beyond what the sort route holds in registers / LDS, genes
     that must fall back to the sort route (fractional, negative, >= 2048) next to count-valued ones."""
     rng = np.random.RandomState(13)
@@ -152,7 +176,7 @@ def test_ovr_ragged(engine):
 
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
-def test_column_window_batching_and_strides(engine, test):
+def test_column_window_batching_and_strides(engine, test, route):
     X, rng = make_counts(21, 2000, 301, 0.5)
     labels = make_labels(rng, 2000, 6, n_ref=150)
     _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
