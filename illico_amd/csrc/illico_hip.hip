@@ -437,31 +437,25 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     constexpr int RT = FUSED_RT;
     void *v;
     int rc;
-    size_t bytes = (size_t)nb * RT * 4 + (size_t)nb * (RT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * 4 + 64;
+    size_t bytes = (size_t)nb * (RT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * 4 + 64;
     if ((rc = get_scratch(c, "fused_tables", bytes, &v))) return rc;
     FusedParams P;
     P.X = X; P.ld = ld; P.col0 = b0; P.ncols = nb; P.perm = c->d_perm; P.pos_ptr = c->d_posptr; P.counts = c->d_counts;
     P.G = (int)c->n_groups; P.ref = (int)c->ref;
     P.ref_TA = (u64 *)v;
     P.ref_sum = P.ref_TA + nb;
-    P.ref_hist = (u32 *)(P.ref_sum + nb);
-    P.ref_cum = P.ref_hist + (size_t)nb * RT;
+    P.ref_cum = (u32 *)(P.ref_sum + nb);
     P.gene_flags = P.ref_cum + (size_t)nb * (RT + 1);
     P.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;
     P.tie_correct = (flags & ILLICO_FLAG_TIE_CORRECT) ? 1 : 0;
     P.alternative = alternative;
     P.out_p = o.p + col_off; P.out_u = o.u + col_off; P.out_fc = o.fc + col_off; P.out_ld = o.ld;
-    const int n_ref = c->h_counts[c->ref];
-    P.ref_rows_per_wg = 1024;
     P.groups_per_wg = 8;
     const int tiles = (nb + 63) / 64;
-    HIPCHK(c, hipMemsetAsync(P.ref_hist, 0, (size_t)nb * RT * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(P.gene_flags, 0, (size_t)nb * 4, c->stream));
     {
         ProfScope ps(c, KID_FUSED_REF);
-        hipLaunchKernelGGL((k_fused_ref_hist<InT, RT>), dim3(tiles, (n_ref + P.ref_rows_per_wg - 1) / P.ref_rows_per_wg), dim3(FUSED_NT), 0,
-                           c->stream, P);
-        hipLaunchKernelGGL((k_fused_ref_scan<RT>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, P);
+        hipLaunchKernelGGL((k_fused_ref<InT, RT>), dim3(tiles), dim3(FUSED_REF_NT), 0, c->stream, P);
         HIPCHK(c, hipGetLastError());
     }
     {

@@ -9,7 +9,7 @@
 // Per element with value c of gene `lane`:
 //     S2  += cum[c] + cum[c+1]                    (= 2 #ref<c + #ref==c; cum = cumulative reference histogram)
 //     o    = (number of earlier cells of this group with the same value)   -- LDS fetch-and-add, lane-private
-//     tie += 3 a^2 + 3 a (2o+1) + 3 o (o+1),  a = cum[c+1]-cum[c]
+//     tie += 3 a^2 + 3 a (2o+1) + 3 o (o+1) = 3 t (t+1),  a = cum[c+1]-cum[c],  t = a + o
 // Summed over a group, sum_o (2o+1) = tB^2 and sum_o (3o^2+3o+1) = tB^3, so this is exactly
 // T_A + sum_v tB (3 tA (tA+tB) + tB^2 - 1) of kernels_ovo.h -- the same integers, bit-exact -- without any
 // sort, merge or per-group histogram scan.  The wavefront then evaluates U, p and fold change for its 64
@@ -23,7 +23,7 @@
 #include "kernels_finalize.h"
 
 #define FUSED_NT 256
-#define FUSED_U 16
+#define FUSED_U 32
 
 struct FusedParams {
     const void *X;
@@ -33,7 +33,6 @@ struct FusedParams {
     const int *pos_ptr;       // [G+1]
     const int *counts;        // [G]
     int G, ref;
-    u32 *ref_hist;            // [ncols][RT]   reference histogram (zeroed by the host)
     u32 *ref_cum;             // [ncols][RT+1] cumulative
     u64 *ref_TA;              // [ncols] sum_v (tA^3 - tA)
     u64 *ref_sum;             // [ncols] sum of reference values
@@ -42,7 +41,6 @@ struct FusedParams {
     double *out_p, *out_u, *out_fc; // [G][out_ld], already offset to column col0's slot
     long long out_ld;
     int groups_per_wg;
-    int ref_rows_per_wg;
 };
 
 template <typename InT> __device__ __forceinline__ u32 small_count(InT v, int RT, bool &ok);
@@ -67,63 +65,134 @@ template <> __device__ __forceinline__ u32 small_count<int64_t>(int64_t v, int R
     return ok ? (u32)v : 0u;
 }
 
-// ---- reference histogram: grid (tiles, row chunks); lane = gene; per-wave LDS histogram, flushed with atomics ----
-template <typename InT, int RT>
-__global__ __launch_bounds__(FUSED_NT) void k_fused_ref_hist(FusedParams P) {
-    constexpr int NW = FUSED_NT / 64, STR = RT / 2 + 1; // two 16-bit bins per word, odd stride: conflict-free
-    __shared__ u32 h[NW][64 * STR];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
-    const bool act = gene < P.ncols;
-    u32 *hw = h[wave] + lane * STR;
-    for (int i = 0; i < STR; ++i) hw[i] = 0;
-    const int p0 = P.pos_ptr[P.ref], p1 = P.pos_ptr[P.ref + 1];
-    const int chunk = P.ref_rows_per_wg;                 // <= 65535 * NW rows per workgroup
-    const int wb = p0 + blockIdx.y * chunk, we = min(wb + chunk, p1);
-    const InT *X = (const InT *)P.X;
-    bool bad = false;
-    for (int p = wb + wave; p < we; p += NW) {
-        const long long row = P.perm[p];
-        if (act) {
-            bool ok;
-            u32 c = small_count<InT>(X[row * P.ld + P.col0 + gene], RT, ok);
-            bad |= !ok;
-            c = min(c, (u32)(RT - 1));
-            hw[c >> 1] += (c & 1u) ? 0x10000u : 1u;      // lane-private: plain read-modify-write
-        }
-    }
-    if (act) {
-        if (bad) P.gene_flags[gene] = 1u;
-        for (int w = 0; w < RT / 2; ++w) {
-            u32 word = hw[w];
-            if (word & 0xFFFFu) atomicAdd(&P.ref_hist[(size_t)gene * RT + 2 * w], word & 0xFFFFu);
-            if (word >> 16) atomicAdd(&P.ref_hist[(size_t)gene * RT + 2 * w + 1], word >> 16);
-        }
-    }
+// Table index of a value, clamped into [0, RT-1], and whether the value IS that integer (else the gene leaves
+// this route).  One v_med3 replaces the range compares: out-of-range, fractional and NaN all fail `exact`.
+template <typename InT, int RT> __device__ __forceinline__ u32 clamp_count(InT v, bool &exact);
+template <> __device__ __forceinline__ u32 clamp_count<float, 64>(float v, bool &exact) {
+    const float m = __builtin_amdgcn_fmed3f(v, 0.0f, 63.0f);
+    const u32 c = (u32)m;
+    exact = (float)c == v;
+    return c;
+}
+template <> __device__ __forceinline__ u32 clamp_count<double, 64>(double v, bool &exact) {
+    const double m = fmin(fmax(v, 0.0), 63.0); // NaN -> 0
+    const u32 c = (u32)m;
+    exact = (double)c == v;
+    return c;
+}
+template <> __device__ __forceinline__ u32 clamp_count<int32_t, 64>(int32_t v, bool &exact) {
+    const u32 c = (u32)min(max(v, 0), 63);
+    exact = (int32_t)c == v;
+    return c;
+}
+template <> __device__ __forceinline__ u32 clamp_count<int64_t, 64>(int64_t v, bool &exact) {
+    const u32 c = (u32)min(max(v, (int64_t)0), (int64_t)63);
+    exact = (int64_t)c == v;
+    return c;
 }
 
-// ---- per gene: histogram -> cumulative table, T_A, reference sum; also writes the reference group's row ----
-template <int RT> __global__ void k_fused_ref_scan(FusedParams P) {
-    const int gene = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gene >= P.ncols) return;
-    const u32 *h = P.ref_hist + (size_t)gene * RT;
-    u32 *cum = P.ref_cum + (size_t)gene * (RT + 1);
-    u32 run = 0;
-    u64 ta = 0, sum = 0;
-    cum[0] = 0;
-    for (int c = 0; c < RT; ++c) {
-        u64 t = h[c];
-        run += (u32)t;
-        cum[c + 1] = run;
-        ta += t * t * t - t;
-        sum += t * (u64)c;
+// One chunk of UU rows of one group for the wavefront's 64 genes.  Straight-line: one vector load fetches the
+// chunk's row indices, UU row segments are requested back to back, then consumed in order (counted vmcnt waits).
+// Per element (value c, reference multiplicity a = cum[c+1]-cum[c], o = earlier cells of the group with value c):
+//     S2 += cum[c] + cum[c+1];      TT += t (t+1),  t = a + o      [= a^2 + a(2o+1) + o(o+1)]
+// PRED: rows at or past p1 (group end) re-read the last row and are masked out.
+template <typename InT, int RT, int UU, bool PRED>
+__device__ __forceinline__ void fused_chunk(const InT *__restrict__ Xg, long long ld, const int *__restrict__ perm, int p, int p1,
+                                            int lane, int lane_c, const u32 *ca, u32 *cb, u64 &S2, u64 &TT, u32 &vsum,
+                                            bool &inexact) {
+    const int pidx = perm[PRED ? min(p + (lane & (UU - 1)), p1 - 1) : p + (lane & (UU - 1))];
+    InT v[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        const long long row = __builtin_amdgcn_readlane(pidx, u);
+        v[u] = Xg[row * ld + lane_c];
     }
-    P.ref_TA[gene] = ta;
-    P.ref_sum[gene] = sum;
-    const size_t o = (size_t)P.ref * P.out_ld + gene;
-    P.out_p[o] = 1.0;                                                            // sparse_ovo.py:140-143
-    P.out_u[o] = -1.0;
-    P.out_fc[o] = (sum == 0) ? __longlong_as_double(0x7FF0000000000000ll) : 1.0; // math.py:190-192 with mu_tgt == mu_ref
+    u32 s2c = 0;
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        bool exact;
+        const u32 c = clamp_count<InT, RT>(v[u], exact);
+        const u32 lo = ca[c], hi = ca[c + 1];
+        const u32 sh = (c & 1u) << 4;
+        if (PRED) {
+            const bool valid = p + u < p1; // wave-uniform
+            inexact |= valid && !exact;
+            const u32 old = atomicAdd(&cb[c >> 1], valid ? (1u << sh) : 0u);
+            const u32 t = valid ? (hi - lo) + __builtin_amdgcn_ubfe(old, sh, 16) : 0u;
+            s2c += valid ? lo + hi : 0u;
+            TT += (u64)t * (t + 1u);
+            vsum += valid ? c : 0u;
+        } else {
+            inexact |= !exact;
+            const u32 old = atomicAdd(&cb[c >> 1], 1u << sh); // lane-private word (two 16-bit bins): fetch-and-add
+            const u32 t = (hi - lo) + __builtin_amdgcn_ubfe(old, sh, 16);
+            s2c += lo + hi;
+            TT += (u64)t * (t + 1u);
+            vsum += c;
+        }
+    }
+    S2 += s2c;
+}
+
+// ---- reference tables: one 1024-thread workgroup per 64-gene tile; lane = gene.  All 16 wavefronts add into one
+// LDS histogram (columns are lane-private, so the only contention is between wavefronts), then wavefront 0 scans
+// each gene's bins into the cumulative table, T_A and the reference sum, and writes the reference group's row.
+#define FUSED_REF_NT 1024
+template <typename InT, int RT>
+__global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
+    constexpr int NW = FUSED_REF_NT / 64, STR = RT + 1, UR = 16;
+    __shared__ u32 h[64 * STR];
+    __shared__ int s_bad[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
+    const bool act = gene < P.ncols;
+    for (int i = tid; i < 64 * STR; i += FUSED_REF_NT) h[i] = 0;
+    if (tid < 64) s_bad[tid] = 0;
+    __syncthreads();
+    const int p0 = P.pos_ptr[P.ref], p1 = P.pos_ptr[P.ref + 1];
+    const InT *Xg = (const InT *)P.X + P.col0 + gene0;
+    const int lane_c = act ? lane : 0;
+    u32 *hl = h + lane * STR;
+    bool bad = false;
+    for (int p = p0 + wave * UR; p < p1; p += NW * UR) {
+        const int pidx = P.perm[min(p + (lane & (UR - 1)), p1 - 1)];
+        InT v[UR];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const long long row = __builtin_amdgcn_readlane(pidx, u);
+            v[u] = Xg[row * P.ld + lane_c];
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const bool valid = p + u < p1;
+            bool exact;
+            const u32 c = clamp_count<InT, RT>(v[u], exact);
+            bad |= valid && !exact;
+            atomicAdd(&hl[c], valid ? 1u : 0u);
+        }
+    }
+    if (bad) s_bad[lane] = 1;
+    __syncthreads();
+    if (wave == 0 && act) {
+        u32 *cum = P.ref_cum + (size_t)gene * STR;
+        u32 run = 0;
+        u64 ta = 0, sum = 0;
+        cum[0] = 0;
+        for (int c = 0; c < RT; ++c) {
+            const u64 t = hl[c];
+            run += (u32)t;
+            cum[c + 1] = run;
+            ta += t * t * t - t;
+            sum += t * (u64)c;
+        }
+        P.ref_TA[gene] = ta;
+        P.ref_sum[gene] = sum;
+        if (s_bad[lane]) P.gene_flags[gene] = 1u;
+        const size_t o = (size_t)P.ref * P.out_ld + gene;
+        P.out_p[o] = 1.0;                                                            // sparse_ovo.py:140-143
+        P.out_u[o] = -1.0;
+        P.out_fc[o] = (sum == 0) ? __longlong_as_double(0x7FF0000000000000ll) : 1.0; // math.py:190-192 with mu_tgt == mu_ref
+    }
 }
 
 // ---- main pass: grid (tiles, group chunks); 4 wavefronts per workgroup, one group at a time per wavefront ----
@@ -160,46 +229,21 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
     bool bad = false;
 
     const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
+    const int lane_c = act ? lane : 0; // inactive lanes (tile wider than the batch) re-read a valid column
+    const InT *Xg = X + P.col0 + gene0;
     for (int g = gbeg + wave; g < gend; g += NW) {
         if (g == P.ref) continue;
         const int p0 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g]);
         const int p1 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g + 1]);
-        u64 S2 = 0, A2 = 0, AB = 0, OO = 0;
+        u64 S2 = 0, TT = 0;
         u32 vsum = 0;
-        for (int p = p0; p < p1; p += U) {
-            InT v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                v[u] = (InT)0;
-                if (p + u < p1) { // wave-uniform
-                    const long long row = __builtin_amdgcn_readfirstlane(P.perm[p + u]);
-                    const InT *rp = X + row * P.ld + P.col0 + gene0;
-                    if (act) v[u] = rp[lane];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (p + u < p1) {
-                    bool ok;
-                    u32 c = small_count<InT>(v[u], RT, ok);
-                    bad |= !ok;
-                    c = min(c, (u32)(RT - 1));
-                    const u32 lo = ca[c], hi = ca[c + 1];
-                    const u32 old = atomicAdd(&cb[c >> 1], (c & 1u) ? 0x10000u : 1u); // lane-private word: fetch-and-add
-                    const u32 o = (c & 1u) ? (old >> 16) : (old & 0xFFFFu);
-                    const u32 a = hi - lo;
-                    S2 += (u64)lo + hi;
-                    A2 += (u64)a * a;
-                    AB += (u64)a * (2u * o + 1u);
-                    OO += (u64)o * (o + 1u);
-                    vsum += c;
-                }
-            }
-        }
+        int p = p0;
+        for (; p + U <= p1; p += U) fused_chunk<InT, RT, U, false>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
+        for (; p < p1; p += 8) fused_chunk<InT, RT, 8, true>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
         // ---- this lane's (group, gene) result ----
         const long long n_tgt = p1 - p0;
         if (act) {
-            const u64 tie_i = T_A + 3ull * (A2 + AB + OO);
+            const u64 tie_i = T_A + 3ull * TT;
             const long long two_u = 2ll * n_ref * n_tgt - (long long)S2;
             const double Ustat = 0.5 * (double)two_u;
             const double tie = P.tie_correct ? (double)tie_i : 0.0;
