@@ -25,6 +25,7 @@ enum {
     KID_OVO_RANK,
     KID_OVO_COUNTS,
     KID_OVO_FUSED,
+    KID_OVR_FUSED,
     KID_FUSED_REF,
     KID_FINALIZE,
     KID_RADIX_SORT,
@@ -34,7 +35,7 @@ enum {
     KID_MISC,
     KID_COUNT
 };
-static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_fused_ref", "k_finalize",   "k_radix_sort",
+static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused", "k_fused_tables", "k_finalize",   "k_radix_sort",
                                               "k_ovr_scan",          "k_sparse_seg", "k_gene_totals", "misc"};
 
 struct ProfEvent {
@@ -365,6 +366,11 @@ static int launch_transpose(illico_ctx *c, const void *X, int64_t ld, int64_t co
 static bool counts_path_allowed(const illico_ctx *c, int flags) {
     return !(flags & ILLICO_FLAG_LOG1P) && c->ref >= 0 && c->max_nonref <= 65535 && !c->no_counts_path;
 }
+// fused single-pass routes (OVO and OVR): integer value sums (no expm1), 16-bit running multiplicities (OVO),
+// 32-bit chunk partial sums (n_cells < 2^25)
+static bool fused_path_allowed(const illico_ctx *c, int flags) {
+    return !(flags & ILLICO_FLAG_LOG1P) && c->max_nonref <= 65535 && c->n_cells < (1ll << 25) && !c->no_counts_path && !c->no_fused_path;
+}
 
 static int launch_finalize(illico_ctx *c, const long long *s2u, const u64 *stie, const double *ssum, const double *gene_total,
                            int nb, int flags, int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld,
@@ -435,9 +441,10 @@ template <typename InT>
 static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, int flags, int alternative,
                          const OutPlanes &o, int64_t col_off, std::vector<u32> &h_flags) {
     constexpr int RT = FUSED_RT;
+    const bool ovr = c->ref < 0;
     void *v;
     int rc;
-    size_t bytes = (size_t)nb * (RT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * 4 + 64;
+    size_t bytes = (size_t)nb * (RT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * 4 + (ovr ? (size_t)nb * RT * 4 : 0) + 64;
     if ((rc = get_scratch(c, "fused_tables", bytes, &v))) return rc;
     FusedParams P;
     P.X = X; P.ld = ld; P.col0 = b0; P.ncols = nb; P.perm = c->d_perm; P.pos_ptr = c->d_posptr; P.counts = c->d_counts;
@@ -446,6 +453,9 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.ref_sum = P.ref_TA + nb;
     P.ref_cum = (u32 *)(P.ref_sum + nb);
     P.gene_flags = P.ref_cum + (size_t)nb * (RT + 1);
+    P.hist_all = ovr ? P.gene_flags + nb : nullptr;
+    P.n_cells = c->n_cells;
+    P.rows_per_wg = (int)std::max<int64_t>(1024, (c->n_cells + 31) / 32);
     P.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;
     P.tie_correct = (flags & ILLICO_FLAG_TIE_CORRECT) ? 1 : 0;
     P.alternative = alternative;
@@ -453,15 +463,27 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.groups_per_wg = 8;
     const int tiles = (nb + 63) / 64;
     HIPCHK(c, hipMemsetAsync(P.gene_flags, 0, (size_t)nb * 4, c->stream));
-    {
-        ProfScope ps(c, KID_FUSED_REF);
-        hipLaunchKernelGGL((k_fused_ref<InT, RT>), dim3(tiles), dim3(FUSED_REF_NT), 0, c->stream, P);
-        HIPCHK(c, hipGetLastError());
-    }
-    {
+    const dim3 main_grid(tiles, ((int)c->n_groups + P.groups_per_wg - 1) / P.groups_per_wg);
+    if (!ovr) {
+        {
+            ProfScope ps(c, KID_FUSED_REF);
+            hipLaunchKernelGGL((k_fused_ref<InT, RT>), dim3(tiles), dim3(FUSED_REF_NT), 0, c->stream, P);
+            HIPCHK(c, hipGetLastError());
+        }
         ProfScope ps(c, KID_OVO_FUSED);
-        hipLaunchKernelGGL((k_ovo_fused<InT, RT>), dim3(tiles, ((int)c->n_groups + P.groups_per_wg - 1) / P.groups_per_wg), dim3(FUSED_NT), 0,
-                           c->stream, P);
+        hipLaunchKernelGGL((k_ovo_fused<InT, RT, false>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemsetAsync(P.hist_all, 0, (size_t)nb * RT * 4, c->stream));
+        {
+            ProfScope ps(c, KID_FUSED_REF);
+            const int chunks = (int)((c->n_cells + P.rows_per_wg - 1) / P.rows_per_wg);
+            hipLaunchKernelGGL((k_fused_hist_all<InT, RT>), dim3(tiles, chunks), dim3(FUSED_NT), 0, c->stream, P);
+            hipLaunchKernelGGL((k_fused_tables_all<RT>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, P);
+            HIPCHK(c, hipGetLastError());
+        }
+        ProfScope ps(c, KID_OVR_FUSED);
+        hipLaunchKernelGGL((k_ovo_fused<InT, RT, true>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
         HIPCHK(c, hipGetLastError());
     }
     h_flags.resize(nb);
@@ -483,7 +505,7 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
 
     // ---- route 1 (device-resident dense OVO): fused single pass; it reports the genes it could not take ----
     std::vector<std::pair<int64_t, int64_t>> runs; // column ranges still to be computed by the two-pass routes
-    if (!ovr && in_dev && counts_path_allowed(c, flags) && !c->no_fused_path) {
+    if (in_dev && fused_path_allowed(c, flags)) {
         std::vector<u32> hf;
         if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf))) return rc;
         for (int64_t j = 0; j < W;) {

@@ -36,6 +36,9 @@ struct FusedParams {
     u32 *ref_cum;             // [ncols][RT+1] cumulative
     u64 *ref_TA;              // [ncols] sum_v (tA^3 - tA)
     u64 *ref_sum;             // [ncols] sum of reference values
+    u32 *hist_all;            // [ncols][RT] whole-column histogram (OVR; zeroed by the host)
+    long long n_cells;
+    int rows_per_wg;          // OVR histogram pass: rows per workgroup
     u32 *gene_flags;          // [ncols] set to 1 when the gene cannot take this route
     int use_continuity, tie_correct, alternative;
     double *out_p, *out_u, *out_fc; // [G][out_ld], already offset to column col0's slot
@@ -195,8 +198,95 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
     }
 }
 
-// ---- main pass: grid (tiles, group chunks); 4 wavefronts per workgroup, one group at a time per wavefront ----
+// ---- OVR tables.  For one-versus-rest every cell is ranked against the whole column, so the table is the
+// histogram of ALL cells: rank of value c = cum[c] + (cnt[c]+1)/2, and the tie term sum_v (t^3 - t) is a
+// property of the column alone (ranking.py:31-47) -- no per-group multiplicities are needed.
+// Pass A: grid (tiles, row chunks); the workgroup's wavefronts add into one LDS histogram, flushed with global
+// integer atomics (non-empty bins only).
 template <typename InT, int RT>
+__global__ __launch_bounds__(FUSED_NT) void k_fused_hist_all(FusedParams P) {
+    constexpr int NW = FUSED_NT / 64, STR = RT + 1, UR = 32;
+    __shared__ u32 h[64 * STR];
+    __shared__ int s_bad[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
+    const bool act = gene < P.ncols;
+    for (int i = tid; i < 64 * STR; i += FUSED_NT) h[i] = 0;
+    if (tid < 64) s_bad[tid] = 0;
+    __syncthreads();
+    const long long r0 = (long long)blockIdx.y * P.rows_per_wg, r1 = min(r0 + P.rows_per_wg, P.n_cells);
+    const InT *Xg = (const InT *)P.X + P.col0 + gene0;
+    const int lane_c = act ? lane : 0;
+    u32 *hl = h + lane * STR;
+    bool bad = false;
+    for (long long r = r0 + wave * UR; r < r1; r += NW * UR) {
+        InT v[UR];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) v[u] = Xg[min(r + u, r1 - 1) * P.ld + lane_c];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const bool valid = r + u < r1;
+            bool exact;
+            const u32 c = clamp_count<InT, RT>(v[u], exact);
+            bad |= valid && !exact;
+            atomicAdd(&hl[c], valid ? 1u : 0u);
+        }
+    }
+    if (bad) s_bad[lane] = 1;
+    __syncthreads();
+    for (int i = tid; i < 64 * RT; i += FUSED_NT) {
+        const int l = i / RT, c = i - l * RT;
+        const u32 cnt = h[l * STR + c];
+        if (cnt && gene0 + l < P.ncols) atomicAdd(&P.hist_all[(size_t)(gene0 + l) * RT + c], cnt);
+    }
+    if (tid < 64 && act && s_bad[tid]) P.gene_flags[gene] = 1u;
+}
+// per gene: histogram -> cumulative table, column tie sum, column total
+template <int RT> __global__ void k_fused_tables_all(FusedParams P) {
+    const int gene = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gene >= P.ncols) return;
+    const u32 *h = P.hist_all + (size_t)gene * RT;
+    u32 *cum = P.ref_cum + (size_t)gene * (RT + 1);
+    u32 run = 0;
+    u64 ta = 0, sum = 0;
+    cum[0] = 0;
+    for (int c = 0; c < RT; ++c) {
+        const u64 t = h[c];
+        run += (u32)t;
+        cum[c + 1] = run;
+        ta += t * t * t - t;
+        sum += t * (u64)c;
+    }
+    P.ref_TA[gene] = ta;
+    P.ref_sum[gene] = sum;
+}
+
+// One chunk of the OVR rank-sum pass: R2 += cum[c] + cum[c+1] (= 2 #cells<c + #cells==c), value sum.
+template <typename InT, int RT, int UU, bool PRED>
+__device__ __forceinline__ void fused_chunk_ovr(const InT *__restrict__ Xg, long long ld, const int *__restrict__ perm, int p, int p1,
+                                                int lane, int lane_c, const u32 *ca, u64 &R2, u32 &vsum) {
+    const int pidx = perm[PRED ? min(p + (lane & (UU - 1)), p1 - 1) : p + (lane & (UU - 1))];
+    InT v[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        const long long row = __builtin_amdgcn_readlane(pidx, u);
+        v[u] = Xg[row * ld + lane_c];
+    }
+    u32 r2c = 0; // <= UU * 2 * n_cells: fits 32 bits for n_cells < 2^25 per chunk of 32
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        bool exact;
+        const u32 c = clamp_count<InT, RT>(v[u], exact);
+        const u32 lo = ca[c], hi = ca[c + 1];
+        const bool valid = !PRED || (p + u < p1);
+        r2c += valid ? lo + hi : 0u;
+        vsum += valid ? c : 0u;
+    }
+    R2 += r2c;
+}
+
+// ---- main pass: grid (tiles, group chunks); 4 wavefronts per workgroup, one group at a time per wavefront ----
+template <typename InT, int RT, bool OVR>
 __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
     constexpr int NW = FUSED_NT / 64, CSTR = RT + 1, BSTR = RT / 2 + 1, U = FUSED_U;
     __shared__ u32 cumA[64 * CSTR];        // cumA[lane*CSTR + c] = # reference cells of gene `lane` with value < c
@@ -222,7 +312,7 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
     __syncthreads();
     const u32 *ca = cumA + lane * CSTR;
     const InT *X = (const InT *)P.X;
-    const long long n_ref = P.counts[P.ref];
+    const long long n_ref = OVR ? 0 : P.counts[OVR ? 0 : P.ref];
     const u64 T_A = act ? P.ref_TA[gene] : 0ull;
     const double ref_sum = act ? (double)P.ref_sum[gene] : 0.0;
     const double cc = P.use_continuity ? 0.5 : 0.0;
@@ -232,31 +322,50 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
     const int lane_c = act ? lane : 0; // inactive lanes (tile wider than the batch) re-read a valid column
     const InT *Xg = X + P.col0 + gene0;
     for (int g = gbeg + wave; g < gend; g += NW) {
-        if (g == P.ref) continue;
+        if (!OVR && g == P.ref) continue;
         const int p0 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g]);
         const int p1 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g + 1]);
         u64 S2 = 0, TT = 0;
         u32 vsum = 0;
         int p = p0;
-        for (; p + U <= p1; p += U) fused_chunk<InT, RT, U, false>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
-        for (; p < p1; p += 8) fused_chunk<InT, RT, 8, true>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
+        if (OVR) {
+            for (; p + U <= p1; p += U) fused_chunk_ovr<InT, RT, U, false>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, S2, vsum);
+            for (; p < p1; p += 8) fused_chunk_ovr<InT, RT, 8, true>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, S2, vsum);
+        } else {
+            for (; p + U <= p1; p += U) fused_chunk<InT, RT, U, false>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
+            for (; p < p1; p += 8) fused_chunk<InT, RT, 8, true>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
+        }
         // ---- this lane's (group, gene) result ----
         const long long n_tgt = p1 - p0;
         if (act) {
-            const u64 tie_i = T_A + 3ull * TT;
-            const long long two_u = 2ll * n_ref * n_tgt - (long long)S2;
-            const double Ustat = 0.5 * (double)two_u;
-            const double tie = P.tie_correct ? (double)tie_i : 0.0;
-            const double mu = (double)(n_ref * n_tgt) / 2.0;
-            const double pv = pval_device(n_ref, n_tgt, n_ref + n_tgt, tie, Ustat, mu, cc, P.alternative);
+            double pv, Ustat, fc;
             const double mu_tgt = (double)vsum / (double)n_tgt;
-            const double mu_ref = ref_sum / (double)n_ref;
-            const double fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+            if (OVR) { // dense_ovr.py:57-75: the "reference" of group g is every other cell
+                const long long n_rest = P.n_cells - n_tgt;
+                // 2*ranksum = S2 + n_tgt (2 rank = 2 #less + #equal + 1);  U = n_rest n_tgt + n_tgt(n_tgt+1)/2 - ranksum
+                const long long two_u = 2ll * n_rest * n_tgt + n_tgt * (n_tgt + 1) - ((long long)S2 + n_tgt);
+                Ustat = 0.5 * (double)two_u;
+                const double tie = P.tie_correct ? (double)T_A : 0.0;
+                const double mu = (double)(n_rest * n_tgt) / 2.0;
+                pv = pval_device(n_rest, n_tgt, P.n_cells, tie, Ustat, mu, cc, P.alternative);
+                const double mu_ref = (ref_sum - (double)vsum) / (double)n_rest; // math.py:185-188
+                fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+            } else {
+                const u64 tie_i = T_A + 3ull * TT;
+                const long long two_u = 2ll * n_ref * n_tgt - (long long)S2;
+                Ustat = 0.5 * (double)two_u;
+                const double tie = P.tie_correct ? (double)tie_i : 0.0;
+                const double mu = (double)(n_ref * n_tgt) / 2.0;
+                pv = pval_device(n_ref, n_tgt, n_ref + n_tgt, tie, Ustat, mu, cc, P.alternative);
+                const double mu_ref = ref_sum / (double)n_ref;
+                fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+            }
             const size_t o = (size_t)g * P.out_ld + gene;
             P.out_p[o] = pv;
             P.out_u[o] = Ustat;
             P.out_fc[o] = fc;
         }
+        if (OVR) continue;
         for (int i = 0; i < BSTR; ++i) cb[i] = 0; // lane-private, in-order LDS: no barrier needed
     }
     if (act && bad) P.gene_flags[gene] = 1u;
