@@ -315,31 +315,43 @@ static int launch_ovo_t(illico_ctx *c, const OvoParams &P, size_t lds, const u32
     return ILLICO_OK;
 }
 
+// Does the in-LDS sort route (k_ovo_rank) hold these sizes?  (reference column in LDS, groups <= 1024 keys)
+template <typename KeyT> static bool ovo_sort_route_fits(int64_t max_ref_nnz, int64_t max_grp_nnz) {
+    int ref_cap = (int)std::max<int64_t>(max_ref_nnz, 1);
+    bool runend = ref_cap <= 65535 && ovo_lds_bytes<KeyT>(ref_cap, true, kOvoThreads) <= kMaxLds;
+    return max_grp_nnz <= 1024 && ovo_lds_bytes<KeyT>(ref_cap, runend, kOvoThreads) <= kMaxLds;
+}
+
+struct OvoGlobalBufs { // scratch of the global-sort fallback (same element count as the key buffer)
+    void *kb = nullptr;
+    u32 *va = nullptr, *vb = nullptr;
+};
+
 // flags: per-gene routing word written by the ingest kernels (0 = count-valued gene -> k_ovo_counts,
-// non-zero -> k_ovo_rank); nullptr routes every gene through the general sort path.
-template <typename KeyT> static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz, const u32 *flags) {
+// non-zero -> sort route); nullptr routes every gene through the sort route.  The sort route is k_ovo_rank when
+// the reference column and the groups fit LDS / registers, else the per-gene global radix sort (k_ovr_gene in
+// OVO mode), which has no size limit.
+template <typename KeyT>
+static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz, const u32 *flags,
+                      const OvoGlobalBufs *gb, bool sparse) {
     if (flags) {
         ProfScope ps(c, KID_OVO_COUNTS);
         hipLaunchKernelGGL((k_ovo_counts<KeyT>), dim3(P.n_genes), dim3(COUNTS_NT), 0, c->stream, P, flags);
         HIPCHK(c, hipGetLastError());
     }
+    if (!ovo_sort_route_fits<KeyT>(max_ref_nnz, max_grp_nnz)) {
+        if (!gb || !gb->kb) return fail(c, ILLICO_ERR_UNSUPPORTED, "internal: global-sort scratch missing");
+        OvrParams Q;
+        Q.keys_a = (void *)P.Xs; Q.keys_b = gb->kb; Q.vals_a = gb->va; Q.vals_b = gb->vb;
+        Q.code_by_pos = sparse ? nullptr : c->d_code_by_pos; Q.seg_ptr = P.seg_ptr; Q.stride = P.gene_stride;
+        Q.pos_ptr = P.pos_ptr; Q.counts = P.counts; Q.G = P.G; Q.n_genes = P.n_genes; Q.dt = P.dt; Q.is_log1p = P.is_log1p;
+        Q.n_cells = c->n_cells; Q.ref = P.ref; Q.gene_flags = flags;
+        Q.out_2u = P.out_2u; Q.out_tie = P.out_tie; Q.out_sum = P.out_sum;
+        return sparse ? launch_ovr_gene<KeyT, true, true>(c, Q) : launch_ovr_gene<KeyT, false, true>(c, Q);
+    }
     int ref_cap = (int)std::max<int64_t>(max_ref_nnz, 1);
     bool runend = ref_cap <= 65535 && ovo_lds_bytes<KeyT>(ref_cap, true, kOvoThreads) <= kMaxLds;
     size_t lds = ovo_lds_bytes<KeyT>(ref_cap, runend, kOvoThreads);
-    const bool fits = max_grp_nnz <= 1024 && lds <= kMaxLds;
-    if (!fits) {
-        bool any_general = true;
-        if (flags) { // only genes the histogram path could not take need the sort path: are there any?
-            std::vector<u32> h(P.n_genes);
-            HIPCHK(c, hipMemcpyAsync(h.data(), flags, (size_t)P.n_genes * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            any_general = std::any_of(h.begin(), h.end(), [](u32 f) { return f != 0; });
-        }
-        if (!any_general) return ILLICO_OK;
-        if (max_grp_nnz > 1024)
-            return fail(c, ILLICO_ERR_UNSUPPORTED, "OVO on non-count data with a non-reference group of %lld cells (> 1024) is not supported by this build yet", (long long)max_grp_nnz);
-        return fail(c, ILLICO_ERR_UNSUPPORTED, "OVO on non-count data with a reference group of %lld cells does not fit the 160 KiB LDS of a CU in this build", (long long)max_ref_nnz);
-    }
     P.ref_cap = ref_cap;
     bool big = max_grp_nnz > 256;
     if (big) return runend ? launch_ovo_t<KeyT, 16, true>(c, P, lds, flags) : launch_ovo_t<KeyT, 16, false>(c, P, lds, flags);
@@ -523,7 +535,9 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
     for (auto &r : runs) widest = std::max(widest, r.second - r.first);
 
     // ---- routes 2/3: transpose pass + per-gene rank kernels, in gene batches bounded by the scratch cap ----
-    size_t per_gene = (size_t)stride * sizeof(KeyT) * (ovr ? 2 : 1) + (ovr ? (size_t)stride * 4 * 2 : 0) +
+    const bool need_glob = !ovr && !ovo_sort_route_fits<KeyT>(c->h_counts[c->ref], c->max_nonref);
+    const bool pingpong = ovr || need_glob;
+    size_t per_gene = (size_t)stride * sizeof(KeyT) * (pingpong ? 2 : 1) + (pingpong ? (size_t)stride * 4 * 2 : 0) +
                       (in_dev ? 0 : (size_t)N * sizeof(InT)) + (size_t)G * 24 + 64;
     int64_t nb_max = c->gene_batch > 0 ? c->gene_batch : std::max<int64_t>(64, (int64_t)(c->scratch_bytes / per_gene));
     nb_max = std::min<int64_t>(nb_max, widest);
@@ -541,6 +555,15 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
     if (counts_path_allowed(c, flags)) {
         if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
         gflags = (u32 *)v;
+    }
+    OvoGlobalBufs gb;
+    if (need_glob) {
+        if ((rc = get_scratch(c, "ovr_kb", (size_t)nb_max * stride * sizeof(KeyT), &v))) return rc;
+        gb.kb = v;
+        if ((rc = get_scratch(c, "ovr_va", (size_t)nb_max * stride * 4, &v))) return rc;
+        gb.va = (u32 *)v;
+        if ((rc = get_scratch(c, "ovr_vb", (size_t)nb_max * stride * 4, &v))) return rc;
+        gb.vb = (u32 *)v;
     }
     InT *xin = nullptr;
     if (!in_dev) {
@@ -564,7 +587,7 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
             P.Xs = Xt; P.gene_stride = stride; P.pos_ptr = c->d_posptr; P.seg_ptr = nullptr; P.counts = c->d_counts;
             P.G = G; P.ref = (int)c->ref; P.n_genes = nb; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
             P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
-            if ((rc = launch_ovo<KeyT>(c, P, c->h_counts[c->ref], c->max_nonref, gflags))) return rc;
+            if ((rc = launch_ovo<KeyT>(c, P, c->h_counts[c->ref], c->max_nonref, gflags, &gb, false))) return rc;
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
         } else {
             if ((rc = run_ovr_dense_batch<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot))) return rc;

@@ -26,6 +26,8 @@ struct OvrParams {
     const int *counts;        // [G]
     int G, n_genes, dt, is_log1p;
     long long n_cells;
+    int ref;                  // OVO-through-global-sort mode: reference group code
+    const u32 *gene_flags;    // OVO mode: process only genes whose flag is non-zero (nullptr = all)
     long long *out_2u;        // [n_genes][G]
     u64 *out_tie;             // [n_genes][G]
     double *out_sum;          // [n_genes][G]
@@ -71,7 +73,44 @@ template <int NT> __device__ __forceinline__ int block_incl_scan_min_rev(int x, 
     return min(wi, wp);
 }
 
-template <typename KeyT, bool SPARSE>
+// exclusive add-scan over the workgroup in thread order; `carry` (total of earlier chunks) is added and updated
+template <int NT> __device__ __forceinline__ int block_excl_scan_add(int x, int &carry, int *wtot, int tid) {
+    constexpr int NW = NT / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    int wi = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(wi, d);
+        if (lane >= d) wi += o;
+    }
+    if (lane == 63) wtot[wave] = wi;
+    __syncthreads();
+    int before = carry, total = 0;
+    for (int w = 0; w < NW; ++w) { if (w < wave) before += wtot[w]; total += wtot[w]; }
+    __syncthreads();
+    carry += total;
+    return before + wi - x;
+}
+// same from the last thread towards the first: number of flagged threads strictly after this one (+ carry)
+template <int NT> __device__ __forceinline__ int block_excl_scan_add_rev(int x, int &carry, int *wtot, int tid) {
+    constexpr int NW = NT / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    int wi = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_down(wi, d);
+        if (lane + d < 64) wi += o;
+    }
+    if (lane == 0) wtot[wave] = wi;
+    __syncthreads();
+    int after = carry, total = 0;
+    for (int w = 0; w < NW; ++w) { if (w > wave) after += wtot[w]; total += wtot[w]; }
+    __syncthreads();
+    carry += total;
+    return after + wi - x;
+}
+
+template <typename KeyT, bool SPARSE, bool OVO>
 __global__ __launch_bounds__(OVR_NT) void k_ovr_gene(OvrParams P) {
     constexpr int NT = OVR_NT, NW = NT / 64, E = OVR_E;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
@@ -82,14 +121,16 @@ __global__ __launch_bounds__(OVR_NT) void k_ovr_gene(OvrParams P) {
     int *wtot = (int *)(dbase + 256);        // [NW]
     u64 *red = (u64 *)(wtot + NW + (NW & 1)); // [NW]
     int *flag = (int *)(red + NW);           // [4]
-    u64 *R2 = (u64 *)(flag + 4);             // [G]
-    u32 *gcnt = (u32 *)(R2 + P.G);           // [G] (SPARSE only)
+    u64 *R2 = (u64 *)(flag + 4);             // [G]  OVR: 2*ranksum;  OVO: S2
+    u64 *tieg = R2 + P.G;                    // [G]  OVO only: per-group tie term
+    u32 *gcnt = (u32 *)(OVO ? tieg + P.G : tieg); // [G] (SPARSE OVR only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = P.G;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     for (int gene = blockIdx.x; gene < P.n_genes; gene += gridDim.x) {
+        if (OVO && P.gene_flags && P.gene_flags[gene] == 0) continue; // handled by the histogram route
         long long start;
         int n;
         const u32 *sp = nullptr;
@@ -203,6 +244,100 @@ __global__ __launch_bounds__(OVR_NT) void k_ovr_gene(OvrParams P) {
         const KeyT *K = ksrc;
         const u32 *V = vsrc;
 
+        if constexpr (OVO) {
+            // ---- one-versus-reference from the globally sorted column (any group / reference size) ----
+            // The pairs went into the stable sort group by group, so inside a run of equal keys the members are
+            // ordered by group: every (value, group) sub-run is contiguous.  With R(i) = # reference cells at
+            // sorted slots < i, a cell b of a value-run [s, e) has #ref<b = R(s), #ref==b = R(e)-R(s):
+            //   S2[g]  += R(s) + R(e)                                  (forward sweep adds R(s), backward R(e))
+            //   tie[g] += tB (3 a (a+tB) + tB^2 - 1), a = R(e)-R(s)    (at the tail of each (value, group) sub-run)
+            //   T_A    += tA^3 - tA                                    (at the tail of each reference sub-run)
+            u32 *tmpRs = vdst;            // free ping-pong buffers hold R(s) and the sub-run start
+            u32 *tmpSS = (u32 *)kdst;
+            const int ref = P.ref;
+            const int n_ref = P.counts[ref];
+            const int nA = SPARSE ? (int)(sp[ref + 1] - sp[ref]) : n_ref;
+            const u64 zA = (u64)(n_ref - nA);
+            for (int g = tid; g < G; g += NT) { R2[g] = 0; tieg[g] = 0; }
+            __syncthreads();
+            int carryR = 0, carryRs = 0, carrySS = 0;
+            u64 nneg_l = 0;
+            for (int cbase = 0; cbase < n; cbase += NT) {
+                const int i = cbase + tid;
+                const bool valid = i < n;
+                const KeyT k = valid ? K[i] : (KeyT)0;
+                const int gcode = valid ? (int)V[i] : -1;
+                const bool isref = valid && gcode == ref;
+                const int Rex = block_excl_scan_add<NT>(isref ? 1 : 0, carryR, wtot, tid);
+                const bool hv = valid && (i == 0 || K[i - 1] != k);
+                int dummy;
+                const int Rs = block_incl_scan_max<NT>(hv ? Rex : -1, carryRs, wtot, tid, dummy);
+                const bool hs = valid && (hv || (int)V[i - 1] != gcode);
+                const int ss = block_incl_scan_max<NT>(hs ? i : -1, carrySS, wtot, tid, dummy);
+                if (valid) {
+                    tmpRs[i] = (u32)Rs;
+                    tmpSS[i] = (u32)ss;
+                    if (!isref) atomicAdd(&R2[gcode], (u64)Rs + ((SPARSE && k > ZEROK) ? 2ull * zA : 0ull));
+                    else if (k < ZEROK) ++nneg_l;
+                }
+                const int last = min(n - 1 - cbase, NT - 1);
+                if (tid == last) { flag[1] = Rs; flag[2] = ss; }
+                __syncthreads();
+                carryRs = flag[1];
+                carrySS = flag[2];
+                __syncthreads();
+            }
+            __threadfence_block();
+            __syncthreads();
+            int carrySuf = 0, carryRe = nA;
+            u64 ta = 0;
+            const int nchunks = (n + NT - 1) / NT;
+            for (int c = nchunks - 1; c >= 0; --c) {
+                const int i = c * NT + tid;
+                const bool valid = i < n;
+                const KeyT k = valid ? K[i] : (KeyT)0;
+                const int gcode = valid ? (int)V[i] : -1;
+                const bool isref = valid && gcode == ref;
+                const int Rsuf = block_excl_scan_add_rev<NT>(isref ? 1 : 0, carrySuf, wtot, tid);
+                const int Rin = nA - Rsuf; // # reference cells at slots <= i
+                const bool tv = valid && (i == n - 1 || K[i + 1] != k);
+                const int Re = block_incl_scan_min_rev<NT>(tv ? Rin : 0x7FFFFFFF, carryRe, wtot, tid);
+                if (valid) {
+                    if (!isref) atomicAdd(&R2[gcode], (u64)Re);
+                    const bool ts = tv || (int)V[i + 1] != gcode;
+                    if (ts) {
+                        const u64 tB = (u64)(i - (int)tmpSS[i] + 1);
+                        if (isref) ta += tB * tB * tB - tB;
+                        else {
+                            const u64 a = (u64)(Re - (int)tmpRs[i]);
+                            atomicAdd(&tieg[gcode], tB * (3ull * a * (a + tB) + tB * tB - 1ull));
+                        }
+                    }
+                }
+                if (tid == 0) flag[1] = Re;
+                __syncthreads();
+                carryRe = flag[1];
+                __syncthreads();
+            }
+            ta = wave_sum(ta);
+            nneg_l = wave_sum(nneg_l);
+            if (lane == 0) { red[wave] = ta; ((u64 *)wcnt)[wave] = nneg_l; }
+            __syncthreads();
+            u64 T_A = 0, nneg = 0;
+            for (int w = 0; w < NW; ++w) { T_A += red[w]; nneg += ((u64 *)wcnt)[w]; }
+            for (int g = tid; g < G; g += NT) {
+                const size_t o = (size_t)gene * G + g;
+                if (g == ref) { P.out_2u[o] = -2; P.out_tie[o] = 0; continue; }
+                const long long n_g = P.counts[g];
+                const u64 zB = SPARSE ? (u64)(n_g - (long long)(sp[g + 1] - sp[g])) : 0ull;
+                const u64 s2 = R2[g] + zB * (2ull * nneg + zA);
+                const u64 t0 = zA + zB;
+                P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)s2;
+                P.out_tie[o] = T_A + tieg[g] + (t0 * t0 * t0 - t0);
+            }
+            __syncthreads();
+            continue;
+        }
         // ---- sweeps over the sorted column ----
         for (int g = tid; g < G; g += NT) { R2[g] = 0; if (SPARSE) gcnt[g] = 0; }
         __syncthreads();
@@ -274,9 +409,9 @@ __global__ __launch_bounds__(OVR_NT) void k_ovr_gene(OvrParams P) {
     }
 }
 
-static inline size_t ovr_lds_bytes(int G, bool sparse) {
+static inline size_t ovr_lds_bytes(int G, bool sparse, bool ovo = false) {
     const int NW = OVR_NT / 64;
     size_t b = (size_t)NW * 256 * 4 + 256 * 4 + 256 * 4 + (NW + (NW & 1)) * 4 + NW * 8 + 16;
-    b += (size_t)G * 8 + (sparse ? (size_t)G * 4 : 0);
+    b += (size_t)G * 8 + (ovo ? (size_t)G * 8 : 0) + (sparse ? (size_t)G * 4 : 0);
     return b;
 }

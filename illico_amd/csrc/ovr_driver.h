@@ -1,12 +1,12 @@
 // Host-side launch of the OVR per-gene kernel (included by illico_hip.hip after the context helpers).
 #pragma once
 
-template <typename KeyT, bool SPARSE>
+template <typename KeyT, bool SPARSE, bool OVO = false>
 static int launch_ovr_gene(illico_ctx *c, const OvrParams &P) {
-    size_t lds = ovr_lds_bytes(P.G, SPARSE);
+    size_t lds = ovr_lds_bytes(P.G, SPARSE, OVO);
     if (lds > kMaxLds)
-        return fail(c, ILLICO_ERR_UNSUPPORTED, "OVR with %d groups does not fit the LDS accumulators of this build", P.G);
-    auto kern = k_ovr_gene<KeyT, SPARSE>;
+        return fail(c, ILLICO_ERR_UNSUPPORTED, "%d groups do not fit the LDS accumulators of the global-sort route in this build", P.G);
+    auto kern = k_ovr_gene<KeyT, SPARSE, OVO>;
     HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         ProfScope ps(c, KID_OVR_SCAN);
@@ -38,7 +38,7 @@ static int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     P.keys_a = Xt; P.keys_b = kb; P.vals_a = va; P.vals_b = vb;
     P.code_by_pos = c->d_code_by_pos; P.seg_ptr = nullptr; P.stride = stride; P.pos_ptr = c->d_posptr;
     P.counts = c->d_counts; P.G = (int)c->n_groups; P.n_genes = nb; P.dt = dtype;
-    P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = N;
+    P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = N; P.ref = -1; P.gene_flags = nullptr;
     P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
     if ((rc = launch_ovr_gene<KeyT, false>(c, P))) return rc;
     return launch_gene_totals(c, ssum, (int)c->n_groups, nb, gtot);

@@ -92,7 +92,8 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         for (int64_t j = 0; j < W; ++j) gene_nnz[j] = h_cc[j];
     }
 
-    const size_t per_nnz = sizeof(KeyT) * (ovr ? 2 : 1) + (ovr ? 8 : 0) + ((!in_dev && !is_csr) ? sizeof(InT) + sizeof(IdxT) : 0);
+    const bool may_glob = !ovr && !ovo_sort_route_fits<KeyT>(c->h_counts[c->ref], c->max_nonref);
+    const size_t per_nnz = sizeof(KeyT) * ((ovr || may_glob) ? 2 : 1) + ((ovr || may_glob) ? 8 : 0) + ((!in_dev && !is_csr) ? sizeof(InT) + sizeof(IdxT) : 0);
     const size_t per_gene = (size_t)(G + 1) * 4 * (is_csr ? 2 : 1) + (size_t)G * 24 + 64;
     auto batches = plan_batches(gene_nnz, col_lb, per_nnz, per_gene, c->gene_batch, (size_t)c->scratch_bytes);
 
@@ -105,7 +106,10 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         u32 *seg = (u32 *)v;
         u32 *va = nullptr, *vb = nullptr;
         void *kb = nullptr;
-        if (ovr) {
+        const int64_t ref_cap_b = ovr ? 0 : std::min<int64_t>(c->h_counts[c->ref], b.max_gene);
+        const int64_t grp_cap_b = std::min<int64_t>(c->max_nonref, b.max_gene);
+        const bool need_glob = !ovr && !ovo_sort_route_fits<KeyT>(ref_cap_b, grp_cap_b);
+        if (ovr || need_glob) {
             if ((rc = get_scratch(c, "ovr_kb", nnz * sizeof(KeyT), &v))) return rc;
             kb = v;
             if ((rc = get_scratch(c, "ovr_va", nnz * 4, &v))) return rc;
@@ -172,15 +176,15 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             P.Xs = Xs; P.gene_stride = 0; P.pos_ptr = c->d_posptr; P.seg_ptr = seg; P.counts = c->d_counts;
             P.G = G; P.ref = (int)c->ref; P.n_genes = nb; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
             P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
-            int64_t ref_cap = std::min<int64_t>(c->h_counts[c->ref], b.max_gene);
-            int64_t grp_cap = std::min<int64_t>(c->max_nonref, b.max_gene);
-            if ((rc = launch_ovo<KeyT>(c, P, ref_cap, grp_cap, gflags))) return rc;
+            OvoGlobalBufs gb;
+            gb.kb = kb; gb.va = va; gb.vb = vb;
+            if ((rc = launch_ovo<KeyT>(c, P, ref_cap_b, grp_cap_b, gflags, &gb, true))) return rc;
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b.g0 - col_lb))) return rc;
         } else {
             OvrParams P;
             P.keys_a = Xs; P.keys_b = kb; P.vals_a = va; P.vals_b = vb; P.code_by_pos = nullptr; P.seg_ptr = seg;
             P.stride = 0; P.pos_ptr = nullptr; P.counts = c->d_counts; P.G = G; P.n_genes = nb; P.dt = dtype;
-            P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows;
+            P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.ref = -1; P.gene_flags = nullptr;
             P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
             if ((rc = launch_ovr_gene<KeyT, true>(c, P))) return rc;
             if ((rc = launch_gene_totals(c, ssum, G, nb, gtot))) return rc;

@@ -138,11 +138,14 @@ def _counts_route_body(engine):
     assert_planes_match(got, want, what="counts route, big groups")
     for dt in (np.int32, np.float64, np.int64):
         assert_planes_match(_run(engine, X.astype(dt), g), want, what=f"counts route {dt}")
-    # a gene outside the table needs the sort route, which cannot hold these group sizes: loud failure
-    Xbad = X.copy()
-    Xbad[0, 2] = 0.5
-    with pytest.raises(NotImplementedError):
-        _run(engine, Xbad, g)
+    # genes outside the tables take the sort route; at these sizes that is the global radix-sort fallback
+    Xmix = X.copy()
+    Xmix[0, 2] = 0.5
+    Xmix[:, 7] = rng.randn(n)                     # continuous, mixed sign
+    Xmix[:, 8] = np.round(rng.randn(n) * 2) / 2   # heavy ties at half-integers
+    assert_planes_match(_run(engine, Xmix, g), oracle.run(Xmix, g), fc_rtol=1e-9, what="global-sort fallback")
+    assert_planes_match(_run(engine, Xmix.astype(np.float64), g), oracle.run(Xmix.astype(np.float64), g), fc_rtol=1e-9,
+                        what="global-sort fallback f64")
     # moderate sizes: mixed routes in one call
     sizes = [900, 700, 300, 64, 1]
     codes = np.concatenate([np.full(s, i) for i, s in enumerate(sizes)])

@@ -128,3 +128,23 @@ def test_csr_sorted_check_and_drop_in(engine):
         want = oracle.run(X, g)
         got = df.values.reshape(len(uniq), X.shape[1], 3)
         assert_planes_match((got[:, :, 0], got[:, :, 1], got[:, :, 2]), want, ref_row=g.encoded_ref_group, what=fmt)
+
+
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+def test_sparse_ovo_big_groups_any_values(engine, fmt):
+    """Group / reference sizes beyond the in-LDS sort route with non-count values: global radix-sort fallback."""
+    rng = np.random.RandomState(17)
+    sizes = [30000, 2500, 1200, 300, 5]
+    codes = np.concatenate([np.full(s, i) for i, s in enumerate(sizes)])
+    rng.shuffle(codes)
+    labels = np.array([f"g{c:02d}" for c in codes])
+    n = codes.size
+    X = (rng.rand(n, 10) * (rng.rand(n, 10) < 0.4)).astype(np.float32)   # continuous positives, 60 % zeros
+    X[:, 1] = np.where(rng.rand(n) < 0.5, 0, rng.randint(1, 5, size=n))  # count-valued gene (histogram route)
+    X[:, 2] = np.where(rng.rand(n) < 0.7, 0, rng.randn(n))               # negatives stored explicitly
+    M = (sparse.csc_matrix if fmt == "csc" else sparse.csr_matrix)(X)
+    for ref in ("g00", "g02"):
+        _, g = oracle.encode_and_count_groups(labels, ref)
+        want = oracle.run(X, g)     # dense semantics (negatives rank below the zero block)
+        got = _run(engine, M, g)
+        assert_planes_match(got, want, fc_rtol=1e-9, what=f"{fmt} ref={ref}")
