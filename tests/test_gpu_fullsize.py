@@ -1,0 +1,119 @@
+"""Full-size (BASELINE.json configs 2-4) checks on the GPU through size-independent properties, plus spot
+checks of sampled genes against the CPU oracle.  Data are generated on the device (bench.py recipe)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import assert_planes_match
+
+pytestmark = pytest.mark.gpu
+
+N, M, G = 300_000, 8_000, 2_000
+
+
+@pytest.fixture(scope="module")
+def c2():
+    import torch
+    from bench import group_container, make_labels, make_matrix
+    from illico_amd._lib import Engine
+    dev = torch.device("cuda", 0)
+    codes = make_labels(N, G, 0)
+    X = make_matrix(torch, N, M, 0.5, 0, dev)
+    eng = Engine(0)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    yield {"torch": torch, "X": X, "codes": codes, "eng": eng, "gc": group_container}
+    eng.close()
+
+
+def _planes(c2, grpc, X=None, lb=0, ub=None, **kw):
+    torch = c2["torch"]
+    X = c2["X"] if X is None else X
+    ub = X.shape[1] if ub is None else ub
+    c2["eng"].set_groups(grpc)
+    out = c2["eng"].run_dense(X, lb, ub, device_out=True, **kw)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_c2_ovo_full_pass_properties_and_spot_checks(c2):
+    torch = c2["torch"]
+    grpc = c2["gc"](c2["codes"], G, False)
+    p, u, fc = _planes(c2, grpc)
+    counts = torch.from_numpy(grpc.counts).cuda().double()
+    n_ref = float(grpc.counts[0])
+    # ranges: 0 <= U <= n_ref * n_g, 2U integral, 0 <= p <= 1, reference row = (1, -1)
+    assert bool((u[1:] >= 0).all()) and bool((u[1:] <= (n_ref * counts[1:]).unsqueeze(1)).all())
+    assert bool(((2 * u[1:]) == torch.round(2 * u[1:])).all())
+    assert bool(((p >= 0) & (p <= 1)).all()) and bool((p[0] == 1).all()) and bool((u[0] == -1).all())
+    assert bool(torch.isfinite(fc[1:]).all())
+    # spot check: sampled genes against the CPU oracle at full N and G
+    cols = [0, 1, 1234, 4000, 7999]
+    Xs = c2["X"][:, cols].contiguous().cpu().numpy()
+    want = oracle.run(Xs, grpc, batch_size=1, n_threads=len(cols))
+    got = tuple(a[:, cols].cpu().numpy() for a in (p, u, fc))
+    assert_planes_match(got, want, ref_row=0, what="C2 OVO spot check")
+
+
+def test_c2_routes_agree_bitwise_on_a_gene_slice(c2):
+    """Fused single-pass route == two-pass histogram route == sort route (same integers, same finalisation)."""
+    grpc = c2["gc"](c2["codes"], G, False)
+    eng = c2["eng"]
+    ref = [a.cpu().numpy() for a in _planes(c2, grpc, lb=512, ub=768)]
+    for opt in ("no_fused_path", "no_counts_path"):
+        eng.set_option(opt, 1)
+        try:
+            got = [a.cpu().numpy() for a in _planes(c2, grpc, lb=512, ub=768)]
+        finally:
+            eng.set_option(opt, 0)
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a, b, err_msg=opt)
+
+
+def test_c2_ovo_reference_swap_symmetry(c2):
+    """U(ref=A, grp=B) + U(ref=B, grp=A) = n_A n_B, and the two-sided p-values agree (a size-independent identity)."""
+    codes = c2["codes"]
+    gA = c2["gc"](codes, G, False)                      # reference = group 0
+    u_ab = _planes(c2, gA, ub=256)[1][7].cpu().numpy()  # U of the reference vs group 7
+    p_ab = _planes(c2, gA, ub=256)[0][7].cpu().numpy()
+    from illico_amd.utils.groups import GroupContainer
+    gB = GroupContainer(gA.encoded_groups, gA.counts, gA.indices, gA.indptr, 7)
+    out = _planes(c2, gB, ub=256)
+    u_ba, p_ba = out[1][0].cpu().numpy(), out[0][0].cpu().numpy()
+    np.testing.assert_array_equal(u_ab + u_ba, float(gA.counts[0]) * float(gA.counts[7]))
+    np.testing.assert_allclose(p_ab, p_ba, rtol=1e-12, atol=0)
+
+
+def test_c4_ovr_rank_sum_checksum_and_spot_checks(c2):
+    """OVR: per gene sum_g ranksum_g = N(N+1)/2, with ranksum_g = n_rest n_g + n_g(n_g+1)/2 - U_g (dense_ovr.py:57-61)."""
+    torch = c2["torch"]
+    grpc = c2["gc"](c2["codes"], G, True)
+    p, u, fc = _planes(c2, grpc)
+    n_g = torch.from_numpy(grpc.counts).cuda().double().unsqueeze(1)
+    ranksum = (N - n_g) * n_g + n_g * (n_g + 1) / 2 - u
+    total = ranksum.sum(0)
+    assert bool((total == N * (N + 1) / 2).all())
+    assert bool(((p >= 0) & (p <= 1)).all())
+    cols = [3, 2500, 7998]
+    Xs = c2["X"][:, cols].contiguous().cpu().numpy()
+    want = oracle.run(Xs, grpc, batch_size=1, n_threads=len(cols))
+    got = tuple(a[:, cols].cpu().numpy() for a in (p, u, fc))
+    assert_planes_match(got, want, what="C4 OVR spot check")
+
+
+def test_c3_sparse_formats_equal_dense_on_a_gene_slice(c2):
+    """CSC and CSR inputs give the same planes as the dense input of the same data (90 % zeros), OVO and OVR."""
+    torch = c2["torch"]
+    from scipy import sparse
+    Xd = c2["X"][:, 1000:1192].contiguous()
+    Xd = Xd * (torch.rand(Xd.shape, device=Xd.device) < 0.2)   # ~90 % zeros overall
+    Xh = Xd.cpu().numpy()
+    eng = c2["eng"]
+    for ovr in (False, True):
+        grpc = c2["gc"](c2["codes"], G, ovr)
+        dense = [a.cpu().numpy() for a in _planes(c2, grpc, X=Xd)]
+        for fmt, ctor in (("csc", sparse.csc_matrix), ("csr", sparse.csr_matrix)):
+            Ms = ctor(Xh)
+            eng.set_groups(grpc)
+            got = eng.run_sparse(fmt, Ms.data, Ms.indices, Ms.indptr, Ms.shape, 0, Ms.shape[1])
+            for a, b in zip(got, dense):
+                np.testing.assert_array_equal(a, b, err_msg=f"{fmt} ovr={ovr}")
