@@ -213,6 +213,8 @@ class Engine:
                 planes = tuple(np.empty((G, W), dtype=np.float64) for _ in range(3))
         else:
             planes = tuple(out)
+        if W == 0:  # empty chunk (lb == ub is legal, asymptotic_wilcoxon.py:49): nothing to compute
+            return planes, None, 0, 1
         ptrs, flag, ld = [], 0, None
         for p in planes:
             if _is_torch_tensor(p):
@@ -253,6 +255,8 @@ class Engine:
             raise ValueError(f"Invalid chunk bounds: {(col_lb, col_ub)} for data with {n_cols} columns.")
         G, W = self.n_groups, col_ub - col_lb
         planes, ptrs, oflag, out_ld = self._outputs(out, G, W, device_out)
+        if ptrs is None:
+            return planes
         flags = self._flags(is_log1p, use_continuity, tie_correct) | (FLAG_INPUT_DEVICE if on_dev else 0) | oflag
         self._check(self.lib.illico_run_dense(self.h, buf_ptr, dt, n_rows, n_cols, ld, col_lb, col_ub, flags, alt,
                                               ptrs[0], ptrs[1], ptrs[2], out_ld))
@@ -277,6 +281,8 @@ class Engine:
             raise ValueError(f"Invalid chunk bounds: {(col_lb, col_ub)} for data with {n_cols} columns.")
         G, W = self.n_groups, col_ub - col_lb
         planes, ptrs, oflag, out_ld = self._outputs(out, G, W, device_out)
+        if ptrs is None:
+            return planes
         flags = self._flags(is_log1p, use_continuity, tie_correct) | (FLAG_INPUT_DEVICE if d.on_device else 0) | oflag
         fn = self.lib.illico_run_csc if fmt == "csc" else self.lib.illico_run_csr
         self._check(fn(self.h, d.ptr, dtype_code(d.np_dtype), i.ptr, p.ptr, IDX_I32 if i.np_dtype == np.int32 else IDX_I64,

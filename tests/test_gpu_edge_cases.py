@@ -1,0 +1,105 @@
+"""Degenerate shapes and values through the C-ABI (dense + sparse, host + device input) vs the oracle."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import oracle
+from conftest import assert_planes_match
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from illico_amd._lib import get_engine
+    return get_engine()
+
+
+def _all_inputs(X):
+    import torch
+    yield "dense-host", lambda e, lb, ub, **kw: e.run_dense(X, lb, ub, **kw)
+    Xd = torch.from_numpy(np.ascontiguousarray(X)).cuda()
+    yield "dense-device", lambda e, lb, ub, **kw: e.run_dense(Xd, lb, ub, **kw)
+    for fmt, ctor in (("csc", sparse.csc_matrix), ("csr", sparse.csr_matrix)):
+        M = ctor(X)
+        yield fmt, (lambda e, lb, ub, M=M, fmt=fmt, **kw: e.run_sparse(fmt, M.data, M.indices, M.indptr, M.shape, lb, ub, **kw))
+
+
+def _check(engine, X, labels, ref, what, **kw):
+    _, g = oracle.encode_and_count_groups(labels, ref)
+    want = oracle.run(X, g, **kw)
+    engine.set_groups(g)
+    for name, fn in _all_inputs(X):
+        got = fn(engine, 0, X.shape[1], **kw)
+        assert_planes_match(got, want, ref_row=g.encoded_ref_group if ref is not None else None, fc_rtol=1e-9,
+                            what=f"{what} [{name}]")
+
+
+@pytest.mark.parametrize("ref", ["a", None])
+def test_two_groups_one_gene(engine, ref):
+    rng = np.random.RandomState(0)
+    X = rng.poisson(2.0, size=(50, 1)).astype(np.float32)
+    labels = np.array(["a"] * 20 + ["b"] * 30)
+    _check(engine, X, labels, ref, "2 groups x 1 gene")
+
+
+@pytest.mark.parametrize("ref", ["g0", None])
+def test_single_cell_groups_and_reference_of_one_cell(engine, ref):
+    rng = np.random.RandomState(1)
+    labels = np.array(["g0"] + ["g1"] + ["g2"] * 5 + ["g3"] * 70)
+    X = rng.poisson(1.5, size=(labels.size, 7)).astype(np.float32)
+    _check(engine, X, labels, ref, "single-cell groups")
+
+
+@pytest.mark.parametrize("ref", ["a", None])
+def test_all_zero_and_constant_matrices(engine, ref):
+    labels = np.array(["a"] * 10 + ["b"] * 12 + ["c"] * 3)
+    for X in (np.zeros((25, 5), np.float32), np.full((25, 5), 3.0, np.float32)):
+        # tie_corr == 0 -> p = 1 (math.py:96,117-118); all-zero columns give fold change inf (0/0 -> inf, math.py:192)
+        _check(engine, X, labels, ref, "constant matrix")
+
+
+def test_ovr_single_group(engine):
+    # one group: "the rest" is empty (n_ref = 0): the reference divides by zero the same way (nan / inf planes)
+    X = np.arange(12, dtype=np.float32).reshape(6, 2)
+    labels = np.array(["only"] * 6)
+    _, g = oracle.encode_and_count_groups(labels, None)
+    with np.errstate(all="ignore"):
+        want = oracle.run(X, g)
+    engine.set_groups(g)
+    got = engine.run_dense(X, 0, 2)
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_array_equal(np.isnan(got[0]), np.isnan(want[0]))
+
+
+def test_empty_window_and_many_options(engine):
+    rng = np.random.RandomState(2)
+    X = rng.poisson(3.0, size=(300, 9)).astype(np.float32)
+    labels = np.array([f"g{i % 4}" for i in range(300)])
+    _, g = oracle.encode_and_count_groups(labels, "g1")
+    engine.set_groups(g)
+    p, u, fc = engine.run_dense(X, 4, 4)   # empty chunk: three [G, 0] planes (asymptotic_wilcoxon.py:49: lb == ub allowed)
+    assert p.shape == (4, 0) and u.shape == (4, 0) and fc.shape == (4, 0)
+    for alt in ("two-sided", "less", "greater"):
+        for cc in (True, False):
+            for tc in (True, False):
+                _check(engine, X, labels, "g1", f"{alt} {cc} {tc}", alternative=alt, use_continuity=cc, tie_correct=tc)
+                _check(engine, X, labels, None, f"ovr {alt} {cc} {tc}", alternative=alt, use_continuity=cc, tie_correct=tc)
+
+
+def test_large_values_and_table_boundaries(engine):
+    """Values around the histogram-table limits (63/64 and 2047/2048) and beyond, negative zero, huge floats."""
+    rng = np.random.RandomState(3)
+    n = 900
+    labels = np.array([f"g{i % 6}" for i in range(n)])
+    X = np.zeros((n, 8), np.float32)
+    X[:, 0] = rng.randint(0, 64, size=n)
+    X[:, 1] = rng.randint(0, 65, size=n)
+    X[:, 2] = rng.randint(0, 2048, size=n)
+    X[:, 3] = rng.randint(0, 2049, size=n)
+    X[:, 4] = rng.randint(0, 3, size=n) * 1e30
+    X[:, 5] = np.where(rng.rand(n) < 0.5, -0.0, 0.0) + rng.randint(0, 2, size=n)
+    X[:, 6] = rng.randint(-3, 4, size=n)
+    X[:, 7] = rng.randint(0, 4, size=n) + 0.5
+    _check(engine, X, labels, "g2", "table boundaries ovo")
+    _check(engine, X, labels, None, "table boundaries ovr")
