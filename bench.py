@@ -45,10 +45,11 @@ def parse():
     ap.add_argument("--sparsity", type=float, default=0.5)
     ap.add_argument("--test", choices=["ovo", "ovr"], default="ovo")
     ap.add_argument("--gene-batch", type=int, default=0, help="genes per engine pass (0 = auto)")
-    ap.add_argument("--gather-batches", type=int, default=4, help="gene blocks per step whose gather overlaps compute (N>1)")
+    ap.add_argument("--gather-batches", type=int, default=8, help="gene blocks per step whose gather overlaps compute (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--engine-option", action="append", default=[], help="key=value passed to illico_ctx_set_option")
     return ap.parse_args()
 
 
@@ -117,6 +118,9 @@ def main():
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.gene_batch:
         eng.set_option("gene_batch", args.gene_batch)
+    for kv in args.engine_option:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     eng.set_groups(grpc)
     n_blocks = max(1, args.gather_batches) if world > 1 else 1
     blocks = shard_bounds(M, n_blocks)

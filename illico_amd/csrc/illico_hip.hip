@@ -63,6 +63,7 @@ struct illico_ctx {
     int64_t scratch_bytes = 24ll << 30;
     bool no_counts_path = false;
     bool no_fused_path = false;
+    int fused_groups_per_wg = 0; // 0 = auto
     bool profile = false;
     std::vector<ProfEvent> events;
     double prof_ms[KID_COUNT] = {0};
@@ -206,6 +207,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "profile")) c->profile = value != 0;
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
+    else if (!strcmp(key, "fused_groups_per_wg")) c->fused_groups_per_wg = (int)std::max<int64_t>(0, value);
     else return fail(c, ILLICO_ERR_ARG, "unknown option '%s'", key);
     return ILLICO_OK;
 }
@@ -305,9 +307,9 @@ template <typename KeyT> static size_t ovo_lds_bytes(int ref_cap, bool runend, i
     return b;
 }
 
-template <typename KeyT, int KMAX, bool RUNEND>
+template <typename KeyT, int KMAX, bool RUNEND, bool LG>
 static int launch_ovo_t(illico_ctx *c, const OvoParams &P, size_t lds, const u32 *flags) {
-    auto kern = k_ovo_rank<KeyT, KMAX, RUNEND, kOvoThreads>;
+    auto kern = k_ovo_rank<KeyT, KMAX, RUNEND, kOvoThreads, LG>;
     HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(c, KID_OVO_RANK);
     hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(kOvoThreads), lds, c->stream, P, flags);
@@ -354,8 +356,12 @@ static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t m
     size_t lds = ovo_lds_bytes<KeyT>(ref_cap, runend, kOvoThreads);
     P.ref_cap = ref_cap;
     bool big = max_grp_nnz > 256;
-    if (big) return runend ? launch_ovo_t<KeyT, 16, true>(c, P, lds, flags) : launch_ovo_t<KeyT, 16, false>(c, P, lds, flags);
-    return runend ? launch_ovo_t<KeyT, 4, true>(c, P, lds, flags) : launch_ovo_t<KeyT, 4, false>(c, P, lds, flags);
+    if (sparse) { // sparse layouts get the lane-per-group form as well
+        if (big) return runend ? launch_ovo_t<KeyT, 16, true, true>(c, P, lds, flags) : launch_ovo_t<KeyT, 16, false, true>(c, P, lds, flags);
+        return runend ? launch_ovo_t<KeyT, 4, true, true>(c, P, lds, flags) : launch_ovo_t<KeyT, 4, false, true>(c, P, lds, flags);
+    }
+    if (big) return runend ? launch_ovo_t<KeyT, 16, true, false>(c, P, lds, flags) : launch_ovo_t<KeyT, 16, false, false>(c, P, lds, flags);
+    return runend ? launch_ovo_t<KeyT, 4, true, false>(c, P, lds, flags) : launch_ovo_t<KeyT, 4, false, false>(c, P, lds, flags);
 }
 
 template <typename InT, typename KeyT>
@@ -472,8 +478,13 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.tie_correct = (flags & ILLICO_FLAG_TIE_CORRECT) ? 1 : 0;
     P.alternative = alternative;
     P.out_p = o.p + col_off; P.out_u = o.u + col_off; P.out_fc = o.fc + col_off; P.out_ld = o.ld;
-    P.groups_per_wg = 8;
     const int tiles = (nb + 63) / 64;
+    int gpw = c->fused_groups_per_wg;
+    if (gpw <= 0) { // 32 groups per workgroup measured best at C2; keep >= ~2048 workgroups on smaller problems
+        gpw = 32;
+        while (gpw > 4 && (int64_t)tiles * ((c->n_groups + gpw - 1) / gpw) < 2048) gpw >>= 1;
+    }
+    P.groups_per_wg = gpw;
     HIPCHK(c, hipMemsetAsync(P.gene_flags, 0, (size_t)nb * 4, c->stream));
     const dim3 main_grid(tiles, ((int)c->n_groups + P.groups_per_wg - 1) / P.groups_per_wg);
     if (!ovr) {
@@ -483,7 +494,10 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             HIPCHK(c, hipGetLastError());
         }
         ProfScope ps(c, KID_OVO_FUSED);
-        hipLaunchKernelGGL((k_ovo_fused<InT, RT, false>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        if (c->max_nonref <= 255) // 8-bit running multiplicities: 34 KB of LDS per workgroup instead of 50 KB
+            hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        else
+            hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
         HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipMemsetAsync(P.hist_all, 0, (size_t)nb * RT * 4, c->stream));
@@ -495,7 +509,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             HIPCHK(c, hipGetLastError());
         }
         ProfScope ps(c, KID_OVR_FUSED);
-        hipLaunchKernelGGL((k_ovo_fused<InT, RT, true>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
         HIPCHK(c, hipGetLastError());
     }
     h_flags.resize(nb);

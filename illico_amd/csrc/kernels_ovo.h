@@ -216,8 +216,54 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, c
     sumout = s;
 }
 
-template <typename KeyT, int KMAX, bool RUNEND, int NT>
-__global__ __launch_bounds__(NT, (KMAX <= 4 ? 1024 : 512) / NT * (NT / 256)) void k_ovo_rank(OvoParams P, const u32 *__restrict__ gene_flags) {
+// 64 SMALL groups at once, one per lane (sparse layouts: a (gene, group) run holds a handful of non-zeros, so a
+// wavefront per group would idle most lanes).  Each lane walks its own run; the number of earlier equal values
+// `o` is counted against the lane's own history in registers, and per element
+//     S2 += 2 #A<q + #A==q,      TT += t (t+1),  t = #A==q + o        (3 sum t(t+1) is the group's tie term)
+// -- the same integers as the run-based form of ovo_wave_group.  Returns per-lane (= per-group) totals.
+template <typename KeyT, int SMALL, bool RUNEND>
+__device__ __forceinline__ void ovo_lane_groups(const KeyT *__restrict__ Xs, long long bstart, int n, int nmax, const KeyT *A,
+                                                const u16 *runend, u32 nA, u32 topA, u32 zA, int dt, int is_log1p,
+                                                u64 &S2out, u64 &TTout, double &sumout) {
+    constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
+    KeyT e[SMALL];
+#pragma unroll
+    for (int j = 0; j < SMALL; ++j) e[j] = (j < n) ? Xs[bstart + j] : MAXK; // all loads in flight together
+    u64 S2 = 0, TT = 0;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < SMALL; ++j) {
+        if (j < nmax) { // wave-uniform
+            const KeyT q = e[j];
+            const bool valid = j < n;
+            u32 o = 0;
+#pragma unroll
+            for (int i = 0; i < j; ++i) o += (e[i] == q) ? 1u : 0u;
+            const u32 lb = lower_bound_pow2(A, nA, topA, q);
+            u32 a = 0;
+            if (lb < nA && A[lb] == q) {
+                if (RUNEND) a = (u32)runend[lb] - lb;
+                else a = upper_bound_pow2(A, nA, topA, q) - lb;
+            }
+            if (valid) {
+                const u64 lt = (u64)lb + ((q > ZEROK) ? (u64)zA : 0ull);
+                const u64 t = (u64)a + o;
+                S2 += 2ull * lt + a;
+                TT += t * (t + 1ull);
+                s += is_log1p ? key_to_expm1(q, dt) : key_to_double(q, dt);
+            }
+        }
+    }
+    S2out = S2;
+    TTout = TT;
+    sumout = s;
+}
+
+// LG: also compile the lane-per-group form for blocks of 64 short runs (sparse layouts); it needs more registers
+// (the lane's history), so the dense instantiations leave it out and keep 4 waves per SIMD.
+template <typename KeyT, int KMAX, bool RUNEND, int NT, bool LG>
+__global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 256)) void k_ovo_rank(OvoParams P, const u32 *__restrict__ gene_flags) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NW = NT / 64;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
@@ -296,6 +342,36 @@ __global__ __launch_bounds__(NT, (KMAX <= 4 ? 1024 : 512) / NT * (NT / 256)) voi
         KeyT *sk = sk_all + wave * 256;
         u32 *sb = sb_all + wave * 256;
         for (int g0 = wave * 64; g0 < G; g0 += NW * 64) {
+            if (LG && sp) { // sparse layout: are all 64 runs of this block small enough for the lane-per-group form?
+                constexpr int SMALL = sizeof(KeyT) == 4 ? 32 : 16;
+                const int gl = g0 + lane;
+                const bool has = gl < G && gl != ref;
+                const long long bs = has ? (long long)sp[gl] : 0;
+                const int n = has ? (int)(sp[gl + 1] - sp[gl]) : 0;
+                const int nmax = __builtin_amdgcn_readlane(wave_incl_scan_max(n), 63);
+                if (nmax <= SMALL) {
+                    u64 S2, TT;
+                    double sum;
+                    ovo_lane_groups<KeyT, SMALL, RUNEND>(Xs, bs, n, nmax, A, runend, nA, topA, zA, P.dt, P.is_log1p, S2, TT, sum);
+                    if (gl < G) {
+                        size_t o = (size_t)gene * G + gl;
+                        if (gl == ref) {
+                            P.out_2u[o] = -2;
+                            P.out_tie[o] = 0;
+                            P.out_sum[o] = refsum;
+                        } else {
+                            const long long n_g = P.counts[gl];
+                            const u64 zB = (u64)(n_g - n);
+                            S2 += zB * (2ull * nnegA + zA);
+                            const u64 t0 = (u64)zA + zB;
+                            P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
+                            P.out_tie[o] = T_A + 3ull * TT + (t0 * t0 * t0 - t0);
+                            P.out_sum[o] = sum;
+                        }
+                    }
+                    continue;
+                }
+            }
             TrReduce<u64> rS2, rTie;
             TrReduce<double> rSum;
             // The next group's keys are fetched into registers while the current group is processed: one

@@ -99,7 +99,9 @@ template <> __device__ __forceinline__ u32 clamp_count<int64_t, 64>(int64_t v, b
 // Per element (value c, reference multiplicity a = cum[c+1]-cum[c], o = earlier cells of the group with value c):
 //     S2 += cum[c] + cum[c+1];      TT += t (t+1),  t = a + o      [= a^2 + a(2o+1) + o(o+1)]
 // PRED: rows at or past p1 (group end) re-read the last row and are masked out.
-template <typename InT, int RT, int UU, bool PRED>
+// CB = bits per running-multiplicity counter: 16 (groups up to 65535 cells) or 8 (groups up to 255 cells: half
+// the LDS, so one more workgroup per CU).
+template <typename InT, int RT, int UU, bool PRED, int CB>
 __device__ __forceinline__ void fused_chunk(const InT *__restrict__ Xg, long long ld, const int *__restrict__ perm, int p, int p1,
                                             int lane, int lane_c, const u32 *ca, u32 *cb, u64 &S2, u64 &TT, u32 &vsum,
                                             bool &inexact) {
@@ -116,19 +118,20 @@ __device__ __forceinline__ void fused_chunk(const InT *__restrict__ Xg, long lon
         bool exact;
         const u32 c = clamp_count<InT, RT>(v[u], exact);
         const u32 lo = ca[c], hi = ca[c + 1];
-        const u32 sh = (c & 1u) << 4;
+        constexpr int PW = 32 / CB, LG = (CB == 16 ? 1 : 2), LB = (CB == 16 ? 4 : 3); // counters per word
+        const u32 sh = (c & (u32)(PW - 1)) << LB;
         if (PRED) {
             const bool valid = p + u < p1; // wave-uniform
             inexact |= valid && !exact;
-            const u32 old = atomicAdd(&cb[c >> 1], valid ? (1u << sh) : 0u);
-            const u32 t = valid ? (hi - lo) + __builtin_amdgcn_ubfe(old, sh, 16) : 0u;
+            const u32 old = atomicAdd(&cb[c >> LG], valid ? (1u << sh) : 0u);
+            const u32 t = valid ? (hi - lo) + __builtin_amdgcn_ubfe(old, sh, CB) : 0u;
             s2c += valid ? lo + hi : 0u;
             TT += (u64)t * (t + 1u);
             vsum += valid ? c : 0u;
         } else {
             inexact |= !exact;
-            const u32 old = atomicAdd(&cb[c >> 1], 1u << sh); // lane-private word (two 16-bit bins): fetch-and-add
-            const u32 t = (hi - lo) + __builtin_amdgcn_ubfe(old, sh, 16);
+            const u32 old = atomicAdd(&cb[c >> LG], 1u << sh); // lane-private word of packed counters: fetch-and-add
+            const u32 t = (hi - lo) + __builtin_amdgcn_ubfe(old, sh, CB);
             s2c += lo + hi;
             TT += (u64)t * (t + 1u);
             vsum += c;
@@ -286,9 +289,9 @@ __device__ __forceinline__ void fused_chunk_ovr(const InT *__restrict__ Xg, long
 }
 
 // ---- main pass: grid (tiles, group chunks); 4 wavefronts per workgroup, one group at a time per wavefront ----
-template <typename InT, int RT, bool OVR>
+template <typename InT, int RT, bool OVR, int CB>
 __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
-    constexpr int NW = FUSED_NT / 64, CSTR = RT + 1, BSTR = RT / 2 + 1, U = FUSED_U;
+    constexpr int NW = FUSED_NT / 64, CSTR = RT + 1, BSTR = (OVR ? 0 : RT * CB / 32) + 1, U = FUSED_U;
     __shared__ u32 cumA[64 * CSTR];        // cumA[lane*CSTR + c] = # reference cells of gene `lane` with value < c
     __shared__ u32 cntB[NW][64 * BSTR];    // per wavefront, per gene: running multiplicity of each value (16-bit pairs)
     __shared__ int s_skip;
@@ -332,8 +335,8 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
             for (; p + U <= p1; p += U) fused_chunk_ovr<InT, RT, U, false>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, S2, vsum);
             for (; p < p1; p += 8) fused_chunk_ovr<InT, RT, 8, true>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, S2, vsum);
         } else {
-            for (; p + U <= p1; p += U) fused_chunk<InT, RT, U, false>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
-            for (; p < p1; p += 8) fused_chunk<InT, RT, 8, true>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
+            for (; p + U <= p1; p += U) fused_chunk<InT, RT, U, false, CB>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
+            for (; p < p1; p += 8) fused_chunk<InT, RT, 8, true, CB>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
         }
         // ---- this lane's (group, gene) result ----
         const long long n_tgt = p1 - p0;

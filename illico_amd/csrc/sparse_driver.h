@@ -178,7 +178,11 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
             OvoGlobalBufs gb;
             gb.kb = kb; gb.va = va; gb.vb = vb;
-            if ((rc = launch_ovo<KeyT>(c, P, ref_cap_b, grp_cap_b, gflags, &gb, true))) return rc;
+            // When the in-LDS sort route holds this batch it serves every gene (its lane-per-group form makes the
+            // short runs of a sparse layout cheap for any key type); the histogram route is kept for the sizes it
+            // alone can take without the global-sort fallback.
+            const u32 *route_flags = need_glob ? gflags : nullptr;
+            if ((rc = launch_ovo<KeyT>(c, P, ref_cap_b, grp_cap_b, route_flags, &gb, true))) return rc;
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b.g0 - col_lb))) return rc;
         } else {
             OvrParams P;
