@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gene-batch", type=int, default=0, help="genes per engine pass (0 = auto)")
     ap.add_argument("--gather-batches", type=int, default=8, help="gene blocks per step whose gather overlaps compute (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--engine-option", action="append", default=[], help="key=value passed to illico_ctx_set_option")
     return ap.parse_args()
