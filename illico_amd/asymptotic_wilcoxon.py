@@ -19,6 +19,33 @@ from illico_amd.utils.registry import DataHandler, Test, data_handler_registry, 
 
 __all__ = ["asymptotic_wilcoxon", "operator"]
 
+#: host bytes of one streamed gene chunk of a backed input (two chunks are alive at any time)
+STREAM_CHUNK_BYTES = 256 << 20
+
+
+def _run_streaming(data_handler, iterator, group_container, is_log1p, use_continuity, alternative, tie_correct, planes):
+    """Backed inputs: chunk k+1 is read from storage by a prefetch thread while chunk k is copied to the GPU and
+    computed (file reads and the ctypes engine call both release the GIL).  At most two chunks live on the host."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    test = Test.OVR if group_container.encoded_ref_group == -1 else Test.OVO
+    dispatcher = dispatcher_registry.get(test, data_handler.kernel_data_format())
+
+    def fetch(bounds):
+        lb, ub = bounds
+        data, local = data_handler.fetch(lb, ub)
+        return data_handler.to_nb(data), local
+
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = pool.submit(fetch, iterator[0])
+        for k, (lb, ub) in enumerate(iterator):
+            X, local = nxt.result()
+            if k + 1 < len(iterator):
+                nxt = pool.submit(fetch, iterator[k + 1])
+            out = tuple(planes[j][:, lb:ub] for j in range(3))
+            dispatcher(X, *local, group_container, is_log1p, use_continuity, tie_correct, alternative, out=out)
+            del X
+
 
 def operator(data_handler: DataHandler, lb: int, ub: int, group_container: GroupContainer, is_log1p: bool,
              use_continuity: bool, alternative: str, tie_correct: bool, out=None):
@@ -85,7 +112,14 @@ def asymptotic_wilcoxon(
     n_genes = X.shape[1]
     n_groups = int(group_container.counts.size)
 
-    if n_genes < 256 or batch_size == "auto":
+    streams = bool(getattr(data_handler, "streams", False))
+    if streams and (batch_size == "auto" or n_genes < 256):
+        # out-of-core input: stream gene chunks of about STREAM_CHUNK_BYTES from storage (registry.py:162-188)
+        per_gene = max(1, X.shape[0] * getattr(getattr(X, "dtype", None), "itemsize", 4))
+        w = int(max(1, min(n_genes, STREAM_CHUNK_BYTES // per_gene)))
+        bounds = np.append(np.arange(0, n_genes, w), n_genes)
+        iterator = list(zip(bounds[:-1].tolist(), bounds[1:].tolist()))
+    elif n_genes < 256 or batch_size == "auto":
         iterator = [(0, n_genes)]
     elif isinstance(batch_size, (int, np.integer)) and not isinstance(batch_size, bool):
         bs = min(int(batch_size), math.ceil(n_genes / max(int(n_threads), 1)))
@@ -98,11 +132,13 @@ def asymptotic_wilcoxon(
 
     # three [G, n_genes] planes; each chunk writes its [:, lb:ub] window in place
     planes = np.empty((3, n_groups, n_genes), dtype=np.float64)
-    for lb, ub in iterator:
-        if ub == lb:
-            continue
-        out = tuple(planes[k][:, lb:ub] for k in range(3))
-        operator(data_handler, lb, ub, group_container, is_log1p, use_continuity, alternative, tie_correct, out=out)
+    iterator = [(lb, ub) for lb, ub in iterator if ub > lb]
+    if streams and len(iterator) > 1:
+        _run_streaming(data_handler, iterator, group_container, is_log1p, use_continuity, alternative, tie_correct, planes)
+    else:
+        for lb, ub in iterator:
+            out = tuple(planes[k][:, lb:ub] for k in range(3))
+            operator(data_handler, lb, ub, group_container, is_log1p, use_continuity, alternative, tie_correct, out=out)
 
     cols = pd.Series(np.asarray(adata.var_names), name="feature", dtype=str)
     rows = pd.Series(unique_raw_groups, name="pert", dtype=str)

@@ -94,6 +94,10 @@ class DataHandler(ABC):
 
 
 class InRAMDataHandler(DataHandler):
+    #: backed handlers (h5py / anndata backed / np.memmap) set this: fetch() reads one gene chunk from storage and
+    #: the driver streams chunks with a prefetch thread instead of handing the whole range to the engine
+    streams = False
+
     def fetch(self, lb: int, ub: int) -> tuple:
         return self.data, (lb, ub)
 
@@ -138,6 +142,20 @@ class CSCDataHandler(InRAMDataHandler):
         return self.data.data.nbytes + self.data.indptr.nbytes + self.data.indices.nbytes
 
 
+@data_handler_registry.register(np.memmap)
+class MemmapDenseDataHandler(DenseDataHandler):
+    """Dense matrix backed by a file (``np.load(..., mmap_mode="r")`` / ``np.memmap``): out-of-core like the
+    reference's h5py handler (registry.py:162-168) -- one gene chunk is paged in per fetch."""
+    streams = True
+
+    def fetch(self, lb: int, ub: int) -> tuple:
+        return np.ascontiguousarray(self.data[:, lb:ub]), (0, ub - lb)
+
+    @classmethod
+    def to_nb(cls, X) -> np.ndarray:
+        return np.asarray(X)
+
+
 for _name in ("csr_array", "csc_array"):  # scipy's array API twins
     _t = getattr(py_sparse, _name, None)
     if _t is not None:
@@ -165,6 +183,8 @@ try:  # out-of-core handlers (registry.py:162-188) when h5py / anndata are insta
 
     @data_handler_registry.register(_h5py.Dataset)
     class H5pyDatasetDataHandler(DenseDataHandler):
+        streams = True
+
         def fetch(self, lb: int, ub: int) -> tuple:
             return self.data[:, lb:ub], (0, ub - lb)
 except Exception:  # pragma: no cover
@@ -175,6 +195,8 @@ try:
 
     @data_handler_registry.register(_ad._core.sparse_dataset._CSCDataset)
     class H5pyBackedCSCDataHandler(CSCDataHandler):
+        streams = True
+
         def footprint(self) -> int:
             return self.data._data.nbytes + self.data._indptr.nbytes + self.data._indices.nbytes
 

@@ -252,3 +252,24 @@ def test_drop_in_call_dataframe(test):
         asymptotic_wilcoxon(AnnDataLite([[1.0]], obs=pd.DataFrame({"pert": ["a"]})) if False else
                             type("A", (), {"X": object(), "layers": {}, "obs": {"pert": ["a"]}, "var_names": ["g"]})(),
                             is_log1p=False, group_keys="pert")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_backed_memmap_input_streams_chunks(tmp_path, test, monkeypatch):
+    """Out-of-core dense input (np.memmap, the stand-in for the reference's h5py handler, registry.py:162-168):
+    gene chunks are streamed with a prefetch thread; results equal the in-RAM call; the file is not modified."""
+    import sys
+    from illico_amd import AnnDataLite, asymptotic_wilcoxon
+    aw = sys.modules["illico_amd.asymptotic_wilcoxon"]  # the module (the package attribute of that name is the function)
+    X, rng = make_counts(77, 1500, 300, 0.5)
+    X[:, 7] = rng.rand(1500)                       # a gene for the sort route
+    labels = make_labels(rng, 1500, 7, n_ref=120)
+    np.save(tmp_path / "x.npy", X)
+    mm = np.load(tmp_path / "x.npy", mmap_mode="r")
+    monkeypatch.setattr(aw, "STREAM_CHUNK_BYTES", 1500 * 4 * 37)   # 37 genes per chunk -> 9 chunks
+    ref = "non-targeting" if test == "ovo" else None
+    obs = pd.DataFrame({"pert": labels})
+    got = asymptotic_wilcoxon(AnnDataLite(mm, obs=obs), is_log1p=False, group_keys="pert", reference=ref)
+    want = asymptotic_wilcoxon(AnnDataLite(X, obs=obs), is_log1p=False, group_keys="pert", reference=ref)
+    pd.testing.assert_frame_equal(got, want)
+    np.testing.assert_array_equal(np.load(tmp_path / "x.npy"), X)

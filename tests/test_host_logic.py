@@ -148,3 +148,16 @@ def test_shard_bounds():
             assert max(w) - min(w) <= 1
         r = [rank_gene_range(n, k, 8) for k in range(8)]
         assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(7))
+
+
+def test_memmap_handler_is_backed_and_fetches_chunks(tmp_path):
+    from illico_amd.utils.registry import KernelDataFormat, data_handler_registry
+    X, _ = make_counts(0, 40, 12, 0.5)
+    np.save(tmp_path / "x.npy", X)
+    mm = np.load(tmp_path / "x.npy", mmap_mode="r")
+    h = data_handler_registry.get(mm)
+    assert h.streams and h.kernel_data_format() == KernelDataFormat.DENSE
+    chunk, bounds = h.fetch(3, 9)
+    assert bounds == (0, 6) and type(chunk) is np.ndarray and chunk.flags.c_contiguous
+    np.testing.assert_array_equal(chunk, X[:, 3:9])
+    assert not data_handler_registry.get(X).streams
