@@ -66,10 +66,8 @@ def load() -> ctypes.CDLL:
         lib.illico_profile_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
         lib.illico_profile_reset.argtypes = [vp]
         lib.illico_version.restype = ctypes.c_char_p
-        for name in SYMBOLS:
-            f = getattr(lib, name)
-            if f.restype is ctypes.c_int and name not in ("illico_profile_num_kernels",):
-                pass
+        for name in SYMBOLS:  # fail at load time, not at first use, if the library and the header have drifted
+            getattr(lib, name)
         _lib = lib
         return lib
 

@@ -28,15 +28,13 @@ enum {
     KID_OVR_FUSED,
     KID_FUSED_REF,
     KID_FINALIZE,
-    KID_RADIX_SORT,
     KID_OVR_SCAN,
     KID_SPARSE_SEG,
     KID_GENE_TOTALS,
-    KID_MISC,
     KID_COUNT
 };
-static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused", "k_fused_tables", "k_finalize",   "k_radix_sort",
-                                              "k_ovr_scan",          "k_sparse_seg", "k_gene_totals", "misc"};
+static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_gene_totals"};
 
 struct ProfEvent {
     int kid;

@@ -46,28 +46,6 @@ struct FusedParams {
     int groups_per_wg;
 };
 
-template <typename InT> __device__ __forceinline__ u32 small_count(InT v, int RT, bool &ok);
-template <> __device__ __forceinline__ u32 small_count<float>(float v, int RT, bool &ok) {
-    const bool inr = v >= 0.0f && v < (float)RT; // false for NaN
-    const u32 c = inr ? (u32)v : 0u;
-    ok = inr && (float)c == v;
-    return c;
-}
-template <> __device__ __forceinline__ u32 small_count<double>(double v, int RT, bool &ok) {
-    const bool inr = v >= 0.0 && v < (double)RT;
-    const u32 c = inr ? (u32)v : 0u;
-    ok = inr && (double)c == v;
-    return c;
-}
-template <> __device__ __forceinline__ u32 small_count<int32_t>(int32_t v, int RT, bool &ok) {
-    ok = v >= 0 && v < RT;
-    return ok ? (u32)v : 0u;
-}
-template <> __device__ __forceinline__ u32 small_count<int64_t>(int64_t v, int RT, bool &ok) {
-    ok = v >= 0 && v < (int64_t)RT;
-    return ok ? (u32)v : 0u;
-}
-
 // Table index of a value, clamped into [0, RT-1], and whether the value IS that integer (else the gene leaves
 // this route).  One v_med3 replaces the range compares: out-of-range, fractional and NaN all fail `exact`.
 template <typename InT, int RT> __device__ __forceinline__ u32 clamp_count(InT v, bool &exact);
