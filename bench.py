@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--groups", type=int, default=2_000)
     ap.add_argument("--sparsity", type=float, default=0.5)
     ap.add_argument("--test", choices=["ovo", "ovr"], default="ovo")
+    ap.add_argument("--values", choices=["counts", "continuous"], default="counts",
+                    help="counts: the headline Poisson counts; continuous: log1p(counts * U(0.5,1.5)), the secondary stress of SURVEY.md 8d")
     ap.add_argument("--gene-batch", type=int, default=0, help="genes per engine pass (0 = auto)")
     ap.add_argument("--gather-batches", type=int, default=8, help="gene blocks per gather (N>1)")
     ap.add_argument("--gather-in-step", action="store_true", help="N>1: gather every step's planes to rank 0 inside the timed region")
@@ -75,7 +77,7 @@ def group_container(codes, n_groups, ovr):
     return GroupContainer(codes.astype(np.int64), counts, indices, indptr, -1 if ovr else 0)
 
 
-def make_matrix(torch, n_cells, n_genes, sparsity, seed, device):
+def make_matrix(torch, n_cells, n_genes, sparsity, seed, device, continuous=False):
     """Poisson(gene mean ~ U(0.1, 15)) float32 with `sparsity` of the entries zeroed, generated on device."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -87,6 +89,8 @@ def make_matrix(torch, n_cells, n_genes, sparsity, seed, device):
         rates = m.unsqueeze(0).expand(n_cells, m.numel()).contiguous()
         blk = torch.poisson(rates, generator=gen)
         keep = torch.rand(blk.shape, device=device, generator=gen) >= sparsity
+        if continuous:  # normalised-like data: (almost) no ties among the non-zeros
+            blk = torch.log1p(blk * torch.empty_like(blk).uniform_(0.5, 1.5, generator=gen))
         X[:, j:j + step] = blk * keep
     return X
 
@@ -116,7 +120,7 @@ def main():
     ovr = args.test == "ovr"
     codes = make_labels(N, G, args.seed)
     grpc = group_container(codes, G, ovr)
-    X = make_matrix(torch, N, M, args.sparsity, args.seed + 1000 * rank, device)  # this rank's gene shard
+    X = make_matrix(torch, N, M, args.sparsity, args.seed + 1000 * rank, device, args.values == "continuous")  # this rank's gene shard
     torch.cuda.synchronize()
 
     eng = Engine(local_rank)
@@ -241,8 +245,8 @@ def main():
             "metric": "(group x gene) tests/sec", "value": round(value, 1), "unit": "tests/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"dense {N}x{M}x{G} {args.test.upper()} (K562-shaped, BASELINE configs[1])" if not ovr
-                       else f"dense {N}x{M}x{G} OVR", "cells": N, "genes_per_gpu": M, "groups": G,
+            "config": {"workload": (f"dense {N}x{M}x{G} {args.test.upper()} (K562-shaped, BASELINE configs[1])" if not ovr
+                                    else f"dense {N}x{M}x{G} OVR") + ("" if args.values == "counts" else " [continuous values]"), "cells": N, "genes_per_gpu": M, "groups": G,
                        "sparsity": args.sparsity, "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU",
                        "p_value_rtol_vs_cpu": 1e-12},
             "roofline": roofline, "cpu_baseline": cpu,

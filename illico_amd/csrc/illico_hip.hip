@@ -18,6 +18,7 @@
 #include "kernels_ovo_fused.h"
 #include "kernels_ovr.h"
 #include "kernels_sparse.h"
+#include "kernels_csc_gene.h"
 
 // ---- profiled kernel ids ---------------------------------------------------------------------
 enum {
@@ -30,11 +31,12 @@ enum {
     KID_FINALIZE,
     KID_OVR_SCAN,
     KID_SPARSE_SEG,
+    KID_CSC_GENE,
     KID_GENE_TOTALS,
     KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
-                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_gene_totals"};
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals"};
 
 struct ProfEvent {
     int kid;
@@ -61,7 +63,9 @@ struct illico_ctx {
     int64_t scratch_bytes = 24ll << 30;
     bool no_counts_path = false;
     bool no_fused_path = false;
+    bool no_csc_gene_path = false;
     int fused_groups_per_wg = 0; // 0 = auto
+    int ovr_threads = 256;
     bool profile = false;
     std::vector<ProfEvent> events;
     double prof_ms[KID_COUNT] = {0};
@@ -205,6 +209,8 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "profile")) c->profile = value != 0;
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
+    else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
+    else if (!strcmp(key, "ovr_threads")) c->ovr_threads = (int)value;
     else if (!strcmp(key, "fused_groups_per_wg")) c->fused_groups_per_wg = (int)std::max<int64_t>(0, value);
     else return fail(c, ILLICO_ERR_ARG, "unknown option '%s'", key);
     return ILLICO_OK;
@@ -390,8 +396,9 @@ static bool fused_path_allowed(const illico_ctx *c, int flags) {
 
 static int launch_finalize(illico_ctx *c, const long long *s2u, const u64 *stie, const double *ssum, const double *gene_total,
                            int nb, int flags, int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld,
-                           int64_t col_off) {
+                           int64_t col_off, const int *col_map = nullptr) {
     FinalizeParams F;
+    F.col_map = col_map;
     F.in_2u = s2u; F.in_tie = stie; F.in_sum = ssum; F.gene_total = gene_total;
     F.counts = c->d_counts; F.G = (int)c->n_groups; F.ref = (int)c->ref; F.nb = nb; F.n_cells = c->n_cells;
     F.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;

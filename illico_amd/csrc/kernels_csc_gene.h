@@ -1,0 +1,181 @@
+// CSC one-versus-reference in ONE kernel per gene: the gene's stored non-zeros are regrouped by group code inside
+// LDS (counting sort: LDS histogram -> scan -> LDS scatter), the reference run is sorted in place, and the
+// lane-per-group rank code (kernels_ovo.h: ovo_lane_groups) reads its runs straight from LDS.  Nothing but the
+// CSC arrays is read from HBM and nothing but the [gene][G] statistics is written: the two-kernel route
+// (k_csc_segment + k_ovo_rank) writes 7.4 GB of scattered 4-byte stores for 0.9 GB of keys at C3.
+//
+// Device counterpart of csc_get_contig_cols_into_csr + csr_get_rows_into_csc + _sort_csc_columns_inplace +
+// single_group_sparse_ovo_mwu_kernel (utils/sparse/csc.py:139-183, csr.py:103-141, ranking.py:161-172,
+// ovo/sparse_ovo.py:22-100) for one gene at a time.
+//
+// A gene that does not fit (more stored values than the LDS key buffer, a non-reference group with more than 128
+// stored values, a reference run longer than the run-end table) sets fallback[gene]; the host sends those genes
+// through the two-kernel route.
+#pragma once
+#include "common.h"
+#include "kernels_ovo.h"
+#include "kernels_sparse.h"
+
+#define CSCG_NT 1024
+#define CSCG_SMALL 32   // longest run the register-history lane-per-group form takes
+#define CSCG_MEDIUM 128 // longest run the LDS-history form takes; beyond: the gene leaves this kernel
+
+struct CscGeneParams {
+    const void *data, *indices, *indptr; // CSC arrays (device); entry k lives at data[k], indices[k]
+    long long col0;                      // first gene of the batch
+    int nb;
+    const int *codes;                    // [n_cells] group code per cell
+    const int *counts;                   // [G]
+    int G, ref, dt, is_log1p;
+    int key_cap;                         // LDS key slots
+    int runend_cap;                      // LDS run-end slots (reference run length limit)
+    u32 *fallback;                       // [nb] set to 1 for genes this kernel cannot take
+    long long *out_2u;
+    u64 *out_tie;
+    double *out_sum;
+};
+
+static inline size_t cscg_lds_bytes(int G, int key_cap, int runend_cap, size_t key_size) {
+    size_t b = (size_t)((G + 1 + 3) & ~3) * 4;          // ends
+    b += (size_t)CSCG_NT * 4;                            // scan scratch
+    b += ((size_t)runend_cap * 2 + 15) & ~(size_t)15;    // run ends
+    b += 256;                                            // reductions
+    b += (size_t)key_cap * key_size;
+    return b;
+}
+
+template <typename InT, typename IdxT, typename KeyT>
+__global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
+    constexpr int NT = CSCG_NT, NW = NT / 64;
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
+    extern __shared__ __align__(16) unsigned char smem[];
+    u32 *ends = (u32 *)smem;
+    size_t off = (size_t)((P.G + 1 + 3) & ~3) * 4;
+    u32 *tmp = (u32 *)(smem + off);
+    off += (size_t)NT * 4;
+    u16 *runend = (u16 *)(smem + off);
+    off += ((size_t)P.runend_cap * 2 + 15) & ~(size_t)15;
+    u64 *s_red = (u64 *)(smem + off);          // [NW]
+    double *s_redd = (double *)(s_red + NW);   // [NW]
+    u32 *s_misc = (u32 *)(s_redd + NW);        // [8]
+    off += 256;
+    KeyT *keybuf = (KeyT *)(smem + off);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = P.G, ref = P.ref;
+    const InT *data = (const InT *)P.data;
+    const IdxT *indices = (const IdxT *)P.indices, *indptr = (const IdxT *)P.indptr;
+    const int n_ref = P.counts[ref];
+
+    for (int gene = blockIdx.x; gene < P.nb; gene += gridDim.x) {
+        const long long k0 = (long long)indptr[P.col0 + gene], k1 = (long long)indptr[P.col0 + gene + 1];
+        // ---- 1. stored non-zeros per group ----
+        for (int g = tid; g <= G; g += NT) ends[g] = 0;
+        __syncthreads();
+        constexpr int UL = 8; // independent entries per thread in flight
+        for (long long kb = k0; kb < k1; kb += NT * UL) {
+            InT v[UL];
+            int cd[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const long long k = kb + u * NT + tid;
+                v[u] = k < k1 ? data[k] : (InT)0;
+                cd[u] = k < k1 ? P.codes[(long long)indices[k]] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u)
+                if (v[u] != (InT)0) atomicAdd(&ends[cd[u]], 1u);
+        }
+        __syncthreads();
+        const u32 nA = ends[ref];
+        u32 mx = 0;
+        for (int g = tid; g < G; g += NT)
+            if (g != ref) mx = max(mx, ends[g]);
+        mx = (u32)wave_incl_scan_max((int)mx);
+        if (lane == 63) tmp[wave] = mx;
+        __syncthreads();
+        u32 maxg = 0;
+        for (int w = 0; w < NW; ++w) maxg = max(maxg, tmp[w]);
+        __syncthreads();
+        // ---- 2. run offsets ----
+        const u32 total = block_excl_scan_inplace<NT>(ends, G, tmp, tid);
+        if (total > (u32)P.key_cap || maxg > (u32)CSCG_MEDIUM || nA > (u32)P.runend_cap) { // uniform: this gene takes the two-kernel route
+            if (tid == 0) P.fallback[gene] = 1u;
+            __syncthreads();
+            continue;
+        }
+        // ---- 3. regroup the keys in LDS ----
+        for (long long kb = k0; kb < k1; kb += NT * UL) {
+            InT v[UL];
+            int cd[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const long long k = kb + u * NT + tid;
+                v[u] = k < k1 ? data[k] : (InT)0;
+                cd[u] = k < k1 ? P.codes[(long long)indices[k]] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u)
+                if (v[u] != (InT)0) keybuf[atomicAdd(&ends[cd[u]], 1u)] = key_of(v[u]);
+        }
+        __syncthreads();
+        // now ends[g] = one past the last key of group g; its run starts at ends[g-1] (0 for g = 0)
+        // ---- 4. reference run: sort in place, run ends, T_A, sum ----
+        const u32 rstart = ref ? ends[ref - 1] : 0u;
+        KeyT *A = keybuf + rstart;
+        const u32 zA = (u32)n_ref - nA;
+        double rs = 0.0;
+        for (u32 i = tid; i < nA; i += NT) rs += P.is_log1p ? key_to_expm1(A[i], P.dt) : key_to_double(A[i], P.dt);
+        rs = wave_sum(rs);
+        if (lane == 0) s_redd[wave] = rs;
+        __syncthreads();
+        block_bitonic_sort<KeyT, NT>(A, (int)nA, tid);
+        const u32 topA = top_pow2(nA);
+        u64 ta = 0;
+        for (u32 i = tid; i < nA; i += NT) {
+            const KeyT k = A[i];
+            if (i == 0 || A[i - 1] != k) {
+                const u32 e = upper_bound_pow2(A, nA, topA, k);
+                runend[i] = (u16)e;
+                const u64 t = e - i;
+                ta += t * t * t - t;
+            }
+        }
+        ta = wave_sum(ta);
+        if (lane == 0) s_red[wave] = ta;
+        __syncthreads();
+        u64 T_A = 0;
+        double refsum = 0.0;
+        for (int w = 0; w < NW; ++w) { T_A += s_red[w]; refsum += s_redd[w]; }
+        const u32 nnegA = lower_bound_pow2(A, nA, topA, ZEROK);
+        // ---- 5. every other group: 64 runs per wavefront, one per lane ----
+        for (int g0 = wave * 64; g0 < G; g0 += NW * 64) {
+            const int gl = g0 + lane;
+            const bool has = gl < G && gl != ref;
+            const u32 start = (has && gl > 0) ? ends[gl - 1] : 0u;
+            const int n = has ? (int)(ends[gl] - start) : 0;
+            const int nmax = __builtin_amdgcn_readlane(wave_incl_scan_max(n), 63);
+            u64 S2, TT;
+            double sum;
+            if (nmax <= CSCG_SMALL) ovo_lane_groups<KeyT, CSCG_SMALL, true>(keybuf, (long long)start, n, nmax, A, runend, nA, topA, zA, P.dt, P.is_log1p, S2, TT, sum);
+            else ovo_lane_groups_mem<KeyT, true>(keybuf, (long long)start, n, nmax, A, runend, nA, topA, zA, P.dt, P.is_log1p, S2, TT, sum);
+            if (gl < G) {
+                const size_t o = (size_t)gene * G + gl;
+                if (gl == ref) {
+                    P.out_2u[o] = -2;
+                    P.out_tie[o] = 0;
+                    P.out_sum[o] = refsum;
+                } else {
+                    const long long n_g = P.counts[gl];
+                    const u64 zB = (u64)(n_g - n);
+                    S2 += zB * (2ull * nnegA + zA);
+                    const u64 t0 = (u64)zA + zB;
+                    P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
+                    P.out_tie[o] = T_A + 3ull * TT + (t0 * t0 * t0 - t0);
+                    P.out_sum[o] = sum;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}

@@ -17,6 +17,7 @@ struct FinalizeParams {
     int use_continuity, tie_correct, alternative;
     double *out_p, *out_u, *out_fc; // [G][out_ld], column offset already applied
     long long out_ld;
+    const int *col_map;       // optional: output column of batch gene j (relative to the offset); nullptr = j
 };
 
 __device__ __forceinline__ double pval_device(long long n_ref, long long n_tgt, long long n, double tie_sum, double U,
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     for (int gy = ty; gy < 32; gy += 8) {
         int g = grp0 + gy, gene = gene0 + tx;
         if (gene < P.nb && g < P.G) {
-            size_t o = (size_t)g * P.out_ld + gene;
+            size_t o = (size_t)g * P.out_ld + (P.col_map ? P.col_map[gene] : gene);
             P.out_p[o] = tp[tx][gy];
             P.out_u[o] = tu[tx][gy];
             P.out_fc[o] = tf[tx][gy];

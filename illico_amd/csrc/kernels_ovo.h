@@ -260,6 +260,41 @@ __device__ __forceinline__ void ovo_lane_groups(const KeyT *__restrict__ Xs, lon
     sumout = s;
 }
 
+// Same as ovo_lane_groups for longer runs (up to a few hundred keys): the lane re-reads its own run from memory
+// (LDS in k_csc_gene) instead of keeping a register history.  O(n^2/2) reads per lane: meant for the rare block
+// whose longest run exceeds the register form's limit.
+template <typename KeyT, bool RUNEND>
+__device__ __forceinline__ void ovo_lane_groups_mem(const KeyT *Xs, long long bstart, int n, int nmax, const KeyT *A,
+                                                    const u16 *runend, u32 nA, u32 topA, u32 zA, int dt, int is_log1p,
+                                                    u64 &S2out, u64 &TTout, double &sumout) {
+    constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
+    u64 S2 = 0, TT = 0;
+    double s = 0.0;
+    for (int j = 0; j < nmax; ++j) {
+        const bool valid = j < n;
+        const KeyT q = valid ? Xs[bstart + j] : MAXK;
+        u32 o = 0;
+        for (int i = 0; i < j; ++i) o += (valid && Xs[bstart + i] == q) ? 1u : 0u;
+        const u32 lb = lower_bound_pow2(A, nA, topA, q);
+        u32 a = 0;
+        if (lb < nA && A[lb] == q) {
+            if (RUNEND) a = (u32)runend[lb] - lb;
+            else a = upper_bound_pow2(A, nA, topA, q) - lb;
+        }
+        if (valid) {
+            const u64 lt = (u64)lb + ((q > ZEROK) ? (u64)zA : 0ull);
+            const u64 t = (u64)a + o;
+            S2 += 2ull * lt + a;
+            TT += t * (t + 1ull);
+            s += is_log1p ? key_to_expm1(q, dt) : key_to_double(q, dt);
+        }
+    }
+    S2out = S2;
+    TTout = TT;
+    sumout = s;
+}
+
 // LG: also compile the lane-per-group form for blocks of 64 short runs (sparse layouts); it needs more registers
 // (the lane's history), so the dense instantiations leave it out and keep 4 waves per SIMD.
 template <typename KeyT, int KMAX, bool RUNEND, int NT, bool LG>

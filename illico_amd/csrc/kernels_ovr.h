@@ -55,6 +55,26 @@ template <int NT> __device__ __forceinline__ int block_incl_scan_max(int x, int 
     return max(wi, wp);
 }
 
+// inclusive min-scan from the last thread towards the first; next_out = scan value of the NEXT thread (carry for the last)
+template <int NT> __device__ __forceinline__ int block_incl_scan_min_rev2(int x, int carry, int *wtot, int tid, int &next_out) {
+    constexpr int NW = NT / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    int wi = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_down(wi, d);
+        if (lane + d < 64) wi = min(wi, o);
+    }
+    if (lane == 0) wtot[wave] = wi;
+    __syncthreads();
+    int wp = carry;
+    for (int w = NW - 1; w > wave; --w) wp = min(wp, wtot[w]);
+    int dn = __shfl_down(wi, 1);
+    next_out = lane < 63 ? min(dn, wp) : wp;
+    __syncthreads();
+    return min(wi, wp);
+}
+
 template <int NT> __device__ __forceinline__ int block_incl_scan_min_rev(int x, int carry, int *wtot, int tid) {
     // inclusive min-scan from the last thread towards the first
     constexpr int NW = NT / 64;
@@ -110,9 +130,9 @@ template <int NT> __device__ __forceinline__ int block_excl_scan_add_rev(int x, 
     return after + wi - x;
 }
 
-template <typename KeyT, bool SPARSE, bool OVO>
-__global__ __launch_bounds__(OVR_NT) void k_ovr_gene(OvrParams P) {
-    constexpr int NT = OVR_NT, NW = NT / 64, E = OVR_E;
+template <typename KeyT, bool SPARSE, bool OVO, int NT>
+__global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
+    constexpr int NW = NT / 64, E = (NT >= 1024 ? 4 : 8);
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     extern __shared__ __align__(16) unsigned char smem[];
     u32 *wcnt = (u32 *)smem;                 // [NW][256]
@@ -341,38 +361,82 @@ __global__ __launch_bounds__(OVR_NT) void k_ovr_gene(OvrParams P) {
         // ---- sweeps over the sorted column ----
         for (int g = tid; g < G; g += NT) { R2[g] = 0; if (SPARSE) gcnt[g] = 0; }
         __syncthreads();
+        // Each thread owns SE consecutive sorted slots per round: run heads / tails are resolved inside the thread
+        // first, one block scan per round links the threads (8x fewer barriers than one slot per thread).
+        constexpr int SE = 8;
         u64 tie = 0;
-        int carry = 0;
-        for (int cbase = 0; cbase < n; cbase += NT) { // forward: s(i)+1, run lengths
-            int i = cbase + tid;
-            bool valid = i < n;
-            KeyT k = valid ? K[i] : (KeyT)0;
-            bool head = valid && (i == 0 || K[i - 1] != k);
-            int sprev;
-            int s = block_incl_scan_max<NT>(head ? i : -1, carry, wtot, tid, sprev);
-            if (head && i > 0) { u64 t = (u64)(i - sprev); tie += t * t * t - t; }
-            if (valid) {
-                u64 add = (u64)s + 1ull + ((SPARSE && k > ZEROK) ? 2ull * (u64)n0 : 0ull);
-                atomicAdd(&R2[V[i]], add);
-                if (SPARSE) atomicAdd(&gcnt[V[i]], 1u);
+        int carry = 0; // run start of the last slot of the previous round
+        for (int cbase = 0; cbase < n; cbase += NT * SE) { // forward: s(i)+1, run lengths
+            const int i0 = cbase + tid * SE;
+            KeyT k[SE];
+            int sl[SE];
+            bool hd[SE];
+            KeyT prev = (i0 > 0 && i0 < n) ? K[i0 - 1] : (KeyT)0;
+            int lh = -1;
+#pragma unroll
+            for (int e = 0; e < SE; ++e) {
+                const int i = i0 + e;
+                const bool valid = i < n;
+                k[e] = valid ? K[i] : (KeyT)0;
+                hd[e] = valid && (i == 0 || k[e] != prev);
+                if (hd[e]) lh = i;
+                sl[e] = lh;
+                prev = k[e];
             }
-            int last = min(n - 1 - cbase, NT - 1);
-            if (tid == last) flag[1] = s;
+            int cin; // run start inherited from the slots before this thread's range
+            block_incl_scan_max<NT>(lh, carry, wtot, tid, cin);
+            int s_last = cin;
+#pragma unroll
+            for (int e = 0; e < SE; ++e) {
+                const int i = i0 + e;
+                if (i < n) {
+                    const int s = sl[e] >= 0 ? sl[e] : cin;
+                    if (hd[e] && i > 0) { u64 t = (u64)(i - s_last); tie += t * t * t - t; }
+                    s_last = s;
+                    u64 add = (u64)s + 1ull + ((SPARSE && k[e] > ZEROK) ? 2ull * (u64)n0 : 0ull);
+                    atomicAdd(&R2[V[i]], add);
+                    if (SPARSE) atomicAdd(&gcnt[V[i]], 1u);
+                }
+            }
+            const int last_i = min(n, cbase + NT * SE) - 1; // last valid slot of this round
+            if (last_i >= i0 && last_i < i0 + SE) flag[1] = s_last;
             __syncthreads();
             carry = flag[1];
             __syncthreads();
         }
         if (tid == 0 && n > 0) { u64 t = (u64)(n - carry); tie += t * t * t - t; }
         int carry_e = n;
-        const int nchunks = (n + NT - 1) / NT;
-        for (int c = nchunks - 1; c >= 0; --c) { // backward: e(i)
-            int i = c * NT + tid;
-            bool valid = i < n;
-            KeyT k = valid ? K[i] : (KeyT)0;
-            bool tail = valid && (i == n - 1 || K[i + 1] != k);
-            int e = block_incl_scan_min_rev<NT>(tail ? i + 1 : 0x7FFFFFFF, carry_e, wtot, tid);
-            if (valid) atomicAdd(&R2[V[i]], (u64)e);
-            if (tid == 0) flag[1] = e;
+        const int nrounds = (n + NT * SE - 1) / (NT * SE);
+        for (int c = nrounds - 1; c >= 0; --c) { // backward: e(i)
+            const int i0 = c * NT * SE + tid * SE;
+            KeyT k[SE];
+            int el[SE];
+#pragma unroll
+            for (int e = 0; e < SE; ++e) k[e] = (i0 + e < n) ? K[i0 + e] : (KeyT)0;
+            KeyT next = (i0 + SE < n) ? K[i0 + SE] : (KeyT)0;
+            int le = 0x7FFFFFFF;
+#pragma unroll
+            for (int e = SE - 1; e >= 0; --e) {
+                const int i = i0 + e;
+                const bool valid = i < n;
+                const bool tail = valid && (i == n - 1 || k[e] != next);
+                if (tail) le = i + 1;
+                el[e] = le;
+                if (valid) next = k[e];
+            }
+            int cnext; // run end inherited from the slots after this thread's range
+            block_incl_scan_min_rev2<NT>(le, carry_e, wtot, tid, cnext);
+            int e_first = cnext;
+#pragma unroll
+            for (int e = SE - 1; e >= 0; --e) {
+                const int i = i0 + e;
+                if (i < n) {
+                    const int ee = el[e] != 0x7FFFFFFF ? el[e] : cnext;
+                    atomicAdd(&R2[V[i]], (u64)ee);
+                    e_first = ee;
+                }
+            }
+            if (tid == 0) flag[1] = e_first;
             __syncthreads();
             carry_e = flag[1];
             __syncthreads();
@@ -409,8 +473,8 @@ __global__ __launch_bounds__(OVR_NT) void k_ovr_gene(OvrParams P) {
     }
 }
 
-static inline size_t ovr_lds_bytes(int G, bool sparse, bool ovo = false) {
-    const int NW = OVR_NT / 64;
+static inline size_t ovr_lds_bytes(int G, bool sparse, bool ovo, int nt) {
+    const int NW = nt / 64;
     size_t b = (size_t)NW * 256 * 4 + 256 * 4 + 256 * 4 + (NW + (NW & 1)) * 4 + NW * 8 + 16;
     b += (size_t)G * 8 + (ovo ? (size_t)G * 8 : 0) + (sparse ? (size_t)G * 4 : 0);
     return b;

@@ -44,15 +44,19 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
                                                         const IdxT *__restrict__ indptr, long long col0, int nb,
                                                         const int *__restrict__ codes, int G, KeyT *__restrict__ Xs,
                                                         u32 *__restrict__ vals, u32 *__restrict__ seg_ptr,
-                                                        u32 *__restrict__ gene_flags, int count_limit) {
+                                                        u32 *__restrict__ gene_flags, int count_limit,
+                                                        const int *__restrict__ gene_cols, const u32 *__restrict__ gene_base) {
     extern __shared__ __align__(16) unsigned char smem[];
     u32 *hist = (u32 *)smem;
     u32 *tmp = hist + ((G + 3) & ~3);
     const int tid = threadIdx.x;
+    // batch = columns col0 .. col0+nb-1, or (gene_cols != nullptr) an arbitrary list of columns whose keys are
+    // packed at gene_base[gene]
     const long long base0 = (long long)indptr[col0];
     for (int gene = blockIdx.x; gene < nb; gene += gridDim.x) {
-        const long long k0 = (long long)indptr[col0 + gene], k1 = (long long)indptr[col0 + gene + 1];
-        const u32 gbase = (u32)(k0 - base0);
+        const long long col = gene_cols ? (long long)gene_cols[gene] : col0 + gene;
+        const long long k0 = (long long)indptr[col], k1 = (long long)indptr[col + 1];
+        const u32 gbase = gene_cols ? gene_base[gene] : (u32)(k0 - base0);
         for (int g = tid; g < G; g += SEG_NT) hist[g] = 0;
         __syncthreads();
         for (long long k = k0 + tid; k < k1; k += SEG_NT)

@@ -34,6 +34,55 @@ static std::vector<SparseBatch> plan_batches(const std::vector<int64_t> &gene_nn
     return out;
 }
 
+// Single-kernel CSC OVO route over genes [g0, g1): statistics + finalize for every gene it can take; the genes it
+// cannot take come back as column runs for the two-kernel route.
+template <typename InT, typename IdxT, typename KeyT>
+static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int dtype,
+                              int64_t g0, int64_t g1, int64_t col_lb, int flags, int alternative, const OutPlanes &o,
+                              std::vector<int64_t> &fallback_cols) {
+    const int G = (int)c->n_groups;
+    int rc;
+    void *v;
+    const int runend_cap = (int)std::max<int64_t>(1, std::min<int64_t>(c->h_counts[c->ref], 8192));
+    const size_t fixed = cscg_lds_bytes(G, 0, runend_cap, sizeof(KeyT));
+    if (fixed + 1024 * sizeof(KeyT) > kMaxLds) {
+        for (int64_t j = g0; j < g1; ++j) fallback_cols.push_back(j);
+        return ILLICO_OK;
+    }
+    const int key_cap = (int)((kMaxLds - fixed) / sizeof(KeyT));
+    const size_t lds = cscg_lds_bytes(G, key_cap, runend_cap, sizeof(KeyT));
+    const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(g1 - g0, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
+    if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
+    long long *s2u = (long long *)v;
+    u64 *stie = (u64 *)(s2u + (size_t)nb_max * G);
+    double *ssum = (double *)(stie + (size_t)nb_max * G);
+    if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
+    u32 *fb = (u32 *)v;
+    std::vector<u32> h_fb;
+    auto kern = k_csc_gene<InT, IdxT, KeyT>;
+    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int64_t b0 = g0; b0 < g1; b0 += nb_max) {
+        const int nb = (int)std::min<int64_t>(nb_max, g1 - b0);
+        HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)nb * 4, c->stream));
+        CscGeneParams P;
+        P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.col0 = b0; P.nb = nb; P.codes = c->d_codes;
+        P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
+        P.key_cap = key_cap; P.runend_cap = runend_cap; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
+        {
+            ProfScope ps(c, KID_CSC_GENE);
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCG_NT), lds, c->stream, P);
+            HIPCHK(c, hipGetLastError());
+        }
+        if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
+        h_fb.resize(nb);
+        HIPCHK(c, hipMemcpyAsync(h_fb.data(), fb, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int64_t j = 0; j < nb; ++j)
+            if (h_fb[j]) fallback_cols.push_back(b0 + j);
+    }
+    return ILLICO_OK;
+}
+
 template <typename InT, typename IdxT, typename KeyT>
 static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indices, const void *indptr, int dtype,
                         int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
@@ -54,22 +103,23 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     const int64_t total_nnz = (int64_t)h_indptr[n_ptr - 1];
     if (h_indptr[0] != 0) return fail(c, ILLICO_ERR_ARG, "indptr[0] must be 0");
 
-    // device views of the matrix
+    // device views of the matrix: entry k of the caller's arrays is d_data[k] / d_indices[k]
     const InT *d_data = (const InT *)data;
     const IdxT *d_indices = (const IdxT *)indices, *d_indptr = (const IdxT *)indptr;
-    int64_t kshift = 0; // d_data[k - kshift] holds stored entry k
     if (!in_dev) {
         if ((rc = get_scratch(c, "sp_indptr", n_ptr * sizeof(IdxT), &v))) return rc;
         HIPCHK(c, hipMemcpyAsync(v, indptr, n_ptr * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
         d_indptr = (const IdxT *)v;
-        if (is_csr) { // rows span every column: the whole matrix goes to the device once
-            if ((rc = get_scratch(c, "sp_data", std::max<size_t>(total_nnz, 1) * sizeof(InT), &v))) return rc;
-            HIPCHK(c, hipMemcpyAsync(v, data, total_nnz * sizeof(InT), hipMemcpyHostToDevice, c->stream));
-            d_data = (const InT *)v;
-            if ((rc = get_scratch(c, "sp_indices", std::max<size_t>(total_nnz, 1) * sizeof(IdxT), &v))) return rc;
-            HIPCHK(c, hipMemcpyAsync(v, indices, total_nnz * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
-            d_indices = (const IdxT *)v;
-        }
+        // CSR rows span every column: the whole matrix goes up; CSC: only the stored entries of the requested window
+        const int64_t k0 = is_csr ? 0 : (int64_t)h_indptr[col_lb];
+        const int64_t k1 = is_csr ? total_nnz : (int64_t)h_indptr[col_ub];
+        const size_t cnt = (size_t)std::max<int64_t>(k1 - k0, 1);
+        if ((rc = get_scratch(c, "sp_data", cnt * sizeof(InT), &v))) return rc;
+        HIPCHK(c, hipMemcpyAsync(v, (const InT *)data + k0, (size_t)(k1 - k0) * sizeof(InT), hipMemcpyHostToDevice, c->stream));
+        d_data = (const InT *)v - k0;
+        if ((rc = get_scratch(c, "sp_indices", cnt * sizeof(IdxT), &v))) return rc;
+        HIPCHK(c, hipMemcpyAsync(v, (const IdxT *)indices + k0, (size_t)(k1 - k0) * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
+        d_indices = (const IdxT *)v - k0;
     }
 
     // per-gene stored-entry counts of the requested window
@@ -92,13 +142,34 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         for (int64_t j = 0; j < W; ++j) gene_nnz[j] = h_cc[j];
     }
 
-    const bool may_glob = !ovr && !ovo_sort_route_fits<KeyT>(c->h_counts[c->ref], c->max_nonref);
-    const size_t per_nnz = sizeof(KeyT) * ((ovr || may_glob) ? 2 : 1) + ((ovr || may_glob) ? 8 : 0) + ((!in_dev && !is_csr) ? sizeof(InT) + sizeof(IdxT) : 0);
-    const size_t per_gene = (size_t)(G + 1) * 4 * (is_csr ? 2 : 1) + (size_t)G * 24 + 64;
-    auto batches = plan_batches(gene_nnz, col_lb, per_nnz, per_gene, c->gene_batch, (size_t)c->scratch_bytes);
+    // ---- CSC OVO: single-kernel route first; it reports the genes it could not take ----
+    // `cols`: the columns the two-kernel route still has to compute.  CSC batches are arbitrary column LISTS (the
+    // stragglers of the single-kernel route are batched together); CSR batches are contiguous windows.
+    std::vector<int64_t> cols;
+    if (!is_csr && !ovr && !c->no_csc_gene_path) {
+        if ((rc = run_csc_gene_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, dtype, col_lb, col_ub, col_lb, flags,
+                                                      alternative, o, cols)))
+            return rc;
+        if (cols.empty()) return ILLICO_OK;
+    } else {
+        cols.resize(W);
+        for (int64_t j = 0; j < W; ++j) cols[j] = col_lb + j;
+    }
 
-    for (const SparseBatch &b : batches) {
+    // ---- two-kernel route (regroup into HBM, then rank) ----
+    const bool may_glob = !ovr && !ovo_sort_route_fits<KeyT>(c->h_counts[c->ref], c->max_nonref);
+    const size_t per_nnz = sizeof(KeyT) * ((ovr || may_glob) ? 2 : 1) + ((ovr || may_glob) ? 8 : 0);
+    const size_t per_gene = (size_t)(G + 1) * 4 * (is_csr ? 2 : 1) + (size_t)G * 24 + 64;
+    std::vector<int64_t> list_nnz(cols.size());
+    for (size_t j = 0; j < cols.size(); ++j) list_nnz[j] = gene_nnz[cols[j] - col_lb];
+    auto batches = plan_batches(list_nnz, 0, per_nnz, per_gene, c->gene_batch, (size_t)c->scratch_bytes); // g0/g1 index `cols`
+    {
+    for (const SparseBatch &bi : batches) {
+        SparseBatch b = bi;
         const int nb = (int)(b.g1 - b.g0);
+        const int64_t i0 = b.g0;
+        b.g0 = cols[i0];                 // first column (CSR windows are contiguous: cols[i] = col_lb + i)
+        b.g1 = cols[i0 + nb - 1] + 1;
         const size_t nnz = (size_t)std::max<int64_t>(b.nnz, 1);
         if ((rc = get_scratch(c, "xt", nnz * sizeof(KeyT), &v))) return rc;
         KeyT *Xs = (KeyT *)v;
@@ -128,25 +199,34 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             gflags = (u32 *)v;
             HIPCHK(c, hipMemsetAsync(gflags, 0, (size_t)nb * 4, c->stream));
         }
+        // CSC: column list of this batch + where each gene's keys start in Xs
+        const int *d_cols = nullptr;
+        const u32 *d_base = nullptr;
+        if (!is_csr) {
+            std::vector<int> h_cols(nb);
+            std::vector<u32> h_base(nb);
+            u32 run = 0;
+            for (int j = 0; j < nb; ++j) {
+                h_cols[j] = (int)cols[i0 + j];
+                h_base[j] = run;
+                run += (u32)list_nnz[i0 + j];
+            }
+            if ((rc = get_scratch(c, "sp_cols", (size_t)nb * 8, &v))) return rc;
+            HIPCHK(c, hipMemcpyAsync(v, h_cols.data(), (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync((char *)v + (size_t)nb * 4, h_base.data(), (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream)); // the host vectors go out of scope
+            d_cols = (const int *)v;
+            d_base = (const u32 *)((char *)v + (size_t)nb * 4);
+        }
+        const int64_t fin_off = is_csr ? b.g0 - col_lb : -col_lb; // CSC: col_map holds absolute columns
 
         if (!is_csr) {
-            const int64_t k0 = (int64_t)h_indptr[b.g0];
-            const InT *bd = d_data;
-            const IdxT *bi = d_indices;
-            if (!in_dev) { // upload this batch's slice of data / indices
-                if ((rc = get_scratch(c, "sp_data", nnz * sizeof(InT), &v))) return rc;
-                HIPCHK(c, hipMemcpyAsync(v, (const InT *)data + k0, b.nnz * sizeof(InT), hipMemcpyHostToDevice, c->stream));
-                bd = (const InT *)v - k0;
-                if ((rc = get_scratch(c, "sp_indices", nnz * sizeof(IdxT), &v))) return rc;
-                HIPCHK(c, hipMemcpyAsync(v, (const IdxT *)indices + k0, b.nnz * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
-                bi = (const IdxT *)v - k0;
-            }
             ProfScope ps(c, KID_SPARSE_SEG);
             auto kern = k_csc_segment<InT, IdxT, KeyT>;
             size_t lds = seg_lds_bytes(G);
             HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(nb), dim3(SEG_NT), lds, c->stream, bd, bi, d_indptr, (long long)b.g0, nb,
-                               (const int *)c->d_codes, G, Xs, va, seg, gflags, COUNTS_R);
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(SEG_NT), lds, c->stream, d_data, d_indices, d_indptr, (long long)b.g0, nb,
+                               (const int *)c->d_codes, G, Xs, va, seg, gflags, COUNTS_R, d_cols, d_base);
             HIPCHK(c, hipGetLastError());
         } else {
             if ((rc = get_scratch(c, "sp_cursor", (size_t)nb * (G + 1) * 4 + (size_t)nb * 8, &v))) return rc;
@@ -183,7 +263,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             // alone can take without the global-sort fallback.
             const u32 *route_flags = need_glob ? gflags : nullptr;
             if ((rc = launch_ovo<KeyT>(c, P, ref_cap_b, grp_cap_b, route_flags, &gb, true))) return rc;
-            if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b.g0 - col_lb))) return rc;
+            if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, fin_off, d_cols))) return rc;
         } else {
             OvrParams P;
             P.keys_a = Xs; P.keys_b = kb; P.vals_a = va; P.vals_b = vb; P.code_by_pos = nullptr; P.seg_ptr = seg;
@@ -192,8 +272,9 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
             if ((rc = launch_ovr_gene<KeyT, true>(c, P))) return rc;
             if ((rc = launch_gene_totals(c, ssum, G, nb, gtot))) return rc;
-            if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b.g0 - col_lb))) return rc;
+            if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, fin_off, d_cols))) return rc;
         }
+    }
     }
     return ILLICO_OK;
 }

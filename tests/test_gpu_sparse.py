@@ -22,10 +22,14 @@ def _run(engine, M, grpc, **kw):
     return engine.run_sparse(M.format, M.data, M.indices, M.indptr, M.shape, lb, ub, **kw)
 
 
-@pytest.fixture(params=["counts+sort", "sort-only"])
+@pytest.fixture(params=["single-kernel", "two-kernel", "two-kernel-sort-only"])
 def route(request, engine):
-    engine.set_option("no_counts_path", 1 if request.param == "sort-only" else 0)
+    """CSC OVO has a single-kernel route (regroup + rank in LDS) with the two-kernel route (regroup into HBM, then
+    histogram / sort rank kernels) as fallback; the params force each so that all are exercised on the same data."""
+    engine.set_option("no_csc_gene_path", 0 if request.param == "single-kernel" else 1)
+    engine.set_option("no_counts_path", 1 if request.param.endswith("sort-only") else 0)
     yield request.param
+    engine.set_option("no_csc_gene_path", 0)
     engine.set_option("no_counts_path", 0)
 
 
@@ -148,3 +152,29 @@ def test_sparse_ovo_big_groups_any_values(engine, fmt):
         want = oracle.run(X, g)     # dense semantics (negatives rank below the zero block)
         got = _run(engine, M, g)
         assert_planes_match(got, want, fc_rtol=1e-9, what=f"{fmt} ref={ref}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_csc_interleaved_dense_and_sparse_genes(engine, test):
+    """Every other gene is too dense for the single-kernel CSC route (runs above 128 stored values): the stragglers
+    are batched as a column list through the two-kernel route; medium runs (33..128) use the LDS-history form."""
+    rng = np.random.RandomState(23)
+    sizes = [400, 900, 300, 200, 60, 40]
+    codes = np.concatenate([np.full(s, i) for i, s in enumerate(sizes)])
+    rng.shuffle(codes)
+    labels = np.array([f"g{c:02d}" for c in codes])
+    n, m = codes.size, 41
+    X = np.zeros((n, m), np.float32)
+    for j in range(m):
+        dens = (0.9, 0.05, 0.3)[j % 3]          # dense gene, very sparse gene, medium gene
+        X[:, j] = rng.poisson(2.0, size=n) * (rng.rand(n) < dens)
+        if j % 5 == 0:
+            X[:, j] *= rng.rand(n)              # non-count values
+    M = sparse.csc_matrix(X)
+    _, g = oracle.encode_and_count_groups(labels, "g00" if test == "ovo" else None)
+    want = oracle.run(X, g)
+    got = _run(engine, M, g)
+    assert_planes_match(got, want, fc_rtol=1e-9, what=f"interleaved {test}")
+    got = _run(engine, M, g, col_lb=3, col_ub=38)
+    want = oracle.run(X, g, col_lb=3, col_ub=38)
+    assert_planes_match(got, want, fc_rtol=1e-9, what=f"interleaved window {test}")
