@@ -220,7 +220,7 @@ def main():
 
         # ---- CPU baseline: the oracle (C port of illico's algorithm) on this box's host cores ----
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # contract: CPU baseline on rank 0 at N = 1 only
             import oracle
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             ns = min(M, 32)
