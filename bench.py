@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # test hook: gloo
+    ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)  # test hook: every rank on GPU 0
     ap.add_argument("--engine-option", action="append", default=[], help="key=value passed to illico_ctx_set_option")
     return ap.parse_args()
 
@@ -108,10 +110,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from illico_amd._lib import Engine
     from illico_amd.distributed import gather_block_async, shard_bounds
@@ -176,7 +183,8 @@ def main():
     eng.profile(False)
     gather_ms = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        red_dev = device if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         if not in_step:  # the final gather, once, timed on its own (second call: RCCL connections already set up)
@@ -185,7 +193,7 @@ def main():
             tg = time.perf_counter()
             final_gather()
             sync()
-            t = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=device)
+            t = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             gather_ms = float(t.item()) * 1e3
 
@@ -207,8 +215,12 @@ def main():
             traffic = None
             tf = ROOT / "profiles" / "traffic.json"
             if tf.exists():
-                try:
-                    traffic = json.loads(tf.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+                try:  # PMC traffic is only valid for the workload it was collected on
+                    ent = json.loads(tf.read_text()).get(dom, {})
+                    w = ent.get("workload", {})
+                    if (w.get("cells"), w.get("genes_per_gpu"), w.get("groups"), w.get("test"), w.get("values")) == \
+                            (N, M, G, args.test, args.values) and launches == args.steps * w.get("launches_per_step", 1):
+                        traffic = ent.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

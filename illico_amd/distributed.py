@@ -27,7 +27,26 @@ def gather_block_async(stage, recv_list, rank: int, world: int, dst: int = 0, gr
     ``recv_list`` (on dst): one tensor per rank shaped like ``stage``; ignored elsewhere.
     """
     import torch.distributed as dist
+    if stage.is_cuda and dist.get_backend(group) == "gloo":
+        # test mode (no RCCL, e.g. several ranks sharing one GPU): stage the block through host memory
+        cpu = stage.cpu()
+        lst = [torch_empty_like_cpu(cpu) for _ in range(world)] if rank == dst else None
+        dist.gather(cpu, gather_list=lst, dst=dst, group=group)
+        if rank == dst:
+            for r, t in zip(recv_list, lst):
+                r.copy_(t)
+        return _DoneWork()
     return dist.gather(stage, gather_list=recv_list if rank == dst else None, dst=dst, group=group, async_op=True)
+
+
+class _DoneWork:
+    def wait(self):
+        return True
+
+
+def torch_empty_like_cpu(t):
+    import torch
+    return torch.empty_like(t, device="cpu")
 
 
 def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, reference=None, *, alternative="two-sided",
