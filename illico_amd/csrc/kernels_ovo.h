@@ -134,9 +134,16 @@ struct OvoParams {
 
 // One group's values (nB <= 64*K keys) handled by one wavefront.  Returns PER-LANE partial sums
 // (S2, tie, value sum); the caller folds 64 groups' partials with a transpose-reduce.
+__device__ __forceinline__ u32 bloom_hash1(u32 k) { return (k * 0x9E3779B1u) >> 19; } // 13 bits
+__device__ __forceinline__ u32 bloom_hash2(u32 k) { return ((k ^ (k >> 15)) * 0x85EBCA6Bu) >> 19; }
+__device__ __forceinline__ u32 bloom_fold(u32 k) { return k; }
+__device__ __forceinline__ u32 bloom_fold(u64 k) { return (u32)(k ^ (k >> 32)); }
+
+// sk / sb (256 entries each, per wavefront) must be all-zero on entry and are all-zero again on exit: they serve
+// first as two 8192-bit Bloom tables, then as compaction scratch.
 template <typename KeyT, int K, int KIN, bool RUNEND>
 __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, const KeyT *A,
-                                               const u16 *runend, u32 nA, u32 topA, u32 zA, KeyT *sk, u32 *sb,
+                                               const u16 *runend, u32 nA, u32 topA, u32 zA, u32 lbZ, u32 aZ, KeyT *sk, u32 *sb,
                                                int lane, int dt, int is_log1p, u64 &S2out, u64 &tieout,
                                                double &sumout) {
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
@@ -147,6 +154,81 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, c
     for (int r = 0; r < K; ++r) { // vin[r] holds element r*64 + lane of the group (MAXK beyond nB)
         v[r] = vin[r];
         if (r * 64 + lane < nB) s += is_log1p ? key_to_expm1(v[r], dt) : key_to_double(v[r], dt);
+    }
+
+    // ---- distinct-values fast path (normalised / continuous data) ----
+    // If the group's non-zero keys are pairwise distinct, every non-zero key is a run of length 1 and the zeros are
+    // one run: no sort is needed, each key is only looked up in the reference.  Distinctness is PROVEN by a
+    // two-table Bloom test in LDS (a key whose bit was still clear in either table cannot equal an earlier key);
+    // any possible duplicate sends the whole group to the exact sort path below.
+    if constexpr (K <= 4) {
+        u32 *bm1 = sb, *bm2 = (u32 *)sk;
+        const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        bool maybe_dup = false;
+        u32 zc = 0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const bool valid = r * 64 + lane < nB;
+            const bool nz = valid && v[r] != ZEROK;
+            zc += (u32)__popcll(__ballot(valid && v[r] == ZEROK));
+            if (nz) {
+                const u32 f = bloom_fold(v[r]);
+                const u32 h1 = bloom_hash1(f), h2 = bloom_hash2(f);
+                const u32 o1 = atomicOr(&bm1[h1 >> 5], 1u << (h1 & 31));
+                const u32 o2 = atomicOr(&bm2[h2 >> 5], 1u << (h2 & 31));
+                maybe_dup |= ((o1 >> (h1 & 31)) & (o2 >> (h2 & 31)) & 1u) != 0;
+            }
+        }
+        const bool any_dup = __ballot(maybe_dup) != 0ull;
+#pragma unroll
+        for (int r = 0; r < K; ++r) { // wipe the words this lane touched (LDS is in order within a wavefront)
+            if (r * 64 + lane < nB && v[r] != ZEROK) {
+                const u32 f = bloom_fold(v[r]);
+                bm1[bloom_hash1(f) >> 5] = 0u;
+                bm2[bloom_hash2(f) >> 5] = 0u;
+            }
+        }
+        wave_lds_fence();
+        if (!any_dup) {
+            // compact the non-zero keys through sk, then one lookup per key
+            int base = 0;
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                const bool nz = (r * 64 + lane < nB) && v[r] != ZEROK;
+                const u64 m = __ballot(nz);
+                if (nz) sk[base + __popcll(m & lt_mask)] = v[r];
+                base += __popcll(m);
+            }
+            wave_lds_fence();
+            u64 S2 = 0, TT = 0;
+            for (int j = 0; j * 64 < base; ++j) {
+                const int slot = j * 64 + lane;
+                if (slot < base) {
+                    const KeyT q = sk[slot];
+                    const u32 lb = lower_bound_pow2(A, nA, topA, q);
+                    u64 a = 0;
+                    if (lb < nA && A[lb] == q) {
+                        if (RUNEND) a = (u32)runend[lb] - lb;
+                        else a = upper_bound_pow2(A, nA, topA, q) - lb;
+                    }
+                    const u64 lt = (u64)lb + ((q > ZEROK) ? (u64)zA : 0ull);
+                    S2 += 2ull * lt + a;
+                    TT += a * (a + 1ull); // run of length 1: tB (3 a (a+1) + 1 - 1) / 3
+                    sk[slot] = (KeyT)0;
+                }
+            }
+            wave_lds_fence();
+            u64 tie = 3ull * TT;
+            if (lane == 0 && zc) { // the group's explicit zeros: one run of length zc against aZ reference zeros
+                const u64 b = zc, a = aZ;
+                S2 += b * (2ull * lbZ + a);
+                tie += b * (3ull * a * (a + b) + b * b - 1ull);
+            }
+            S2out = S2;
+            tieout = tie;
+            sumout = s;
+            return;
+        }
     }
     wave_bitonic_sort<KeyT, K>(v, lane);
 
@@ -207,6 +289,8 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, c
                 u64 lt = (u64)lb + ((q > ZEROK) ? (u64)zA : 0ull);  // implicit zeros of A rank below positives
                 S2 += b * (2ull * lt + a);
                 tie += b * (3ull * a * (a + b) + b * b - 1ull);
+                sk[slot] = (KeyT)0; // leave the scratch zeroed (it doubles as the Bloom tables)
+                sb[slot] = 0u;
             }
         }
         wave_lds_fence();
@@ -320,6 +404,9 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
     const KeyT *Xs = (const KeyT *)P.Xs;
     const int G = P.G, ref = P.ref;
     const int n_ref = P.counts[ref];
+    // the per-wave scratch doubles as Bloom tables: it starts zeroed and every user leaves it zeroed
+    for (int i = tid; i < NW * 256; i += NT) { sk_all[i] = (KeyT)0; sb_all[i] = 0u; }
+    __syncthreads();
 
     for (int gene = blockIdx.x; gene < P.n_genes; gene += gridDim.x) {
         if (gene_flags && gene_flags[gene] == 0) continue; // count-valued gene: handled by k_ovo_counts
@@ -372,6 +459,9 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
         const u64 T_A = *s_TA;
         const double refsum = *s_refsum;
         const u32 nnegA = P.seg_ptr ? lower_bound_pow2(A, nA, topA, ZEROK) : 0u;
+        // reference cells below zero / equal to zero (explicit zeros of the dense layout), for a group's zero run
+        const u32 lbZ = lower_bound_pow2(A, nA, topA, ZEROK);
+        const u32 aZ = upper_bound_pow2(A, nA, topA, ZEROK) - lbZ;
 
         // ---- every other group: one wavefront each, 64 groups per output block ----
         KeyT *sk = sk_all + wave * 256;
@@ -443,11 +533,11 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                 u64 S2 = 0, tie = 0;
                 double sum = 0.0;
                 if (g < G && g != ref) {
-                    if (nB <= 64) ovo_wave_group<KeyT, 1, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                    else if (nB <= 128) ovo_wave_group<KeyT, 2, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                    else if (nB <= 256) ovo_wave_group<KeyT, 4, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                    else if (KMAX >= 8 && nB <= 512) ovo_wave_group<KeyT, (KMAX >= 8 ? 8 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                    else if (KMAX >= 16 && nB <= 1024) ovo_wave_group<KeyT, (KMAX >= 16 ? 16 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    if (nB <= 64) ovo_wave_group<KeyT, 1, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    else if (nB <= 128) ovo_wave_group<KeyT, 2, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    else if (nB <= 256) ovo_wave_group<KeyT, 4, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    else if (KMAX >= 8 && nB <= 512) ovo_wave_group<KeyT, (KMAX >= 8 ? 8 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    else if (KMAX >= 16 && nB <= 1024) ovo_wave_group<KeyT, (KMAX >= 16 ? 16 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
                     if (lane == 0) {
                         // implicit zeros of B (sparse layout): each ranks above A's negatives and ties with A's zeros
                         S2 += (u64)zB * (2ull * nnegA + zA);
