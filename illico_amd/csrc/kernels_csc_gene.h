@@ -21,7 +21,8 @@
 #define CSCG_MEDIUM 128 // longest run the LDS-history form takes; beyond: the gene leaves this kernel
 
 struct CscGeneParams {
-    const void *data, *indices, *indptr; // CSC arrays (device); entry k lives at data[k], indices[k]
+    const void *data, *indices, *indptr; // CSC arrays (device); stored entry k lives at data[k - kshift], indices[k - kshift]
+    long long kshift;
     long long col0;                      // first gene of the batch
     int nb;
     const int *codes;                    // [n_cells] group code per cell
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
     const int n_ref = P.counts[ref];
 
     for (int gene = blockIdx.x; gene < P.nb; gene += gridDim.x) {
-        const long long k0 = (long long)indptr[P.col0 + gene], k1 = (long long)indptr[P.col0 + gene + 1];
+        const long long k0 = (long long)indptr[P.col0 + gene] - P.kshift, k1 = (long long)indptr[P.col0 + gene + 1] - P.kshift;
         // ---- 1. stored non-zeros per group ----
         for (int g = tid; g <= G; g += NT) ends[g] = 0;
         __syncthreads();

@@ -45,13 +45,15 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
                                                         const int *__restrict__ codes, int G, KeyT *__restrict__ Xs,
                                                         u32 *__restrict__ vals, u32 *__restrict__ seg_ptr,
                                                         u32 *__restrict__ gene_flags, int count_limit,
-                                                        const int *__restrict__ gene_cols, const u32 *__restrict__ gene_base) {
+                                                        const int *__restrict__ gene_cols, const u32 *__restrict__ gene_base,
+                                                        long long kshift) {
     extern __shared__ __align__(16) unsigned char smem[];
     u32 *hist = (u32 *)smem;
     u32 *tmp = hist + ((G + 3) & ~3);
     const int tid = threadIdx.x;
     // batch = columns col0 .. col0+nb-1, or (gene_cols != nullptr) an arbitrary list of columns whose keys are
-    // packed at gene_base[gene]
+    // packed at gene_base[gene].  Stored entry k of the caller's matrix lives at data[k - kshift] / indices[k - kshift]
+    // (a host-resident matrix is staged from its first needed entry on).
     const long long base0 = (long long)indptr[col0];
     for (int gene = blockIdx.x; gene < nb; gene += gridDim.x) {
         const long long col = gene_cols ? (long long)gene_cols[gene] : col0 + gene;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
         const u32 gbase = gene_cols ? gene_base[gene] : (u32)(k0 - base0);
         for (int g = tid; g < G; g += SEG_NT) hist[g] = 0;
         __syncthreads();
-        for (long long k = k0 + tid; k < k1; k += SEG_NT)
+        for (long long k = k0 - kshift + tid; k < k1 - kshift; k += SEG_NT)
             if (data[k] != (InT)0) atomicAdd(&hist[codes[(long long)indices[k]]], 1u);
         __syncthreads();
         u32 total = block_excl_scan_inplace<SEG_NT>(hist, G, tmp, tid);
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
         if (tid == 0) sp[G] = gbase + total;
         __syncthreads();
         bool viol = false;
-        for (long long k = k0 + tid; k < k1; k += SEG_NT) {
+        for (long long k = k0 - kshift + tid; k < k1 - kshift; k += SEG_NT) {
             InT v = data[k];
             if (v != (InT)0) {
                 int c = codes[(long long)indices[k]];

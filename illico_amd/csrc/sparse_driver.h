@@ -37,7 +37,7 @@ static std::vector<SparseBatch> plan_batches(const std::vector<int64_t> &gene_nn
 // Single-kernel CSC OVO route over genes [g0, g1): statistics + finalize for every gene it can take; the genes it
 // cannot take come back as column runs for the two-kernel route.
 template <typename InT, typename IdxT, typename KeyT>
-static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int dtype,
+static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, int dtype,
                               int64_t g0, int64_t g1, int64_t col_lb, int flags, int alternative, const OutPlanes &o,
                               std::vector<int64_t> &fallback_cols) {
     const int G = (int)c->n_groups;
@@ -65,7 +65,7 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
         const int nb = (int)std::min<int64_t>(nb_max, g1 - b0);
         HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)nb * 4, c->stream));
         CscGeneParams P;
-        P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.col0 = b0; P.nb = nb; P.codes = c->d_codes;
+        P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = b0; P.nb = nb; P.codes = c->d_codes;
         P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
         P.key_cap = key_cap; P.runend_cap = runend_cap; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
         {
@@ -103,9 +103,10 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     const int64_t total_nnz = (int64_t)h_indptr[n_ptr - 1];
     if (h_indptr[0] != 0) return fail(c, ILLICO_ERR_ARG, "indptr[0] must be 0");
 
-    // device views of the matrix: entry k of the caller's arrays is d_data[k] / d_indices[k]
+    // device views of the matrix: stored entry k of the caller's arrays is d_data[k - kshift] / d_indices[k - kshift]
     const InT *d_data = (const InT *)data;
     const IdxT *d_indices = (const IdxT *)indices, *d_indptr = (const IdxT *)indptr;
+    int64_t kshift = 0;
     if (!in_dev) {
         if ((rc = get_scratch(c, "sp_indptr", n_ptr * sizeof(IdxT), &v))) return rc;
         HIPCHK(c, hipMemcpyAsync(v, indptr, n_ptr * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
@@ -116,10 +117,11 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         const size_t cnt = (size_t)std::max<int64_t>(k1 - k0, 1);
         if ((rc = get_scratch(c, "sp_data", cnt * sizeof(InT), &v))) return rc;
         HIPCHK(c, hipMemcpyAsync(v, (const InT *)data + k0, (size_t)(k1 - k0) * sizeof(InT), hipMemcpyHostToDevice, c->stream));
-        d_data = (const InT *)v - k0;
+        d_data = (const InT *)v;
+        kshift = k0;
         if ((rc = get_scratch(c, "sp_indices", cnt * sizeof(IdxT), &v))) return rc;
         HIPCHK(c, hipMemcpyAsync(v, (const IdxT *)indices + k0, (size_t)(k1 - k0) * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
-        d_indices = (const IdxT *)v - k0;
+        d_indices = (const IdxT *)v;
     }
 
     // per-gene stored-entry counts of the requested window
@@ -147,7 +149,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     // stragglers of the single-kernel route are batched together); CSR batches are contiguous windows.
     std::vector<int64_t> cols;
     if (!is_csr && !ovr && !c->no_csc_gene_path) {
-        if ((rc = run_csc_gene_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, dtype, col_lb, col_ub, col_lb, flags,
+        if ((rc = run_csc_gene_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, dtype, col_lb, col_ub, col_lb, flags,
                                                       alternative, o, cols)))
             return rc;
         if (cols.empty()) return ILLICO_OK;
@@ -226,7 +228,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             size_t lds = seg_lds_bytes(G);
             HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(nb), dim3(SEG_NT), lds, c->stream, d_data, d_indices, d_indptr, (long long)b.g0, nb,
-                               (const int *)c->d_codes, G, Xs, va, seg, gflags, COUNTS_R, d_cols, d_base);
+                               (const int *)c->d_codes, G, Xs, va, seg, gflags, COUNTS_R, d_cols, d_base, (long long)kshift);
             HIPCHK(c, hipGetLastError());
         } else {
             if ((rc = get_scratch(c, "sp_cursor", (size_t)nb * (G + 1) * 4 + (size_t)nb * 8, &v))) return rc;
