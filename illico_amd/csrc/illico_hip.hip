@@ -66,6 +66,7 @@ struct illico_ctx {
     bool no_csc_gene_path = false;
     int fused_groups_per_wg = 0; // 0 = auto
     int ovr_threads = 256;
+    int fused_layout = 0; // 0: LDS tables [lane][value] (odd stride); 1: [value][lane] (conflict-free, measured 0.8 % slower)
     bool profile = false;
     std::vector<ProfEvent> events;
     double prof_ms[KID_COUNT] = {0};
@@ -211,6 +212,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
     else if (!strcmp(key, "ovr_threads")) c->ovr_threads = (int)value;
+    else if (!strcmp(key, "fused_layout")) c->fused_layout = (int)value;
     else if (!strcmp(key, "fused_groups_per_wg")) c->fused_groups_per_wg = (int)std::max<int64_t>(0, value);
     else return fail(c, ILLICO_ERR_ARG, "unknown option '%s'", key);
     return ILLICO_OK;
@@ -499,10 +501,14 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             HIPCHK(c, hipGetLastError());
         }
         ProfScope ps(c, KID_OVO_FUSED);
-        if (c->max_nonref <= 255) // 8-bit running multiplicities: 34 KB of LDS per workgroup instead of 50 KB
-            hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
-        else
-            hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        const bool tl = c->fused_layout != 0;
+        if (c->max_nonref <= 255) { // 8-bit running multiplicities: 34 KB of LDS per workgroup instead of 50 KB
+            if (tl) hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8, true>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+            else hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8, false>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        } else {
+            if (tl) hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16, true>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+            else hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16, false>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        }
         HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipMemsetAsync(P.hist_all, 0, (size_t)nb * RT * 4, c->stream));
@@ -514,7 +520,8 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             HIPCHK(c, hipGetLastError());
         }
         ProfScope ps(c, KID_OVR_FUSED);
-        hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        if (c->fused_layout != 0) hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16, true>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        else hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16, false>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
         HIPCHK(c, hipGetLastError());
     }
     h_flags.resize(nb);

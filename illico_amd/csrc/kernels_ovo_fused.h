@@ -79,7 +79,9 @@ template <> __device__ __forceinline__ u32 clamp_count<int64_t, 64>(int64_t v, b
 // PRED: rows at or past p1 (group end) re-read the last row and are masked out.
 // CB = bits per running-multiplicity counter: 16 (groups up to 65535 cells) or 8 (groups up to 255 cells: half
 // the LDS, so one more workgroup per CU).
-template <typename InT, int RT, int UU, bool PRED, int CB>
+// TL: tables laid out [value][lane] (LS = 64: the LDS bank is the lane, never a conflict) or [lane][value] (LS = 1,
+// odd lane stride: equal values never conflict, different values collide at random).
+template <typename InT, int RT, int UU, bool PRED, int CB, bool TL>
 __device__ __forceinline__ void fused_chunk(const InT *__restrict__ Xg, long long ld, const int *__restrict__ perm, int p, int p1,
                                             int lane, int lane_c, const u32 *ca, u32 *cb, u64 &S2, u64 &TT, u32 &vsum,
                                             bool &inexact) {
@@ -95,20 +97,21 @@ __device__ __forceinline__ void fused_chunk(const InT *__restrict__ Xg, long lon
     for (int u = 0; u < UU; ++u) {
         bool exact;
         const u32 c = clamp_count<InT, RT>(v[u], exact);
-        const u32 lo = ca[c], hi = ca[c + 1];
+        constexpr int LS = TL ? 64 : 1;
+        const u32 lo = ca[c * LS], hi = ca[c * LS + LS];
         constexpr int PW = 32 / CB, LG = (CB == 16 ? 1 : 2), LB = (CB == 16 ? 4 : 3); // counters per word
         const u32 sh = (c & (u32)(PW - 1)) << LB;
         if (PRED) {
             const bool valid = p + u < p1; // wave-uniform
             inexact |= valid && !exact;
-            const u32 old = atomicAdd(&cb[c >> LG], valid ? (1u << sh) : 0u);
+            const u32 old = atomicAdd(&cb[(c >> LG) * LS], valid ? (1u << sh) : 0u);
             const u32 t = valid ? (hi - lo) + __builtin_amdgcn_ubfe(old, sh, CB) : 0u;
             s2c += valid ? lo + hi : 0u;
             TT += (u64)t * (t + 1u);
             vsum += valid ? c : 0u;
         } else {
             inexact |= !exact;
-            const u32 old = atomicAdd(&cb[c >> LG], 1u << sh); // lane-private word of packed counters: fetch-and-add
+            const u32 old = atomicAdd(&cb[(c >> LG) * LS], 1u << sh); // lane-private word of packed counters: fetch-and-add
             const u32 t = (hi - lo) + __builtin_amdgcn_ubfe(old, sh, CB);
             s2c += lo + hi;
             TT += (u64)t * (t + 1u);
@@ -243,7 +246,7 @@ template <int RT> __global__ void k_fused_tables_all(FusedParams P) {
 }
 
 // One chunk of the OVR rank-sum pass: R2 += cum[c] + cum[c+1] (= 2 #cells<c + #cells==c), value sum.
-template <typename InT, int RT, int UU, bool PRED>
+template <typename InT, int RT, int UU, bool PRED, bool TL>
 __device__ __forceinline__ void fused_chunk_ovr(const InT *__restrict__ Xg, long long ld, const int *__restrict__ perm, int p, int p1,
                                                 int lane, int lane_c, const u32 *ca, u64 &R2, u32 &vsum) {
     const int pidx = perm[PRED ? min(p + (lane & (UU - 1)), p1 - 1) : p + (lane & (UU - 1))];
@@ -258,7 +261,8 @@ __device__ __forceinline__ void fused_chunk_ovr(const InT *__restrict__ Xg, long
     for (int u = 0; u < UU; ++u) {
         bool exact;
         const u32 c = clamp_count<InT, RT>(v[u], exact);
-        const u32 lo = ca[c], hi = ca[c + 1];
+        constexpr int LS = TL ? 64 : 1;
+        const u32 lo = ca[c * LS], hi = ca[c * LS + LS];
         const bool valid = !PRED || (p + u < p1);
         r2c += valid ? lo + hi : 0u;
         vsum += valid ? c : 0u;
@@ -267,11 +271,15 @@ __device__ __forceinline__ void fused_chunk_ovr(const InT *__restrict__ Xg, long
 }
 
 // ---- main pass: grid (tiles, group chunks); 4 wavefronts per workgroup, one group at a time per wavefront ----
-template <typename InT, int RT, bool OVR, int CB>
+template <typename InT, int RT, bool OVR, int CB, bool TL>
 __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
-    constexpr int NW = FUSED_NT / 64, CSTR = RT + 1, BSTR = (OVR ? 0 : RT * CB / 32) + 1, U = FUSED_U;
-    __shared__ u32 cumA[64 * CSTR];        // cumA[lane*CSTR + c] = # reference cells of gene `lane` with value < c
-    __shared__ u32 cntB[NW][64 * BSTR];    // per wavefront, per gene: running multiplicity of each value (16-bit pairs)
+    constexpr int NW = FUSED_NT / 64, CSTR = RT + 1, BW = OVR ? 1 : RT * CB / 32, U = FUSED_U;
+    constexpr int BSTR = BW + 1;                 // [lane][value] layout: odd lane stride
+    constexpr int LS = TL ? 64 : 1;
+    // Both tables are laid out [value][lane]: the LDS bank of an access is the lane id whatever the value, so the
+    // data-dependent lookups and fetch-and-adds never conflict (64 consecutive words per value).
+    __shared__ u32 cumA[CSTR * 64];        // # reference cells of gene `lane` with value < c
+    __shared__ u32 cntB[NW][BSTR * 64];    // per wavefront: running multiplicity of each value of gene `lane` (packed counters)
     __shared__ int s_skip;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
@@ -285,13 +293,13 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
     __syncthreads();
     if (s_skip) return;
     for (int i = tid; i < 64 * CSTR; i += FUSED_NT) {
-        const int l = i / CSTR, c = i - l * CSTR;
-        cumA[i] = (gene0 + l < P.ncols) ? P.ref_cum[(size_t)(gene0 + l) * CSTR + c] : 0u;
+        const int l = i / CSTR, c = i - l * CSTR; // consecutive threads read consecutive words of the [gene][value] table
+        cumA[TL ? c * 64 + l : l * CSTR + c] = (gene0 + l < P.ncols) ? P.ref_cum[(size_t)(gene0 + l) * CSTR + c] : 0u;
     }
-    u32 *cb = cntB[wave] + lane * BSTR;
-    for (int i = 0; i < BSTR; ++i) cb[i] = 0;
+    u32 *cb = cntB[wave] + (TL ? lane : lane * BSTR);
+    for (int i = 0; i < BW; ++i) cb[i * LS] = 0;
     __syncthreads();
-    const u32 *ca = cumA + lane * CSTR;
+    const u32 *ca = cumA + (TL ? lane : lane * CSTR);
     const InT *X = (const InT *)P.X;
     const long long n_ref = OVR ? 0 : P.counts[OVR ? 0 : P.ref];
     const u64 T_A = act ? P.ref_TA[gene] : 0ull;
@@ -310,11 +318,11 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
         u32 vsum = 0;
         int p = p0;
         if (OVR) {
-            for (; p + U <= p1; p += U) fused_chunk_ovr<InT, RT, U, false>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, S2, vsum);
-            for (; p < p1; p += 8) fused_chunk_ovr<InT, RT, 8, true>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, S2, vsum);
+            for (; p + U <= p1; p += U) fused_chunk_ovr<InT, RT, U, false, TL>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, S2, vsum);
+            for (; p < p1; p += 8) fused_chunk_ovr<InT, RT, 8, true, TL>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, S2, vsum);
         } else {
-            for (; p + U <= p1; p += U) fused_chunk<InT, RT, U, false, CB>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
-            for (; p < p1; p += 8) fused_chunk<InT, RT, 8, true, CB>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
+            for (; p + U <= p1; p += U) fused_chunk<InT, RT, U, false, CB, TL>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
+            for (; p < p1; p += 8) fused_chunk<InT, RT, 8, true, CB, TL>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
         }
         // ---- this lane's (group, gene) result ----
         const long long n_tgt = p1 - p0;
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
             P.out_fc[o] = fc;
         }
         if (OVR) continue;
-        for (int i = 0; i < BSTR; ++i) cb[i] = 0; // lane-private, in-order LDS: no barrier needed
+        for (int i = 0; i < BW; ++i) cb[i * LS] = 0; // lane-private, in-order LDS: no barrier needed
     }
     if (act && bad) P.gene_flags[gene] = 1u;
 }
