@@ -1,9 +1,9 @@
 // OVO ranking for count-valued genes: a gene whose values are all integers in [0, COUNTS_R) needs no
 // sort.  The reference column becomes a histogram in LDS (cumA[v] = #ref < v, cntA[v] = #ref == v);
-// each group is histogrammed by one wavefront (LDS integer atomics, zeros counted by ballot), and every
-// occupied bin v with multiplicity tB contributes
-//     S2  += tB * (2*cumA[v] + cntA[v])        tie += tB * (3*tA*(tA+tB) + tB^2 - 1),  tA = cntA[v]
-// exactly as the sort path does for a run of equal keys (kernels_ovo.h) -- same integers, bit-exact.
+// each group is walked by one wavefront (lane = cell): a fetch-and-add on the wavefront's LDS counter table gives
+// o = number of earlier cells of the group with the same value (zeros are ranked by ballot), and per cell
+//     S2 += cumA[c] + cumA[c+1]                 TT += t (t+1),  t = cntA[c] + o      (tie term = 3 sum TT)
+// -- the same integers as the run-based form of the sort path (kernels_ovo.h), bit-exact.
 // Group and reference sizes are unbounded here (nothing has to fit in registers or LDS but the tables).
 //
 // Genes are routed per gene: k_transpose_permute* (dense) and the sparse ingest kernels set
@@ -103,73 +103,101 @@ __global__ __launch_bounds__(COUNTS_NT, 4) void k_ovo_counts(OvoParams P, const 
         __syncthreads();
         // now cumA[v] = # reference values < v for v in [0, R], cntA[v] = cumA[v+1] - cumA[v]
 
-        // ---- groups: one wavefront each ----
+        // ---- groups: one wavefront each; lane = cell.  Per cell with value c (a = cntA[c], o = earlier cells of
+        // the group with the same value, from a fetch-and-add on the wavefront's counter table; zeros are ranked by
+        // ballot instead of 64 same-address atomics):  S2 += cum[c] + cum[c+1],  TT += t (t+1), t = a + o.
         for (int g0 = wave * 64; g0 < G; g0 += NW * 64) {
             TrReduce<u64> rS2, rTie, rSum;
-            for (int j = 0; j < 64; ++j) {
-                const int g = g0 + j;
-                u64 S2 = 0, tie = 0, sum = 0;
+            // next group's first 256 keys are fetched while the current group is processed
+            KeyT nxt[4];
+            int nB_n = 0, zB_n = 0;
+            long long bs_n = 0;
+            auto fetch = [&](int g) {
+                nB_n = 0; zB_n = 0; bs_n = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nxt[r] = (KeyT)0;
                 if (g < G && g != ref) {
                     const int n_g = P.counts[g];
-                    long long bstart;
-                    int nB;
-                    if (sp) { bstart = sp[g]; nB = (int)(sp[g + 1] - sp[g]); }
-                    else { bstart = (long long)gene * P.gene_stride + P.pos_ptr[g]; nB = n_g; }
-                    const u32 zB = (u32)(n_g - nB);
-                    const KeyT *seg = Xs + bstart;
-                    u32 nzero = 0, vmax = 0;
-                    for (int i0 = 0; i0 < nB; i0 += 256) { // 4 keys per lane per trip
+                    if (sp) { bs_n = sp[g]; nB_n = (int)(sp[g + 1] - sp[g]); }
+                    else { bs_n = (long long)gene * P.gene_stride + P.pos_ptr[g]; nB_n = n_g; }
+                    zB_n = n_g - nB_n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = r * 64 + lane;
+                        if (i < nB_n) nxt[r] = Xs[bs_n + i];
+                    }
+                }
+            };
+            fetch(g0);
+            const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            for (int j = 0; j < 64; ++j) {
+                const int g = g0 + j;
+                KeyT cur[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cur[r] = nxt[r];
+                const int nB = nB_n;
+                const u32 zB = (u32)zB_n;
+                const long long bstart = bs_n;
+                fetch(g + 1 < g0 + 64 ? g + 1 : G);
+                u64 S2 = 0, TT = 0, sum = 0;
+                if (g < G && g != ref) {
+                    const u64 a0 = cumA[1]; // cntA[0]
+                    u32 zseen = 0;          // zeros of this group seen so far (wave-uniform)
+                    for (int i0 = 0; i0 < nB; i0 += 256) {
                         u32 c[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            int i = i0 + r * 64 + lane;
-                            c[r] = i < nB ? count_of_key(seg[i], P.dt) : 0u;
+                            const int i = i0 + r * 64 + lane;
+                            const KeyT k = (i0 == 0) ? cur[r] : (i < nB ? Xs[bstart + i] : (KeyT)0);
+                            c[r] = i < nB ? count_of_key(k, P.dt) : 0u;
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            int i = i0 + r * 64 + lane;
-                            bool valid = i < nB;
-                            nzero += (u32)__popcll(__ballot(valid && c[r] == 0));
-                            if (valid && c[r] != 0) atomicAdd(&hw[c[r] >> 1], (c[r] & 1u) ? 0x10000u : 1u);
-                            vmax = max(vmax, c[r]);
+                            const int i = i0 + r * 64 + lane;
+                            const bool valid = i < nB;
+                            const u64 zb = __ballot(valid && c[r] == 0);
+                            if (valid) {
+                                u32 o, a, lo, hi;
+                                if (c[r] == 0) {
+                                    o = zseen + (u32)__popcll(zb & lt_mask);
+                                    lo = 0; hi = (u32)a0;
+                                } else {
+                                    const u32 sh = (c[r] & 1u) << 4;
+                                    o = __builtin_amdgcn_ubfe(atomicAdd(&hw[c[r] >> 1], 1u << sh), sh, 16);
+                                    lo = cumA[c[r]]; hi = cumA[c[r] + 1];
+                                }
+                                a = hi - lo;
+                                const u64 t = (u64)a + o;
+                                S2 += (u64)lo + hi + 2ull * (c[r] ? zA : 0u); // implicit zeros of A rank below c > 0
+                                TT += t * (t + 1ull);
+                                sum += c[r];
+                            }
+                            zseen += (u32)__popcll(zb);
                         }
                     }
-                    // wave max of the values seen (bins to visit)
-                    vmax = (u32)wave_incl_scan_max((int)vmax);
-                    vmax = (u32)__builtin_amdgcn_readlane((int)vmax, 63);
                     wave_lds_fence();
-                    for (u32 w0 = 0; w0 * 2 <= vmax; w0 += 64) {
-                        const u32 w = w0 + lane;
-                        u32 word = (w * 2 <= vmax) ? hw[w] : 0u;
-                        if (word) {
-                            hw[w] = 0; // leave the table clean for the next group
+                    // wipe the counter words the group touched (plain stores; LDS is in order within a wavefront)
+                    for (int i0 = 0; i0 < nB; i0 += 256) {
 #pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const u32 v = 2 * w + h;
-                                const u64 b = h ? (word >> 16) : (word & 0xFFFFu);
-                                if (b) {
-                                    const u64 lt = (u64)cumA[v] + zA;        // implicit zeros of A rank below v > 0
-                                    const u64 a = cumA[v + 1] - cumA[v];
-                                    S2 += b * (2ull * lt + a);
-                                    tie += b * (3ull * a * (a + b) + b * b - 1ull);
-                                    sum += b * v;
-                                }
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = i0 + r * 64 + lane;
+                            if (i < nB) {
+                                const KeyT k = (i0 == 0) ? cur[r] : Xs[bstart + i];
+                                const u32 cc = count_of_key(k, P.dt);
+                                if (cc) hw[cc >> 1] = 0u;
                             }
                         }
                     }
                     wave_lds_fence();
                     if (lane == 0) {
-                        // value 0: explicit zeros of B (dense layout) tie with the reference's explicit zeros;
                         // implicit zeros of both sides (sparse layout) form one block, as in kernels_ovo.h
-                        const u64 b0 = nzero, a0 = cumA[1]; // cntA[0]
-                        if (b0) {
-                            S2 += b0 * a0; // lt = 0
-                            tie += b0 * (3ull * a0 * (a0 + b0) + b0 * b0 - 1ull);
-                        }
                         S2 += (u64)zB * zA;
-                        const u64 t0 = (u64)zA + zB;
-                        tie += T_A + (t0 * t0 * t0 - t0);
                     }
+                }
+                u64 tie = 3ull * TT;
+                if (lane == 0 && g < G && g != ref) {
+                    const u64 t0 = (u64)zA + zB;
+                    tie += T_A + (t0 * t0 * t0 - t0);
                 }
                 rS2.push(S2, j, lane);
                 rTie.push(tie, j, lane);
