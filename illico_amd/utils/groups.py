@@ -6,10 +6,8 @@ from typing import Any
 
 import numpy as np
 
-GroupContainer = namedtuple(
-    "GroupContainer",
-    ["encoded_groups", "counts", "indices", "indptr", "encoded_ref_group"],
-)
+# same five fields, in the same order, as the reference's container (illico/utils/groups.py:6-15)
+GroupContainer = namedtuple("GroupContainer", "encoded_groups counts indices indptr encoded_ref_group")
 
 
 def encode_and_count_groups(groups, ref_group: Any):

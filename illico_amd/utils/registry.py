@@ -1,23 +1,24 @@
-"""Dispatch keys and data handlers -- the reference's plugin seam (illico/utils/registry.py).
+"""Dispatch keys and data handlers: the plugin seam the MI355X engine sits behind.
 
-``dispatcher_registry[(Test, KernelDataFormat)]`` holds the six chunk kernels with the reference's
-dispatcher signature (registry.py:26-43); ``data_handler_registry`` maps the Python type of ``X``
-onto a handler (registry.py:46-58).  Handlers keep the reference's contract
-(``fetch / to_nb / kernel_data_format / footprint``, registry.py:67-94); ``input_signature`` is a
-Numba notion and returns ``None`` here (HIP code objects are built ahead of time).
+Same public surface as the reference's ``illico/utils/registry.py`` so that its driver code and tests read the
+same here: ``Test`` / ``KernelDataFormat`` enums (registry.py:15-23), ``dispatcher_registry.register(test, fmt)`` /
+``.get(test, fmt)`` holding the six chunk kernels (registry.py:26-43), ``data_handler_registry.get(X)`` mapping the
+Python type of ``X`` onto a handler (registry.py:46-58), and handlers with ``fetch / to_nb / kernel_data_format /
+footprint`` (registry.py:67-94).  ``input_signature`` is a Numba notion (HIP code objects are built ahead of time)
+and returns ``None``.  Handlers whose ``streams`` flag is set read one gene chunk from storage per ``fetch`` and are
+driven through the prefetching chunk pipeline of ``illico_amd.asymptotic_wilcoxon``.
 """
 from __future__ import annotations
 
-from abc import ABC, abstractmethod
 from collections import namedtuple
 from enum import Enum
-from typing import Any
 
 import numpy as np
-from scipy import sparse as py_sparse
+from scipy import sparse as _sp
 
-CSCMatrix = namedtuple("CSCMatrix", ["data", "indices", "indptr", "shape"])  # utils/sparse/csc.py:10
-CSRMatrix = namedtuple("CSRMatrix", ["data", "indices", "indptr", "shape"])  # utils/sparse/csr.py:16
+# kernel-side containers of the sparse formats (utils/sparse/csc.py:10, utils/sparse/csr.py:16)
+CSCMatrix = namedtuple("CSCMatrix", ["data", "indices", "indptr", "shape"])
+CSRMatrix = namedtuple("CSRMatrix", ["data", "indices", "indptr", "shape"])
 
 
 class Test(Enum):
@@ -32,153 +33,152 @@ class KernelDataFormat(Enum):
 
 
 class DispatcherRegistry(dict):
-    def register(self, test: Test, data_format: KernelDataFormat):
-        test = Test(test)
-        data_format = KernelDataFormat(data_format)
+    """``(Test, KernelDataFormat) -> chunk kernel``; enum members or their string values are accepted."""
 
-        def decorator(obj):
-            self[(test, data_format)] = obj
-            return obj
+    @staticmethod
+    def _key(test, data_format):
+        return Test(test), KernelDataFormat(data_format)
 
-        return decorator
+    def register(self, test, data_format):
+        key = self._key(test, data_format)
 
-    def get(self, test: Test, data_format: KernelDataFormat):
-        key = (Test(test), KernelDataFormat(data_format))
-        try:
-            return self[key]
-        except KeyError as e:
-            raise KeyError(f"No dispatcher registered for test {test} and data format {data_format}.") from e
+        def _bind(kernel):
+            self[key] = kernel
+            return kernel
+
+        return _bind
+
+    def get(self, test, data_format):
+        key = self._key(test, data_format)
+        if key not in self:
+            raise KeyError(f"No dispatcher registered for test {test} and data format {data_format}.")
+        return self[key]
 
 
 class DataHandlerRegistry(dict):
-    def register(self, data_format):
-        def decorator(obj):
-            self[data_format] = obj
-            return obj
+    """``type(X) -> DataHandler subclass``; ``get(X)`` instantiates the handler of ``X``'s exact type."""
 
-        return decorator
+    def register(self, container_type):
+        def _bind(handler_cls):
+            self[container_type] = handler_cls
+            return handler_cls
 
-    def get(self, key):
-        try:
-            return self[type(key)](key)
-        except KeyError as e:
-            raise KeyError(f"Support for data type {type(key)} is not implemented.") from e
+        return _bind
+
+    def get(self, X):
+        handler_cls = dict.get(self, type(X))
+        if handler_cls is None:
+            raise KeyError(f"Support for data type {type(X)} is not implemented.")
+        return handler_cls(X)
 
 
 data_handler_registry = DataHandlerRegistry()
 dispatcher_registry = DispatcherRegistry()
 
 
-class DataHandler(ABC):
+class DataHandler:
+    """Base handler: in-RAM containers hand themselves over whole and let the engine slice on the device."""
+
+    #: True for backed containers: ``fetch`` reads just the requested gene chunk from storage
+    streams = False
+    fmt: KernelDataFormat = KernelDataFormat.DENSE
+
     def __init__(self, data):
         self.data = data
 
     def input_signature(self, *args, **kwargs):
         return None
 
-    @abstractmethod
-    def fetch(self, lb: int, ub: int) -> tuple:
-        """Return (data, (lb', ub')) -- registry.py:97-100,164-165,187-188."""
-
-    @abstractmethod
-    def to_nb(self, X) -> Any:
-        """Convert to the kernel-side container."""
-
-    @abstractmethod
     def kernel_data_format(self) -> KernelDataFormat:
-        pass
-
-    @abstractmethod
-    def footprint(self) -> int:
-        pass
-
-
-class InRAMDataHandler(DataHandler):
-    #: backed handlers (h5py / anndata backed / np.memmap) set this: fetch() reads one gene chunk from storage and
-    #: the driver streams chunks with a prefetch thread instead of handing the whole range to the engine
-    streams = False
+        return self.fmt
 
     def fetch(self, lb: int, ub: int) -> tuple:
+        """``(container, (lb', ub'))``: the columns to compute inside the returned container (registry.py:97-100)."""
         return self.data, (lb, ub)
+
+    @classmethod
+    def to_nb(cls, X):
+        return X
+
+    def footprint(self) -> int:
+        raise NotImplementedError
+
+
+InRAMDataHandler = DataHandler  # the reference's name for the same thing
 
 
 @data_handler_registry.register(np.ndarray)
-class DenseDataHandler(InRAMDataHandler):
-    def kernel_data_format(self) -> KernelDataFormat:
-        return KernelDataFormat.DENSE
+class DenseDataHandler(DataHandler):
+    fmt = KernelDataFormat.DENSE
 
     def footprint(self) -> int:
-        return self.data.nbytes
+        return int(self.data.nbytes)
 
     @classmethod
-    def to_nb(cls, X: np.ndarray) -> np.ndarray:
-        assert isinstance(X, np.ndarray)
+    def to_nb(cls, X):
+        if not isinstance(X, np.ndarray):
+            raise TypeError(f"dense handler got {type(X)}")
         return X
-
-
-@data_handler_registry.register(py_sparse.csr_matrix)
-class CSRDataHandler(InRAMDataHandler):
-    @classmethod
-    def to_nb(cls, X) -> CSRMatrix:
-        return CSRMatrix(X.data, X.indices, X.indptr, X.shape)
-
-    def kernel_data_format(self) -> KernelDataFormat:
-        return KernelDataFormat.CSR
-
-    def footprint(self) -> int:
-        return self.data.data.nbytes + self.data.indptr.nbytes + self.data.indices.nbytes
-
-
-@data_handler_registry.register(py_sparse.csc_matrix)
-class CSCDataHandler(InRAMDataHandler):
-    @classmethod
-    def to_nb(cls, X) -> CSCMatrix:
-        return CSCMatrix(X.data, X.indices, X.indptr, X.shape)
-
-    def kernel_data_format(self) -> KernelDataFormat:
-        return KernelDataFormat.CSC
-
-    def footprint(self) -> int:
-        return self.data.data.nbytes + self.data.indptr.nbytes + self.data.indices.nbytes
 
 
 @data_handler_registry.register(np.memmap)
 class MemmapDenseDataHandler(DenseDataHandler):
     """Dense matrix backed by a file (``np.load(..., mmap_mode="r")`` / ``np.memmap``): out-of-core like the
     reference's h5py handler (registry.py:162-168) -- one gene chunk is paged in per fetch."""
+
     streams = True
 
     def fetch(self, lb: int, ub: int) -> tuple:
         return np.ascontiguousarray(self.data[:, lb:ub]), (0, ub - lb)
 
     @classmethod
-    def to_nb(cls, X) -> np.ndarray:
+    def to_nb(cls, X):
         return np.asarray(X)
 
 
-for _name in ("csr_array", "csc_array"):  # scipy's array API twins
-    _t = getattr(py_sparse, _name, None)
-    if _t is not None:
-        data_handler_registry[_t] = CSRDataHandler if _name.startswith("csr") else CSCDataHandler
+class _CompressedHandler(DataHandler):
+    """Shared part of the CSR / CSC handlers: ``(data, indices, indptr, shape)`` goes to the kernel side."""
 
-try:  # device-resident dense input (torch.Tensor on the MI355X): no H2D copy inside the call
+    container = CSRMatrix
+
+    def footprint(self) -> int:
+        m = self.data
+        return int(m.data.nbytes + m.indices.nbytes + m.indptr.nbytes)
+
+    @classmethod
+    def to_nb(cls, X):
+        return cls.container(X.data, X.indices, X.indptr, X.shape)
+
+
+class CSRDataHandler(_CompressedHandler):
+    fmt = KernelDataFormat.CSR
+    container = CSRMatrix
+
+
+class CSCDataHandler(_CompressedHandler):
+    fmt = KernelDataFormat.CSC
+    container = CSCMatrix
+
+
+for _name, _handler in (("csr_matrix", CSRDataHandler), ("csc_matrix", CSCDataHandler),
+                        ("csr_array", CSRDataHandler), ("csc_array", CSCDataHandler)):
+    _type = getattr(_sp, _name, None)
+    if _type is not None:
+        data_handler_registry[_type] = _handler
+
+try:  # device-resident dense input (a torch.Tensor on the MI355X): no H2D copy inside the call
     import torch as _torch
 
     @data_handler_registry.register(_torch.Tensor)
-    class TorchDenseDataHandler(InRAMDataHandler):
-        def kernel_data_format(self) -> KernelDataFormat:
-            return KernelDataFormat.DENSE
+    class TorchDenseDataHandler(DataHandler):
+        fmt = KernelDataFormat.DENSE
 
         def footprint(self) -> int:
-            return self.data.numel() * self.data.element_size()
-
-        @classmethod
-        def to_nb(cls, X):
-            return X
+            return int(self.data.numel() * self.data.element_size())
 except Exception:  # pragma: no cover
     pass
 
-try:  # out-of-core handlers (registry.py:162-188) when h5py / anndata are installed
+try:  # out-of-core handlers of the reference (registry.py:162-188), when h5py / anndata are importable
     import h5py as _h5py
 
     @data_handler_registry.register(_h5py.Dataset)
@@ -198,13 +198,14 @@ try:
         streams = True
 
         def footprint(self) -> int:
-            return self.data._data.nbytes + self.data._indptr.nbytes + self.data._indices.nbytes
+            d = self.data
+            return int(d._data.nbytes + d._indptr.nbytes + d._indices.nbytes)
 
         def fetch(self, lb: int, ub: int) -> tuple:
             return self.data[:, lb:ub], (0, ub - lb)
 except Exception:  # pragma: no cover
     pass
 
-# import the kernel modules to trigger registration (registry.py:193-202)
+# importing the kernel modules registers the six dispatchers (the reference does the same, registry.py:193-202)
 from illico_amd import ovo as _ovo  # noqa: E402,F401
 from illico_amd import ovr as _ovr  # noqa: E402,F401
