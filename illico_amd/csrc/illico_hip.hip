@@ -65,7 +65,6 @@ struct illico_ctx {
     bool no_fused_path = false;
     bool no_csc_gene_path = false;
     int fused_groups_per_wg = 0; // 0 = auto
-    int ovr_threads = 256;
     int fused_layout = 0; // 0: LDS tables [lane][value] (odd stride); 1: [value][lane] (conflict-free, measured 0.8 % slower)
     bool profile = false;
     std::vector<ProfEvent> events;
@@ -211,7 +210,6 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
-    else if (!strcmp(key, "ovr_threads")) c->ovr_threads = (int)value;
     else if (!strcmp(key, "fused_layout")) c->fused_layout = (int)value;
     else if (!strcmp(key, "fused_groups_per_wg")) c->fused_groups_per_wg = (int)std::max<int64_t>(0, value);
     else return fail(c, ILLICO_ERR_ARG, "unknown option '%s'", key);

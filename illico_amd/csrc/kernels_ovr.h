@@ -28,6 +28,7 @@ struct OvrParams {
     long long n_cells;
     int ref;                  // OVO-through-global-sort mode: reference group code
     const u32 *gene_flags;    // OVO mode: process only genes whose flag is non-zero (nullptr = all)
+    u64 *acc_global;          // ACCG: per-gene accumulators [n_genes][3*G] in HBM (group counts beyond what LDS holds)
     long long *out_2u;        // [n_genes][G]
     u64 *out_tie;             // [n_genes][G]
     double *out_sum;          // [n_genes][G]
@@ -130,7 +131,8 @@ template <int NT> __device__ __forceinline__ int block_excl_scan_add_rev(int x, 
     return after + wi - x;
 }
 
-template <typename KeyT, bool SPARSE, bool OVO, int NT>
+// ACCG: the per-group accumulators live in HBM (global 64-bit atomics) instead of LDS -- any number of groups.
+template <typename KeyT, bool SPARSE, bool OVO, int NT, bool ACCG>
 __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
     constexpr int NW = NT / 64, E = (NT >= 1024 ? 4 : 8);
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
     u64 *R2 = (u64 *)(flag + 4);             // [G]  OVR: 2*ranksum;  OVO: S2
     u64 *tieg = R2 + P.G;                    // [G]  OVO only: per-group tie term
     u32 *gcnt = (u32 *)(OVO ? tieg + P.G : tieg); // [G] (SPARSE OVR only)
+    (void)R2; (void)tieg; (void)gcnt;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = P.G;
@@ -151,6 +154,11 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
 
     for (int gene = blockIdx.x; gene < P.n_genes; gene += gridDim.x) {
         if (OVO && P.gene_flags && P.gene_flags[gene] == 0) continue; // handled by the histogram route
+        if (ACCG) { // this gene's accumulator block in HBM
+            R2 = P.acc_global + (size_t)gene * 3 * P.G;
+            tieg = R2 + P.G;
+            gcnt = (u32 *)(R2 + 2 * (size_t)P.G);
+        }
         long long start;
         int n;
         const u32 *sp = nullptr;
@@ -350,10 +358,10 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
                 if (g == ref) { P.out_2u[o] = -2; P.out_tie[o] = 0; continue; }
                 const long long n_g = P.counts[g];
                 const u64 zB = SPARSE ? (u64)(n_g - (long long)(sp[g + 1] - sp[g])) : 0ull;
-                const u64 s2 = R2[g] + zB * (2ull * nneg + zA);
+                const u64 s2 = (ACCG ? atomicAdd(&R2[g], 0ull) : R2[g]) + zB * (2ull * nneg + zA);
                 const u64 t0 = zA + zB;
                 P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)s2;
-                P.out_tie[o] = T_A + tieg[g] + (t0 * t0 * t0 - t0);
+                P.out_tie[o] = T_A + (ACCG ? atomicAdd(&tieg[g], 0ull) : tieg[g]) + (t0 * t0 * t0 - t0);
             }
             __syncthreads();
             continue;
@@ -460,9 +468,9 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
         const long long nneg = flag[2];
         for (int g = tid; g < G; g += NT) {
             long long n_g = P.counts[g];
-            u64 r2 = R2[g];
+            u64 r2 = ACCG ? atomicAdd(&R2[g], 0ull) : R2[g]; // HBM accumulators: read at L2, where the atomics landed
             if (SPARSE) {
-                long long z = n_g - (long long)gcnt[g];
+                long long z = n_g - (long long)(ACCG ? atomicAdd(&gcnt[g], 0u) : gcnt[g]);
                 r2 += (u64)z * (u64)(2 * nneg + n0 + 1);
             }
             long long two_u = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;
@@ -473,9 +481,9 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
     }
 }
 
-static inline size_t ovr_lds_bytes(int G, bool sparse, bool ovo, int nt) {
+static inline size_t ovr_lds_bytes(int G, bool sparse, bool ovo, int nt, bool acc_global) {
     const int NW = nt / 64;
     size_t b = (size_t)NW * 256 * 4 + 256 * 4 + 256 * 4 + (NW + (NW & 1)) * 4 + NW * 8 + 16;
-    b += (size_t)G * 8 + (ovo ? (size_t)G * 8 : 0) + (sparse ? (size_t)G * 4 : 0);
+    if (!acc_global) b += (size_t)G * 8 + (ovo ? (size_t)G * 8 : 0) + (sparse ? (size_t)G * 4 : 0);
     return b;
 }

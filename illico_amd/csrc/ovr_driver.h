@@ -1,29 +1,32 @@
 // Host-side launch of the OVR per-gene kernel (included by illico_hip.hip after the context helpers).
 #pragma once
 
-template <typename KeyT, bool SPARSE, bool OVO, int NT>
-static int launch_ovr_gene_nt(illico_ctx *c, const OvrParams &P) {
-    size_t lds = ovr_lds_bytes(P.G, SPARSE, OVO, NT);
-    if (lds > kMaxLds)
-        return fail(c, ILLICO_ERR_UNSUPPORTED, "%d groups do not fit the LDS accumulators of the global-sort route in this build", P.G);
-    auto kern = k_ovr_gene<KeyT, SPARSE, OVO, NT>;
-    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    {
-        ProfScope ps(c, KID_OVR_SCAN);
-        hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(NT), lds, c->stream, P);
-        HIPCHK(c, hipGetLastError());
-    }
-    return ILLICO_OK;
-}
+constexpr int kOvrThreads = 256; // several small workgroups per CU overlap each other's barriers (1024 measured the same)
 
-// workgroup size of the per-gene sort kernel: several smaller workgroups per CU overlap each other's barriers
+// Per-group accumulators in LDS when they fit, else in HBM (one [3*G] u64 block per gene of the batch).
 template <typename KeyT, bool SPARSE, bool OVO = false>
-static int launch_ovr_gene(illico_ctx *c, const OvrParams &P) {
-    switch (c->ovr_threads) {
-    case 1024: return launch_ovr_gene_nt<KeyT, SPARSE, OVO, 1024>(c, P);
-    case 512: return launch_ovr_gene_nt<KeyT, SPARSE, OVO, 512>(c, P);
-    default: return launch_ovr_gene_nt<KeyT, SPARSE, OVO, 256>(c, P);
+static int launch_ovr_gene(illico_ctx *c, OvrParams P) {
+    const bool accg = ovr_lds_bytes(P.G, SPARSE, OVO, kOvrThreads, false) > kMaxLds;
+    const size_t lds = ovr_lds_bytes(P.G, SPARSE, OVO, kOvrThreads, accg);
+    P.acc_global = nullptr;
+    if (accg) {
+        void *v;
+        int rc = get_scratch(c, "ovr_acc", (size_t)P.n_genes * 3 * P.G * 8, &v);
+        if (rc) return rc;
+        P.acc_global = (u64 *)v;
     }
+    ProfScope ps(c, KID_OVR_SCAN);
+    if (accg) {
+        auto kern = k_ovr_gene<KeyT, SPARSE, OVO, kOvrThreads, true>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(kOvrThreads), lds, c->stream, P);
+    } else {
+        auto kern = k_ovr_gene<KeyT, SPARSE, OVO, kOvrThreads, false>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(kOvrThreads), lds, c->stream, P);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
 }
 
 static int launch_gene_totals(illico_ctx *c, const double *ssum, int G, int nb, double *gtot) {

@@ -103,3 +103,25 @@ def test_large_values_and_table_boundaries(engine):
     X[:, 7] = rng.randint(0, 4, size=n) + 0.5
     _check(engine, X, labels, "g2", "table boundaries ovo")
     _check(engine, X, labels, None, "table boundaries ovr")
+
+
+@pytest.mark.parametrize("ref", ["g00000", None])
+def test_many_groups_beyond_lds_accumulators(engine, ref):
+    """20 000 groups: the radix routes keep their per-group accumulators in HBM instead of LDS (non-count data;
+    for OVO one group is large enough to need the global-sort fallback)."""
+    rng = np.random.RandomState(5)
+    G = 20000
+    codes = np.concatenate([np.zeros(1500, dtype=int), np.repeat(np.arange(1, G), 2)])
+    rng.shuffle(codes)
+    labels = np.array([f"g{c:05d}" for c in codes])
+    n = codes.size
+    X = np.where(rng.rand(n, 3) < 0.4, 0, rng.rand(n, 3)).astype(np.float32)
+    X[:, 1] = np.round(X[:, 1] * 4) / 4   # ties
+    _, g = oracle.encode_and_count_groups(labels, ref)
+    want = oracle.run(X, g)
+    engine.set_groups(g)
+    got = engine.run_dense(X, 0, 3)
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group if ref else None, fc_rtol=1e-9, what="20k groups dense")
+    M = sparse.csc_matrix(X)
+    got = engine.run_sparse("csc", M.data, M.indices, M.indptr, M.shape, 0, 3)
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group if ref else None, fc_rtol=1e-9, what="20k groups csc")
