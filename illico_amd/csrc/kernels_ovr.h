@@ -132,8 +132,12 @@ template <int NT> __device__ __forceinline__ int block_excl_scan_add_rev(int x, 
 }
 
 // ACCG: the per-group accumulators live in HBM (global 64-bit atomics) instead of LDS -- any number of groups.
-template <typename KeyT, bool SPARSE, bool OVO, int NT, bool ACCG>
+// DC (dense layout, OVR): the gene's zeros are compacted away before the sort and ranked as one analytic tie block
+// (exactly the sparse layout's semantics), so the sort passes and the sweeps touch only the non-zeros.
+template <typename KeyT, bool SPARSE, bool OVO, int NT, bool ACCG, bool DC>
 __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
+    static_assert(!DC || (!SPARSE && !OVO), "zero compaction is the dense OVR variant");
+    constexpr bool ZS = SPARSE || DC; // zeros are implicit during the sort and the sweeps
     constexpr int NW = NT / 64, E = (NT >= 1024 ? 4 : 8);
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -166,7 +170,6 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
         else { start = (long long)gene * P.stride; n = (int)P.n_cells; }
         KeyT *ka = (KeyT *)P.keys_a + start, *kb = (KeyT *)P.keys_b + start;
         u32 *va = P.vals_a + start, *vb = P.vals_b + start;
-        const long long n0 = P.n_cells - n; // implicit zeros
 
         // ---- per-group sums of values for the fold change (deterministic order; runs are group-contiguous) ----
         for (int g = wave; g < G; g += NW) {
@@ -184,6 +187,31 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
         KeyT *ksrc = ka, *kdst = kb;
         u32 *vsrc = va, *vdst = vb;
         bool have_vals = SPARSE;
+        if (DC) { // (key, group code) of the non-zeros -> the other buffer, in any order (the sort follows)
+            if (tid == 0) flag[3] = 0;
+            __syncthreads();
+            for (int i0 = 0; i0 < n; i0 += NT) {
+                const int i = i0 + tid;
+                const KeyT k = i < n ? ka[i] : ZEROK;
+                const bool nz = k != ZEROK;
+                const u64 m = __ballot(nz);
+                int base = 0;
+                if (lane == 0 && m) base = atomicAdd(&flag[3], (int)__popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (nz) {
+                    const int pos = base + (int)__popcll(m & lt_mask);
+                    kb[pos] = k;
+                    vb[pos] = (u32)P.code_by_pos[i];
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            n = flag[3];
+            ksrc = kb; kdst = ka; vsrc = vb; vdst = va;
+            have_vals = true;
+            __syncthreads();
+        }
+        const long long n0 = P.n_cells - n; // implicit zeros
         for (int shift = 0; shift < (int)sizeof(KeyT) * 8; shift += 8) {
             for (int i = tid; i < 256; i += NT) hist[i] = 0;
             if (tid == 0) flag[0] = 0;
@@ -367,7 +395,7 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
             continue;
         }
         // ---- sweeps over the sorted column ----
-        for (int g = tid; g < G; g += NT) { R2[g] = 0; if (SPARSE) gcnt[g] = 0; }
+        for (int g = tid; g < G; g += NT) { R2[g] = 0; if (ZS) gcnt[g] = 0; }
         __syncthreads();
         // Each thread owns SE consecutive sorted slots per round: run heads / tails are resolved inside the thread
         // first, one block scan per round links the threads (8x fewer barriers than one slot per thread).
@@ -401,9 +429,9 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
                     const int s = sl[e] >= 0 ? sl[e] : cin;
                     if (hd[e] && i > 0) { u64 t = (u64)(i - s_last); tie += t * t * t - t; }
                     s_last = s;
-                    u64 add = (u64)s + 1ull + ((SPARSE && k[e] > ZEROK) ? 2ull * (u64)n0 : 0ull);
+                    u64 add = (u64)s + 1ull + ((ZS && k[e] > ZEROK) ? 2ull * (u64)n0 : 0ull);
                     atomicAdd(&R2[V[i]], add);
-                    if (SPARSE) atomicAdd(&gcnt[V[i]], 1u);
+                    if (ZS) atomicAdd(&gcnt[V[i]], 1u);
                 }
             }
             const int last_i = min(n, cbase + NT * SE) - 1; // last valid slot of this round
@@ -454,7 +482,7 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
         if (lane == 0) red[wave] = tie;
         if (tid == 0) { // number of negative keys (sparse layout only)
             int P0 = 0;
-            if (SPARSE && n > 0) {
+            if (ZS && n > 0) {
                 int lo = 0, hi = n;
                 while (lo < hi) { int mid = (lo + hi) >> 1; if (K[mid] < ZEROK) lo = mid + 1; else hi = mid; }
                 P0 = lo;
@@ -469,7 +497,7 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
         for (int g = tid; g < G; g += NT) {
             long long n_g = P.counts[g];
             u64 r2 = ACCG ? atomicAdd(&R2[g], 0ull) : R2[g]; // HBM accumulators: read at L2, where the atomics landed
-            if (SPARSE) {
+            if (ZS) {
                 long long z = n_g - (long long)(ACCG ? atomicAdd(&gcnt[g], 0u) : gcnt[g]);
                 r2 += (u64)z * (u64)(2 * nneg + n0 + 1);
             }
@@ -481,7 +509,7 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
     }
 }
 
-static inline size_t ovr_lds_bytes(int G, bool sparse, bool ovo, int nt, bool acc_global) {
+static inline size_t ovr_lds_bytes(int G, bool sparse /* or zero-compacted dense */, bool ovo, int nt, bool acc_global) {
     const int NW = nt / 64;
     size_t b = (size_t)NW * 256 * 4 + 256 * 4 + 256 * 4 + (NW + (NW & 1)) * 4 + NW * 8 + 16;
     if (!acc_global) b += (size_t)G * 8 + (ovo ? (size_t)G * 8 : 0) + (sparse ? (size_t)G * 4 : 0);

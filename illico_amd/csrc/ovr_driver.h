@@ -6,8 +6,9 @@ constexpr int kOvrThreads = 256; // several small workgroups per CU overlap each
 // Per-group accumulators in LDS when they fit, else in HBM (one [3*G] u64 block per gene of the batch).
 template <typename KeyT, bool SPARSE, bool OVO = false>
 static int launch_ovr_gene(illico_ctx *c, OvrParams P) {
-    const bool accg = ovr_lds_bytes(P.G, SPARSE, OVO, kOvrThreads, false) > kMaxLds;
-    const size_t lds = ovr_lds_bytes(P.G, SPARSE, OVO, kOvrThreads, accg);
+    constexpr bool DC = !SPARSE && !OVO; // dense OVR: compact the zeros away inside the kernel
+    const bool accg = ovr_lds_bytes(P.G, SPARSE || DC, OVO, kOvrThreads, false) > kMaxLds;
+    const size_t lds = ovr_lds_bytes(P.G, SPARSE || DC, OVO, kOvrThreads, accg);
     P.acc_global = nullptr;
     if (accg) {
         void *v;
@@ -17,11 +18,11 @@ static int launch_ovr_gene(illico_ctx *c, OvrParams P) {
     }
     ProfScope ps(c, KID_OVR_SCAN);
     if (accg) {
-        auto kern = k_ovr_gene<KeyT, SPARSE, OVO, kOvrThreads, true>;
+        auto kern = k_ovr_gene<KeyT, SPARSE, OVO, kOvrThreads, true, DC>;
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(kOvrThreads), lds, c->stream, P);
     } else {
-        auto kern = k_ovr_gene<KeyT, SPARSE, OVO, kOvrThreads, false>;
+        auto kern = k_ovr_gene<KeyT, SPARSE, OVO, kOvrThreads, false, DC>;
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(kOvrThreads), lds, c->stream, P);
     }
