@@ -107,7 +107,7 @@ def asymptotic_wilcoxon(
     if alternative not in ("two-sided", "less", "greater"):
         raise ValueError(f"Unsupported alternative hypothesis: {alternative}")
 
-    raw_groups = np.asarray(adata.obs[group_keys])
+    raw_groups = adata.obs[group_keys]  # a categorical column is encoded from its codes (no pass over N strings)
     unique_raw_groups, group_container = encode_and_count_groups(groups=raw_groups, ref_group=reference)
     n_genes = X.shape[1]
     n_groups = int(group_container.counts.size)

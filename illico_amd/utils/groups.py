@@ -19,6 +19,9 @@ def encode_and_count_groups(groups, ref_group: Any):
     argsort of the codes gives ``indices`` sorted inside each group (the order the reference's
     own TODO at groups.py:46 asks for).
     """
+    cat = getattr(groups, "cat", None)  # pandas categorical column (the usual dtype of AnnData.obs columns)
+    if cat is not None and not groups.isna().any():
+        return _encode_categorical(groups, ref_group)
     groups = np.asarray(groups)
     if ref_group is not None and not np.any(groups == ref_group):
         raise ValueError(f"Reference group `{ref_group}` is not present in the group labels.")
@@ -38,3 +41,26 @@ def encode_and_count_groups(groups, ref_group: Any):
         indptr=group_indptr,
         encoded_ref_group=encoded_ref,
     )
+
+
+def _encode_categorical(col, ref_group: Any):
+    """Same container as above from a pandas categorical column, without touching the N labels as strings:
+    the categories that occur are ordered the way ``np.unique`` orders the labels, the per-cell codes are remapped."""
+    cats = np.asarray(col.cat.categories)
+    codes = np.asarray(col.cat.codes, dtype=np.int64)
+    present = np.bincount(codes, minlength=cats.size) > 0
+    order = np.argsort(cats, kind="stable")          # np.unique's order of the distinct labels
+    order = order[present[order]]
+    unique_groups = cats[order]
+    if unique_groups.dtype == object:                # np.unique of a list of str gives a '<U' array
+        unique_groups = np.array(unique_groups.tolist())
+    if ref_group is not None and not np.any(unique_groups == ref_group):
+        raise ValueError(f"Reference group `{ref_group}` is not present in the group labels.")
+    remap = np.full(cats.size, -1, dtype=np.int64)
+    remap[order] = np.arange(order.size)
+    encoded_groups = remap[codes]
+    group_counts = np.bincount(encoded_groups, minlength=order.size).astype(np.int64)
+    group_indices = np.argsort(encoded_groups, kind="stable").astype(np.int64)
+    group_indptr = np.concatenate([[0], np.cumsum(group_counts)]).astype(np.int64)
+    encoded_ref = -1 if ref_group is None else int(np.flatnonzero(unique_groups == ref_group)[0])
+    return unique_groups, GroupContainer(encoded_groups, group_counts, group_indices, group_indptr, encoded_ref)

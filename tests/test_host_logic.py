@@ -161,3 +161,25 @@ def test_memmap_handler_is_backed_and_fetches_chunks(tmp_path):
     assert bounds == (0, 6) and type(chunk) is np.ndarray and chunk.flags.c_contiguous
     np.testing.assert_array_equal(chunk, X[:, 3:9])
     assert not data_handler_registry.get(X).streams
+
+
+def test_categorical_group_column_encodes_like_strings():
+    from illico_amd.utils.groups import encode_and_count_groups
+    rng = np.random.RandomState(0)
+    labels = np.array([f"pert_{i}" for i in rng.randint(0, 25, size=500)] + ["ctrl"] * 20)
+    rng.shuffle(labels)
+    # categories in a non-sorted order, with one unused category
+    cats = list(np.unique(labels)[::-1]) + ["never_used"]
+    col = pd.Series(pd.Categorical(labels, categories=cats))
+    for ref in ("ctrl", None, "pert_10"):
+        u1, a = encode_and_count_groups(labels, ref)
+        u2, b = encode_and_count_groups(col, ref)
+        np.testing.assert_array_equal(u1, u2)
+        assert u2.dtype.kind == "U"
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    with pytest.raises(ValueError, match="not present"):
+        encode_and_count_groups(col, "never_used")
+    # a plain object / string Series takes the generic path
+    u3, c = encode_and_count_groups(pd.Series(labels), "ctrl")
+    np.testing.assert_array_equal(u3, np.unique(labels))
