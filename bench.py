@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--gather-batches", type=int, default=8, help="gene blocks per gather (N>1)")
     ap.add_argument("--gather-in-step", action="store_true", help="N>1: gather every step's planes to rank 0 inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # test hook: gloo
@@ -172,8 +173,19 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # One untimed step with HIP events around every kernel: the per-kernel breakdown, and which kernel dominates.
+    # Inside the timed region only that kernel carries events (each event pair drains the stream around a launch).
     eng.profile(True)
     eng.profile_reset()
+    step()
+    sync()
+    breakdown = eng.profile_get()
+    dom = max(breakdown.items(), key=lambda kv: kv[1]["ms"])[0] if breakdown else None
+    eng.profile_only(dom)
+    eng.profile_reset()
+    if args.no_events:  # diagnostic only: the contract wants the dominant kernel timed inside the timed region
+        eng.profile(False)
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -181,6 +193,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_get()
     eng.profile(False)
+    eng.profile_only(None)
     gather_ms = None
     if world > 1:
         red_dev = device if args.backend == "nccl" else torch.device("cpu")
@@ -204,10 +217,9 @@ def main():
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel (HIP events recorded on the engine's stream) ----
-        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])[0] if prof else None
         alg_bytes_step = N * M * 4 + 4 * N + 24 * G * M  # input once + codes + three f64 planes
         roofline = None
-        if dom:
+        if dom and dom in prof:
             launches = prof[dom]["launches"]
             avg_ms = prof[dom]["ms"] / launches
             bytes_per_launch = alg_bytes_step * args.steps / launches
@@ -227,8 +239,9 @@ def main():
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                        "all_kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in prof.items()},
-                        "pipeline_achieved": round(alg_bytes_step / (sum(v["ms"] for v in prof.values()) / args.steps * 1e-3) / 1e9, 2)}
+                        "all_kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in breakdown.items()},
+                        "all_kernels_note": "one untimed step with events around every kernel, taken before the timed region",
+                        "pipeline_achieved": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9, 2)}
 
         # ---- CPU baseline: the oracle (C port of illico's algorithm) on this box's host cores ----
         cpu = None

@@ -301,6 +301,14 @@ class Engine:
     def profile(self, on: bool = True):
         self.set_option("profile", 1 if on else 0)
 
+    def profile_only(self, kernel_name=None):
+        """Restrict event timing to one kernel (by name); ``None`` times every kernel again."""
+        kid = -1
+        if kernel_name is not None:
+            names = [self.lib.illico_profile_kernel_name(k).decode() for k in range(self.lib.illico_profile_num_kernels())]
+            kid = names.index(kernel_name)
+        self.set_option("profile_only", kid)
+
     def profile_reset(self):
         self._check(self.lib.illico_profile_reset(self.h))
 

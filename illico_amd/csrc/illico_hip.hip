@@ -65,9 +65,10 @@ struct illico_ctx {
     bool no_fused_path = false;
     bool no_csc_gene_path = false;
     int fused_groups_per_wg = 0; // 0 = auto
-    int fused_layout = 0; // 0: LDS tables [lane][value] (odd stride); 1: [value][lane] (conflict-free, measured 0.8 % slower)
     bool profile = false;
+    int profile_only = -1;        // >= 0: time this kernel id only (the others run without events around them)
     std::vector<ProfEvent> events;
+    std::vector<hipEvent_t> event_pool;
     double prof_ms[KID_COUNT] = {0};
     int64_t prof_n[KID_COUNT] = {0};
     // grow-only scratch
@@ -114,19 +115,33 @@ static int get_scratch(illico_ctx *c, const char *name, size_t bytes, void **out
     return ILLICO_OK;
 }
 
+// Timing events come from a pool (no create / destroy per launch) and carry no system-scope fence: recording one
+// must not flush the L2 between kernels of the timed region.
+static hipEvent_t take_event(illico_ctx *c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) hipEventCreate(&e);
+    return e;
+}
+
 struct ProfScope {
     illico_ctx *c;
     int kid;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(illico_ctx *c_, int kid_) : c(c_), kid(kid_) {
-        if (c->profile) {
-            hipEventCreate(&a);
-            hipEventCreate(&b);
+    bool on;
+    ProfScope(illico_ctx *c_, int kid_) : c(c_), kid(kid_), on(c_->profile && (c_->profile_only < 0 || c_->profile_only == kid_)) {
+        if (on) {
+            a = take_event(c);
+            b = take_event(c);
             hipEventRecord(a, c->stream);
         }
     }
     ~ProfScope() {
-        if (c->profile) {
+        if (on) {
             hipEventRecord(b, c->stream);
             c->events.push_back({kid, a, b});
         }
@@ -142,8 +157,8 @@ static void drain_events(illico_ctx *c) {
             c->prof_ms[e.kid] += ms;
             c->prof_n[e.kid] += 1;
         }
-        hipEventDestroy(e.a);
-        hipEventDestroy(e.b);
+        c->event_pool.push_back(e.a);
+        c->event_pool.push_back(e.b);
     }
     c->events.clear();
 }
@@ -183,6 +198,7 @@ int illico_ctx_destroy(illico_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     drain_events(c);
+    for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     free_groups(c);
     for (auto &kv : c->scratch)
         if (kv.second.first) hipFree(kv.second.first);
@@ -207,10 +223,10 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "gene_batch")) c->gene_batch = value;
     else if (!strcmp(key, "scratch_bytes")) c->scratch_bytes = value;
     else if (!strcmp(key, "profile")) c->profile = value != 0;
+    else if (!strcmp(key, "profile_only")) c->profile_only = (value >= 0 && value < KID_COUNT) ? (int)value : -1;
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
-    else if (!strcmp(key, "fused_layout")) c->fused_layout = (int)value;
     else if (!strcmp(key, "fused_groups_per_wg")) c->fused_groups_per_wg = (int)std::max<int64_t>(0, value);
     else return fail(c, ILLICO_ERR_ARG, "unknown option '%s'", key);
     return ILLICO_OK;
@@ -252,7 +268,8 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_groups(c);
-    std::vector<int> codes(n_cells), perm(n_cells), cbp(n_cells), posptr(n_groups + 1), cnt(n_groups);
+    // perm is padded with valid indices: tail chunks of k_ovo_fused read (and discard) up to 8 entries past a group's end
+    std::vector<int> codes(n_cells), perm(n_cells + 64, 0), cbp(n_cells), posptr(n_groups + 1), cnt(n_groups);
     int64_t tot = 0, max_nonref = 0;
     for (int64_t g = 0; g < n_groups; ++g) {
         if (counts[g] < 0 || indptr[g] != tot) return fail(c, ILLICO_ERR_ARG, "indptr/counts inconsistent at group %lld", (long long)g);
@@ -499,14 +516,9 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             HIPCHK(c, hipGetLastError());
         }
         ProfScope ps(c, KID_OVO_FUSED);
-        const bool tl = c->fused_layout != 0;
-        if (c->max_nonref <= 255) { // 8-bit running multiplicities: 34 KB of LDS per workgroup instead of 50 KB
-            if (tl) hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8, true>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
-            else hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8, false>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
-        } else {
-            if (tl) hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16, true>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
-            else hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16, false>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
-        }
+        if (c->max_nonref <= 255) // 8-bit running multiplicities: 34 KB of LDS per workgroup instead of 50 KB
+            hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        else hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
         HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipMemsetAsync(P.hist_all, 0, (size_t)nb * RT * 4, c->stream));
@@ -518,8 +530,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             HIPCHK(c, hipGetLastError());
         }
         ProfScope ps(c, KID_OVR_FUSED);
-        if (c->fused_layout != 0) hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16, true>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
-        else hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16, false>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+        hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
         HIPCHK(c, hipGetLastError());
     }
     h_flags.resize(nb);
@@ -541,7 +552,7 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
 
     // ---- route 1 (device-resident dense OVO): fused single pass; it reports the genes it could not take ----
     std::vector<std::pair<int64_t, int64_t>> runs; // column ranges still to be computed by the two-pass routes
-    if (in_dev && fused_path_allowed(c, flags)) {
+    if (in_dev && fused_path_allowed(c, flags) && (uint64_t)ld * sizeof(InT) < (1ull << 32)) { // row pitch: 32-bit byte offsets
         std::vector<u32> hf;
         if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf))) return rc;
         for (int64_t j = 0; j < W;) {

@@ -72,53 +72,100 @@ template <> __device__ __forceinline__ u32 clamp_count<int64_t, 64>(int64_t v, b
     return c;
 }
 
-// One chunk of UU rows of one group for the wavefront's 64 genes.  Straight-line: one vector load fetches the
-// chunk's row indices, UU row segments are requested back to back, then consumed in order (counted vmcnt waits).
-// Per element (value c, reference multiplicity a = cum[c+1]-cum[c], o = earlier cells of the group with value c):
-//     S2 += cum[c] + cum[c+1];      TT += t (t+1),  t = a + o      [= a^2 + a(2o+1) + o(o+1)]
-// PRED: rows at or past p1 (group end) re-read the last row and are masked out.
-// CB = bits per running-multiplicity counter: 16 (groups up to 65535 cells) or 8 (groups up to 255 cells: half
-// the LDS, so one more workgroup per CU).
-// TL: tables laid out [value][lane] (LS = 64: the LDS bank is the lane, never a conflict) or [lane][value] (LS = 1,
-// odd lane stride: equal values never conflict, different values collide at random).
-template <typename InT, int RT, int UU, bool PRED, int CB, bool TL>
-__device__ __forceinline__ void fused_chunk(const InT *__restrict__ Xg, long long ld, const int *__restrict__ perm, int p, int p1,
-                                            int lane, int lane_c, const u32 *ca, u32 *cb, u64 &S2, u64 &TT, u32 &vsum,
-                                            bool &inexact) {
-    const int pidx = perm[PRED ? min(p + (lane & (UU - 1)), p1 - 1) : p + (lane & (UU - 1))];
-    InT v[UU];
+// One chunk = UU rows of one group for the wavefront's 64 genes, in two straight-line halves: gather_rows requests
+// the UU row segments back to back, consume_* works through them in order behind counted vmcnt waits.
+//  * row indices come from scalar loads (the perm array is read through the constant address space, so a uniform
+//    index gives s_load_dwordx8); perm is padded so that a chunk may read past the group's end;
+//  * the row base is a scalar 64-bit address (row * row_bytes: one s_mul_i32 + one s_mul_hi_u32), the lane adds a
+//    32-bit column offset: global_load_dword v, v_off, s[base] -- no vector address arithmetic (the row pitch must
+//    fit 32 bits; the host sends wider matrices through the two-pass routes);
+//  * the running multiplicities are plain CB-bit LDS cells updated by read + write (the table is lane-private and the
+//    LDS executes a wavefront's operations in order, so no atomic is needed): no shift / mask / bit-field extract.
+//    CB = 16 (groups up to 65535 cells) or 8 (groups up to 255 cells: half the LDS, one more workgroup per CU).
+//    Tables are laid out [lane][value] with an odd lane stride: equal values never conflict, different values collide
+//    at random (the conflict-free [value][lane] layout measured 0.8 % slower: one more address instruction per access).
+// History of the OVO loop at C2 (same-process A/B): vector-loaded indices + v_readlane + vector addresses + packed
+// fetch-and-add counters 2.33 ms -> this form 2.07 ms.
+typedef const __attribute__((address_space(4))) int *const_int_p;
+template <int CB> struct CntCell;
+template <> struct CntCell<8> { typedef unsigned char type; };
+template <> struct CntCell<16> { typedef unsigned short type; };
+// UU rows of the wavefront's 64-gene tile, requested back to back: v[u] = X[row_u][gene0 + lane], row_u = perm[p + u].
+// p, p1 are wave-uniform.  PRED: positions at or past p1 (the group's end) re-read the group's last row -- a cache hit,
+// no HBM traffic -- and are masked out by the consumer.
+template <typename InT, int UU, bool PRED, int NV>
+__device__ __forceinline__ void gather_rows(const char *__restrict__ Xg, u32 row_bytes, const_int_p perm, int p, int p1, u32 col_bytes,
+                                            InT (&v)[NV]) {
+    static_assert(UU <= NV, "chunk larger than the value array");
+    p = __builtin_amdgcn_readfirstlane(p); // no-ops when the compiler already knows these are uniform
+    p1 = __builtin_amdgcn_readfirstlane(p1);
+    const int last = PRED ? perm[max(p1 - 1, 0)] : 0;
+    u32 coff = col_bytes;
+    asm volatile("" : "+v"(coff)); // keeps the 32-bit -> 64-bit extension of the lane offset next to the loads (saddr form)
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
-        const long long row = __builtin_amdgcn_readlane(pidx, u);
-        v[u] = Xg[row * ld + lane_c];
+        int row = perm[p + u]; // perm is padded: reading past the group's (or the array's) end is safe
+        if (PRED) row = (p + u < p1) ? row : last;
+        // scalar row base = Xg + row * row_bytes, spelled out: left to itself the compiler moves the row index to a
+        // VGPR and forms every address with v_mad_u64_u32 / v_lshl_add_u64 instead of using the saddr form of the load
+        u32 blo, bhi;
+        asm("s_mul_hi_u32 %1, %2, %3\n\ts_mul_i32 %0, %2, %3\n\ts_add_u32 %0, %0, %4\n\ts_addc_u32 %1, %1, %5"
+            : "=&s"(blo), "=&s"(bhi)
+            : "s"(row), "s"(row_bytes), "s"((u32)(uintptr_t)Xg), "s"((u32)((uintptr_t)Xg >> 32))
+            : "scc");
+        typedef const __attribute__((address_space(1))) char *gchar_p;
+        typedef const __attribute__((address_space(1))) InT *gval_p;
+        const gchar_p rp = (gchar_p)(((u64)bhi << 32) | blo); // uniform row base
+        v[u] = *(gval_p)(rp + coff);
     }
+}
+
+// The arithmetic of one gathered chunk.  Per element (value c, reference multiplicity a = cum[c+1]-cum[c], o = earlier
+// cells of the group with value c):   S2 += cum[c] + cum[c+1];   TT += t (t+1),  t = a + o   [= a^2 + a(2o+1) + o(o+1)]
+// PRED: positions at or past p1 are masked out.
+template <typename InT, int RT, int UU, bool PRED, int CB, int NV>
+__device__ __forceinline__ void consume_rmw(const InT (&v)[NV], int p, int p1, const u32 *ca, typename CntCell<CB>::type *cb, u64 &S2,
+                                            u64 &TT, u32 &vsum, bool &inexact) {
     u32 s2c = 0;
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
         bool exact;
         const u32 c = clamp_count<InT, RT>(v[u], exact);
-        constexpr int LS = TL ? 64 : 1;
-        const u32 lo = ca[c * LS], hi = ca[c * LS + LS];
-        constexpr int PW = 32 / CB, LG = (CB == 16 ? 1 : 2), LB = (CB == 16 ? 4 : 3); // counters per word
-        const u32 sh = (c & (u32)(PW - 1)) << LB;
+        const u32 lo = ca[c], hi = ca[c + 1];
+        const u32 old = cb[c];
         if (PRED) {
             const bool valid = p + u < p1; // wave-uniform
             inexact |= valid && !exact;
-            const u32 old = atomicAdd(&cb[(c >> LG) * LS], valid ? (1u << sh) : 0u);
-            const u32 t = valid ? (hi - lo) + __builtin_amdgcn_ubfe(old, sh, CB) : 0u;
+            cb[c] = (typename CntCell<CB>::type)(old + (valid ? 1u : 0u));
+            const u32 t = valid ? (hi - lo) + old : 0u;
             s2c += valid ? lo + hi : 0u;
             TT += (u64)t * (t + 1u);
             vsum += valid ? c : 0u;
         } else {
             inexact |= !exact;
-            const u32 old = atomicAdd(&cb[(c >> LG) * LS], 1u << sh); // lane-private word of packed counters: fetch-and-add
-            const u32 t = (hi - lo) + __builtin_amdgcn_ubfe(old, sh, CB);
+            cb[c] = (typename CntCell<CB>::type)(old + 1u);
+            const u32 t = (hi - lo) + old;
             s2c += lo + hi;
             TT += (u64)t * (t + 1u);
             vsum += c;
         }
     }
     S2 += s2c;
+}
+// OVR: R2 += cum[c] + cum[c+1] (= 2 #cells<c + #cells==c), value sum.
+template <typename InT, int RT, int UU, bool PRED, int NV>
+__device__ __forceinline__ void consume_ovr(const InT (&v)[NV], int p, int p1, const u32 *ca, u64 &R2, u32 &vsum) {
+    u32 r2c = 0; // <= UU * 2 * n_cells: fits 32 bits for n_cells < 2^25 per chunk of 32
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        bool exact;
+        const u32 c = clamp_count<InT, RT>(v[u], exact);
+        const u32 lo = ca[c], hi = ca[c + 1];
+        const bool valid = !PRED || (p + u < p1);
+        r2c += valid ? lo + hi : 0u;
+        vsum += valid ? c : 0u;
+    }
+    R2 += r2c;
 }
 
 // ---- reference tables: one 1024-thread workgroup per 64-gene tile; lane = gene.  All 16 wavefronts add into one
@@ -142,13 +189,9 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
     u32 *hl = h + lane * STR;
     bool bad = false;
     for (int p = p0 + wave * UR; p < p1; p += NW * UR) {
-        const int pidx = P.perm[min(p + (lane & (UR - 1)), p1 - 1)];
         InT v[UR];
-#pragma unroll
-        for (int u = 0; u < UR; ++u) {
-            const long long row = __builtin_amdgcn_readlane(pidx, u);
-            v[u] = Xg[row * P.ld + lane_c];
-        }
+        // rows past p1 are other groups' (or the padding's): valid memory, masked below
+        gather_rows<InT, UR, false>((const char *)Xg, (u32)P.ld * (u32)sizeof(InT), (const_int_p)P.perm, p, p1, (u32)lane_c * (u32)sizeof(InT), v);
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
             const bool valid = p + u < p1;
@@ -160,18 +203,18 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
     }
     if (bad) s_bad[lane] = 1;
     __syncthreads();
-    if (wave == 0 && act) {
-        u32 *cum = P.ref_cum + (size_t)gene * STR;
+    if (wave == 0) { // counts -> cumulative counts, in place: h[lane][c] = # reference cells < c, c = 0 .. RT
         u32 run = 0;
         u64 ta = 0, sum = 0;
-        cum[0] = 0;
         for (int c = 0; c < RT; ++c) {
             const u64 t = hl[c];
+            hl[c] = run;
             run += (u32)t;
-            cum[c + 1] = run;
             ta += t * t * t - t;
             sum += t * (u64)c;
         }
+        hl[RT] = run;
+        if (act) {
         P.ref_TA[gene] = ta;
         P.ref_sum[gene] = sum;
         if (s_bad[lane]) P.gene_flags[gene] = 1u;
@@ -179,7 +222,13 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
         P.out_p[o] = 1.0;                                                            // sparse_ovo.py:140-143
         P.out_u[o] = -1.0;
         P.out_fc[o] = (sum == 0) ? __longlong_as_double(0x7FF0000000000000ll) : 1.0; // math.py:190-192 with mu_tgt == mu_ref
+        }
     }
+    __syncthreads();
+    // the tile's [gene][RT+1] table is one contiguous block of ref_cum: coalesced copy-out
+    const int nvalid = min(64, P.ncols - gene0) * STR;
+    u32 *dst = P.ref_cum + (size_t)gene0 * STR;
+    for (int i = tid; i < nvalid; i += FUSED_REF_NT) dst[i] = h[i];
 }
 
 // ---- OVR tables.  For one-versus-rest every cell is ranked against the whole column, so the table is the
@@ -245,39 +294,11 @@ template <int RT> __global__ void k_fused_tables_all(FusedParams P) {
     P.ref_sum[gene] = sum;
 }
 
-// One chunk of the OVR rank-sum pass: R2 += cum[c] + cum[c+1] (= 2 #cells<c + #cells==c), value sum.
-template <typename InT, int RT, int UU, bool PRED, bool TL>
-__device__ __forceinline__ void fused_chunk_ovr(const InT *__restrict__ Xg, long long ld, const int *__restrict__ perm, int p, int p1,
-                                                int lane, int lane_c, const u32 *ca, u64 &R2, u32 &vsum) {
-    const int pidx = perm[PRED ? min(p + (lane & (UU - 1)), p1 - 1) : p + (lane & (UU - 1))];
-    InT v[UU];
-#pragma unroll
-    for (int u = 0; u < UU; ++u) {
-        const long long row = __builtin_amdgcn_readlane(pidx, u);
-        v[u] = Xg[row * ld + lane_c];
-    }
-    u32 r2c = 0; // <= UU * 2 * n_cells: fits 32 bits for n_cells < 2^25 per chunk of 32
-#pragma unroll
-    for (int u = 0; u < UU; ++u) {
-        bool exact;
-        const u32 c = clamp_count<InT, RT>(v[u], exact);
-        constexpr int LS = TL ? 64 : 1;
-        const u32 lo = ca[c * LS], hi = ca[c * LS + LS];
-        const bool valid = !PRED || (p + u < p1);
-        r2c += valid ? lo + hi : 0u;
-        vsum += valid ? c : 0u;
-    }
-    R2 += r2c;
-}
-
 // ---- main pass: grid (tiles, group chunks); 4 wavefronts per workgroup, one group at a time per wavefront ----
-template <typename InT, int RT, bool OVR, int CB, bool TL>
-__global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
-    constexpr int NW = FUSED_NT / 64, CSTR = RT + 1, BW = OVR ? 1 : RT * CB / 32, U = FUSED_U;
+template <typename InT, int RT, bool OVR, int CB>
+__global__ __launch_bounds__(FUSED_NT, (OVR || CB == 8) ? 4 : 3) void k_ovo_fused(FusedParams P) {
+    constexpr int NT = FUSED_NT, NW = NT / 64, CSTR = RT + 1, BW = OVR ? 1 : RT * CB / 32, U = FUSED_U;
     constexpr int BSTR = BW + 1;                 // [lane][value] layout: odd lane stride
-    constexpr int LS = TL ? 64 : 1;
-    // Both tables are laid out [value][lane]: the LDS bank of an access is the lane id whatever the value, so the
-    // data-dependent lookups and fetch-and-adds never conflict (64 consecutive words per value).
     __shared__ u32 cumA[CSTR * 64];        // # reference cells of gene `lane` with value < c
     __shared__ u32 cntB[NW][BSTR * 64];    // per wavefront: running multiplicity of each value of gene `lane` (packed counters)
     __shared__ int s_skip;
@@ -292,14 +313,14 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
     }
     __syncthreads();
     if (s_skip) return;
-    for (int i = tid; i < 64 * CSTR; i += FUSED_NT) {
+    for (int i = tid; i < 64 * CSTR; i += NT) {
         const int l = i / CSTR, c = i - l * CSTR; // consecutive threads read consecutive words of the [gene][value] table
-        cumA[TL ? c * 64 + l : l * CSTR + c] = (gene0 + l < P.ncols) ? P.ref_cum[(size_t)(gene0 + l) * CSTR + c] : 0u;
+        cumA[l * CSTR + c] = (gene0 + l < P.ncols) ? P.ref_cum[(size_t)(gene0 + l) * CSTR + c] : 0u;
     }
-    u32 *cb = cntB[wave] + (TL ? lane : lane * BSTR);
-    for (int i = 0; i < BW; ++i) cb[i * LS] = 0;
+    u32 *cb = cntB[wave] + lane * BSTR;
+    for (int i = 0; i < BW; ++i) cb[i] = 0;
     __syncthreads();
-    const u32 *ca = cumA + (TL ? lane : lane * CSTR);
+    const u32 *ca = cumA + lane * CSTR;
     const InT *X = (const InT *)P.X;
     const long long n_ref = OVR ? 0 : P.counts[OVR ? 0 : P.ref];
     const u64 T_A = act ? P.ref_TA[gene] : 0ull;
@@ -310,6 +331,45 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
     const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
     const int lane_c = act ? lane : 0; // inactive lanes (tile wider than the batch) re-read a valid column
     const InT *Xg = X + P.col0 + gene0;
+
+    // ---- this lane's (group, gene) result from the group's integer statistics ----
+    auto emit = [&](int g, long long n_tgt, u64 S2, u64 TT, u32 vsum) {
+        if (!act) return;
+        double pv, Ustat, fc;
+        const double mu_tgt = (double)vsum / (double)n_tgt;
+        if (OVR) { // dense_ovr.py:57-75: the "reference" of group g is every other cell
+            const long long n_rest = P.n_cells - n_tgt;
+            // 2*ranksum = S2 + n_tgt (2 rank = 2 #less + #equal + 1);  U = n_rest n_tgt + n_tgt(n_tgt+1)/2 - ranksum
+            const long long two_u = 2ll * n_rest * n_tgt + n_tgt * (n_tgt + 1) - ((long long)S2 + n_tgt);
+            Ustat = 0.5 * (double)two_u;
+            const double tie = P.tie_correct ? (double)T_A : 0.0;
+            const double mu = (double)(n_rest * n_tgt) / 2.0;
+            pv = pval_device(n_rest, n_tgt, P.n_cells, tie, Ustat, mu, cc, P.alternative);
+            const double mu_ref = (ref_sum - (double)vsum) / (double)n_rest; // math.py:185-188
+            fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+        } else {
+            const u64 tie_i = T_A + 3ull * TT;
+            const long long two_u = 2ll * n_ref * n_tgt - (long long)S2;
+            Ustat = 0.5 * (double)two_u;
+            const double tie = P.tie_correct ? (double)tie_i : 0.0;
+            const double mu = (double)(n_ref * n_tgt) / 2.0;
+            pv = pval_device(n_ref, n_tgt, n_ref + n_tgt, tie, Ustat, mu, cc, P.alternative);
+            const double mu_ref = ref_sum / (double)n_ref;
+            fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+        }
+        const size_t o = (size_t)g * P.out_ld + gene;
+        P.out_p[o] = pv;
+        P.out_u[o] = Ustat;
+        P.out_fc[o] = fc;
+    };
+
+    // Scalar row addressing and read/write counters (gather_rows / consume_rmw).  The p-values are evaluated here:
+    // splitting them into a second pass (tie sums parked in the p plane) and requesting the next group's first
+    // rows before the evaluation were both measured and did not pay.
+    typedef typename CntCell<CB>::type cell_t;
+    const char *Xb = (const char *)Xg;
+    const u32 row_bytes = (u32)P.ld * (u32)sizeof(InT), col_bytes = (u32)lane_c * (u32)sizeof(InT);
+    const const_int_p permc = (const_int_p)P.perm;
     for (int g = gbeg + wave; g < gend; g += NW) {
         if (!OVR && g == P.ref) continue;
         const int p0 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g]);
@@ -317,45 +377,20 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovo_fused(FusedParams P) {
         u64 S2 = 0, TT = 0;
         u32 vsum = 0;
         int p = p0;
-        if (OVR) {
-            for (; p + U <= p1; p += U) fused_chunk_ovr<InT, RT, U, false, TL>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, S2, vsum);
-            for (; p < p1; p += 8) fused_chunk_ovr<InT, RT, 8, true, TL>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, S2, vsum);
-        } else {
-            for (; p + U <= p1; p += U) fused_chunk<InT, RT, U, false, CB, TL>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
-            for (; p < p1; p += 8) fused_chunk<InT, RT, 8, true, CB, TL>(Xg, P.ld, P.perm, p, p1, lane, lane_c, ca, cb, S2, TT, vsum, bad);
+        InT v[U];
+        for (; p + U <= p1; p += U) {
+            gather_rows<InT, U, false>(Xb, row_bytes, permc, p, p1, col_bytes, v);
+            if (OVR) consume_ovr<InT, RT, U, false>(v, p, p1, ca, S2, vsum);
+            else consume_rmw<InT, RT, U, false, CB>(v, p, p1, ca, (cell_t *)cb, S2, TT, vsum, bad);
         }
-        // ---- this lane's (group, gene) result ----
-        const long long n_tgt = p1 - p0;
-        if (act) {
-            double pv, Ustat, fc;
-            const double mu_tgt = (double)vsum / (double)n_tgt;
-            if (OVR) { // dense_ovr.py:57-75: the "reference" of group g is every other cell
-                const long long n_rest = P.n_cells - n_tgt;
-                // 2*ranksum = S2 + n_tgt (2 rank = 2 #less + #equal + 1);  U = n_rest n_tgt + n_tgt(n_tgt+1)/2 - ranksum
-                const long long two_u = 2ll * n_rest * n_tgt + n_tgt * (n_tgt + 1) - ((long long)S2 + n_tgt);
-                Ustat = 0.5 * (double)two_u;
-                const double tie = P.tie_correct ? (double)T_A : 0.0;
-                const double mu = (double)(n_rest * n_tgt) / 2.0;
-                pv = pval_device(n_rest, n_tgt, P.n_cells, tie, Ustat, mu, cc, P.alternative);
-                const double mu_ref = (ref_sum - (double)vsum) / (double)n_rest; // math.py:185-188
-                fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
-            } else {
-                const u64 tie_i = T_A + 3ull * TT;
-                const long long two_u = 2ll * n_ref * n_tgt - (long long)S2;
-                Ustat = 0.5 * (double)two_u;
-                const double tie = P.tie_correct ? (double)tie_i : 0.0;
-                const double mu = (double)(n_ref * n_tgt) / 2.0;
-                pv = pval_device(n_ref, n_tgt, n_ref + n_tgt, tie, Ustat, mu, cc, P.alternative);
-                const double mu_ref = ref_sum / (double)n_ref;
-                fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
-            }
-            const size_t o = (size_t)g * P.out_ld + gene;
-            P.out_p[o] = pv;
-            P.out_u[o] = Ustat;
-            P.out_fc[o] = fc;
+        for (; p < p1; p += 8) {
+            gather_rows<InT, 8, true>(Xb, row_bytes, permc, p, p1, col_bytes, v);
+            if (OVR) consume_ovr<InT, RT, 8, true>(v, p, p1, ca, S2, vsum);
+            else consume_rmw<InT, RT, 8, true, CB>(v, p, p1, ca, (cell_t *)cb, S2, TT, vsum, bad);
         }
-        if (OVR) continue;
-        for (int i = 0; i < BW; ++i) cb[i * LS] = 0; // lane-private, in-order LDS: no barrier needed
+        emit(g, p1 - p0, S2, TT, vsum);
+        if (!OVR)
+            for (int i = 0; i < BW; ++i) cb[i] = 0; // lane-private, in-order LDS: no barrier needed
     }
     if (act && bad) P.gene_flags[gene] = 1u;
 }

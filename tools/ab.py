@@ -17,6 +17,12 @@ X = make_matrix(torch, N, M, 0.5, 0, dev)
 eng = Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
 eng.set_groups(group_container(make_labels(N, G, 0), G, a.test == "ovr"))
 out = tuple(torch.empty((G, M), dtype=torch.float64, device=dev) for _ in range(3))
+# calibration of the box: streaming read of the same matrix through torch (boxes differ by several per cent)
+torch.cuda.synchronize(); X.sum(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5): X.sum()
+torch.cuda.synchronize()
+print(f"calibration: torch X.sum() reads {X.numel() * 4 / ((time.perf_counter() - t0) / 5) / 1e12:.2f} TB/s")
 res = {v: [] for v in a.values}
 for r in range(a.rounds + 1):
     for v in a.values:
