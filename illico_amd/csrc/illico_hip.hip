@@ -484,7 +484,8 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     const bool ovr = c->ref < 0;
     void *v;
     int rc;
-    size_t bytes = (size_t)nb * (RT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * 4 + (ovr ? (size_t)nb * RT * 4 : 0) + 64;
+    const size_t nb64 = ((size_t)nb + 63) & ~(size_t)63; // the cumulative tables are stored per 64-gene tile
+    size_t bytes = nb64 * (RT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * 4 + (ovr ? (size_t)nb * RT * 4 : 0) + 64;
     if ((rc = get_scratch(c, "fused_tables", bytes, &v))) return rc;
     FusedParams P;
     P.X = X; P.ld = ld; P.col0 = b0; P.ncols = nb; P.perm = c->d_perm; P.pos_ptr = c->d_posptr; P.counts = c->d_counts;
@@ -492,7 +493,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.ref_TA = (u64 *)v;
     P.ref_sum = P.ref_TA + nb;
     P.ref_cum = (u32 *)(P.ref_sum + nb);
-    P.gene_flags = P.ref_cum + (size_t)nb * (RT + 1);
+    P.gene_flags = P.ref_cum + nb64 * (RT + 1);
     P.hist_all = ovr ? P.gene_flags + nb : nullptr;
     P.n_cells = c->n_cells;
     P.rows_per_wg = (int)std::max<int64_t>(1024, (c->n_cells + 31) / 32);
@@ -502,8 +503,9 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.out_p = o.p + col_off; P.out_u = o.u + col_off; P.out_fc = o.fc + col_off; P.out_ld = o.ld;
     const int tiles = (nb + 63) / 64;
     int gpw = c->fused_groups_per_wg;
-    if (gpw <= 0) { // 32 groups per workgroup measured best at C2; keep >= ~2048 workgroups on smaller problems
-        gpw = 32;
+    if (gpw <= 0) { // 8 groups per workgroup (two per wavefront) measured best at C2 (4: +2 %, 16: +1 %, 32: +3 %: shorter
+        // workgroups leave a shorter tail at the end of the launch); keep >= ~2048 workgroups on smaller problems
+        gpw = 8;
         while (gpw > 4 && (int64_t)tiles * ((c->n_groups + gpw - 1) / gpw) < 2048) gpw >>= 1;
     }
     P.groups_per_wg = gpw;

@@ -19,11 +19,14 @@
 // A gene that shows a value outside the table anywhere sets gene_flags[gene]; the host re-runs flagged genes
 // through the two-pass routes (k_ovo_counts / k_ovo_rank), which overwrite the columns.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "kernels_finalize.h"
 
 #define FUSED_NT 256
+#ifndef FUSED_U
 #define FUSED_U 32
+#endif
 
 struct FusedParams {
     const void *X;
@@ -33,7 +36,7 @@ struct FusedParams {
     const int *pos_ptr;       // [G+1]
     const int *counts;        // [G]
     int G, ref;
-    u32 *ref_cum;             // [ncols][RT+1] cumulative
+    u32 *ref_cum;             // [tile][RT+1][64] cumulative counts, tile = 64 consecutive genes (the LDS image of k_ovo_fused)
     u64 *ref_TA;              // [ncols] sum_v (tA^3 - tA)
     u64 *ref_sum;             // [ncols] sum of reference values
     u32 *hist_all;            // [ncols][RT] whole-column histogram (OVR; zeroed by the host)
@@ -123,7 +126,7 @@ __device__ __forceinline__ void gather_rows(const char *__restrict__ Xg, u32 row
 // The arithmetic of one gathered chunk.  Per element (value c, reference multiplicity a = cum[c+1]-cum[c], o = earlier
 // cells of the group with value c):   S2 += cum[c] + cum[c+1];   TT += t (t+1),  t = a + o   [= a^2 + a(2o+1) + o(o+1)]
 // PRED: positions at or past p1 are masked out.
-template <typename InT, int RT, int UU, bool PRED, int CB, int NV>
+template <typename InT, int RT, int UU, bool PRED, int CB, int LS, int NV>
 __device__ __forceinline__ void consume_rmw(const InT (&v)[NV], int p, int p1, const u32 *ca, typename CntCell<CB>::type *cb, u64 &S2,
                                             u64 &TT, u32 &vsum, bool &inexact) {
     u32 s2c = 0;
@@ -131,19 +134,19 @@ __device__ __forceinline__ void consume_rmw(const InT (&v)[NV], int p, int p1, c
     for (int u = 0; u < UU; ++u) {
         bool exact;
         const u32 c = clamp_count<InT, RT>(v[u], exact);
-        const u32 lo = ca[c], hi = ca[c + 1];
-        const u32 old = cb[c];
+        const u32 lo = ca[c * LS], hi = ca[c * LS + LS];
+        const u32 old = cb[c * LS];
         if (PRED) {
             const bool valid = p + u < p1; // wave-uniform
             inexact |= valid && !exact;
-            cb[c] = (typename CntCell<CB>::type)(old + (valid ? 1u : 0u));
+            cb[c * LS] = (typename CntCell<CB>::type)(old + (valid ? 1u : 0u));
             const u32 t = valid ? (hi - lo) + old : 0u;
             s2c += valid ? lo + hi : 0u;
             TT += (u64)t * (t + 1u);
             vsum += valid ? c : 0u;
         } else {
             inexact |= !exact;
-            cb[c] = (typename CntCell<CB>::type)(old + 1u);
+            cb[c * LS] = (typename CntCell<CB>::type)(old + 1u);
             const u32 t = (hi - lo) + old;
             s2c += lo + hi;
             TT += (u64)t * (t + 1u);
@@ -153,14 +156,14 @@ __device__ __forceinline__ void consume_rmw(const InT (&v)[NV], int p, int p1, c
     S2 += s2c;
 }
 // OVR: R2 += cum[c] + cum[c+1] (= 2 #cells<c + #cells==c), value sum.
-template <typename InT, int RT, int UU, bool PRED, int NV>
+template <typename InT, int RT, int UU, bool PRED, int LS, int NV>
 __device__ __forceinline__ void consume_ovr(const InT (&v)[NV], int p, int p1, const u32 *ca, u64 &R2, u32 &vsum) {
     u32 r2c = 0; // <= UU * 2 * n_cells: fits 32 bits for n_cells < 2^25 per chunk of 32
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
         bool exact;
         const u32 c = clamp_count<InT, RT>(v[u], exact);
-        const u32 lo = ca[c], hi = ca[c + 1];
+        const u32 lo = ca[c * LS], hi = ca[c * LS + LS];
         const bool valid = !PRED || (p + u < p1);
         r2c += valid ? lo + hi : 0u;
         vsum += valid ? c : 0u;
@@ -225,10 +228,9 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
         }
     }
     __syncthreads();
-    // the tile's [gene][RT+1] table is one contiguous block of ref_cum: coalesced copy-out
-    const int nvalid = min(64, P.ncols - gene0) * STR;
-    u32 *dst = P.ref_cum + (size_t)gene0 * STR;
-    for (int i = tid; i < nvalid; i += FUSED_REF_NT) dst[i] = h[i];
+    // copy-out as the [value][lane] image k_ovo_fused keeps in LDS: coalesced stores, conflict-free LDS reads
+    u32 *dst = P.ref_cum + (size_t)blockIdx.x * (64 * STR);
+    for (int i = tid; i < 64 * STR; i += FUSED_REF_NT) dst[i] = h[(i & 63) * STR + (i >> 6)];
 }
 
 // ---- OVR tables.  For one-versus-rest every cell is ranked against the whole column, so the table is the
@@ -279,14 +281,14 @@ template <int RT> __global__ void k_fused_tables_all(FusedParams P) {
     const int gene = blockIdx.x * blockDim.x + threadIdx.x;
     if (gene >= P.ncols) return;
     const u32 *h = P.hist_all + (size_t)gene * RT;
-    u32 *cum = P.ref_cum + (size_t)gene * (RT + 1);
+    u32 *cum = P.ref_cum + (size_t)(gene >> 6) * (64 * (RT + 1)) + (gene & 63); // [tile][value][lane]
     u32 run = 0;
     u64 ta = 0, sum = 0;
     cum[0] = 0;
     for (int c = 0; c < RT; ++c) {
         const u64 t = h[c];
         run += (u32)t;
-        cum[c + 1] = run;
+        cum[(c + 1) * 64] = run;
         ta += t * t * t - t;
         sum += t * (u64)c;
     }
@@ -295,42 +297,49 @@ template <int RT> __global__ void k_fused_tables_all(FusedParams P) {
 }
 
 // ---- main pass: grid (tiles, group chunks); 4 wavefronts per workgroup, one group at a time per wavefront ----
-template <typename InT, int RT, bool OVR, int CB>
+// (Building the reference tables inside this kernel, per workgroup, instead of reading k_fused_ref's was measured at
+// C2: no gain -- the 0.08 ms of k_fused_ref are matched by the redundant per-workgroup work.)
+template <typename InT, int RT, bool OVR, int CB, int U = FUSED_U>
 __global__ __launch_bounds__(FUSED_NT, (OVR || CB == 8) ? 4 : 3) void k_ovo_fused(FusedParams P) {
-    constexpr int NT = FUSED_NT, NW = NT / 64, CSTR = RT + 1, BW = OVR ? 1 : RT * CB / 32, U = FUSED_U;
-    constexpr int BSTR = BW + 1;                 // [lane][value] layout: odd lane stride
-    __shared__ u32 cumA[CSTR * 64];        // # reference cells of gene `lane` with value < c
-    __shared__ u32 cntB[NW][BSTR * 64];    // per wavefront: running multiplicity of each value of gene `lane` (packed counters)
+    constexpr int NT = FUSED_NT, NW = NT / 64, CSTR = RT + 1, BW = OVR ? 1 : RT * CB / 32;
+    // Both tables are laid out [value][lane]: the LDS bank of a lookup is set by the lane alone, whatever the values
+    // (32-bit cells: conflict-free; 8- / 16-bit cells: four / two neighbouring lanes share a bank).  With [lane][value]
+    // rows and an odd lane stride the data-dependent lookups collided at random (4.8 extra LDS cycles per instruction,
+    // SQ_LDS_BANK_CONFLICT); same-process A/B: this layout 0.4 % faster.
+    constexpr int LS = 64;                 // cell stride between consecutive values
+    __shared__ u32 cumA[CSTR * 64];        // cumA[c][lane] = # reference cells of gene `lane` with value < c
+    __shared__ u32 cntB[NW][BW * 64];      // per wavefront: running multiplicities [value][lane], CB bits each
     __shared__ int s_skip;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
     const bool act = gene < P.ncols;
+    const int lane_c = act ? lane : 0; // inactive lanes (tile wider than the batch) re-read a valid column
+    const InT *Xg = (const InT *)P.X + P.col0 + gene0;
+    const char *Xb = (const char *)Xg;
+    const u32 row_bytes = (u32)P.ld * (u32)sizeof(InT), col_bytes = (u32)lane_c * (u32)sizeof(InT);
+    const const_int_p permc = (const_int_p)P.perm;
+    bool bad = false;
     // every gene of this tile already sent to the slow routes? then there is nothing to do here
     if (wave == 0) {
         const bool flagged = !act || P.gene_flags[gene] != 0;
         const bool all = __all(flagged);
         if (lane == 0) s_skip = all ? 1 : 0;
     }
+    u32 *cbw = cntB[wave];                 // the wavefront's counter block as words: lane zeroes words lane, lane + 64, ..
+    for (int i = 0; i < BW; ++i) cbw[i * 64 + lane] = 0;
     __syncthreads();
     if (s_skip) return;
-    for (int i = tid; i < 64 * CSTR; i += NT) {
-        const int l = i / CSTR, c = i - l * CSTR; // consecutive threads read consecutive words of the [gene][value] table
-        cumA[l * CSTR + c] = (gene0 + l < P.ncols) ? P.ref_cum[(size_t)(gene0 + l) * CSTR + c] : 0u;
-    }
-    u32 *cb = cntB[wave] + lane * BSTR;
-    for (int i = 0; i < BW; ++i) cb[i] = 0;
+    for (int i = tid; i < 64 * CSTR; i += NT) cumA[i] = P.ref_cum[(size_t)blockIdx.x * (64 * CSTR) + i];
     __syncthreads();
-    const u32 *ca = cumA + lane * CSTR;
-    const InT *X = (const InT *)P.X;
-    const long long n_ref = OVR ? 0 : P.counts[OVR ? 0 : P.ref];
     const u64 T_A = act ? P.ref_TA[gene] : 0ull;
     const double ref_sum = act ? (double)P.ref_sum[gene] : 0.0;
+    const u32 *ca = cumA + lane;
+    typedef typename CntCell<CB>::type cell_t;
+    cell_t *cb = (cell_t *)cbw + lane;
+    const long long n_ref = OVR ? 0 : P.counts[OVR ? 0 : P.ref];
     const double cc = P.use_continuity ? 0.5 : 0.0;
-    bool bad = false;
 
     const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
-    const int lane_c = act ? lane : 0; // inactive lanes (tile wider than the batch) re-read a valid column
-    const InT *Xg = X + P.col0 + gene0;
 
     // ---- this lane's (group, gene) result from the group's integer statistics ----
     auto emit = [&](int g, long long n_tgt, u64 S2, u64 TT, u32 vsum) {
@@ -366,10 +375,6 @@ __global__ __launch_bounds__(FUSED_NT, (OVR || CB == 8) ? 4 : 3) void k_ovo_fuse
     // Scalar row addressing and read/write counters (gather_rows / consume_rmw).  The p-values are evaluated here:
     // splitting them into a second pass (tie sums parked in the p plane) and requesting the next group's first
     // rows before the evaluation were both measured and did not pay.
-    typedef typename CntCell<CB>::type cell_t;
-    const char *Xb = (const char *)Xg;
-    const u32 row_bytes = (u32)P.ld * (u32)sizeof(InT), col_bytes = (u32)lane_c * (u32)sizeof(InT);
-    const const_int_p permc = (const_int_p)P.perm;
     for (int g = gbeg + wave; g < gend; g += NW) {
         if (!OVR && g == P.ref) continue;
         const int p0 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g]);
@@ -378,19 +383,25 @@ __global__ __launch_bounds__(FUSED_NT, (OVR || CB == 8) ? 4 : 3) void k_ovo_fuse
         u32 vsum = 0;
         int p = p0;
         InT v[U];
-        for (; p + U <= p1; p += U) {
-            gather_rows<InT, U, false>(Xb, row_bytes, permc, p, p1, col_bytes, v);
-            if (OVR) consume_ovr<InT, RT, U, false>(v, p, p1, ca, S2, vsum);
-            else consume_rmw<InT, RT, U, false, CB>(v, p, p1, ca, (cell_t *)cb, S2, TT, vsum, bad);
-        }
-        for (; p < p1; p += 8) {
-            gather_rows<InT, 8, true>(Xb, row_bytes, permc, p, p1, col_bytes, v);
-            if (OVR) consume_ovr<InT, RT, 8, true>(v, p, p1, ca, S2, vsum);
-            else consume_rmw<InT, RT, 8, true, CB>(v, p, p1, ca, (cell_t *)cb, S2, TT, vsum, bad);
-        }
+        auto chunk = [&](auto uu, auto pred) {
+            constexpr int UU = decltype(uu)::value;
+            constexpr bool PRED = decltype(pred)::value;
+            gather_rows<InT, UU, PRED>(Xb, row_bytes, permc, p, p1, col_bytes, v);
+            if (OVR) consume_ovr<InT, RT, UU, PRED, LS>(v, p, p1, ca, S2, vsum);
+            else consume_rmw<InT, RT, UU, PRED, CB, LS>(v, p, p1, ca, cb, S2, TT, vsum, bad);
+            p += UU;
+        };
+        typedef std::integral_constant<bool, false> full_t;
+        typedef std::integral_constant<bool, true> pred_t;
+        while (p + U <= p1) chunk(std::integral_constant<int, U>(), full_t());
+        // the remainder (< U rows): halving full chunks, then one predicated chunk of 8
+        if constexpr (U > 32) { if (p + 32 <= p1) chunk(std::integral_constant<int, 32>(), full_t()); }
+        if constexpr (U > 16) { if (p + 16 <= p1) chunk(std::integral_constant<int, 16>(), full_t()); }
+        if (p + 8 <= p1) chunk(std::integral_constant<int, 8>(), full_t());
+        if (p < p1) chunk(std::integral_constant<int, 8>(), pred_t());
         emit(g, p1 - p0, S2, TT, vsum);
         if (!OVR)
-            for (int i = 0; i < BW; ++i) cb[i] = 0; // lane-private, in-order LDS: no barrier needed
+            for (int i = 0; i < BW; ++i) cbw[i * 64 + lane] = 0; // the wavefront's own block, in-order LDS: no barrier needed
     }
     if (act && bad) P.gene_flags[gene] = 1u;
 }
