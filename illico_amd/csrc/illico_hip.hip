@@ -64,6 +64,7 @@ struct illico_ctx {
     bool no_counts_path = false;
     bool no_fused_path = false;
     bool no_csc_gene_path = false;
+    bool no_dense_window_path = false; // 1: CSR never goes through dense float32 windows + the fused kernels
     int fused_groups_per_wg = 0; // 0 = auto
     bool profile = false;
     int profile_only = -1;        // >= 0: time this kernel id only (the others run without events around them)
@@ -227,6 +228,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
+    else if (!strcmp(key, "no_dense_window_path")) c->no_dense_window_path = value != 0;
     else if (!strcmp(key, "fused_groups_per_wg")) c->fused_groups_per_wg = (int)std::max<int64_t>(0, value);
     else return fail(c, ILLICO_ERR_ARG, "unknown option '%s'", key);
     return ILLICO_OK;

@@ -202,6 +202,72 @@ __global__ void k_csr_col_nnz(const IdxT *__restrict__ indices, long long nnz, l
     }
 }
 
+// CSR rows -> a dense float32 window D[n_rows][ldD] of columns [c0, c0 + W): the dense fused single-pass kernels then
+// read the window once.  One workgroup builds one row at a time in LDS (zero, scatter the row's stored entries, copy
+// out): HBM sees only coalesced 16-byte stores, never a partial-sector scatter.  A stored value that float32 cannot
+// hold exactly becomes NaN, which makes the fused kernel hand that gene to the exact sparse route.
+// Device counterpart of csr_get_contig_cols_into_csc (utils/sparse/csr.py:19-100) for count-valued windows: the
+// reference regroups the chunk's non-zeros by column on the CPU; at the 5-10 % density of expression matrices a dense
+// window (N x W x 4 bytes, written and read once at HBM speed) is cheaper on this machine than regrouping 8-byte
+// (value, row) pairs with scattered stores.
+#define DENS_NT 256
+#define DENS_WB 8192 // columns per LDS row block
+template <typename InT, typename IdxT>
+__global__ __launch_bounds__(DENS_NT) void k_csr_densify(const InT *__restrict__ data, const IdxT *__restrict__ indices,
+                                                         const IdxT *__restrict__ indptr, int n_rows, long long c0, int W,
+                                                         float *__restrict__ D, long long ldD) {
+    __shared__ __align__(16) float row[DENS_WB];
+    constexpr int UL = 4; // stored entries per thread requested together (column and value loads are independent)
+    const int tid = threadIdx.x;
+    long long col[UL]; // column (relative to c0) of the entries in flight; < 0: none
+    InT v[UL];
+    auto fetch = [&](long long k0, long long e) {
+#pragma unroll
+        for (int j = 0; j < UL; ++j) {
+            const long long k = k0 + j * DENS_NT + tid;
+            col[j] = k < e ? (long long)indices[k] - c0 : -1;
+            v[j] = k < e ? data[k] : (InT)0;
+        }
+    };
+    auto scatter = [&](int cb, int wb) {
+#pragma unroll
+        for (int j = 0; j < UL; ++j) {
+            const long long cj = col[j] - cb;
+            if (col[j] >= 0 && cj >= 0 && cj < wb) {
+                float f = (float)v[j];
+                if (!((InT)f == v[j])) f = __int_as_float(0x7FC00000); // not representable (or NaN): send the gene elsewhere
+                row[cj] = f;
+            }
+        }
+    };
+    int r = blockIdx.x;
+    long long s = 0, e = 0;
+    if (r < n_rows) { s = (long long)indptr[r]; e = (long long)indptr[r + 1]; fetch(s, e); }
+    for (; r < n_rows; r += gridDim.x) {
+        const int rn = r + gridDim.x;
+        long long sn = 0, en = 0;
+        if (rn < n_rows) { sn = (long long)indptr[rn]; en = (long long)indptr[rn + 1]; }
+        for (int cb = 0; cb < W; cb += DENS_WB) {
+            const int wb = min(DENS_WB, W - cb), wb4 = (wb + 3) & ~3;
+            for (int i = tid * 4; i < wb4; i += DENS_NT * 4) *(float4 *)&row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
+            if (cb > 0) fetch(s, e); // wide windows: the row is walked once per column block
+            scatter(cb, wb);
+            for (long long k0 = s + DENS_NT * UL; k0 < e; k0 += DENS_NT * UL) { fetch(k0, e); scatter(cb, wb); }
+            __syncthreads();
+            // the next row's first entries are requested before this row is copied out: their latency hides behind the stores
+            if (cb + DENS_WB >= W) fetch(sn, en);
+            float *dst = D + (long long)r * ldD + cb; // ldD and cb are multiples of 4: 16-byte aligned
+            for (int i = tid * 4; i < wb4; i += DENS_NT * 4) {
+                if (i + 4 <= wb) *(float4 *)&dst[i] = *(const float4 *)&row[i];
+                else for (int j = i; j < wb; ++j) dst[j] = row[j];
+            }
+            __syncthreads();
+        }
+        s = sn; e = en;
+    }
+}
+
 // replaces check_indices_sorted_per_parcel (utils/ranking.py:245-273) for device-resident CSR
 template <typename IdxT>
 __global__ void k_csr_sorted_check(const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr, int n_rows, int *__restrict__ bad) {

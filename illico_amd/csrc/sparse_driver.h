@@ -86,7 +86,7 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
 template <typename InT, typename IdxT, typename KeyT>
 static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indices, const void *indptr, int dtype,
                         int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                        const OutPlanes &o) {
+                        const OutPlanes &o, bool allow_dense_window = true) {
     const int G = (int)c->n_groups;
     const bool ovr = c->ref < 0;
     const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
@@ -122,6 +122,41 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         if ((rc = get_scratch(c, "sp_indices", cnt * sizeof(IdxT), &v))) return rc;
         HIPCHK(c, hipMemcpyAsync(v, (const IdxT *)indices + k0, (size_t)(k1 - k0) * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
         d_indices = (const IdxT *)v;
+    }
+
+    // ---- CSR, count-valued, not too sparse: dense float32 windows + the fused single-pass kernels (k_csr_densify) ----
+    const double density = (double)total_nnz / ((double)std::max<int64_t>(n_rows, 1) * (double)std::max<int64_t>(n_cols, 1));
+    if (is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) && density >= 0.015 &&
+        (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes) {
+        int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * 4)) & ~63ll;
+        wmax = std::min<int64_t>(wmax, (1ll << 29));
+        if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, (c->gene_batch + 63) & ~63ll);
+        int64_t bad_lo = -1, bad_hi = -1;
+        std::vector<u32> hf;
+        for (int64_t w0 = col_lb; w0 < col_ub; w0 += wmax) {
+            const int64_t wn = std::min<int64_t>(wmax, col_ub - w0), ldD = (wn + 63) & ~63ll;
+            if ((rc = get_scratch(c, "dense_window", (size_t)n_rows * ldD * 4, &v))) return rc;
+            float *D = (float *)v;
+            {
+                ProfScope ps(c, KID_SPARSE_SEG);
+                hipLaunchKernelGGL((k_csr_densify<InT, IdxT>), dim3((unsigned)std::min<int64_t>(n_rows, 1 << 16)), dim3(DENS_NT), 0, c->stream,
+                                   d_data, d_indices, d_indptr, (int)n_rows, (long long)w0, (int)wn, D, (long long)ldD);
+                HIPCHK(c, hipGetLastError());
+            }
+            if ((rc = run_fused_ovo<float>(c, D, ldD, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc;
+            for (int64_t j = 0; j < wn; ++j)
+                if (hf[j]) {
+                    if (bad_lo < 0) bad_lo = w0 + j;
+                    bad_hi = w0 + j;
+                }
+        }
+        if (bad_lo < 0) return ILLICO_OK;
+        // genes the fused kernels could not take (values outside the small-integer table): the exact sparse route
+        // over the column window that covers them (it recomputes, identically, the good genes in between)
+        OutPlanes o2 = o;
+        o2.p += bad_lo - col_lb; o2.u += bad_lo - col_lb; o2.fc += bad_lo - col_lb;
+        return run_sparse_t<InT, IdxT, KeyT>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, bad_lo, bad_hi + 1, flags,
+                                             alternative, o2, false);
     }
 
     // per-gene stored-entry counts of the requested window

@@ -25,11 +25,15 @@ def _run(engine, M, grpc, **kw):
 @pytest.fixture(params=["single-kernel", "two-kernel", "two-kernel-sort-only"])
 def route(request, engine):
     """CSC OVO has a single-kernel route (regroup + rank in LDS) with the two-kernel route (regroup into HBM, then
-    histogram / sort rank kernels) as fallback; the params force each so that all are exercised on the same data."""
+    histogram / sort rank kernels) as fallback; CSR first tries dense float32 windows + the fused dense kernels
+    (count-valued data) and falls back to its two-kernel route.  The params force each so that all are exercised
+    on the same data: "single-kernel" = the defaults (CSC single kernel, CSR dense window)."""
     engine.set_option("no_csc_gene_path", 0 if request.param == "single-kernel" else 1)
+    engine.set_option("no_dense_window_path", 0 if request.param == "single-kernel" else 1)
     engine.set_option("no_counts_path", 1 if request.param.endswith("sort-only") else 0)
     yield request.param
     engine.set_option("no_csc_gene_path", 0)
+    engine.set_option("no_dense_window_path", 0)
     engine.set_option("no_counts_path", 0)
 
 
@@ -178,3 +182,42 @@ def test_csc_interleaved_dense_and_sparse_genes(engine, test):
     got = _run(engine, M, g, col_lb=3, col_ub=38)
     want = oracle.run(X, g, col_lb=3, col_ub=38)
     assert_planes_match(got, want, fc_rtol=1e-9, what=f"interleaved window {test}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64])
+def test_csr_dense_window_route(engine, test, dtype):
+    """CSR through dense float32 windows + the fused kernels: a window wider than one LDS row block (8192 columns),
+    windows split by gene_batch, and genes the fused kernels must hand back to the exact sparse route
+    (fractional values, a value float32 cannot hold, values beyond the small-integer table, negatives)."""
+    rng = np.random.RandomState(101)
+    n, m = 260, 8300
+    X = (rng.poisson(1.5, size=(n, m)) * (rng.rand(n, m) < 0.12)).astype(np.float64)
+    bad_cols = [5, 4100, 8250]
+    if dtype != np.int64:
+        X[:, 5] = np.where(rng.rand(n) < 0.5, 0.0, rng.rand(n))                 # fractional
+        X[3, 4100] = 1.0 + 2.0 ** -30 if dtype == np.float64 else 1.5           # not a float32 integer
+    else:
+        X[:, 5] = np.where(rng.rand(n) < 0.5, 0, rng.randint(-3, 4, size=n))    # negatives
+        X[3, 4100] = 2 ** 40 + 1                                                # beyond float32's integers
+    X[7, 8250] = 77                                                             # beyond the table (>= 64)
+    labels = make_labels(rng, n, 6, n_ref=40)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    X = X.astype(dtype).astype(np.float64)   # the values the engine sees (float32 rounds the fractional gene)
+    M = sparse.csr_matrix(X.astype(dtype))
+    want = oracle.run(X, g)
+    engine.set_option("profile", 1)
+    engine.profile_reset()
+    try:
+        got = _run(engine, M, g)
+        prof = engine.profile_get()
+    finally:
+        engine.set_option("profile", 0)
+    assert "k_ovo_fused" in prof or "k_ovr_fused" in prof, prof   # the dense-window route ran
+    assert_planes_match(got, want, fc_rtol=1e-9, what=f"csr dense window {test} {dtype.__name__}")
+    engine.set_option("gene_batch", 3000)
+    try:
+        got = _run(engine, M, g, col_lb=100, col_ub=8290)
+    finally:
+        engine.set_option("gene_batch", 0)
+    assert_planes_match(got, oracle.run(X, g, col_lb=100, col_ub=8290), fc_rtol=1e-9, what=f"csr dense window batches {test}")
