@@ -567,6 +567,28 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
             j = e;
         }
         if (runs.empty()) return ILLICO_OK;
+    } else if (!in_dev && fused_path_allowed(c, flags)) {
+        // host matrix: column windows are copied up row-major (one 2-D copy each) and take the same fused pass
+        int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)N * sizeof(InT))) & ~63ll;
+        wmax = std::min<int64_t>(std::max<int64_t>(wmax, 64), (int64_t)((1ull << 32) / sizeof(InT)) - 64);
+        if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, c->gene_batch);
+        std::vector<u32> hf;
+        for (int64_t w0 = col_lb; w0 < col_ub; w0 += wmax) {
+            const int64_t wn = std::min<int64_t>(wmax, col_ub - w0);
+            if ((rc = get_scratch(c, "xin", (size_t)wn * N * sizeof(InT), &v))) return rc;
+            HIPCHK(c, hipMemcpy2DAsync(v, (size_t)wn * sizeof(InT), (const InT *)X + w0, (size_t)ld * sizeof(InT), (size_t)wn * sizeof(InT),
+                                       (size_t)N, hipMemcpyHostToDevice, c->stream));
+            if ((rc = run_fused_ovo<InT>(c, v, wn, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc;
+            for (int64_t j = 0; j < wn;) {
+                if (!hf[j]) { ++j; continue; }
+                int64_t e = j;
+                while (e < wn && hf[e]) ++e;
+                if (!runs.empty() && runs.back().second == w0 + j) runs.back().second = w0 + e;
+                else runs.push_back({w0 + j, w0 + e});
+                j = e;
+            }
+        }
+        if (runs.empty()) return ILLICO_OK;
     } else {
         runs.push_back({col_lb, col_ub});
     }

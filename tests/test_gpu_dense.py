@@ -34,16 +34,18 @@ def _run(engine, X, grpc, **kw):
     return engine.run_dense(X, kw.pop("col_lb", 0), kw.pop("col_ub", X.shape[1]), **kw)
 
 
-@pytest.fixture(params=["fused+counts+sort", "counts+sort", "sort-only"])
+@pytest.fixture(params=["fused+counts+sort", "fused-host+counts+sort", "counts+sort", "sort-only"])
 def route(request, engine):
-    """Dense OVO has three device routes per gene: the fused single-pass histogram kernel (device-resident X,
-    integer values < 64), the two-pass histogram kernel (integer values < 2048) and the general sort route.
-    The params switch routes off so that each one is exercised on the same data."""
+    """Dense OVO has three device routes per gene: the fused single-pass histogram kernel (integer values < 64; X
+    device-resident, or a host matrix copied up in column windows), the two-pass histogram kernel (integer values
+    < 2048) and the general sort route.  The params switch routes off so that each one is exercised on the same data."""
     global _DEVICE_INPUT
-    _DEVICE_INPUT = request.param.startswith("fused")
+    _DEVICE_INPUT = request.param == "fused+counts+sort"
+    engine.set_option("no_fused_path", 0 if request.param.startswith("fused") else 1)
     engine.set_option("no_counts_path", 1 if request.param == "sort-only" else 0)
     yield request.param
     engine.set_option("no_counts_path", 0)
+    engine.set_option("no_fused_path", 0)
     _DEVICE_INPUT = False
 
 
