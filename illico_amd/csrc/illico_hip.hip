@@ -64,8 +64,10 @@ struct illico_ctx {
     bool no_counts_path = false;
     bool no_fused_path = false;
     bool no_csc_gene_path = false;
+    bool no_ovr_one_pass = false;      // 1: dense OVR reads X twice (column histogram, then rank sums) instead of once
     bool no_dense_window_path = false; // 1: CSR never goes through dense float32 windows + the fused kernels
     int fused_groups_per_wg = 0; // 0 = auto
+    int ovr_hist_groups_per_wg = 0; // k_ovr_from_hists; 0 = auto
     bool profile = false;
     int profile_only = -1;        // >= 0: time this kernel id only (the others run without events around them)
     std::vector<ProfEvent> events;
@@ -228,7 +230,9 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
+    else if (!strcmp(key, "no_ovr_one_pass")) c->no_ovr_one_pass = value != 0;
     else if (!strcmp(key, "no_dense_window_path")) c->no_dense_window_path = value != 0;
+    else if (!strcmp(key, "ovr_hist_groups_per_wg")) c->ovr_hist_groups_per_wg = (int)std::max<int64_t>(0, value);
     else if (!strcmp(key, "fused_groups_per_wg")) c->fused_groups_per_wg = (int)std::max<int64_t>(0, value);
     else return fail(c, ILLICO_ERR_ARG, "unknown option '%s'", key);
     return ILLICO_OK;
@@ -497,6 +501,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.ref_cum = (u32 *)(P.ref_sum + nb);
     P.gene_flags = P.ref_cum + nb64 * (RT + 1);
     P.hist_all = ovr ? P.gene_flags + nb : nullptr;
+    P.group_hist = nullptr;
     P.n_cells = c->n_cells;
     P.rows_per_wg = (int)std::max<int64_t>(1024, (c->n_cells + 31) / 32);
     P.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;
@@ -526,16 +531,40 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
         HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipMemsetAsync(P.hist_all, 0, (size_t)nb * RT * 4, c->stream));
-        {
+        // one pass over X when the per-(group, gene) histograms fit the scratch cap (64 or 128 bytes each)
+        const int cbits = c->max_nonref <= 255 ? 8 : 16;
+        const size_t hist_bytes = (size_t)c->n_groups * tiles * (RT * cbits / 32) * 64 * 4;
+        if (!c->no_ovr_one_pass && hist_bytes <= (size_t)c->scratch_bytes) {
+            if ((rc = get_scratch(c, "group_hist", hist_bytes, &v))) return rc;
+            P.group_hist = (u32 *)v;
+            {
+                ProfScope ps(c, KID_OVR_FUSED);
+                if (cbits == 8) hipLaunchKernelGGL((k_ovr_group_hists<InT, RT, 8>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+                else hipLaunchKernelGGL((k_ovr_group_hists<InT, RT, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+                HIPCHK(c, hipGetLastError());
+            }
             ProfScope ps(c, KID_FUSED_REF);
-            const int chunks = (int)((c->n_cells + P.rows_per_wg - 1) / P.rows_per_wg);
-            hipLaunchKernelGGL((k_fused_hist_all<InT, RT>), dim3(tiles, chunks), dim3(FUSED_NT), 0, c->stream, P);
             hipLaunchKernelGGL((k_fused_tables_all<RT>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, P);
+            // the rank-sum kernel keeps a 64-entry table per lane in registers: more groups per workgroup amortise its fill
+            FusedParams P2 = P;
+            P2.groups_per_wg = c->ovr_hist_groups_per_wg > 0 ? c->ovr_hist_groups_per_wg : 32;
+            while (P2.groups_per_wg > 8 && (int64_t)tiles * ((c->n_groups + P2.groups_per_wg - 1) / P2.groups_per_wg) < 2048) P2.groups_per_wg >>= 1;
+            const dim3 grid2(tiles, ((int)c->n_groups + P2.groups_per_wg - 1) / P2.groups_per_wg);
+            if (cbits == 8) hipLaunchKernelGGL((k_ovr_from_hists<RT, 8>), grid2, dim3(FUSED_NT), 0, c->stream, P2);
+            else hipLaunchKernelGGL((k_ovr_from_hists<RT, 16>), grid2, dim3(FUSED_NT), 0, c->stream, P2);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            {
+                ProfScope ps(c, KID_FUSED_REF);
+                const int chunks = (int)((c->n_cells + P.rows_per_wg - 1) / P.rows_per_wg);
+                hipLaunchKernelGGL((k_fused_hist_all<InT, RT>), dim3(tiles, chunks), dim3(FUSED_NT), 0, c->stream, P);
+                hipLaunchKernelGGL((k_fused_tables_all<RT>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, P);
+                HIPCHK(c, hipGetLastError());
+            }
+            ProfScope ps(c, KID_OVR_FUSED);
+            hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
             HIPCHK(c, hipGetLastError());
         }
-        ProfScope ps(c, KID_OVR_FUSED);
-        hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
-        HIPCHK(c, hipGetLastError());
     }
     h_flags.resize(nb);
     HIPCHK(c, hipMemcpyAsync(h_flags.data(), P.gene_flags, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));

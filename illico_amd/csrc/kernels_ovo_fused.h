@@ -47,6 +47,7 @@ struct FusedParams {
     double *out_p, *out_u, *out_fc; // [G][out_ld], already offset to column col0's slot
     long long out_ld;
     int groups_per_wg;
+    u32 *group_hist;          // OVR one-pass form: [G][tiles][RT * CB / 32][64] words, per-(group, gene) value histograms
 };
 
 // Table index of a value, clamped into [0, RT-1], and whether the value IS that integer (else the gene leaves
@@ -404,4 +405,135 @@ __global__ __launch_bounds__(FUSED_NT, (OVR || CB == 8) ? 4 : 3) void k_ovo_fuse
             for (int i = 0; i < BW; ++i) cbw[i * 64 + lane] = 0; // the wavefront's own block, in-order LDS: no barrier needed
     }
     if (act && bad) P.gene_flags[gene] = 1u;
+}
+
+// ============================================================================================
+// OVR from ONE pass over X.  k_fused_hist_all + k_ovo_fused<OVR> read X twice (column histogram, then rank sums).
+// Here the single pass leaves, per (group, gene), the histogram of the group's values -- RT cells of CB bits, 64 B at
+// CB = 8: 1.0 GB for C4's 2000 x 8000 pairs against 9.6 GB for a second read of X -- plus the column histogram;
+// a second, small kernel turns histograms into rank sums:  2 ranksum(g) = sum_c h_g[c] (cum[c] + cum[c+1]) + n_g.
+// Same integers as the two-pass form (dense_ovr.py:57-75, ranking.py:31-47), bit-exact.
+//
+// Cell (value c, gene lane) lives in the lane-PRIVATE word (c / PW) * 64 + lane of the wavefront's block, PW = 32 / CB
+// cells per word: the dump to HBM is BW coalesced 256-B stores, the second kernel reads its genes' words the same
+// way, and the LDS bank of a cell is the lane (conflict-free).
+template <typename InT, int RT, int CB>
+__global__ __launch_bounds__(FUSED_NT, 4) void k_ovr_group_hists(FusedParams P) {
+    constexpr int NT = FUSED_NT, NW = NT / 64, BW = RT * CB / 32, PW = 32 / CB, U = FUSED_U;
+    __shared__ u32 hcol[RT * 64];          // [value][lane]: histogram of every row this workgroup reads
+    __shared__ u32 cntB[NW][BW * 64];      // per wavefront: the current group's cells
+    typedef typename CntCell<CB>::type cell_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
+    const bool act = gene < P.ncols;
+    const int lane_c = act ? lane : 0;
+    const char *Xb = (const char *)((const InT *)P.X + P.col0 + gene0);
+    const u32 row_bytes = (u32)P.ld * (u32)sizeof(InT), col_bytes = (u32)lane_c * (u32)sizeof(InT);
+    const const_int_p permc = (const_int_p)P.perm;
+    u32 *cbw = cntB[wave];
+    for (int i = tid; i < RT * 64; i += NT) hcol[i] = 0;
+    for (int i = 0; i < BW; ++i) cbw[i * 64 + lane] = 0;
+    __syncthreads();
+    cell_t *cells = (cell_t *)cbw + lane * PW; // cell c: cells[(c / PW) * 64 * PW + c % PW]
+    u32 *hl = hcol + lane;
+    bool bad = false;
+    const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
+    const size_t tiles = gridDim.x;
+    for (int g = gbeg + wave; g < gend; g += NW) {
+        const int p0 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g]);
+        const int p1 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g + 1]);
+        int p = p0;
+        InT v[U];
+        auto chunk = [&](auto uu, auto pred) {
+            constexpr int UU = decltype(uu)::value;
+            constexpr bool PRED = decltype(pred)::value;
+            gather_rows<InT, UU, PRED>(Xb, row_bytes, permc, p, p1, col_bytes, v);
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                const bool valid = !PRED || (p + u < p1);
+                bool exact;
+                const u32 c = clamp_count<InT, RT>(v[u], exact);
+                bad |= valid && !exact;
+                cell_t *cell = cells + (c / PW) * (64 * PW) + (c % PW);
+                *cell = (cell_t)(*cell + (valid ? 1u : 0u));
+                atomicAdd(&hl[c * 64], valid ? 1u : 0u);
+            }
+            p += UU;
+        };
+        typedef std::integral_constant<bool, false> full_t;
+        typedef std::integral_constant<bool, true> pred_t;
+        while (p + U <= p1) chunk(std::integral_constant<int, U>(), full_t());
+        if constexpr (U > 16) { if (p + 16 <= p1) chunk(std::integral_constant<int, 16>(), full_t()); }
+        if (p + 8 <= p1) chunk(std::integral_constant<int, 8>(), full_t());
+        if (p < p1) chunk(std::integral_constant<int, 8>(), pred_t());
+        u32 *dst = P.group_hist + ((size_t)g * tiles + blockIdx.x) * (BW * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < BW; ++i) {
+            dst[i * 64] = cbw[i * 64 + lane];
+            cbw[i * 64 + lane] = 0;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < RT * 64; i += NT) {
+        const int c = i >> 6, l = i & 63;
+        const u32 cnt = hcol[i];
+        if (cnt && gene0 + l < P.ncols) atomicAdd(&P.hist_all[(size_t)(gene0 + l) * RT + c], cnt);
+    }
+    if (act && bad) P.gene_flags[gene] = 1u;
+}
+
+// histograms -> rank sums, U, p, fold change.  grid (tiles, group chunks); lane = gene; s[c] = cum[c] + cum[c+1] sits
+// in registers for the workgroup's lifetime, a group costs BW coalesced word loads and RT multiply-adds per lane.
+template <int RT, int CB>
+__global__ __launch_bounds__(FUSED_NT) void k_ovr_from_hists(FusedParams P) {
+    constexpr int NW = FUSED_NT / 64, BW = RT * CB / 32, PW = 32 / CB, CSTR = RT + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gene = blockIdx.x * 64 + lane;
+    const bool act = gene < P.ncols;
+    if (!act || P.gene_flags[gene] != 0) return; // flagged genes are recomputed by the slower routes
+    u32 s[RT];
+    {
+        const u32 *cum = P.ref_cum + (size_t)blockIdx.x * (64 * CSTR) + lane;
+        u32 prev = cum[0];
+#pragma unroll
+        for (int c = 0; c < RT; ++c) {
+            const u32 nxt = cum[(c + 1) * 64];
+            s[c] = prev + nxt;
+            prev = nxt;
+        }
+    }
+    const u64 T_A = P.ref_TA[gene];
+    const double total = (double)P.ref_sum[gene], cc = P.use_continuity ? 0.5 : 0.0;
+    const double tie = P.tie_correct ? (double)T_A : 0.0;
+    const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
+    const size_t tiles = gridDim.x;
+    for (int g = gbeg + wave; g < gend; g += NW) {
+        const u32 *h = P.group_hist + ((size_t)g * tiles + blockIdx.x) * (BW * 64) + lane;
+        u32 w[BW];
+#pragma unroll
+        for (int i = 0; i < BW; ++i) w[i] = h[i * 64];
+        u64 R2 = 0;
+        u32 vsum = 0;
+#pragma unroll
+        for (int i = 0; i < BW; ++i)
+#pragma unroll
+            for (int k = 0; k < PW; ++k) {
+                const u32 cnt = __builtin_amdgcn_ubfe(w[i], k * CB, CB);
+                R2 += (u64)cnt * s[i * PW + k];
+                vsum += cnt * (u32)(i * PW + k);
+            }
+        // dense_ovr.py:57-75, as in k_ovo_fused<OVR>
+        const long long n_tgt = P.counts[g], n_rest = P.n_cells - n_tgt;
+        const long long two_u = 2ll * n_rest * n_tgt + n_tgt * (n_tgt + 1) - ((long long)R2 + n_tgt);
+        const double Ustat = 0.5 * (double)two_u;
+        const double mu = (double)(n_rest * n_tgt) / 2.0;
+        const double pv = pval_device(n_rest, n_tgt, P.n_cells, tie, Ustat, mu, cc, P.alternative);
+        const double mu_tgt = (double)vsum / (double)n_tgt;
+        const double mu_ref = (total - (double)vsum) / (double)n_rest; // math.py:185-188
+        const double fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+        const size_t o = (size_t)g * P.out_ld + gene;
+        P.out_p[o] = pv;
+        P.out_u[o] = Ustat;
+        P.out_fc[o] = fc;
+    }
 }

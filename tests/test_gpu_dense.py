@@ -43,9 +43,12 @@ def route(request, engine):
     _DEVICE_INPUT = request.param == "fused+counts+sort"
     engine.set_option("no_fused_path", 0 if request.param.startswith("fused") else 1)
     engine.set_option("no_counts_path", 1 if request.param == "sort-only" else 0)
+    # fused OVR has a one-pass form (per-group histograms) and a two-pass form: the host-input param runs the latter
+    engine.set_option("no_ovr_one_pass", 1 if request.param.startswith("fused-host") else 0)
     yield request.param
     engine.set_option("no_counts_path", 0)
     engine.set_option("no_fused_path", 0)
+    engine.set_option("no_ovr_one_pass", 0)
     _DEVICE_INPUT = False
 
 

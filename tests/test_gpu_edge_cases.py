@@ -125,3 +125,18 @@ def test_many_groups_beyond_lds_accumulators(engine, ref):
     M = sparse.csc_matrix(X)
     got = engine.run_sparse("csc", M.data, M.indices, M.indptr, M.shape, 0, 3)
     assert_planes_match(got, want, ref_row=g.encoded_ref_group if ref else None, fc_rtol=1e-9, what="20k groups csc")
+
+
+@pytest.mark.parametrize("ref", ["s017", "s300", None])
+def test_every_group_size_through_the_chunk_cascade(engine, ref):
+    """The fused kernels walk a group in chunks of 32 rows, then 16, 8 and one predicated chunk of up to 7: one group
+    of every size from 1 to 75 plus a few large ones (one above 255 cells: 16-bit multiplicity cells) exercises every
+    combination; 70 genes = one full 64-gene tile and a partial one."""
+    rng = np.random.RandomState(5)
+    sizes = list(range(1, 76)) + [130, 300, 257]
+    labels = np.concatenate([[f"s{sz:03d}"] * sz for sz in sizes])
+    rng.shuffle(labels)
+    X = (rng.poisson(2.5, size=(labels.size, 70)) * (rng.rand(labels.size, 70) < 0.6)).astype(np.float32)
+    X[:, 3] = 0                      # an all-zero gene
+    X[:, 9] = rng.randint(0, 64, size=labels.size)   # the whole table range
+    _check(engine, X, labels, ref, "chunk cascade")
