@@ -202,6 +202,201 @@ __global__ void k_csr_col_nnz(const IdxT *__restrict__ indices, long long nnz, l
     }
 }
 
+// How many of n_samples evenly spaced stored values are NOT integers in [0, limit)?  (route choice only: count-valued
+// matrices go through dense windows + the fused kernels, normalised / log1p data straight to the general routes)
+template <typename InT>
+__global__ void k_sample_noncount(const InT *__restrict__ data, long long nnz, int n_samples, int limit, u32 *__restrict__ n_bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_samples) return;
+    const long long k = (long long)((double)i * (double)nnz / (double)n_samples);
+    const InT v = data[k < nnz ? k : nnz - 1];
+    const bool ok = v >= (InT)0 && v < (InT)limit && (InT)(int)v == v;
+    if (!ok) atomicAdd(n_bad, 1u);
+}
+
+// ---- CSR -> CSC on the device, for a window of W columns [c0, c0 + W): a two-pass blocked transposition.  Row blocks
+// of TR_RB rows are contiguous runs of the CSR arrays, so both passes read them coalesced; per block an LDS table over
+// the window's columns counts (pass 1) or hands out positions (pass 2), and an entry's destination lies in a run of its
+// (block, column) pair -- ~190 neighbouring entries at C3 -- instead of anywhere in the column.  The columns come out
+// with their rows grouped by block (ascending) but unordered inside a block; the CSC kernels do not need row order.
+// Device counterpart of csr_get_contig_cols_into_csc (utils/sparse/csr.py:19-100).
+#define TR_NT 256
+template <typename IdxT>
+__global__ __launch_bounds__(TR_NT) void k_csr_block_count(const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr, int n_rows,
+                                                          int RB, long long c0, int W, u32 *__restrict__ counts) {
+    extern __shared__ u32 tr_cnt[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < W; i += TR_NT) tr_cnt[i] = 0;
+    __syncthreads();
+    const int r0 = blockIdx.x * RB, r1 = min(r0 + RB, n_rows);
+    const long long k0 = (long long)indptr[r0], k1 = (long long)indptr[r1];
+    for (long long k = k0 + tid; k < k1; k += TR_NT) {
+        const long long col = (long long)indices[k] - c0;
+        if (col >= 0 && col < W) atomicAdd(&tr_cnt[col], 1u);
+    }
+    __syncthreads();
+    u32 *dst = counts + (size_t)blockIdx.x * W;
+    for (int i = tid; i < W; i += TR_NT) dst[i] = tr_cnt[i];
+}
+// per column: exclusive scan of the block counts (in place) and the column's total
+__global__ void k_col_block_scan(u32 *__restrict__ counts, int n_blocks, int W, u32 *__restrict__ col_total) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= W) return;
+    u32 run = 0;
+    int b = 0;
+    for (; b + 8 <= n_blocks; b += 8) {
+        u32 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = counts[(size_t)(b + j) * W + col];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { counts[(size_t)(b + j) * W + col] = run; run += t[j]; }
+    }
+    for (; b < n_blocks; ++b) { const u32 t = counts[(size_t)b * W + col]; counts[(size_t)b * W + col] = run; run += t; }
+    col_total[col] = run;
+}
+template <typename InT, typename IdxT>
+__global__ __launch_bounds__(TR_NT) void k_csr_block_scatter(const InT *__restrict__ data, const IdxT *__restrict__ indices,
+                                                            const IdxT *__restrict__ indptr, int n_rows, int RB, long long c0, int W,
+                                                            const u32 *__restrict__ offsets, const u32 *__restrict__ col_ptr,
+                                                            InT *__restrict__ out_data, int *__restrict__ out_rows) {
+    extern __shared__ u32 tr_cur[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 *off = offsets + (size_t)blockIdx.x * W;
+    for (int i = tid; i < W; i += TR_NT) tr_cur[i] = col_ptr[i] + off[i];
+    __syncthreads();
+    const int r0 = blockIdx.x * RB, r1 = min(r0 + RB, n_rows);
+    for (int r = r0 + wave; r < r1; r += TR_NT / 64) {
+        const long long k1 = (long long)indptr[r + 1];
+        for (long long k = (long long)indptr[r] + lane; k < k1; k += 64) {
+            const long long col = (long long)indices[k] - c0;
+            const InT v = data[k];
+            if (col >= 0 && col < W) {
+                const u32 pos = atomicAdd(&tr_cur[col], 1u);
+                out_data[pos] = v;
+                out_rows[pos] = r;
+            }
+        }
+    }
+}
+
+// Pass 2 for rows with SORTED column indices (the reference requires them, tests/test_asymptotic_wilcoxon.py:259-273):
+// one workgroup per row block sweeps the window left to right in tiles of TRG_COLS columns.  Every thread owns RPT
+// rows and keeps a cursor into each: the entries of a row that fall into the current tile are the next few after the
+// cursor (no search, and a row's cache lines are walked once).  The workgroup counting-sorts the tile's entries by
+// column in LDS and writes every (block, column) run -- RB * density entries -- as one contiguous copy.
+// k_csr_block_scatter above sends each entry straight to its final position instead: 8000 open write streams per
+// workgroup, far more than L2 can merge (17 ms at C3 shape).
+#define TRG_COLS 64
+#define TRG_RPT 2
+#define TRG_WIN 8 // entries of a row held in registers
+template <typename T, int N> struct __attribute__((packed, aligned(4))) PackedRun { T v[N]; }; // 4-byte aligned multi-dword load
+template <typename InT, typename IdxT>
+__global__ __launch_bounds__(TR_NT) void k_csr_tile_gather(const InT *__restrict__ data, const IdxT *__restrict__ indices,
+                                                          const IdxT *__restrict__ indptr, int n_rows, int RB, long long c0, int W,
+                                                          const u32 *__restrict__ offsets, const u32 *__restrict__ col_total,
+                                                          const u32 *__restrict__ col_ptr, int cap, InT *__restrict__ out_data,
+                                                          int *__restrict__ out_rows, u32 *__restrict__ overflow) {
+    extern __shared__ __align__(16) unsigned char trg_smem[];
+    __shared__ u32 start[TRG_COLS + 1], cur[TRG_COLS], gbase[TRG_COLS];
+    InT *sval = (InT *)trg_smem;
+    int *srow = (int *)(trg_smem + (size_t)cap * sizeof(InT));
+    unsigned char *scol = (unsigned char *)(srow + cap);
+    constexpr int RPT = TRG_RPT, WN = TRG_WIN;
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * RB, r1 = min(r0 + RB, n_rows);
+    // Per row: a register window of the next WN stored entries (column relative to c0, value), refilled with multi-dword
+    // loads when it runs dry.  A thread walks ITS row, so its loads are uncoalesced across lanes (64 cache lines per
+    // instruction): fetching 8 entries with 2 + 2 wide loads instead of 16 narrow ones is what keeps the texture
+    // addresser from being the limiter (it was: 7 of 8 ms).
+    long long knext[RPT], kend[RPT];
+    int wcol[RPT][WN], wp[RPT], wn[RPT];
+    InT wval[RPT][WN];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int r = r0 + j * TR_NT + tid;
+        knext[j] = kend[j] = 0;
+        wp[j] = wn[j] = 0;
+        if (r < r1) {
+            long long a = (long long)indptr[r], e = (long long)indptr[r + 1], b = e;
+            while (a < b) { const long long m = (a + b) >> 1; if ((long long)indices[m] < c0) a = m + 1; else b = m; } // window start
+            knext[j] = a;
+            kend[j] = e;
+        }
+    }
+    // the (block, column) counts of pass 1 survive as differences of the scanned table: this block's offset against the
+    // next block's (the column total for the last block)
+    const u32 *off = offsets + (size_t)blockIdx.x * W;
+    const u32 *off_next = (blockIdx.x + 1 < gridDim.x) ? off + W : col_total;
+    for (int cb = 0; cb < W; cb += TRG_COLS) {
+        const int ncols = min(TRG_COLS, W - cb);
+        const int chi = cb + ncols; // columns are kept relative to c0
+        if (tid < 64) {
+            const bool in = tid < ncols;
+            const u32 o0 = in ? off[cb + tid] : 0u, o1 = in ? off_next[cb + tid] : 0u, cp = in ? col_ptr[cb + tid] : 0u;
+            const u32 cv = o1 - o0;
+            const u32 incl = (u32)wave_incl_scan_add((int)cv);
+            start[tid] = incl - cv;
+            cur[tid] = incl - cv;
+            gbase[tid] = cp + o0 - (incl - cv); // destination of staged entry i of this column: gbase + i
+            if (tid == 63) start[TRG_COLS] = incl;
+        }
+        __syncthreads();
+        const u32 total = start[TRG_COLS];
+        if (total > (u32)cap) { // uniform: the host redoes this window with the scatter kernel
+            if (tid == 0) *overflow = 1u;
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int r = r0 + j * TR_NT + tid;
+            bool more = true;
+            while (more) {
+#pragma unroll
+                for (int i = 0; i < WN; ++i)
+                    if (i >= wp[j] && i < wn[j]) {
+                        if (more && wcol[j][i] < chi) {
+                            const int col = wcol[j][i] - cb;
+                            const u32 p = atomicAdd(&cur[col], 1u);
+                            sval[p] = wval[j][i];
+                            srow[p] = r;
+                            scol[p] = (unsigned char)col;
+                            wp[j] = i + 1;
+                        } else more = false;
+                    }
+                if (more) { // window consumed: refill, or the row is finished
+                    const long long k = knext[j], left = kend[j] - k;
+                    if (left <= 0) more = false;
+                    else {
+                        if (left >= WN) {
+                            const PackedRun<IdxT, WN> pi = *(const PackedRun<IdxT, WN> *)(indices + k);
+                            const PackedRun<InT, WN> pv = *(const PackedRun<InT, WN> *)(data + k);
+#pragma unroll
+                            for (int i = 0; i < WN; ++i) { wcol[j][i] = (int)((long long)pi.v[i] - c0); wval[j][i] = pv.v[i]; }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < WN; ++i) {
+                                const bool ok = i < left;
+                                wcol[j][i] = ok ? (int)((long long)indices[k + i] - c0) : 0x7FFFFFFF;
+                                wval[j][i] = ok ? data[k + i] : (InT)0;
+                            }
+                        }
+                        wp[j] = 0;
+                        wn[j] = (int)(left < WN ? left : WN);
+                        knext[j] = k + wn[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (u32 i = tid; i < total; i += TR_NT) {
+            const u32 dst = gbase[scol[i]] + i;
+            out_data[dst] = sval[i];
+            out_rows[dst] = srow[i];
+        }
+        __syncthreads();
+    }
+}
+
 // CSR rows -> a dense float32 window D[n_rows][ldD] of columns [c0, c0 + W): the dense fused single-pass kernels then
 // read the window once.  One workgroup builds one row at a time in LDS (zero, scatter the row's stored entries, copy
 // out): HBM sees only coalesced 16-byte stores, never a partial-sector scatter.  A stored value that float32 cannot

@@ -86,7 +86,7 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
 template <typename InT, typename IdxT, typename KeyT>
 static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indices, const void *indptr, int dtype,
                         int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                        const OutPlanes &o, bool allow_dense_window = true) {
+                        const OutPlanes &o, bool allow_dense_window = true, bool allow_transpose = true) {
     const int G = (int)c->n_groups;
     const bool ovr = c->ref < 0;
     const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
@@ -126,8 +126,22 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
 
     // ---- CSR, count-valued, not too sparse: dense float32 windows + the fused single-pass kernels (k_csr_densify) ----
     const double density = (double)total_nnz / ((double)std::max<int64_t>(n_rows, 1) * (double)std::max<int64_t>(n_cols, 1));
-    if (is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) && density >= 0.015 &&
-        (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes) {
+    bool dense_window = is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) && density >= 0.015 &&
+                        (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes && total_nnz > 0;
+    if (dense_window) { // worth it only for count-valued data: look at 64k evenly spaced stored values first
+        const int n_samples = (int)std::min<int64_t>(total_nnz, 1 << 16);
+        if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
+        u32 *d_cnt = (u32 *)v;
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
+        hipLaunchKernelGGL((k_sample_noncount<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, d_data, (long long)total_nnz,
+                           n_samples, FUSED_RT, d_cnt);
+        HIPCHK(c, hipGetLastError());
+        u32 n_bad = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_bad, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dense_window = (double)n_bad <= 0.02 * (double)n_samples; // a few outlier values cost a few genes, not the route
+    }
+    if (dense_window) {
         int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * 4)) & ~63ll;
         wmax = std::min<int64_t>(wmax, (1ll << 29));
         if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, (c->gene_batch + 63) & ~63ll);
@@ -157,6 +171,93 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         o2.p += bad_lo - col_lb; o2.u += bad_lo - col_lb; o2.fc += bad_lo - col_lb;
         return run_sparse_t<InT, IdxT, KeyT>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, bad_lo, bad_hi + 1, flags,
                                              alternative, o2, false);
+    }
+
+    // ---- CSR, any values: transpose the column window into CSC on the device, then the CSC routes ----
+    if (is_csr && allow_transpose && !c->no_csr_transpose_path && n_rows < (1ll << 31)) {
+        // sorted column indices (the reference's contract) allow the gather form of pass 2
+        int sorted = 0;
+        if (!c->no_csr_tile_gather) {
+            if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
+            int *d_bad = (int *)v;
+            HIPCHK(c, hipMemsetAsync(d_bad, 0, 8, c->stream));
+            hipLaunchKernelGGL((k_csr_sorted_check<IdxT>), dim3((unsigned)std::min<int64_t>((n_rows + 3) / 4 + 1, 8192)), dim3(256), 0, c->stream,
+                               d_indices, d_indptr, (int)n_rows, d_bad);
+            HIPCHK(c, hipGetLastError());
+            int bad = 0;
+            HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            sorted = bad ? 0 : 1;
+        }
+        const int cap = 8192; // LDS staging entries of k_csr_tile_gather
+        int RB = 256;
+        if (sorted) { // expected entries per (row block, 64-column tile) <= cap / 2
+            const double per_row = std::max(density * TRG_COLS, 1e-9);
+            RB = TR_NT * TRG_RPT;
+            while (RB > 64 && RB * per_row > cap / 2) RB >>= 1;
+        }
+        const int n_blocks = (int)((n_rows + RB - 1) / RB);
+        int64_t wmax = std::min<int64_t>(W, 32768); // the per-block column tables live in LDS (4 bytes per column)
+        for (int64_t w0 = col_lb; w0 < col_ub;) {
+            const int64_t wn = std::min<int64_t>(wmax, col_ub - w0);
+            if ((rc = get_scratch(c, "tr_counts", (size_t)n_blocks * wn * 4, &v))) return rc;
+            u32 *counts = (u32 *)v;
+            if ((rc = get_scratch(c, "tr_cols", (size_t)(wn + 1) * 8 + 16, &v))) return rc;
+            u32 *col_total = (u32 *)v, *col_ptr = col_total + (wn + 1), *d_over = col_ptr + (wn + 1);
+            u32 total = 0;
+            {
+                ProfScope ps(c, KID_SPARSE_SEG);
+                HIPCHK(c, hipMemsetAsync(col_total + wn, 0, 4, c->stream));
+                HIPCHK(c, hipMemsetAsync(d_over, 0, 4, c->stream));
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_csr_block_count<IdxT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wn * 4)));
+                hipLaunchKernelGGL((k_csr_block_count<IdxT>), dim3(n_blocks), dim3(TR_NT), (size_t)wn * 4, c->stream, d_indices, d_indptr,
+                                   (int)n_rows, RB, (long long)w0, (int)wn, counts);
+                hipLaunchKernelGGL(k_col_block_scan, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, c->stream, counts, n_blocks, (int)wn, col_total);
+                hipLaunchKernelGGL(k_gene_base_scan, dim3(1), dim3(1024), 0, c->stream, (const u32 *)col_total, (int)wn + 1, col_ptr);
+                HIPCHK(c, hipGetLastError());
+            }
+            HIPCHK(c, hipMemcpyAsync(&total, col_ptr + wn, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            // (a window whose stored entries reach 2^31 would wrap the 32-bit scan: such windows are halved before they
+            //  get here -- 2^31 entries do not fit the scratch cap at 8+ bytes each)
+            const size_t need = (size_t)std::max<u32>(total, 1) * (sizeof(InT) + 4);
+            if ((need > (size_t)c->scratch_bytes || (double)total_nnz * (double)wn / (double)std::max<int64_t>(n_cols, 1) > 1.5e9) && wn > 64) {
+                wmax = std::max<int64_t>(64, wn / 2);
+                continue;
+            }
+            if ((rc = get_scratch(c, "tr_data", (size_t)std::max<u32>(total, 1) * sizeof(InT), &v))) return rc;
+            InT *t_data = (InT *)v;
+            if ((rc = get_scratch(c, "tr_rows", (size_t)std::max<u32>(total, 1) * 4, &v))) return rc;
+            int *t_rows = (int *)v;
+            bool done = false;
+            if (sorted) {
+                ProfScope ps(c, KID_SPARSE_SEG);
+                const size_t lds = (size_t)cap * (sizeof(InT) + 4 + 1);
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_csr_tile_gather<InT, IdxT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_csr_tile_gather<InT, IdxT>), dim3(n_blocks), dim3(TR_NT), lds, c->stream,
+                                   d_data, d_indices, d_indptr, (int)n_rows, RB, (long long)w0, (int)wn, (const u32 *)counts, (const u32 *)col_total,
+                                   (const u32 *)col_ptr, cap, t_data, t_rows, d_over);
+                HIPCHK(c, hipGetLastError());
+                u32 over = 0;
+                HIPCHK(c, hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                done = over == 0; // a (block, tile) piece larger than the LDS staging: redo the window with the scatter form
+            }
+            if (!done) {
+                ProfScope ps(c, KID_SPARSE_SEG);
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_csr_block_scatter<InT, IdxT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wn * 4)));
+                hipLaunchKernelGGL((k_csr_block_scatter<InT, IdxT>), dim3(n_blocks), dim3(TR_NT), (size_t)wn * 4, c->stream, d_data, d_indices,
+                                   d_indptr, (int)n_rows, RB, (long long)w0, (int)wn, (const u32 *)counts, (const u32 *)col_ptr, t_data, t_rows);
+                HIPCHK(c, hipGetLastError());
+            }
+            OutPlanes o2 = o;
+            o2.p += w0 - col_lb; o2.u += w0 - col_lb; o2.fc += w0 - col_lb;
+            if ((rc = run_sparse_t<InT, int32_t, KeyT>(c, false, t_data, t_rows, col_ptr, dtype, n_rows, wn, 0, wn,
+                                                       flags | ILLICO_FLAG_INPUT_DEVICE, alternative, o2, false, false)))
+                return rc;
+            w0 += wn;
+        }
+        return ILLICO_OK;
     }
 
     // per-gene stored-entry counts of the requested window

@@ -22,19 +22,28 @@ def _run(engine, M, grpc, **kw):
     return engine.run_sparse(M.format, M.data, M.indices, M.indptr, M.shape, lb, ub, **kw)
 
 
-@pytest.fixture(params=["single-kernel", "two-kernel", "two-kernel-sort-only"])
+@pytest.fixture(params=["default", "two-kernel", "two-kernel-sort-only", "csr-regroup"])
 def route(request, engine):
     """CSC OVO has a single-kernel route (regroup + rank in LDS) with the two-kernel route (regroup into HBM, then
-    histogram / sort rank kernels) as fallback; CSR first tries dense float32 windows + the fused dense kernels
-    (count-valued data) and falls back to its two-kernel route.  The params force each so that all are exercised
-    on the same data: "single-kernel" = the defaults (CSC single kernel, CSR dense window)."""
-    engine.set_option("no_csc_gene_path", 0 if request.param == "single-kernel" else 1)
-    engine.set_option("no_dense_window_path", 0 if request.param == "single-kernel" else 1)
-    engine.set_option("no_counts_path", 1 if request.param.endswith("sort-only") else 0)
+    histogram / sort rank kernels) as fallback.  CSR first tries dense float32 windows + the fused dense kernels
+    (count-valued data), otherwise it is transposed to CSC on the device and takes the CSC routes; the older CSR route
+    (regroup by (gene, group) with global atomics) is kept behind an option.  The params force each so that all are
+    exercised on the same data."""
+    opts = {"no_csc_gene_path": 0, "no_dense_window_path": 0, "no_counts_path": 0, "no_csr_transpose_path": 0,
+            "no_csr_tile_gather": 0}
+    if request.param.startswith("two-kernel"):
+        opts.update(no_csc_gene_path=1, no_dense_window_path=1)
+    if request.param == "two-kernel":
+        opts.update(no_csr_tile_gather=1)   # CSR -> CSC by the scatter form (what unsorted rows get)
+    if request.param.endswith("sort-only"):
+        opts.update(no_counts_path=1)
+    if request.param == "csr-regroup":
+        opts.update(no_dense_window_path=1, no_csr_transpose_path=1)
+    for k, v in opts.items():
+        engine.set_option(k, v)
     yield request.param
-    engine.set_option("no_csc_gene_path", 0)
-    engine.set_option("no_dense_window_path", 0)
-    engine.set_option("no_counts_path", 0)
+    for k in opts:
+        engine.set_option(k, 0)
 
 
 @pytest.mark.parametrize("name", ["c1_1k_200_10", "small_ragged", "sparse90", "continuous"])
