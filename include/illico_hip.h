@@ -64,7 +64,13 @@ int illico_ctx_destroy(illico_ctx *ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int illico_ctx_set_stream(illico_ctx *ctx, void *hip_stream);
 /* Tunables: "gene_batch" (genes per device pass, 0 = auto), "scratch_bytes" (cap of device scratch),
- * "profile" (1 = bracket every kernel launch with HIP events on the context's stream). */
+ * "profile" (1 = bracket kernel launches with HIP events on the context's stream), "profile_only" (kernel id: time
+ * that kernel only, -1 = all), "fused_groups_per_wg" / "ovr_hist_groups_per_wg" (launch geometry, 0 = auto).
+ * Route switches, all 0 by default; every route produces the same integers, the switches exist so that tests and
+ * A/B measurements can force each one: "no_fused_path", "no_counts_path" (dense / segmented histogram routes),
+ * "no_ovr_one_pass" (dense OVR in two passes over X), "no_csc_gene_path" (CSC single-kernel route),
+ * "no_dense_window_path" (CSR through dense float32 windows), "no_csr_transpose_path" / "no_csr_tile_gather"
+ * (CSR -> CSC transposition on the device / its gather form for sorted rows).  Unknown keys return ILLICO_ERR_ARG. */
 int illico_ctx_set_option(illico_ctx *ctx, const char *key, int64_t value);
 const char *illico_last_error(const illico_ctx *ctx);
 int illico_ctx_synchronize(illico_ctx *ctx);
