@@ -230,3 +230,34 @@ def test_csr_dense_window_route(engine, test, dtype):
     finally:
         engine.set_option("gene_batch", 0)
     assert_planes_match(got, oracle.run(X, g, col_lb=100, col_ub=8290), fc_rtol=1e-9, what=f"csr dense window batches {test}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("dtype,idx", [(np.float32, np.int32), (np.float64, np.int64)])
+def test_csr_transposition_route(engine, test, dtype, idx):
+    """CSR with continuous values: transposed to CSC on the device (count pass + tile gather), then the CSC routes.
+    A window wider than one transposition pass (32768 columns), a column window, rows longer than the register
+    window, empty rows, and rows with UNSORTED column indices (those take the scatter form of pass 2)."""
+    rng = np.random.RandomState(211)
+    n, m = 150, 33100
+    X = np.where(rng.rand(n, m) < 0.08, np.log1p(rng.poisson(3.0, size=(n, m)) * rng.uniform(0.5, 1.5, size=(n, m))), 0.0)
+    X[5, :] = 0.0                                  # an empty row
+    X[9, :2000] = rng.rand(2000) + 0.1             # a long dense stretch in one row
+    X = X.astype(dtype).astype(np.float64)
+    labels = make_labels(rng, n, 5, n_ref=30)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    M = sparse.csr_matrix(X.astype(dtype))
+    M.indices = M.indices.astype(idx)
+    M.indptr = M.indptr.astype(idx)
+    want = oracle.run(X, g)
+    got = _run(engine, M, g)
+    assert_planes_match(got, want, fc_rtol=1e-9, what=f"csr transposition {test}")
+    got = _run(engine, M, g, col_lb=777, col_ub=32999)
+    assert_planes_match(got, oracle.run(X, g, col_lb=777, col_ub=32999), fc_rtol=1e-9, what=f"csr transposition window {test}")
+    for r in range(n):                             # shuffle inside every row
+        s, e = M.indptr[r], M.indptr[r + 1]
+        perm = rng.permutation(e - s)
+        M.indices[s:e] = M.indices[s:e][perm]
+        M.data[s:e] = M.data[s:e][perm]
+    got = _run(engine, M, g)
+    assert_planes_match(got, want, fc_rtol=1e-9, what=f"csr transposition, unsorted rows {test}")
