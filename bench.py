@@ -170,7 +170,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # The first ~8 passes of a fresh process run up to 6 % slower than the steady state (tools/ramp.py: 2.13, 2.09, 2.07,
+    # 2.05, 2.04, 2.03, 2.02 ... 2.01 ms): a few settling passes before the W warm-up steps, so that a small W still
+    # measures the steady state.  Untimed, like the warm-up and the data generation.
+    settle = 6
+    for _ in range(settle + args.warmup):
         step()
     sync()
     # One untimed step with HIP events around every kernel: the per-kernel breakdown, and which kernel dominates.
@@ -272,7 +276,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"dense {N}x{M}x{G} {args.test.upper()} (K562-shaped, BASELINE configs[1])" if not ovr
                                     else f"dense {N}x{M}x{G} OVR") + ("" if args.values == "counts" else " [continuous values]"), "cells": N, "genes_per_gpu": M, "groups": G,
-                       "sparsity": args.sparsity, "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU",
+                       "sparsity": args.sparsity, "settle_steps": settle, "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU",
                        "p_value_rtol_vs_cpu": 1e-12},
             "roofline": roofline, "cpu_baseline": cpu,
         }
