@@ -589,7 +589,21 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
 
     // ---- route 1 (device-resident dense OVO): fused single pass; it reports the genes it could not take ----
     std::vector<std::pair<int64_t, int64_t>> runs; // column ranges still to be computed by the two-pass routes
-    if (in_dev && fused_path_allowed(c, flags) && (uint64_t)ld * sizeof(InT) < (1ull << 32)) { // row pitch: 32-bit byte offsets
+    bool try_fused = fused_path_allowed(c, flags) && (uint64_t)ld * sizeof(InT) < (1ull << 32); // row pitch: 32-bit byte offsets
+    if (try_fused && in_dev && N > 0 && W > 0) { // count-valued at all?  64k evenly spaced cells of the window decide
+        const int n_samples = (int)std::min<int64_t>(N * W, 1 << 16);
+        if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
+        u32 *d_cnt = (u32 *)v;
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
+        hipLaunchKernelGGL((k_sample_noncount_dense<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, (const InT *)X, (long long)ld,
+                           (long long)col_lb, (long long)N, (long long)W, n_samples, FUSED_RT, d_cnt);
+        HIPCHK(c, hipGetLastError());
+        u32 n_bad = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_bad, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        try_fused = (double)n_bad <= 0.02 * (double)n_samples; // a few outlier values cost a few genes, not the route
+    }
+    if (in_dev && try_fused) {
         std::vector<u32> hf;
         if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf))) return rc;
         for (int64_t j = 0; j < W;) {
@@ -600,7 +614,7 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
             j = e;
         }
         if (runs.empty()) return ILLICO_OK;
-    } else if (!in_dev && fused_path_allowed(c, flags)) {
+    } else if (!in_dev && try_fused) {
         // host matrix: column windows are copied up row-major (one 2-D copy each) and take the same fused pass
         int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)N * sizeof(InT))) & ~63ll;
         wmax = std::min<int64_t>(std::max<int64_t>(wmax, 64), (int64_t)((1ull << 32) / sizeof(InT)) - 64);
