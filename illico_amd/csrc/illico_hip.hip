@@ -72,6 +72,8 @@ struct illico_ctx {
     int ovr_hist_groups_per_wg = 0; // k_ovr_from_hists; 0 = auto
     bool profile = false;
     int profile_only = -1;        // >= 0: time this kernel id only (the others run without events around them)
+    void *pinned = nullptr;       // pinned host staging for small device -> host results
+    size_t pinned_bytes = 0;
     std::vector<ProfEvent> events;
     std::vector<hipEvent_t> event_pool;
     double prof_ms[KID_COUNT] = {0};
@@ -204,6 +206,7 @@ int illico_ctx_destroy(illico_ctx *c) {
     hipStreamSynchronize(c->stream);
     drain_events(c);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+    if (c->pinned) hipHostFree(c->pinned);
     free_groups(c);
     for (auto &kv : c->scratch)
         if (kv.second.first) hipFree(kv.second.first);
@@ -570,9 +573,17 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             HIPCHK(c, hipGetLastError());
         }
     }
-    h_flags.resize(nb);
-    HIPCHK(c, hipMemcpyAsync(h_flags.data(), P.gene_flags, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+    // route flags back through a pinned staging buffer (a pageable destination makes the copy a blocking, staged one)
+    if (c->pinned_bytes < (size_t)nb * 4) {
+        if (c->pinned) hipHostFree(c->pinned);
+        c->pinned = nullptr;
+        c->pinned_bytes = 0;
+        HIPCHK(c, hipHostMalloc(&c->pinned, (size_t)nb * 4 + 4096, hipHostMallocDefault));
+        c->pinned_bytes = (size_t)nb * 4 + 4096;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->pinned, P.gene_flags, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    h_flags.assign((const u32 *)c->pinned, (const u32 *)c->pinned + nb);
     return ILLICO_OK;
 }
 
