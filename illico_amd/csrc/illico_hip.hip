@@ -19,6 +19,7 @@
 #include "kernels_ovr.h"
 #include "kernels_sparse.h"
 #include "kernels_csc_gene.h"
+#include "kernels_csc_counts.h"
 
 // ---- profiled kernel ids ---------------------------------------------------------------------
 enum {
@@ -33,10 +34,11 @@ enum {
     KID_SPARSE_SEG,
     KID_CSC_GENE,
     KID_GENE_TOTALS,
+    KID_CSC_COUNTS,
     KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
-                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals"};
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts"};
 
 struct ProfEvent {
     int kid;
@@ -64,6 +66,7 @@ struct illico_ctx {
     bool no_counts_path = false;
     bool no_fused_path = false;
     bool no_csc_gene_path = false;
+    bool no_csc_counts_path = false;   // 1: count-valued CSC genes do not take the LDS-histogram kernel (k_csc_counts)
     bool no_ovr_one_pass = false;      // 1: dense OVR reads X twice (column histogram, then rank sums) instead of once
     bool no_csr_tile_gather = false;    // 1: CSR -> CSC always by the scatter form (k_csr_block_scatter), as for unsorted rows
     bool no_csr_transpose_path = false; // 1: CSR is regrouped by (gene, group) with global atomics instead of being transposed to CSC
@@ -234,6 +237,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "profile_only")) c->profile_only = (value >= 0 && value < KID_COUNT) ? (int)value : -1;
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
+    else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
     else if (!strcmp(key, "no_ovr_one_pass")) c->no_ovr_one_pass = value != 0;
     else if (!strcmp(key, "no_csr_tile_gather")) c->no_csr_tile_gather = value != 0;

@@ -23,9 +23,10 @@
 struct CscGeneParams {
     const void *data, *indices, *indptr; // CSC arrays (device); stored entry k lives at data[k - kshift], indices[k - kshift]
     long long kshift;
-    long long col0;                      // first gene of the batch
+    long long col0;                      // first gene of the batch (contiguous batches)
+    const int *gene_cols;                // or: the batch's genes as a column list (absolute indices); nullptr = contiguous
     int nb;
-    const int *codes;                    // [n_cells] group code per cell
+    const int *codes;                    // [n_cells] group code per cell; nullptr: `indices` already holds group codes
     const int *counts;                   // [G]
     int G, ref, dt, is_log1p;
     int key_cap;                         // LDS key slots
@@ -69,7 +70,8 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
     const int n_ref = P.counts[ref];
 
     for (int gene = blockIdx.x; gene < P.nb; gene += gridDim.x) {
-        const long long k0 = (long long)indptr[P.col0 + gene] - P.kshift, k1 = (long long)indptr[P.col0 + gene + 1] - P.kshift;
+        const long long col = P.gene_cols ? (long long)P.gene_cols[gene] : P.col0 + gene;
+        const long long k0 = (long long)indptr[col] - P.kshift, k1 = (long long)indptr[col + 1] - P.kshift;
         // ---- 1. stored non-zeros per group ----
         for (int g = tid; g <= G; g += NT) ends[g] = 0;
         __syncthreads();
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
             for (int u = 0; u < UL; ++u) {
                 const long long k = kb + u * NT + tid;
                 v[u] = k < k1 ? data[k] : (InT)0;
-                cd[u] = k < k1 ? P.codes[(long long)indices[k]] : 0;
+                cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
             }
 #pragma unroll
             for (int u = 0; u < UL; ++u)
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
             for (int u = 0; u < UL; ++u) {
                 const long long k = kb + u * NT + tid;
                 v[u] = k < k1 ? data[k] : (InT)0;
-                cd[u] = k < k1 ? P.codes[(long long)indices[k]] : 0;
+                cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
             }
 #pragma unroll
             for (int u = 0; u < UL; ++u)

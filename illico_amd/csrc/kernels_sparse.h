@@ -62,7 +62,7 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
         for (int g = tid; g < G; g += SEG_NT) hist[g] = 0;
         __syncthreads();
         for (long long k = k0 - kshift + tid; k < k1 - kshift; k += SEG_NT)
-            if (data[k] != (InT)0) atomicAdd(&hist[codes[(long long)indices[k]]], 1u);
+            if (data[k] != (InT)0) atomicAdd(&hist[codes ? codes[(long long)indices[k]] : (int)indices[k]], 1u);
         __syncthreads();
         u32 total = block_excl_scan_inplace<SEG_NT>(hist, G, tmp, tid);
         u32 *sp = seg_ptr + (size_t)gene * (G + 1);
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
         for (long long k = k0 - kshift + tid; k < k1 - kshift; k += SEG_NT) {
             InT v = data[k];
             if (v != (InT)0) {
-                int c = codes[(long long)indices[k]];
+                int c = codes ? codes[(long long)indices[k]] : (int)indices[k];
                 u32 pos = gbase + atomicAdd(&hist[c], 1u);
                 Xs[pos] = key_of(v);
                 if (vals) vals[pos] = (u32)c;
@@ -258,7 +258,8 @@ template <typename InT, typename IdxT>
 __global__ __launch_bounds__(TR_NT) void k_csr_block_scatter(const InT *__restrict__ data, const IdxT *__restrict__ indices,
                                                             const IdxT *__restrict__ indptr, int n_rows, int RB, long long c0, int W,
                                                             const u32 *__restrict__ offsets, const u32 *__restrict__ col_ptr,
-                                                            InT *__restrict__ out_data, int *__restrict__ out_rows) {
+                                                            const int *__restrict__ row_codes, InT *__restrict__ out_data,
+                                                            int *__restrict__ out_rows) {
     extern __shared__ u32 tr_cur[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 *off = offsets + (size_t)blockIdx.x * W;
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(TR_NT) void k_csr_block_scatter(const InT *__restri
     __syncthreads();
     const int r0 = blockIdx.x * RB, r1 = min(r0 + RB, n_rows);
     for (int r = r0 + wave; r < r1; r += TR_NT / 64) {
+        const int tag = row_codes ? row_codes[r] : r; // what the CSC kernels need of a row is its group code
         const long long k1 = (long long)indptr[r + 1];
         for (long long k = (long long)indptr[r] + lane; k < k1; k += 64) {
             const long long col = (long long)indices[k] - c0;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(TR_NT) void k_csr_block_scatter(const InT *__restri
             if (col >= 0 && col < W) {
                 const u32 pos = atomicAdd(&tr_cur[col], 1u);
                 out_data[pos] = v;
-                out_rows[pos] = r;
+                out_rows[pos] = tag;
             }
         }
     }
@@ -294,8 +296,9 @@ template <typename InT, typename IdxT>
 __global__ __launch_bounds__(TR_NT) void k_csr_tile_gather(const InT *__restrict__ data, const IdxT *__restrict__ indices,
                                                           const IdxT *__restrict__ indptr, int n_rows, int RB, long long c0, int W,
                                                           const u32 *__restrict__ offsets, const u32 *__restrict__ col_total,
-                                                          const u32 *__restrict__ col_ptr, int cap, InT *__restrict__ out_data,
-                                                          int *__restrict__ out_rows, u32 *__restrict__ overflow) {
+                                                          const u32 *__restrict__ col_ptr, int cap, const int *__restrict__ row_codes,
+                                                          InT *__restrict__ out_data, int *__restrict__ out_rows,
+                                                          u32 *__restrict__ overflow) {
     extern __shared__ __align__(16) unsigned char trg_smem[];
     __shared__ u32 start[TRG_COLS + 1], cur[TRG_COLS], gbase[TRG_COLS];
     InT *sval = (InT *)trg_smem;
@@ -309,14 +312,16 @@ __global__ __launch_bounds__(TR_NT) void k_csr_tile_gather(const InT *__restrict
     // instruction): fetching 8 entries with 2 + 2 wide loads instead of 16 narrow ones is what keeps the texture
     // addresser from being the limiter (it was: 7 of 8 ms).
     long long knext[RPT], kend[RPT];
-    int wcol[RPT][WN], wp[RPT], wn[RPT];
+    int wcol[RPT][WN], wp[RPT], wn[RPT], tag[RPT]; // tag: what is stored for the row -- its group code, or the row index
     InT wval[RPT][WN];
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
         const int r = r0 + j * TR_NT + tid;
         knext[j] = kend[j] = 0;
         wp[j] = wn[j] = 0;
+        tag[j] = r;
         if (r < r1) {
+            if (row_codes) tag[j] = row_codes[r];
             long long a = (long long)indptr[r], e = (long long)indptr[r + 1], b = e;
             while (a < b) { const long long m = (a + b) >> 1; if ((long long)indices[m] < c0) a = m + 1; else b = m; } // window start
             knext[j] = a;
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(TR_NT) void k_csr_tile_gather(const InT *__restrict
                             const int col = wcol[j][i] - cb;
                             const u32 p = atomicAdd(&cur[col], 1u);
                             sval[p] = wval[j][i];
-                            srow[p] = r;
+                            srow[p] = tag[j];
                             scol[p] = (unsigned char)col;
                             wp[j] = i + 1;
                         } else more = false;

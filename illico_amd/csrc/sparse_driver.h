@@ -36,19 +36,118 @@ static std::vector<SparseBatch> plan_batches(const std::vector<int64_t> &gene_nn
 
 // Single-kernel CSC OVO route over genes [g0, g1): statistics + finalize for every gene it can take; the genes it
 // cannot take come back as column runs for the two-kernel route.
+// device copy of a column list (absolute indices) for the list-driven kernels / k_finalize's col_map
+static int upload_cols(illico_ctx *c, const std::vector<int64_t> &cols, const int **d_cols) {
+    void *v;
+    int rc = get_scratch(c, "sp_collist", std::max<size_t>(cols.size(), 1) * 4, &v);
+    if (rc) return rc;
+    std::vector<int> h(cols.begin(), cols.end());
+    HIPCHK(c, hipMemcpyAsync(v, h.data(), h.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // h goes out of scope
+    *d_cols = (const int *)v;
+    return ILLICO_OK;
+}
+
+// Count-valued CSC genes with small groups: per-group value histograms in LDS (k_csc_counts), OVO and OVR.  `cols` in:
+// the genes to compute; out: the genes it could not take.
+template <typename InT, typename IdxT>
+static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, const int *d_codes,
+                                int64_t n_rows, int64_t col_lb, int flags, int alternative, const OutPlanes &o, std::vector<int64_t> &cols) {
+    const int G = (int)c->n_groups;
+    const bool ovr = c->ref < 0;
+    int rc;
+    void *v;
+    const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
+    const int *d_cols = nullptr;
+    if (!contiguous && (rc = upload_cols(c, cols, &d_cols))) return rc;
+    // groups of more than 255 cells (other than the OVO reference, which has its own table) get 32-bit rows
+    std::vector<signed char> h_slot(G, (signed char)-1);
+    int n_big = 0;
+    for (int g = 0; g < G; ++g)
+        if (g != c->ref && c->h_counts[g] > 255) h_slot[g] = (signed char)n_big++;
+    const signed char *d_slot = nullptr;
+    if (n_big) {
+        if ((rc = get_scratch(c, "cscc_slot", (size_t)G, &v))) return rc;
+        HIPCHK(c, hipMemcpyAsync(v, h_slot.data(), (size_t)G, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        d_slot = (const signed char *)v;
+    }
+    const int rt = cscc_lds_bytes(G, 64) + 8192 <= kMaxLds ? 64 : 32;
+    const size_t lds = cscc_lds_bytes(G, rt);
+    const int64_t n = (int64_t)cols.size();
+    const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
+    if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
+    long long *s2u = (long long *)v;
+    u64 *stie = (u64 *)(s2u + (size_t)nb_max * G);
+    double *ssum = (double *)(stie + (size_t)nb_max * G);
+    double *gtot = ssum + (size_t)nb_max * G;
+    if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
+    u32 *fb = (u32 *)v;
+    std::vector<int64_t> left;
+    for (int64_t b0 = 0; b0 < n; b0 += nb_max) {
+        const int nb = (int)std::min<int64_t>(nb_max, n - b0);
+        HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)nb * 4, c->stream));
+        CscCountsParams P;
+        P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
+        P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref;
+        P.n_cells = n_rows; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot;
+        {
+            ProfScope ps(c, KID_CSC_COUNTS);
+#define CSCC_LAUNCH(OVRF, RTV)                                                                                              \
+    do {                                                                                                                   \
+        if (n_big) {                                                                                                       \
+            auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, true>;                                                          \
+            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCC_NT), lds, c->stream, P);                                          \
+        } else {                                                                                                           \
+            auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, false>;                                                         \
+            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCC_NT), lds, c->stream, P);                                          \
+        }                                                                                                                  \
+    } while (0)
+            if (ovr) { if (rt == 64) CSCC_LAUNCH(true, 64); else CSCC_LAUNCH(true, 32); }
+            else { if (rt == 64) CSCC_LAUNCH(false, 64); else CSCC_LAUNCH(false, 32); }
+#undef CSCC_LAUNCH
+            HIPCHK(c, hipGetLastError());
+        }
+        if (ovr && (rc = launch_gene_totals(c, ssum, G, nb, gtot))) return rc;
+        if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0))) return rc; }
+        else if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb))) return rc;
+        if (c->pinned_bytes < (size_t)nb * 4) {
+            if (c->pinned) hipHostFree(c->pinned);
+            c->pinned = nullptr; c->pinned_bytes = 0;
+            HIPCHK(c, hipHostMalloc(&c->pinned, (size_t)nb * 4 + 4096, hipHostMallocDefault));
+            c->pinned_bytes = (size_t)nb * 4 + 4096;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->pinned, fb, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const u32 *h_fb = (const u32 *)c->pinned;
+        for (int64_t j = 0; j < nb; ++j)
+            if (h_fb[j]) left.push_back(cols[b0 + j]);
+    }
+    cols.swap(left);
+    return ILLICO_OK;
+}
+
+// Single-kernel CSC OVO route over the genes in `cols` (in: to compute; out: the genes it could not take, which go to
+// the two-kernel route): statistics + finalize per batch.
 template <typename InT, typename IdxT, typename KeyT>
-static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, int dtype,
-                              int64_t g0, int64_t g1, int64_t col_lb, int flags, int alternative, const OutPlanes &o,
-                              std::vector<int64_t> &fallback_cols) {
+static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, const int *d_codes,
+                              int dtype, int64_t col_lb, int flags, int alternative, const OutPlanes &o, std::vector<int64_t> &cols) {
+    const int64_t g0 = 0, g1 = (int64_t)cols.size();
+    std::vector<int64_t> fallback_cols;
+    const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
+    const int *d_cols = nullptr;
+    {
+        int rc0;
+        if (!contiguous && (rc0 = upload_cols(c, cols, &d_cols))) return rc0;
+    }
     const int G = (int)c->n_groups;
     int rc;
     void *v;
     const int runend_cap = (int)std::max<int64_t>(1, std::min<int64_t>(c->h_counts[c->ref], 8192));
     const size_t fixed = cscg_lds_bytes(G, 0, runend_cap, sizeof(KeyT));
-    if (fixed + 1024 * sizeof(KeyT) > kMaxLds) {
-        for (int64_t j = g0; j < g1; ++j) fallback_cols.push_back(j);
-        return ILLICO_OK;
-    }
+    if (fixed + 1024 * sizeof(KeyT) > kMaxLds) return ILLICO_OK; // every gene stays in `cols` for the two-kernel route
     const int key_cap = (int)((kMaxLds - fixed) / sizeof(KeyT));
     const size_t lds = cscg_lds_bytes(G, key_cap, runend_cap, sizeof(KeyT));
     const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(g1 - g0, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
@@ -65,7 +164,8 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
         const int nb = (int)std::min<int64_t>(nb_max, g1 - b0);
         HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)nb * 4, c->stream));
         CscGeneParams P;
-        P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = b0; P.nb = nb; P.codes = c->d_codes;
+        P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
+        P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes;
         P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
         P.key_cap = key_cap; P.runend_cap = runend_cap; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
         {
@@ -73,20 +173,25 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
             hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCG_NT), lds, c->stream, P);
             HIPCHK(c, hipGetLastError());
         }
-        if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
+        if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0))) return rc; }
+        else if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb))) return rc;
         h_fb.resize(nb);
         HIPCHK(c, hipMemcpyAsync(h_fb.data(), fb, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (int64_t j = 0; j < nb; ++j)
-            if (h_fb[j]) fallback_cols.push_back(b0 + j);
+            if (h_fb[j]) fallback_cols.push_back(cols[b0 + j]);
     }
+    cols.swap(fallback_cols);
     return ILLICO_OK;
 }
 
 template <typename InT, typename IdxT, typename KeyT>
 static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indices, const void *indptr, int dtype,
                         int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                        const OutPlanes &o, bool allow_dense_window = true, bool allow_transpose = true) {
+                        const OutPlanes &o, bool allow_dense_window = true, bool allow_transpose = true, bool indices_are_codes = false) {
+    // indices_are_codes: CSC whose `indices` hold the group code of each stored entry's cell (what the device CSR -> CSC
+    // transposition writes: the per-entry lookup codes[row] is an uncoalesced gather the CSC kernels then skip)
+    const int *d_codes = indices_are_codes ? nullptr : c->d_codes;
     const int G = (int)c->n_groups;
     const bool ovr = c->ref < 0;
     const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
@@ -236,7 +341,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
                 HIPCHK(c, hipFuncSetAttribute((const void *)k_csr_tile_gather<InT, IdxT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_csr_tile_gather<InT, IdxT>), dim3(n_blocks), dim3(TR_NT), lds, c->stream,
                                    d_data, d_indices, d_indptr, (int)n_rows, RB, (long long)w0, (int)wn, (const u32 *)counts, (const u32 *)col_total,
-                                   (const u32 *)col_ptr, cap, t_data, t_rows, d_over);
+                                   (const u32 *)col_ptr, cap, (const int *)c->d_codes, t_data, t_rows, d_over);
                 HIPCHK(c, hipGetLastError());
                 u32 over = 0;
                 HIPCHK(c, hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, c->stream));
@@ -247,13 +352,13 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
                 ProfScope ps(c, KID_SPARSE_SEG);
                 HIPCHK(c, hipFuncSetAttribute((const void *)k_csr_block_scatter<InT, IdxT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wn * 4)));
                 hipLaunchKernelGGL((k_csr_block_scatter<InT, IdxT>), dim3(n_blocks), dim3(TR_NT), (size_t)wn * 4, c->stream, d_data, d_indices,
-                                   d_indptr, (int)n_rows, RB, (long long)w0, (int)wn, (const u32 *)counts, (const u32 *)col_ptr, t_data, t_rows);
+                                   d_indptr, (int)n_rows, RB, (long long)w0, (int)wn, (const u32 *)counts, (const u32 *)col_ptr, (const int *)c->d_codes, t_data, t_rows);
                 HIPCHK(c, hipGetLastError());
             }
             OutPlanes o2 = o;
             o2.p += w0 - col_lb; o2.u += w0 - col_lb; o2.fc += w0 - col_lb;
             if ((rc = run_sparse_t<InT, int32_t, KeyT>(c, false, t_data, t_rows, col_ptr, dtype, n_rows, wn, 0, wn,
-                                                       flags | ILLICO_FLAG_INPUT_DEVICE, alternative, o2, false, false)))
+                                                       flags | ILLICO_FLAG_INPUT_DEVICE, alternative, o2, false, false, true)))
                 return rc;
             w0 += wn;
         }
@@ -283,15 +388,37 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     // ---- CSC OVO: single-kernel route first; it reports the genes it could not take ----
     // `cols`: the columns the two-kernel route still has to compute.  CSC batches are arbitrary column LISTS (the
     // stragglers of the single-kernel route are batched together); CSR batches are contiguous windows.
-    std::vector<int64_t> cols;
+    std::vector<int64_t> cols(W);
+    for (int64_t j = 0; j < W; ++j) cols[j] = col_lb + j;
+    // CSC, count-valued, groups of at most 255 cells: per-group histograms in LDS (OVO and OVR)
+    int n_big_groups = 0;
+    for (int g = 0; g < G; ++g) n_big_groups += (g != c->ref && c->h_counts[g] > 255) ? 1 : 0;
+    if (!is_csr && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && n_big_groups <= CSCC_MAX_BIG && cscc_lds_bytes(G, 32) + 8192 <= kMaxLds &&
+        n_rows < (1ll << 30) && (ovr || c->h_counts[c->ref] < 30000)) { // 32-bit inner terms of the sweep
+        const int64_t k0 = (int64_t)h_indptr[col_lb], k1 = (int64_t)h_indptr[col_ub];
+        bool counts = k1 > k0;
+        if (counts) { // count-valued at all?  64k evenly spaced stored values of the window decide
+            const int n_samples = (int)std::min<int64_t>(k1 - k0, 1 << 16);
+            if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
+            u32 *d_cnt = (u32 *)v;
+            HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
+            hipLaunchKernelGGL((k_sample_noncount<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, d_data + (k0 - kshift),
+                               (long long)(k1 - k0), n_samples, CSCC_RT, d_cnt);
+            HIPCHK(c, hipGetLastError());
+            u32 n_bad = 0;
+            HIPCHK(c, hipMemcpyAsync(&n_bad, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            counts = (double)n_bad <= 0.02 * (double)n_samples;
+        }
+        if (counts) {
+            if ((rc = run_csc_counts_route<InT, IdxT>(c, d_data, d_indices, d_indptr, kshift, d_codes, n_rows, col_lb, flags, alternative, o, cols))) return rc;
+            if (cols.empty()) return ILLICO_OK;
+        }
+    }
     if (!is_csr && !ovr && !c->no_csc_gene_path) {
-        if ((rc = run_csc_gene_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, dtype, col_lb, col_ub, col_lb, flags,
-                                                      alternative, o, cols)))
+        if ((rc = run_csc_gene_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, d_codes, dtype, col_lb, flags, alternative, o, cols)))
             return rc;
         if (cols.empty()) return ILLICO_OK;
-    } else {
-        cols.resize(W);
-        for (int64_t j = 0; j < W; ++j) cols[j] = col_lb + j;
     }
 
     // ---- two-kernel route (regroup into HBM, then rank) ----
@@ -364,7 +491,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             size_t lds = seg_lds_bytes(G);
             HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(nb), dim3(SEG_NT), lds, c->stream, d_data, d_indices, d_indptr, (long long)b.g0, nb,
-                               (const int *)c->d_codes, G, Xs, va, seg, gflags, COUNTS_R, d_cols, d_base, (long long)kshift);
+                               d_codes, G, Xs, va, seg, gflags, COUNTS_R, d_cols, d_base, (long long)kshift);
             HIPCHK(c, hipGetLastError());
         } else {
             if ((rc = get_scratch(c, "sp_cursor", (size_t)nb * (G + 1) * 4 + (size_t)nb * 8, &v))) return rc;

@@ -24,15 +24,16 @@ def _run(engine, M, grpc, **kw):
 
 @pytest.fixture(params=["default", "two-kernel", "two-kernel-sort-only", "csr-regroup"])
 def route(request, engine):
-    """CSC OVO has a single-kernel route (regroup + rank in LDS) with the two-kernel route (regroup into HBM, then
+    """Count-valued CSC genes with groups of at most 255 cells take the LDS-histogram kernel (OVO and OVR); otherwise
+    CSC OVO has a single-kernel route (regroup + rank in LDS) with the two-kernel route (regroup into HBM, then
     histogram / sort rank kernels) as fallback.  CSR first tries dense float32 windows + the fused dense kernels
     (count-valued data), otherwise it is transposed to CSC on the device and takes the CSC routes; the older CSR route
     (regroup by (gene, group) with global atomics) is kept behind an option.  The params force each so that all are
     exercised on the same data."""
     opts = {"no_csc_gene_path": 0, "no_dense_window_path": 0, "no_counts_path": 0, "no_csr_transpose_path": 0,
-            "no_csr_tile_gather": 0}
+            "no_csr_tile_gather": 0, "no_csc_counts_path": 0}
     if request.param.startswith("two-kernel"):
-        opts.update(no_csc_gene_path=1, no_dense_window_path=1)
+        opts.update(no_csc_gene_path=1, no_dense_window_path=1, no_csc_counts_path=1)
     if request.param == "two-kernel":
         opts.update(no_csr_tile_gather=1)   # CSR -> CSC by the scatter form (what unsorted rows get)
     if request.param.endswith("sort-only"):
@@ -261,3 +262,41 @@ def test_csr_transposition_route(engine, test, dtype, idx):
         M.data[s:e] = M.data[s:e][perm]
     got = _run(engine, M, g)
     assert_planes_match(got, want, fc_rtol=1e-9, what=f"csr transposition, unsorted rows {test}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("many_groups", [False, True])
+def test_csc_counts_route(engine, test, many_groups):
+    """Count-valued CSC through the LDS-histogram kernel: groups above 255 cells (32-bit rows), a reference above and
+    below 255 cells, genes that leave the route (a value of 64+, a fractional value, a negative), explicit stored
+    zeros; with 2600 groups the 64-value table does not fit LDS and the 32-value form runs."""
+    rng = np.random.RandomState(307)
+    if many_groups:
+        sizes = [300, 400] + [3] * 2598
+    else:
+        sizes = [700, 300, 256, 255, 120, 60, 9, 1]
+    labels = np.concatenate([[f"s{i:04d}"] * sz for i, sz in enumerate(sizes)])
+    rng.shuffle(labels)
+    n, m = labels.size, 40
+    X = (rng.poisson(rng.uniform(0.3, 12.0, size=m), size=(n, m)) * (rng.rand(n, m) < 0.3)).astype(np.float32)
+    X[:, 4] = np.where(rng.rand(n) < 0.05, rng.randint(40, 200, size=n), X[:, 4])   # values beyond either table
+    X[:, 11] = np.where(rng.rand(n) < 0.1, 0.5, X[:, 11])                            # fractional
+    X[3, 17] = -2.0                                                                  # negative
+    X[:, 23] = 0.0                                                                   # empty gene
+    M = sparse.csc_matrix(X)
+    M.data[::97] = 0.0                                                               # explicit stored zeros ...
+    Xd = M.toarray()                                                                 # ... are zeros
+    for ref in (["s0000", "s0004"] if test == "ovo" else [None]):
+        _, g = oracle.encode_and_count_groups(labels, ref)
+        want = oracle.run(Xd, g)
+        engine.set_option("profile", 1)
+        engine.profile_reset()
+        try:
+            got = _run(engine, M, g)
+            prof = engine.profile_get()
+        finally:
+            engine.set_option("profile", 0)
+        assert "k_csc_counts" in prof, prof
+        assert_planes_match(got, want, fc_rtol=1e-9, what=f"csc counts {test} ref={ref} many_groups={many_groups}")
+        got = _run(engine, M, g, col_lb=2, col_ub=31)
+        assert_planes_match(got, oracle.run(Xd, g, col_lb=2, col_ub=31), fc_rtol=1e-9, what=f"csc counts window {test}")
