@@ -623,7 +623,7 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
             u32 *d_cnt = (u32 *)v;
             HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
             hipLaunchKernelGGL((k_sample_noncount_dense<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, (const InT *)X, (long long)ld,
-                               (long long)col_lb, (long long)N, (long long)W, n_samples, FUSED_RT, d_cnt);
+                               (long long)col_lb, (long long)N, (long long)W, n_samples, 1 << 24, d_cnt); // integers of any size count as count-like: a gene with large counts leaves the route alone
             HIPCHK(c, hipGetLastError());
             u32 n_bad = 0;
             HIPCHK(c, hipMemcpyAsync(&n_bad, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
@@ -667,6 +667,16 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
         if (runs.empty()) return ILLICO_OK;
     } else {
         runs.push_back({col_lb, col_ub});
+    }
+    // Flagged genes scattered through the window would make one tiny launch sequence each: runs closer than 32 genes
+    // are merged (the good genes in between are recomputed, identically, by the two-pass routes).
+    if (runs.size() > 1) {
+        std::vector<std::pair<int64_t, int64_t>> merged;
+        for (auto &r : runs) {
+            if (!merged.empty() && r.first - merged.back().second < 32) merged.back().second = r.second;
+            else merged.push_back(r);
+        }
+        runs.swap(merged);
     }
     int64_t widest = 0;
     for (auto &r : runs) widest = std::max(widest, r.second - r.first);

@@ -172,7 +172,8 @@ __device__ __forceinline__ void consume_ovr(const InT (&v)[NV], int p, int p1, c
     R2 += r2c;
 }
 
-// How many of n_samples evenly spaced cells of the window are NOT integers in [0, limit)?  (route choice only)
+// Of n_samples evenly spaced cells of the window: n_bad[0] = not a non-negative integer, n_bad[1] = an integer of `limit`
+// or more (as k_sample_noncount; route choice only)
 template <typename InT>
 __global__ void k_sample_noncount_dense(const InT *__restrict__ X, long long ld, long long col0, long long n_rows, long long W, int n_samples,
                                         int limit, u32 *__restrict__ n_bad) {
@@ -181,8 +182,9 @@ __global__ void k_sample_noncount_dense(const InT *__restrict__ X, long long ld,
     const long long k = (long long)((double)i * (double)(n_rows * W) / (double)n_samples);
     const long long r = k / W, j = k - r * W;
     const InT v = X[r * ld + col0 + j];
-    const bool ok = v >= (InT)0 && v < (InT)limit && (InT)(int)v == v;
-    if (!ok) atomicAdd(n_bad, 1u);
+    const bool integer = v >= (InT)0 && v < (InT)(1 << 24) && (InT)(int)v == v;
+    if (!integer) atomicAdd(n_bad, 1u);
+    else if (v >= (InT)limit) atomicAdd(n_bad + 1, 1u);
 }
 
 // ---- reference tables: one 1024-thread workgroup per 64-gene tile; lane = gene.  All 16 wavefronts add into one

@@ -202,16 +202,18 @@ __global__ void k_csr_col_nnz(const IdxT *__restrict__ indices, long long nnz, l
     }
 }
 
-// How many of n_samples evenly spaced stored values are NOT integers in [0, limit)?  (route choice only: count-valued
-// matrices go through dense windows + the fused kernels, normalised / log1p data straight to the general routes)
+// Of n_samples evenly spaced stored values: n_bad[0] = how many are not non-negative integers (normalised / log1p data:
+// no count route applies), n_bad[1] = how many are integers of `limit` or more (their genes leave the table-based
+// kernels one by one).  Route choice only: every route is exact.
 template <typename InT>
 __global__ void k_sample_noncount(const InT *__restrict__ data, long long nnz, int n_samples, int limit, u32 *__restrict__ n_bad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_samples) return;
     const long long k = (long long)((double)i * (double)nnz / (double)n_samples);
     const InT v = data[k < nnz ? k : nnz - 1];
-    const bool ok = v >= (InT)0 && v < (InT)limit && (InT)(int)v == v;
-    if (!ok) atomicAdd(n_bad, 1u);
+    const bool integer = v >= (InT)0 && v < (InT)(1 << 24) && (InT)(int)v == v;
+    if (!integer) atomicAdd(n_bad, 1u);
+    else if (v >= (InT)limit) atomicAdd(n_bad + 1, 1u);
 }
 
 // ---- CSR -> CSC on the device, for a window of W columns [c0, c0 + W): a two-pass blocked transposition.  Row blocks

@@ -237,14 +237,16 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         const int n_samples = (int)std::min<int64_t>(total_nnz, 1 << 16);
         if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
         u32 *d_cnt = (u32 *)v;
-        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
         hipLaunchKernelGGL((k_sample_noncount<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, d_data, (long long)total_nnz,
                            n_samples, FUSED_RT, d_cnt);
         HIPCHK(c, hipGetLastError());
-        u32 n_bad = 0;
-        HIPCHK(c, hipMemcpyAsync(&n_bad, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+        u32 n_bad[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(n_bad, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        dense_window = (double)n_bad <= 0.02 * (double)n_samples; // a few outlier values cost a few genes, not the route
+        // the genes this route cannot take are redone over the column window that covers them, so it needs nearly all of
+        // them to fit: no non-integers, few values beyond the table
+        dense_window = (double)n_bad[0] <= 0.02 * (double)n_samples && (double)n_bad[1] <= 0.005 * (double)n_samples;
     }
     if (dense_window) {
         int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * 4)) & ~63ll;
@@ -401,14 +403,14 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             const int n_samples = (int)std::min<int64_t>(k1 - k0, 1 << 16);
             if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
             u32 *d_cnt = (u32 *)v;
-            HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
+            HIPCHK(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
             hipLaunchKernelGGL((k_sample_noncount<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, d_data + (k0 - kshift),
                                (long long)(k1 - k0), n_samples, CSCC_RT, d_cnt);
             HIPCHK(c, hipGetLastError());
-            u32 n_bad = 0;
-            HIPCHK(c, hipMemcpyAsync(&n_bad, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+            u32 n_bad[2] = {0, 0};
+            HIPCHK(c, hipMemcpyAsync(n_bad, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            counts = (double)n_bad <= 0.02 * (double)n_samples;
+            counts = (double)n_bad[0] <= 0.02 * (double)n_samples; // large integers only take their own genes out (column list)
         }
         if (counts) {
             if ((rc = run_csc_counts_route<InT, IdxT>(c, d_data, d_indices, d_indptr, kshift, d_codes, n_rows, col_lb, flags, alternative, o, cols))) return rc;
