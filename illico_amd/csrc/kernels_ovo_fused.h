@@ -183,8 +183,12 @@ __global__ void k_sample_noncount_dense(const InT *__restrict__ X, long long ld,
     const long long r = k / W, j = k - r * W;
     const InT v = X[r * ld + col0 + j];
     const bool integer = v >= (InT)0 && v < (InT)(1 << 24) && (InT)(int)v == v;
-    if (!integer) atomicAdd(n_bad, 1u);
-    else if (v >= (InT)limit) atomicAdd(n_bad + 1, 1u);
+    // one atomic per wavefront and counter: on normalised data every sample would otherwise hit the same address
+    const u64 b0 = __ballot(!integer), b1 = __ballot(integer && v >= (InT)limit);
+    if ((threadIdx.x & 63) == 0) {
+        if (b0) atomicAdd(n_bad, (u32)__popcll(b0));
+        if (b1) atomicAdd(n_bad + 1, (u32)__popcll(b1));
+    }
 }
 
 // ---- reference tables: one 1024-thread workgroup per 64-gene tile; lane = gene.  All 16 wavefronts add into one

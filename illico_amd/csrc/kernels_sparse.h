@@ -212,8 +212,12 @@ __global__ void k_sample_noncount(const InT *__restrict__ data, long long nnz, i
     const long long k = (long long)((double)i * (double)nnz / (double)n_samples);
     const InT v = data[k < nnz ? k : nnz - 1];
     const bool integer = v >= (InT)0 && v < (InT)(1 << 24) && (InT)(int)v == v;
-    if (!integer) atomicAdd(n_bad, 1u);
-    else if (v >= (InT)limit) atomicAdd(n_bad + 1, 1u);
+    // one atomic per wavefront and counter: on normalised data every sample would otherwise hit the same address
+    const u64 b0 = __ballot(!integer), b1 = __ballot(integer && v >= (InT)limit);
+    if ((threadIdx.x & 63) == 0) {
+        if (b0) atomicAdd(n_bad, (u32)__popcll(b0));
+        if (b1) atomicAdd(n_bad + 1, (u32)__popcll(b1));
+    }
 }
 
 // ---- CSR -> CSC on the device, for a window of W columns [c0, c0 + W): a two-pass blocked transposition.  Row blocks
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(TR_NT) void k_csr_block_scatter(const InT *__restri
 // workgroup, far more than L2 can merge (17 ms at C3 shape).
 #define TRG_COLS 64
 #define TRG_RPT 2
-#define TRG_WIN 8 // entries of a row held in registers
+#define TRG_WIN 8 // entries of a row held in registers (16 measured no better: 146 VGPRs)
 template <typename T, int N> struct __attribute__((packed, aligned(4))) PackedRun { T v[N]; }; // 4-byte aligned multi-dword load
 template <typename InT, typename IdxT>
 __global__ __launch_bounds__(TR_NT) void k_csr_tile_gather(const InT *__restrict__ data, const IdxT *__restrict__ indices,
