@@ -17,9 +17,12 @@ def engine():
 
 def _case(seed):
     rng = np.random.RandomState(1000 + seed)
-    n = int(rng.choice([37, 150, 600, 2500]))
-    m = int(rng.choice([1, 7, 64, 65, 130, 300]))
-    G = int(rng.randint(2, min(40, n // 2) + 1))
+    if seed >= 100:   # a few larger cases: several gene tiles and batches, hundreds of groups, groups above 255 cells
+        n, m, G = 20000, int(rng.choice([520, 700])), int(rng.choice([30, 300]))
+    else:
+        n = int(rng.choice([37, 150, 600, 2500]))
+        m = int(rng.choice([1, 7, 64, 65, 130, 300]))
+        G = int(rng.randint(2, min(40, n // 2) + 1))
     kind = rng.choice(["counts", "counts-large", "continuous", "mixed"])
     density = float(rng.choice([0.02, 0.1, 0.5, 1.0]))
     mask = rng.rand(n, m) < density
@@ -47,7 +50,7 @@ def _case(seed):
     return X, dtype, labels, ref, lb, ub, opts, kind
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", list(range(40)) + [100, 101, 102, 103, 104, 105])
 def test_random_case_all_input_paths(engine, seed):
     import torch
     X, dtype, labels, ref, lb, ub, opts, kind = _case(seed)
