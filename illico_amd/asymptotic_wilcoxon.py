@@ -47,6 +47,18 @@ def _run_streaming(data_handler, iterator, group_container, is_log1p, use_contin
             del X
 
 
+def _csr_to_device(X, data_handler, check=True):
+    """(indices sorted?, handler of a device-resident copy) of an in-RAM scipy CSR matrix."""
+    import torch
+    from illico_amd._lib import get_engine
+    from illico_amd.utils.registry import CSRDataHandler, CSRMatrix
+    eng = get_engine()
+    dev = torch.device("cuda", eng.device)
+    d, i, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (X.data, X.indices, X.indptr))
+    sorted_ok = eng.csr_indices_sorted(i, p, X.shape[0]) if check else True
+    return sorted_ok, CSRDataHandler(CSRMatrix(d, i, p, X.shape))
+
+
 def operator(data_handler: DataHandler, lb: int, ub: int, group_container: GroupContainer, is_log1p: bool,
              use_continuity: bool, alternative: str, tie_correct: bool, out=None):
     """One gene chunk -- the reference's ``operator`` (asymptotic_wilcoxon.py:29-68), not delayed."""
@@ -97,8 +109,18 @@ def asymptotic_wilcoxon(
     data_handler = data_handler_registry.get(X)
 
     if isinstance(X, sparse.csr_matrix) or (hasattr(sparse, "csr_array") and isinstance(X, sparse.csr_array)):
-        from illico_amd.utils.ranking import check_indices_sorted_per_parcel
-        if not check_indices_sorted_per_parcel(X.indices, X.indptr):
+        # CSR rows span every gene, so the engine needs the whole matrix on the device anyway: it goes up once, here, and
+        # both the sortedness check of the reference (asymptotic_wilcoxon.py:186-193) and every chunk run on that copy
+        # (checking 2e8 indices on the host costs as much as the upload + the whole device computation).
+        # (Small matrices are checked on the host first: argument errors then surface before any device work.)
+        if X.nnz <= 1_000_000:
+            from illico_amd.utils.ranking import check_indices_sorted_per_parcel
+            sorted_ok = check_indices_sorted_per_parcel(X.indices, X.indptr)
+            if sorted_ok:
+                _, data_handler = _csr_to_device(X, data_handler, check=False)
+        else:
+            sorted_ok, data_handler = _csr_to_device(X, data_handler)
+        if not sorted_ok:
             raise ValueError(
                 "Input data matrix indices are not sorted. This is very unusual and may lead to incorrect results. "
                 "This can be the result of operations like `adata[:, np.random.choice(…)]` that do not preserve sorting."
