@@ -54,7 +54,11 @@ def _csr_to_device(X, data_handler, check=True):
     from illico_amd.utils.registry import CSRDataHandler, CSRMatrix
     eng = get_engine()
     dev = torch.device("cuda", eng.device)
-    d, i, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (X.data, X.indices, X.indptr))
+    from illico_amd._lib import normalize_values
+    # the same dtype rules as the host path of Engine.run_sparse: values widened losslessly, one index dtype for both arrays
+    idt = np.int32 if (X.indices.dtype == np.int32 and X.indptr.dtype == np.int32) else np.int64
+    host = (normalize_values(np.asarray(X.data)), np.asarray(X.indices, dtype=idt), np.asarray(X.indptr, dtype=idt))
+    d, i, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in host)
     sorted_ok = eng.csr_indices_sorted(i, p, X.shape[0]) if check else True
     return sorted_ok, CSRDataHandler(CSRMatrix(d, i, p, X.shape))
 

@@ -300,3 +300,18 @@ def test_csc_counts_route(engine, test, many_groups):
         assert_planes_match(got, want, fc_rtol=1e-9, what=f"csc counts {test} ref={ref} many_groups={many_groups}")
         got = _run(engine, M, g, col_lb=2, col_ub=31)
         assert_planes_match(got, oracle.run(Xd, g, col_lb=2, col_ub=31), fc_rtol=1e-9, what=f"csc counts window {test}")
+
+
+def test_drop_in_csr_narrow_dtypes(engine):
+    """In-RAM CSR goes to the device inside the drop-in call: value / index dtypes the kernels do not take natively
+    (uint16 counts, int64 indptr with int32 indices) are widened on the way like on the host path."""
+    from illico_amd import AnnDataLite, asymptotic_wilcoxon
+    X, rng = make_counts(77, 900, 33, 0.7)
+    labels = make_labels(rng, 900, 6)
+    M = sparse.csr_matrix(X.astype(np.uint16))
+    M.indptr = M.indptr.astype(np.int64)
+    df = asymptotic_wilcoxon(AnnDataLite(M, obs=pd.DataFrame({"pert": labels})), is_log1p=False, group_keys="pert", reference=labels[0])
+    uniq, g = oracle.encode_and_count_groups(labels, labels[0])
+    want = oracle.run(X, g)
+    got = df.values.reshape(len(uniq), X.shape[1], 3)
+    assert_planes_match((got[:, :, 0], got[:, :, 1], got[:, :, 2]), want, ref_row=g.encoded_ref_group, what="csr uint16")
