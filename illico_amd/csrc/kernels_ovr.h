@@ -32,6 +32,9 @@ struct OvrParams {
     long long *out_2u;        // [n_genes][G]
     u64 *out_tie;             // [n_genes][G]
     double *out_sum;          // [n_genes][G]
+    // split form (MODE 1 / 2: the sort between them is rocPRIM's segmented radix sort)
+    u32 *seg_begin, *seg_end; // [n_genes] element offsets of each gene's (key, code) pairs in the unsorted buffers
+    int *seg_n;               // [n_genes] number of pairs
 };
 
 #define OVR_NT 1024
@@ -134,8 +137,12 @@ template <int NT> __device__ __forceinline__ int block_excl_scan_add_rev(int x, 
 // ACCG: the per-group accumulators live in HBM (global 64-bit atomics) instead of LDS -- any number of groups.
 // DC (dense layout, OVR): the gene's zeros are compacted away before the sort and ranked as one analytic tie block
 // (exactly the sparse layout's semantics), so the sort passes and the sweeps touch only the non-zeros.
-template <typename KeyT, bool SPARSE, bool OVO, int NT, bool ACCG, bool DC>
+// MODE 0: everything in this kernel (per-group sums, zero compaction, LSD radix sort, rank sweeps).
+// MODE 1: sums + compaction only, and the extent of the gene's pairs for the sort that follows.
+// MODE 2: rank sweeps only, over pairs already sorted (into the B buffers for the compacted dense layout, else into A).
+template <typename KeyT, bool SPARSE, bool OVO, int NT, bool ACCG, bool DC, int MODE = 0>
 __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
+    static_assert(MODE == 0 || !OVO, "the split form serves OVR");
     static_assert(!DC || (!SPARSE && !OVO), "zero compaction is the dense OVR variant");
     constexpr bool ZS = SPARSE || DC; // zeros are implicit during the sort and the sweeps
     constexpr int NW = NT / 64, E = (NT >= 1024 ? 4 : 8);
@@ -172,6 +179,7 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
         u32 *va = P.vals_a + start, *vb = P.vals_b + start;
 
         // ---- per-group sums of values for the fold change (deterministic order; runs are group-contiguous) ----
+        if constexpr (MODE != 2)
         for (int g = wave; g < G; g += NW) {
             int p0, p1;
             if (SPARSE) { p0 = (int)(sp[g] - sp[0]); p1 = (int)(sp[g + 1] - sp[0]); }
@@ -187,7 +195,13 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
         KeyT *ksrc = ka, *kdst = kb;
         u32 *vsrc = va, *vdst = vb;
         bool have_vals = SPARSE;
-        if (DC) { // (key, group code) of the non-zeros -> the other buffer, in any order (the sort follows)
+        if constexpr (MODE == 2) { // pairs sorted by the library sort: dense-compacted B -> A, sparse A -> B
+            n = P.seg_n[gene];
+            if (DC) { ksrc = ka; vsrc = va; kdst = kb; vdst = vb; }
+            else { ksrc = kb; vsrc = vb; kdst = ka; vdst = va; }
+            have_vals = true;
+        }
+        if (DC && MODE != 2) { // (key, group code) of the non-zeros -> the other buffer, in any order (the sort follows)
             if (tid == 0) flag[3] = 0;
             __syncthreads();
             for (int i0 = 0; i0 < n; i0 += NT) {
@@ -211,7 +225,18 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
             have_vals = true;
             __syncthreads();
         }
+        if constexpr (MODE == 1) {
+            if (tid == 0) {
+                const long long b = start; // the pairs sit at [start, start + n) of the source buffers
+                P.seg_begin[gene] = (u32)b;
+                P.seg_end[gene] = (u32)(b + n);
+                P.seg_n[gene] = n;
+            }
+            __syncthreads();
+            continue;
+        }
         const long long n0 = P.n_cells - n; // implicit zeros
+        if constexpr (MODE == 0)
         for (int shift = 0; shift < (int)sizeof(KeyT) * 8; shift += 8) {
             for (int i = tid; i < 256; i += NT) hist[i] = 0;
             if (tid == 0) flag[0] = 0;
