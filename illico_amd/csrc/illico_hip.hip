@@ -72,6 +72,7 @@ struct illico_ctx {
     int64_t scratch_bytes = 24ll << 30;
     bool no_counts_path = false;
     bool no_fused_path = false;
+    bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
     bool no_csc_counts_path = false;   // 1: count-valued CSC genes do not take the LDS-histogram kernel (k_csc_counts)
     bool no_ovr_one_pass = false;      // 1: dense OVR reads X twice (column histogram, then rank sums) instead of once
@@ -248,6 +249,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
+    else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
     else if (!strcmp(key, "no_ovr_one_pass")) c->no_ovr_one_pass = value != 0;
     else if (!strcmp(key, "no_ovr_library_sort")) c->no_ovr_library_sort = value != 0;

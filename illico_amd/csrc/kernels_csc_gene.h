@@ -182,3 +182,99 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
         __syncthreads();
     }
 }
+
+// ---- regroup only: the first half of k_csc_gene (count per group, offsets, regroup the keys in LDS) followed by a
+// coalesced copy-out of the gene's keys, their group codes and the (gene, group) offsets -- the layout k_csc_segment
+// produces for the rank kernels of the two-kernel route, without its two uncoalesced passes (a scattered 4-byte store
+// and a codes[row] lookup per entry each: 64 cache lines per wave instruction, which made that kernel address-path
+// bound at 8.5 ms for C3).  The value / group code of every entry is read once and kept in registers between the
+// counting and the scattering pass.  Genes with more stored values than the LDS key buffer, or than CSCR_CACHE entries
+// per thread, set fallback[gene] and are redone by k_csc_segment.
+#define CSCR_CACHE 40 // entries per thread kept in registers (1024 threads: 40960 stored values per gene)
+struct CscRegroupParams {
+    const void *data, *indices, *indptr;
+    long long kshift, col0;
+    const int *gene_cols;   // optional column list (absolute), else col0 + gene
+    const u32 *gene_base;   // with gene_cols: where each gene's keys start in Xs; else k0 - indptr[col0]
+    int nb;
+    const int *codes;       // nullptr: indices already hold group codes
+    int G, key_cap, count_limit;
+    void *Xs;               // out: keys, group-contiguous per gene
+    u32 *vals;              // out (optional): group code per key
+    u32 *seg_ptr;           // out: [nb][G+1]
+    u32 *gene_flags;        // out (optional): a value outside the count table
+    u32 *fallback;          // out: gene not handled here
+};
+template <typename InT, typename IdxT, typename KeyT>
+__global__ __launch_bounds__(CSCG_NT) void k_csc_regroup(CscRegroupParams P) {
+    constexpr int NT = CSCG_NT, UL = 8, NB = CSCR_CACHE / UL;
+    extern __shared__ __align__(16) unsigned char smem[];
+    u32 *ends = (u32 *)smem;
+    u32 *tmp = ends + ((P.G + 1 + 3) & ~3);
+    KeyT *keybuf = (KeyT *)(tmp + NT);
+    const int tid = threadIdx.x;
+    const int G = P.G;
+    const InT *data = (const InT *)P.data;
+    const IdxT *indices = (const IdxT *)P.indices, *indptr = (const IdxT *)P.indptr;
+    const long long base0 = (long long)indptr[P.col0];
+    for (int gene = blockIdx.x; gene < P.nb; gene += gridDim.x) {
+        const long long col = P.gene_cols ? (long long)P.gene_cols[gene] : P.col0 + gene;
+        const long long k0 = (long long)indptr[col] - P.kshift, k1 = (long long)indptr[col + 1] - P.kshift;
+        const u32 gbase = P.gene_cols ? P.gene_base[gene] : (u32)(k0 + P.kshift - base0);
+        if (k1 - k0 > (long long)NT * CSCR_CACHE || k1 - k0 > (long long)P.key_cap) { // uniform
+            if (tid == 0) P.fallback[gene] = 1u;
+            continue;
+        }
+        for (int g = tid; g <= G; g += NT) ends[g] = 0;
+        __syncthreads();
+        InT v[NB][UL];
+        int cd[NB][UL];
+        bool viol = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const long long kb = k0 + (long long)b * NT * UL;
+            if (kb < k1) { // uniform
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const long long k = kb + u * NT + tid;
+                    v[b][u] = k < k1 ? data[k] : (InT)0;
+                    cd[b][u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u)
+                    if (v[b][u] != (InT)0) { atomicAdd(&ends[cd[b][u]], 1u); viol |= !count_ok(v[b][u], P.count_limit); }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UL; ++u) { v[b][u] = (InT)0; cd[b][u] = 0; }
+            }
+        }
+        __syncthreads();
+        const u32 total = block_excl_scan_inplace<NT>(ends, G, tmp, tid);
+        u32 *sp = P.seg_ptr + (size_t)gene * (G + 1);
+        for (int g = tid; g < G; g += NT) sp[g] = gbase + ends[g];
+        if (tid == 0) sp[G] = gbase + total;
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int u = 0; u < UL; ++u)
+                if (v[b][u] != (InT)0) {
+                    const u32 p = atomicAdd(&ends[cd[b][u]], 1u);
+                    keybuf[p] = key_of(v[b][u]);
+                }
+        __syncthreads();
+        KeyT *Xs = (KeyT *)P.Xs + gbase;
+        // after the scatter ends[g] = one past group g's run: the group of staged slot i is the first g with ends[g] > i
+        for (u32 i = tid; i < total; i += NT) {
+            Xs[i] = keybuf[i];
+            if (P.vals) {
+                int lo = 0, hi = G - 1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (ends[mid] > i) hi = mid; else lo = mid + 1; }
+                P.vals[gbase + i] = (u32)lo;
+            }
+        }
+        if (P.gene_flags && viol) P.gene_flags[gene] = 1u;
+        __syncthreads();
+    }
+}
+

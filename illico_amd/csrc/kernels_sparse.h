@@ -46,7 +46,7 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
                                                         u32 *__restrict__ vals, u32 *__restrict__ seg_ptr,
                                                         u32 *__restrict__ gene_flags, int count_limit,
                                                         const int *__restrict__ gene_cols, const u32 *__restrict__ gene_base,
-                                                        long long kshift) {
+                                                        long long kshift, const u32 *__restrict__ only_flagged) {
     extern __shared__ __align__(16) unsigned char smem[];
     u32 *hist = (u32 *)smem;
     u32 *tmp = hist + ((G + 3) & ~3);
@@ -56,13 +56,27 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
     // (a host-resident matrix is staged from its first needed entry on).
     const long long base0 = (long long)indptr[col0];
     for (int gene = blockIdx.x; gene < nb; gene += gridDim.x) {
+        if (only_flagged && only_flagged[gene] == 0) continue; // already regrouped by k_csc_regroup
         const long long col = gene_cols ? (long long)gene_cols[gene] : col0 + gene;
         const long long k0 = (long long)indptr[col], k1 = (long long)indptr[col + 1];
         const u32 gbase = gene_cols ? gene_base[gene] : (u32)(k0 - base0);
         for (int g = tid; g < G; g += SEG_NT) hist[g] = 0;
         __syncthreads();
-        for (long long k = k0 - kshift + tid; k < k1 - kshift; k += SEG_NT)
-            if (data[k] != (InT)0) atomicAdd(&hist[codes ? codes[(long long)indices[k]] : (int)indices[k]], 1u);
+        constexpr int UL = 8; // independent entries per thread in flight (value, row -> group code)
+        for (long long kb = k0 - kshift; kb < k1 - kshift; kb += SEG_NT * UL) {
+            InT v[UL];
+            int cd[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const long long k = kb + u * SEG_NT + tid;
+                const bool in = k < k1 - kshift;
+                v[u] = in ? data[k] : (InT)0;
+                cd[u] = in ? (codes ? codes[(long long)indices[k]] : (int)indices[k]) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u)
+                if (v[u] != (InT)0) atomicAdd(&hist[cd[u]], 1u);
+        }
         __syncthreads();
         u32 total = block_excl_scan_inplace<SEG_NT>(hist, G, tmp, tid);
         u32 *sp = seg_ptr + (size_t)gene * (G + 1);
@@ -70,15 +84,24 @@ __global__ __launch_bounds__(SEG_NT) void k_csc_segment(const InT *__restrict__ 
         if (tid == 0) sp[G] = gbase + total;
         __syncthreads();
         bool viol = false;
-        for (long long k = k0 - kshift + tid; k < k1 - kshift; k += SEG_NT) {
-            InT v = data[k];
-            if (v != (InT)0) {
-                int c = codes ? codes[(long long)indices[k]] : (int)indices[k];
-                u32 pos = gbase + atomicAdd(&hist[c], 1u);
-                Xs[pos] = key_of(v);
-                if (vals) vals[pos] = (u32)c;
-                viol |= !count_ok(v, count_limit);
+        for (long long kb = k0 - kshift; kb < k1 - kshift; kb += SEG_NT * UL) {
+            InT v[UL];
+            int cd[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const long long k = kb + u * SEG_NT + tid;
+                const bool in = k < k1 - kshift;
+                v[u] = in ? data[k] : (InT)0;
+                cd[u] = in ? (codes ? codes[(long long)indices[k]] : (int)indices[k]) : 0;
             }
+#pragma unroll
+            for (int u = 0; u < UL; ++u)
+                if (v[u] != (InT)0) {
+                    const u32 pos = gbase + atomicAdd(&hist[cd[u]], 1u);
+                    Xs[pos] = key_of(v[u]);
+                    if (vals) vals[pos] = (u32)cd[u];
+                    viol |= !count_ok(v[u], count_limit);
+                }
         }
         if (gene_flags && viol) gene_flags[gene] = 1u;
         __syncthreads();

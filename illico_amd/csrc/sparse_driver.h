@@ -489,11 +489,32 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
 
         if (!is_csr) {
             ProfScope ps(c, KID_SPARSE_SEG);
+            // LDS-staged regroup first (coalesced stores, one read of every entry); genes too large for it are redone by
+            // k_csc_segment, which handles any size
+            const size_t fixed = (size_t)((G + 1 + 3) & ~3) * 4 + (size_t)CSCG_NT * 4;
+            const size_t per_key = sizeof(KeyT);
+            const int key_cap = fixed + 4096 < kMaxLds ? (int)std::min<size_t>((kMaxLds - fixed) / per_key, (size_t)CSCG_NT * CSCR_CACHE) : 0;
+            u32 *d_fb = nullptr;
+            const bool staged = !c->no_csc_regroup_lds && key_cap >= 4096;
+            if (staged) {
+                if ((rc = get_scratch(c, "sp_fb", (size_t)nb * 4, &v))) return rc;
+                d_fb = (u32 *)v;
+                HIPCHK(c, hipMemsetAsync(d_fb, 0, (size_t)nb * 4, c->stream));
+                CscRegroupParams R;
+                R.data = d_data; R.indices = d_indices; R.indptr = d_indptr; R.kshift = kshift; R.col0 = b.g0; R.gene_cols = d_cols;
+                R.gene_base = d_base; R.nb = nb; R.codes = d_codes; R.G = G; R.key_cap = key_cap; R.count_limit = COUNTS_R; R.Xs = Xs;
+                R.vals = va; R.seg_ptr = seg; R.gene_flags = gflags; R.fallback = d_fb;
+                auto kern = k_csc_regroup<InT, IdxT, KeyT>;
+                const size_t lds = fixed + (size_t)key_cap * per_key;
+                HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCG_NT), lds, c->stream, R);
+                HIPCHK(c, hipGetLastError());
+            }
             auto kern = k_csc_segment<InT, IdxT, KeyT>;
             size_t lds = seg_lds_bytes(G);
             HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(nb), dim3(SEG_NT), lds, c->stream, d_data, d_indices, d_indptr, (long long)b.g0, nb,
-                               d_codes, G, Xs, va, seg, gflags, COUNTS_R, d_cols, d_base, (long long)kshift);
+                               d_codes, G, Xs, va, seg, gflags, COUNTS_R, d_cols, d_base, (long long)kshift, (const u32 *)d_fb);
             HIPCHK(c, hipGetLastError());
         } else {
             if ((rc = get_scratch(c, "sp_cursor", (size_t)nb * (G + 1) * 4 + (size_t)nb * 8, &v))) return rc;
