@@ -89,11 +89,25 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     }
 }
 
-// per-gene sum over groups, rows added in group order like group_agg_counts.sum(axis=0) (math.py:185)
-__global__ void k_gene_totals(const double *in_sum, int G, int nb, double *gene_total) {
-    int gene = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gene >= nb) return;
+// per-gene sum over groups, rows added in group order like group_agg_counts.sum(axis=0) (math.py:185).
+// One workgroup per 64 genes: [64 genes][64 groups] tiles of in_sum ([gene][G], so a gene's groups are contiguous) are
+// read coalesced along groups and handed through LDS to one thread per gene, which adds them in group order.
+__global__ __launch_bounds__(256) void k_gene_totals(const double *in_sum, int G, int nb, double *gene_total) {
+    __shared__ double tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // ty 0..3
+    const int gene0 = blockIdx.x * 64;
     double t = 0.0;
-    for (int g = 0; g < G; ++g) t += in_sum[(size_t)gene * G + g];
-    gene_total[gene] = t;
+    for (int g0 = 0; g0 < G; g0 += 64) {
+        for (int r = ty; r < 64; r += 4) {
+            const int gene = gene0 + r, g = g0 + tx;
+            tile[r][tx] = (gene < nb && g < G) ? in_sum[(size_t)gene * G + g] : 0.0;
+        }
+        __syncthreads();
+        if (ty == 0) {
+            const int lim = min(64, G - g0);
+            for (int k = 0; k < lim; ++k) t += tile[tx][k];
+        }
+        __syncthreads();
+    }
+    if (ty == 0 && gene0 + tx < nb) gene_total[gene0 + tx] = t;
 }

@@ -179,15 +179,43 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
         u32 *va = P.vals_a + start, *vb = P.vals_b + start;
 
         // ---- per-group sums of values for the fold change (deterministic order; runs are group-contiguous) ----
-        if constexpr (MODE != 2)
-        for (int g = wave; g < G; g += NW) {
-            int p0, p1;
-            if (SPARSE) { p0 = (int)(sp[g] - sp[0]); p1 = (int)(sp[g + 1] - sp[0]); }
-            else { p0 = P.pos_ptr[g]; p1 = P.pos_ptr[g + 1]; }
-            double s = 0.0;
-            for (int i = p0 + lane; i < p1; i += 64) s += P.is_log1p ? key_to_expm1(ka[i], P.dt) : key_to_double(ka[i], P.dt);
-            s = wave_sum(s);
-            if (lane == 0) P.out_sum[(size_t)gene * G + g] = s;
+        // Four groups per wavefront and iteration, their first 256 keys each requested before any is summed: one load
+        // latency per 4 groups instead of one per group (this loop, not the copy of the keys, set the time of the
+        // prepare pass).  The order of additions inside a group does not depend on the batching.
+        if constexpr (MODE != 2) {
+            constexpr int GB = 4, RR = 4;
+            for (int g0 = wave * GB; g0 < G; g0 += NW * GB) {
+                int p0[GB], p1[GB];
+                KeyT kk[GB][RR];
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    const int g = g0 + j;
+                    p0[j] = p1[j] = 0;
+                    if (g < G) {
+                        if (SPARSE) { p0[j] = (int)(sp[g] - sp[0]); p1[j] = (int)(sp[g + 1] - sp[0]); }
+                        else { p0[j] = P.pos_ptr[g]; p1[j] = P.pos_ptr[g + 1]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < RR; ++r) {
+                        const int i = p0[j] + r * 64 + lane;
+                        kk[j][r] = i < p1[j] ? ka[i] : (KeyT)0;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    const int g = g0 + j;
+                    if (g >= G) break;
+                    double s = 0.0;
+#pragma unroll
+                    for (int r = 0; r < RR; ++r) {
+                        const int i = p0[j] + r * 64 + lane;
+                        if (i < p1[j]) s += P.is_log1p ? key_to_expm1(kk[j][r], P.dt) : key_to_double(kk[j][r], P.dt);
+                    }
+                    for (int i = p0[j] + RR * 64 + lane; i < p1[j]; i += 64) s += P.is_log1p ? key_to_expm1(ka[i], P.dt) : key_to_double(ka[i], P.dt);
+                    s = wave_sum(s);
+                    if (lane == 0) P.out_sum[(size_t)gene * G + g] = s;
+                }
+            }
         }
         __syncthreads();
 

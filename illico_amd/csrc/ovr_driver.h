@@ -77,7 +77,7 @@ static int launch_ovr_gene(illico_ctx *c, OvrParams P) {
 
 static int launch_gene_totals(illico_ctx *c, const double *ssum, int G, int nb, double *gtot) {
     ProfScope ps(c, KID_GENE_TOTALS);
-    hipLaunchKernelGGL(k_gene_totals, dim3((nb + 255) / 256), dim3(256), 0, c->stream, ssum, G, nb, gtot);
+    hipLaunchKernelGGL(k_gene_totals, dim3((nb + 63) / 64), dim3(256), 0, c->stream, ssum, G, nb, gtot);
     HIPCHK(c, hipGetLastError());
     return ILLICO_OK;
 }
