@@ -292,6 +292,90 @@ template <typename KeyT, int NT> __device__ __forceinline__ void block_bitonic_s
     }
 }
 
+// Half-cleaner cascade of the same network over one 64*K chunk held K per lane (position lane*K + r): element
+// strides 32K .. K across lanes (DPP / permlane swaps), then K/2 .. 1 inside the lane.  Turns a chunk whose two halves
+// come out of a larger merge stage into a sorted chunk.
+template <typename KeyT, int K> __device__ __forceinline__ void wave_half_clean_chunk(KeyT (&v)[K], int lane) {
+#define ILLICO_HC(LS)                                                           \
+    {                                                                           \
+        const bool km = (lane & (LS)) == 0;                                     \
+        _Pragma("unroll") for (int r = 0; r < K; ++r) {                         \
+            KeyT q = xor_lanes<(LS)>(v[r], lane);                               \
+            v[r] = km ? umin_t(v[r], q) : umax_t(v[r], q);                      \
+        }                                                                       \
+    }
+    ILLICO_HC(32)
+    ILLICO_HC(16)
+    ILLICO_HC(8)
+    ILLICO_HC(4)
+    ILLICO_HC(2)
+    ILLICO_HC(1)
+#undef ILLICO_HC
+#pragma unroll
+    for (int stride = K >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            int p = r ^ stride;
+            if (p > r) compex(v[r], v[p]);
+        }
+    }
+}
+
+// Sort the first `ncap` keys of A (LDS; ncap a multiple of 64*K, slots past the data filled with the largest key) with
+// the whole workgroup: 64*K-key chunks are sorted / merged in registers by one wavefront each, only the stages whose
+// stride reaches across chunks go through LDS.  For 32768 keys and K = 16: 21 passes over LDS instead of the 120 of
+// block_bitonic_sort.  Slots >= ncap are virtual +inf (same all-ascending network, so they never move).
+template <typename KeyT, int NT, int K> __device__ __forceinline__ void block_sort_hybrid(KeyT *A, int ncap, int tid) {
+    constexpr int CH = 64 * K, NW = NT / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nch = ncap / CH;
+    for (int c = wave; c < nch; c += NW) {
+        KeyT v[K];
+        KeyT *p = A + c * CH + lane * K;
+#pragma unroll
+        for (int r = 0; r < K; ++r) v[r] = p[r];
+        wave_bitonic_sort<KeyT, K>(v, lane);
+#pragma unroll
+        for (int r = 0; r < K; ++r) p[r] = v[r];
+    }
+    __syncthreads();
+    int P = CH;
+    while (P < ncap) P <<= 1;
+    const int halfP = P >> 1;
+    for (int size = 2 * CH; size <= P; size <<= 1) {
+        const int half = size >> 1;
+        for (int t = tid; t < halfP; t += NT) {
+            const int blk = t / half, off = t & (half - 1);
+            const int i = blk * size + off, j = blk * size + size - 1 - off;
+            if (j < ncap) {
+                KeyT a = A[i], b = A[j];
+                if (a > b) { A[i] = b; A[j] = a; }
+            }
+        }
+        __syncthreads();
+        for (int stride = half >> 1; stride >= CH; stride >>= 1) {
+            for (int t = tid; t < halfP; t += NT) {
+                const int i = (t / stride) * 2 * stride + (t & (stride - 1)), j = i + stride;
+                if (j < ncap) {
+                    KeyT a = A[i], b = A[j];
+                    if (a > b) { A[i] = b; A[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+        for (int c = wave; c < nch; c += NW) {
+            KeyT v[K];
+            KeyT *p = A + c * CH + lane * K;
+#pragma unroll
+            for (int r = 0; r < K; ++r) v[r] = p[r];
+            wave_half_clean_chunk<KeyT, K>(v, lane);
+#pragma unroll
+            for (int r = 0; r < K; ++r) p[r] = v[r];
+        }
+        __syncthreads();
+    }
+}
+
 // number of elements of sorted A[0..n) that are < q  (top = largest power of two <= n, 0 if n == 0)
 template <typename KeyT> __device__ __forceinline__ u32 lower_bound_pow2(const KeyT *A, u32 n, u32 top, KeyT q) {
     u32 base = 0;

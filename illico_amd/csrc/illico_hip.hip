@@ -22,6 +22,7 @@
 #include "kernels_sparse.h"
 #include "kernels_csc_gene.h"
 #include "kernels_csc_counts.h"
+#include "kernels_csc_ovr.h"
 
 // ---- profiled kernel ids ---------------------------------------------------------------------
 enum {
@@ -37,10 +38,11 @@ enum {
     KID_CSC_GENE,
     KID_GENE_TOTALS,
     KID_CSC_COUNTS,
+    KID_CSC_OVR,
     KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
-                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts"};
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene"};
 
 struct SampleKey {
     const void *ptr; int64_t n, ld, lb, ub; int dtype;
@@ -74,6 +76,7 @@ struct illico_ctx {
     bool no_fused_path = false;
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
+    bool no_csc_ovr_gene_path = false; // 1: CSC OVR never takes the single-kernel LDS-sort route (k_csc_ovr_gene)
     bool no_csc_counts_path = false;   // 1: count-valued CSC genes do not take the LDS-histogram kernel (k_csc_counts)
     bool no_ovr_one_pass = false;      // 1: dense OVR reads X twice (column histogram, then rank sums) instead of once
     bool no_ovr_library_sort = false;   // 1: the general OVR route sorts inside k_ovr_gene (LSD radix passes) instead of rocPRIM's segmented sort
@@ -251,6 +254,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
     else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
+    else if (!strcmp(key, "no_csc_ovr_gene_path")) c->no_csc_ovr_gene_path = value != 0;
     else if (!strcmp(key, "no_ovr_one_pass")) c->no_ovr_one_pass = value != 0;
     else if (!strcmp(key, "no_ovr_library_sort")) c->no_ovr_library_sort = value != 0;
     else if (!strcmp(key, "no_csr_tile_gather")) c->no_csr_tile_gather = value != 0;

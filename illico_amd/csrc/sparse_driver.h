@@ -185,6 +185,64 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
     return ILLICO_OK;
 }
 
+// Single-kernel CSC OVR route (any values) over the genes in `cols` (in: to compute; out: the genes with more stored
+// entries than the LDS key buffer, which go to the general route): statistics + gene totals + finalize per batch.
+template <typename InT, typename IdxT, typename KeyT>
+static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, const int *d_codes,
+                             int dtype, int64_t n_rows, int64_t col_lb, int flags, int alternative, const OutPlanes &o, std::vector<int64_t> &cols) {
+    const int G = (int)c->n_groups;
+    const int key_cap = csco_key_cap(G, sizeof(KeyT), kMaxLds);
+    if (key_cap <= 0 || n_rows >= (1ll << 31)) return ILLICO_OK; // every gene stays in `cols`
+    int rc;
+    void *v;
+    const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
+    const int *d_cols = nullptr;
+    if (!contiguous && (rc = upload_cols(c, cols, &d_cols))) return rc;
+    const size_t lds = csco_fixed_lds_bytes(G) + (size_t)key_cap * sizeof(KeyT);
+    const int64_t n = (int64_t)cols.size();
+    const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
+    if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
+    long long *s2u = (long long *)v;
+    u64 *stie = (u64 *)(s2u + (size_t)nb_max * G);
+    double *ssum = (double *)(stie + (size_t)nb_max * G);
+    double *gtot = ssum + (size_t)nb_max * G;
+    if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
+    u32 *fb = (u32 *)v;
+    auto kern = k_csc_ovr_gene<InT, IdxT, KeyT>;
+    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    std::vector<int64_t> left;
+    for (int64_t b0 = 0; b0 < n; b0 += nb_max) {
+        const int nb = (int)std::min<int64_t>(nb_max, n - b0);
+        HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)nb * 4, c->stream));
+        CscOvrParams P;
+        P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
+        P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.counts = c->d_counts; P.G = G; P.dt = dtype;
+        P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.key_cap = key_cap; P.fallback = fb;
+        P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
+        {
+            ProfScope ps(c, KID_CSC_OVR);
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCO_NT), lds, c->stream, P);
+            HIPCHK(c, hipGetLastError());
+        }
+        if ((rc = launch_gene_totals(c, ssum, G, nb, gtot))) return rc;
+        if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0))) return rc; }
+        else if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb))) return rc;
+        if (c->pinned_bytes < (size_t)nb * 4) {
+            if (c->pinned) hipHostFree(c->pinned);
+            c->pinned = nullptr; c->pinned_bytes = 0;
+            HIPCHK(c, hipHostMalloc(&c->pinned, (size_t)nb * 4 + 4096, hipHostMallocDefault));
+            c->pinned_bytes = (size_t)nb * 4 + 4096;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->pinned, fb, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const u32 *h_fb = (const u32 *)c->pinned;
+        for (int64_t j = 0; j < nb; ++j)
+            if (h_fb[j]) left.push_back(cols[b0 + j]);
+    }
+    cols.swap(left);
+    return ILLICO_OK;
+}
+
 template <typename InT, typename IdxT, typename KeyT>
 static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indices, const void *indptr, int dtype,
                         int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
@@ -419,6 +477,12 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     }
     if (!is_csr && !ovr && !c->no_csc_gene_path) {
         if ((rc = run_csc_gene_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, d_codes, dtype, col_lb, flags, alternative, o, cols)))
+            return rc;
+        if (cols.empty()) return ILLICO_OK;
+    }
+
+    if (!is_csr && ovr && !c->no_csc_ovr_gene_path) {
+        if ((rc = run_csc_ovr_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, d_codes, dtype, n_rows, col_lb, flags, alternative, o, cols)))
             return rc;
         if (cols.empty()) return ILLICO_OK;
     }

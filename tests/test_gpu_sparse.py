@@ -22,19 +22,24 @@ def _run(engine, M, grpc, **kw):
     return engine.run_sparse(M.format, M.data, M.indices, M.indptr, M.shape, lb, ub, **kw)
 
 
-@pytest.fixture(params=["default", "two-kernel", "two-kernel-sort-only", "csr-regroup"])
+@pytest.fixture(params=["default", "two-kernel", "two-kernel-sort-only", "csr-regroup", "ovr-lds-sort"])
 def route(request, engine):
     """Count-valued CSC genes with groups of at most 255 cells take the LDS-histogram kernel (OVO and OVR); otherwise
     CSC OVO has a single-kernel route (regroup + rank in LDS) with the two-kernel route (regroup into HBM, then
     histogram / sort rank kernels) as fallback.  CSR first tries dense float32 windows + the fused dense kernels
     (count-valued data), otherwise it is transposed to CSC on the device and takes the CSC routes; the older CSR route
     (regroup by (gene, group) with global atomics) is kept behind an option.  The params force each so that all are
-    exercised on the same data."""
+    exercised on the same data.  CSC OVR with values the histogram kernel cannot take (and CSR OVR after the device
+    transposition) sorts each gene's stored values inside LDS (k_csc_ovr_gene); genes larger than its key buffer and
+    the two-kernel params use the general route (regroup in HBM, segmented radix sort, sweeps)."""
     opts = {"no_csc_gene_path": 0, "no_dense_window_path": 0, "no_counts_path": 0, "no_csr_transpose_path": 0,
             "no_csr_tile_gather": 0, "no_csc_counts_path": 0, "no_ovr_library_sort": 0,
-            "no_csc_regroup_lds": 0}
+            "no_csc_regroup_lds": 0, "no_csc_ovr_gene_path": 0}
     if request.param.startswith("two-kernel"):
-        opts.update(no_csc_gene_path=1, no_dense_window_path=1, no_csc_counts_path=1)
+        opts.update(no_csc_gene_path=1, no_dense_window_path=1, no_csc_counts_path=1, no_csc_ovr_gene_path=1)
+    if request.param == "ovr-lds-sort":
+        # count-valued data too through the single-kernel CSC OVR route (sort in LDS + look-ups): tie-heavy columns
+        opts.update(no_dense_window_path=1, no_csc_counts_path=1)
     if request.param == "two-kernel":
         opts.update(no_csr_tile_gather=1)   # CSR -> CSC by the scatter form (what unsorted rows get)
     if request.param.endswith("sort-only"):
@@ -317,3 +322,56 @@ def test_drop_in_csr_narrow_dtypes(engine):
     want = oracle.run(X, g)
     got = df.values.reshape(len(uniq), X.shape[1], 3)
     assert_planes_match((got[:, :, 0], got[:, :, 1], got[:, :, 2]), want, ref_row=g.encoded_ref_group, what="csr uint16")
+
+
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+@pytest.mark.parametrize("dtype,idx", [(np.float32, np.int32), (np.float64, np.int64), (np.int32, np.int32)])
+def test_csc_ovr_lds_sort_route(engine, fmt, dtype, idx):
+    """OVR, any values, single kernel per gene (k_csc_ovr_gene): columns whose stored entries fill 1, 3, 5 and 30 sort
+    chunks of 1024 keys (LDS merge levels over a chunk count that is not a power of two), negatives stored explicitly,
+    tie-heavy and all-distinct columns, explicit stored zeros, an empty column, a constant column, and columns with
+    more stored entries than the LDS key buffer holds (those fall back to the general route as a column list)."""
+    rng = np.random.RandomState(401)
+    n, m = 52000, 14
+    sizes = [20000, 9000, 700, 300, 255, 40, 3, 1]
+    sizes.append(n - sum(sizes))
+    labels = np.concatenate([[f"s{i:02d}"] * sz for i, sz in enumerate(sizes)])
+    rng.shuffle(labels)
+    dens = [0.01, 0.05, 0.09, 0.58, 0.97, 0.0, 0.3, 0.02, 0.2, 0.66, 0.5, 0.0007, 0.058, 1.0]
+    X = np.zeros((n, m))
+    for j in range(m):
+        keep = rng.rand(n) < dens[j]
+        if dtype == np.int32:
+            vals = rng.randint(-3, 90, size=n) if j % 2 else rng.randint(1, 4, size=n)
+        elif j % 3 == 0:
+            vals = np.log1p(rng.poisson(3.0, size=n) * rng.uniform(0.5, 1.5, size=n))   # continuous, some exact repeats (0)
+        elif j % 3 == 1:
+            vals = rng.randn(n)                                                         # negatives
+        else:
+            vals = rng.poisson(2.0, size=n).astype(np.float64) + 0.5 * (rng.rand(n) < 0.3)  # tie-heavy
+        X[:, j] = np.where(keep, vals, 0.0)
+    X[:, 6] = np.where(X[:, 6] != 0, 2.5 if dtype != np.int32 else 2, 0)                 # one value only
+    X = X.astype(dtype).astype(np.float64)
+    M = (sparse.csc_matrix if fmt == "csc" else sparse.csr_matrix)(X.astype(dtype))
+    M.indices = M.indices.astype(idx)
+    M.indptr = M.indptr.astype(idx)
+    M.data[::53] = 0                                                                     # explicit stored zeros
+    Xd = M.toarray().astype(np.float64)
+    _, g = oracle.encode_and_count_groups(labels, None)
+    want = oracle.run(Xd, g)
+    engine.set_option("no_dense_window_path", 1)
+    engine.set_option("no_csc_counts_path", 1)
+    engine.set_option("profile", 1)
+    engine.profile_reset()
+    try:
+        got = _run(engine, M, g)
+        prof = engine.profile_get()
+        got_w = _run(engine, M, g, col_lb=2, col_ub=13, alternative="greater", use_continuity=False)
+    finally:
+        engine.set_option("profile", 0)
+        engine.set_option("no_dense_window_path", 0)
+        engine.set_option("no_csc_counts_path", 0)
+    assert "k_csc_ovr_gene" in prof and "k_ovr_gene" in prof, prof   # the new route ran, and the oversized columns fell back
+    assert_planes_match(got, want, fc_rtol=1e-9, what=f"csc ovr lds sort {fmt} {dtype.__name__}")
+    want_w = oracle.run(Xd, g, col_lb=2, col_ub=13, alternative="greater", use_continuity=False)
+    assert_planes_match(got_w, want_w, fc_rtol=1e-9, what=f"csc ovr lds sort window {fmt} {dtype.__name__}")
