@@ -77,6 +77,7 @@ struct illico_ctx {
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
     bool no_csc_ovr_gene_path = false; // 1: CSC OVR never takes the single-kernel LDS-sort route (k_csc_ovr_gene)
+    bool csc_ovr_sorted_form = false;  // 1: k_csc_ovr_gene sorts every gene's keys in LDS (the form tie-heavy columns take) instead of bucketing them
     bool no_csc_counts_path = false;   // 1: count-valued CSC genes do not take the LDS-histogram kernel (k_csc_counts)
     bool no_ovr_one_pass = false;      // 1: dense OVR reads X twice (column histogram, then rank sums) instead of once
     bool no_ovr_library_sort = false;   // 1: the general OVR route sorts inside k_ovr_gene (LSD radix passes) instead of rocPRIM's segmented sort
@@ -255,6 +256,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
     else if (!strcmp(key, "no_csc_ovr_gene_path")) c->no_csc_ovr_gene_path = value != 0;
+    else if (!strcmp(key, "csc_ovr_sorted_form")) c->csc_ovr_sorted_form = value != 0;
     else if (!strcmp(key, "no_ovr_one_pass")) c->no_ovr_one_pass = value != 0;
     else if (!strcmp(key, "no_ovr_library_sort")) c->no_ovr_library_sort = value != 0;
     else if (!strcmp(key, "no_csr_tile_gather")) c->no_csr_tile_gather = value != 0;

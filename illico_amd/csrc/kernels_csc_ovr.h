@@ -1,22 +1,31 @@
-// CSC one-versus-rest for ANY values in ONE kernel per gene: the gene's stored non-zeros are sorted as bare keys inside
-// LDS (no payload: a rank only needs the sorted VALUES), then every stored entry is read a second time, looks its own
-// value up in the sorted column (lower / upper bound = the tie block [s, e) it falls in) and adds 2 * avg_rank =
-// s + e + 1 to its group's LDS accumulator.  Nothing but the CSC arrays is read and nothing but the [gene][G] statistics
-// is written; the general route it replaces regroups the entries in HBM (k_csc_regroup), sorts (key, group) pairs with a
-// segmented radix sort in HBM and sweeps them (k_ovr_gene): 23 ms at C3 shape against 3 ms here.
+// CSC one-versus-rest for ANY values in ONE kernel per gene, without a sort.  A rank needs, for every stored entry, the
+// tie block [s, e) its value occupies in the sorted column.  The gene's stored non-zeros are dealt into LDS buckets by
+// value ((key - kmin) >> shift, 4096 or 8192 buckets: a counting pass, a scan, a scattering pass), and every entry then
+// counts the smaller and the equal keys INSIDE ITS OWN BUCKET (a few keys): s = bucket start + #smaller, e = s + #equal,
+// 2 * avg_rank = s + e + 1 goes to its group's LDS accumulator and e - s (the tie block length t) gives the tie term as
+// sum over entries of (t^2 - 1) = sum over blocks of (t^3 - t).  Nothing but the CSC arrays is read and nothing but the
+// [gene][G] statistics is written; the general route it replaces regroups the entries in HBM (k_csc_regroup), sorts
+// (key, group) pairs with a segmented radix sort in HBM and sweeps them (k_ovr_gene).
+//
+// Columns whose values crowd into few buckets (heavy ties, an outlier stretching the range) take the second form in the
+// same kernel: the keys are sorted in LDS as bare keys (block_sort_hybrid) and every entry looks its value up with two
+// binary searches.
 //
 // Device counterpart of sparse_ovr_mwu_kernel + its CSC entry (illico/ovr/sparse_ovr.py:23-97, :100-155) and
-// _accumulate_group_ranksums_from_argsort (utils/ranking.py:7-49) for one gene at a time: argsort + tie-block walk
-// become sort(values) + two binary searches per entry; the zeros stay implicit (sparse_ovr.py:70-83): n0 = N - nnz
-// cells tie at rank n_neg + (n0 + 1) / 2 and shift every positive entry by n0.
+// _accumulate_group_ranksums_from_argsort (utils/ranking.py:7-49) for one gene at a time; the zeros stay implicit
+// (sparse_ovr.py:70-83): n0 = N - nnz cells tie at rank n_neg + (n0 + 1) / 2 and shift every positive entry by n0.
 //
 // A gene with more stored entries than the LDS key buffer sets fallback[gene]; the host sends those genes through the
 // general route.
 #pragma once
 #include "common.h"
+#include "kernels_sparse.h"
 
 #define CSCO_NT 1024
-#define CSCO_K 16 // keys per lane of the register sort phases: 1024-key chunks
+#define CSCO_K 16        // keys per lane of the register sort phases (sorted form): 1024-key chunks
+#define CSCO_MAX_BUCKET 192 // bucket form only while no bucket holds more keys than this ...
+#define CSCO_MAX_AVG 64     // ... and the average entry shares its bucket with at most this many
+#define CSCO_CNT_SHIFT 40   // acc word: doubled rank sum below, stored non-zeros of the group above
 
 struct CscOvrParams {
     const void *data, *indices, *indptr; // CSC arrays (device); stored entry k lives at data[k - kshift], indices[k - kshift]
@@ -28,35 +37,52 @@ struct CscOvrParams {
     const int *counts;                   // [G]
     int G, dt, is_log1p;
     long long n_cells;
-    int key_cap;                         // LDS key slots (multiple of 64 * CSCO_K)
+    int key_cap;                         // LDS key slots
+    int lg_buckets;                      // log2 of the bucket count
+    int force_sorted;                    // 1: every gene takes the sorted form (tests / A-B)
     u32 *fallback;                       // [nb] set to 1 for genes this kernel cannot take
     long long *out_2u;                   // [nb][G] 2 U (U of "the rest", dense_ovr.py:57-61)
     u64 *out_tie;                        // [nb][G] sum (t^3 - t), the same for every group of a gene
     double *out_sum;                     // [nb][G] per-group value sums
 };
 
-__host__ __device__ static inline size_t csco_fixed_lds_bytes(int G) {
-    // acc (value sums in pass 1, doubled rank sums in pass 2) | stored non-zeros per group | reductions
-    return (size_t)((G + 1) & ~1) * 8 + (size_t)((G + 3) & ~3) * 4 + 256; // a multiple of 16
+__host__ __device__ static inline size_t csco_fixed_lds_bytes(int G, int lg_buckets) {
+    // acc (value sums in pass 1, packed rank sums / counts afterwards) | bucket table | reductions: a multiple of 16
+    return (size_t)((G + 1) & ~1) * 8 + ((size_t)4 << lg_buckets) + 256;
 }
-static inline int csco_key_cap(int G, size_t key_size, size_t lds_max) {
-    const size_t fixed = csco_fixed_lds_bytes(G);
-    if (fixed + (size_t)64 * CSCO_K * key_size > lds_max) return 0;
-    return (int)((lds_max - fixed) / key_size / (64 * CSCO_K)) * (64 * CSCO_K);
+static inline int csco_key_cap(int G, int lg_buckets, size_t key_size, size_t lds_max) {
+    const size_t fixed = csco_fixed_lds_bytes(G, lg_buckets);
+    if (fixed + (size_t)CSCO_NT * 4 > lds_max) return 0; // the scan borrows NT words of the key buffer
+    return (int)((lds_max - fixed) / key_size);
 }
+
+template <typename KeyT> __device__ __forceinline__ KeyT wave_min_key(KeyT x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { KeyT o = __shfl_xor(x, d); x = o < x ? o : x; }
+    return x;
+}
+template <typename KeyT> __device__ __forceinline__ KeyT wave_max_key(KeyT x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { KeyT o = __shfl_xor(x, d); x = o > x ? o : x; }
+    return x;
+}
+__device__ __forceinline__ int key_bits(u32 r) { return r ? 32 - __clz(r) : 0; }
+__device__ __forceinline__ int key_bits(u64 r) { return r ? 64 - __clzll((long long)r) : 0; }
 
 template <typename InT, typename IdxT, typename KeyT>
 __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     constexpr int NT = CSCO_NT, NW = NT / 64, CH = 64 * CSCO_K;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
+    constexpr u64 CNT1 = 1ull << CSCO_CNT_SHIFT, R2MASK = CNT1 - 1ull;
     extern __shared__ __align__(16) unsigned char smem[];
-    const int G = P.G;
+    const int G = P.G, NBKT = 1 << P.lg_buckets;
     u64 *acc = (u64 *)smem;                                   // [G]
-    u32 *gcnt = (u32 *)(smem + (size_t)((G + 1) & ~1) * 8);   // [G]
-    u64 *s_red = (u64 *)(gcnt + ((G + 3) & ~3));              // [NW]
-    u32 *s_misc = (u32 *)(s_red + NW);                        // [4]
-    KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G));
+    u32 *tab = (u32 *)(smem + (size_t)((G + 1) & ~1) * 8);    // [NBKT]
+    u64 *s_red = (u64 *)(tab + NBKT);                         // [NW]
+    KeyT *s_k = (KeyT *)(s_red + NW);                         // [2] smallest / largest non-zero key
+    u32 *s_misc = (u32 *)(s_red + NW + 2);                    // [0] stored zeros  [1] negatives  [2] largest bucket
+    KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G, P.lg_buckets));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const InT *data = (const InT *)P.data;
@@ -72,89 +98,199 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
             continue;
         }
         const int ns = (int)ns_ll;
-        const int ncap = (ns + CH - 1) / CH * CH;
-        // ---- 1. keys -> LDS, per-group stored non-zeros and value sums ----
+        // ---- 1. per-group value sums, key range, stored zeros, negatives ----
         double *sums = (double *)acc;
-        for (int g = tid; g < G; g += NT) { sums[g] = 0.0; gcnt[g] = 0u; }
-        if (tid == 0) s_misc[0] = 0u;
-        for (int i = ns + tid; i < ncap; i += NT) A[i] = MAXK;
+        for (int g = tid; g < G; g += NT) sums[g] = 0.0;
+        for (int b = tid; b < NBKT; b += NT) tab[b] = 0u;
+        if (tid == 0) { s_k[0] = MAXK; s_k[1] = (KeyT)0; s_misc[0] = 0u; s_misc[1] = 0u; s_misc[2] = 0u; }
         __syncthreads();
-        u32 my_zero = 0;
-        for (long long kb = k0; kb < k1; kb += NT * UL) {
-            InT v[UL];
-            int cd[UL];
+        {
+            u32 my_zero = 0, my_neg = 0;
+            KeyT tmin = MAXK, tmax = (KeyT)0;
+            for (long long kb = k0; kb < k1; kb += NT * UL) {
+                InT v[UL];
+                int cd[UL];
 #pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                const long long k = kb + u * NT + tid;
-                v[u] = k < k1 ? data[k] : (InT)0;
-                cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
-            }
+                for (int u = 0; u < UL; ++u) {
+                    const long long k = kb + u * NT + tid;
+                    v[u] = k < k1 ? data[k] : (InT)0;
+                    cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
+                }
 #pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                const long long k = kb + u * NT + tid;
-                if (k < k1) {
-                    const bool nz = v[u] != (InT)0;
-                    const KeyT key = key_of(v[u]);
-                    A[k - k0] = nz ? key : MAXK; // a stored zero is an implicit zero: out of the sorted column
-                    if (nz) {
-                        atomicAdd(&gcnt[cd[u]], 1u);
-                        atomicAdd(&sums[cd[u]], P.is_log1p ? key_to_expm1(key, P.dt) : key_to_double(key, P.dt));
-                    } else ++my_zero;
+                for (int u = 0; u < UL; ++u) {
+                    const long long k = kb + u * NT + tid;
+                    if (k < k1) {
+                        if (v[u] != (InT)0) {
+                            const KeyT key = key_of(v[u]);
+                            atomicAdd(&sums[cd[u]], P.is_log1p ? key_to_expm1(key, P.dt) : key_to_double(key, P.dt));
+                            tmin = key < tmin ? key : tmin;
+                            tmax = key > tmax ? key : tmax;
+                            my_neg += key < ZEROK ? 1u : 0u;
+                        } else ++my_zero; // a stored zero is an implicit zero
+                    }
                 }
             }
+            tmin = wave_min_key(tmin);
+            tmax = wave_max_key(tmax);
+            my_zero = (u32)wave_sum((int)my_zero);
+            my_neg = (u32)wave_sum((int)my_neg);
+            if (lane == 0) {
+                atomicMin(&s_k[0], tmin);
+                atomicMax(&s_k[1], tmax);
+                if (my_zero) atomicAdd(&s_misc[0], my_zero);
+                if (my_neg) atomicAdd(&s_misc[1], my_neg);
+            }
         }
-        if (my_zero) atomicAdd(&s_misc[0], my_zero);
         __syncthreads();
         const int n = ns - (int)s_misc[0];                   // stored non-zeros
         const long long n0 = P.n_cells - n;                  // zeros of the column
+        const long long nneg = (long long)s_misc[1];
+        const KeyT kmin = s_k[0], kmax = s_k[1];
         for (int g = tid; g < G; g += NT) P.out_sum[(size_t)gene * G + g] = sums[g];
         __syncthreads();
         for (int g = tid; g < G; g += NT) acc[g] = 0ull;
-        // ---- 2. sort the column's non-zero values ----
-        block_sort_hybrid<KeyT, NT, CSCO_K>(A, ncap, tid); // starts and ends with a barrier of its own phases
-        const u32 un = (u32)n, top = top_pow2(un);
-        // ---- 3. tie blocks of the non-zeros ----
         u64 tie = 0;
-        for (int i = tid; i < n; i += NT) {
-            const KeyT k = A[i];
-            if ((i == 0 || A[i - 1] != k) && i + 1 < n && A[i + 1] == k) {
-                const u64 t = upper_bound_pow2(A, un, top, k) - (u32)i;
-                tie += t * t * t - t;
+        bool sorted_form = P.force_sorted != 0;
+        const int shift = n > 0 ? max(0, key_bits((KeyT)(kmax - kmin)) - P.lg_buckets) : 0;
+        if (n > 0 && !sorted_form) {
+            // ---- 2. bucket sizes ----
+            for (long long kb = k0; kb < k1; kb += NT * UL) {
+                InT v[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const long long k = kb + u * NT + tid;
+                    v[u] = k < k1 ? data[k] : (InT)0;
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u)
+                    if (v[u] != (InT)0) atomicAdd(&tab[(u32)((KeyT)(key_of(v[u]) - kmin) >> shift)], 1u);
             }
+            __syncthreads();
+            u64 sq = 0;
+            u32 mx = 0;
+            for (int b = tid; b < NBKT; b += NT) { const u32 cb = tab[b]; sq += (u64)cb * cb; mx = max(mx, cb); }
+            sq = wave_sum(sq);
+            mx = (u32)wave_incl_scan_max((int)mx);
+            if (lane == 63) { s_red[wave] = sq; atomicMax(&s_misc[2], mx); }
+            __syncthreads();
+            u64 sumsq = 0;
+            for (int w = 0; w < NW; ++w) sumsq += s_red[w];
+            sorted_form = s_misc[2] > (u32)CSCO_MAX_BUCKET || sumsq > (u64)CSCO_MAX_AVG * (u64)n; // uniform
+            __syncthreads();
         }
-        tie = wave_sum(tie);
-        if (lane == 0) s_red[wave] = tie;
-        // ---- 4. every stored entry: 2 * avg_rank = s + e + 1 (+ 2 n0 above the zeros) into its group ----
-        for (long long kb = k0; kb < k1; kb += NT * UL) {
-            InT v[UL];
-            int cd[UL];
+        if (n > 0 && !sorted_form) {
+            // ---- 3. bucket offsets, keys into their buckets ----
+            block_excl_scan_inplace<NT>(tab, NBKT, (u32 *)A, tid); // the key buffer is still free: scan scratch
+            for (long long kb = k0; kb < k1; kb += NT * UL) {
+                InT v[UL];
 #pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                const long long k = kb + u * NT + tid;
-                v[u] = k < k1 ? data[k] : (InT)0;
-                cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
+                for (int u = 0; u < UL; ++u) {
+                    const long long k = kb + u * NT + tid;
+                    v[u] = k < k1 ? data[k] : (InT)0;
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u)
+                    if (v[u] != (InT)0) {
+                        const KeyT key = key_of(v[u]);
+                        A[atomicAdd(&tab[(u32)((KeyT)(key - kmin) >> shift)], 1u)] = key;
+                    }
             }
+            __syncthreads(); // now tab[b] = one past bucket b; it starts at tab[b - 1]
+            // ---- 4. every stored entry against its own bucket ----
+            for (long long kb = k0; kb < k1; kb += NT * UL) {
+                InT v[UL];
+                int cd[UL];
 #pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                if (v[u] != (InT)0) {
-                    const KeyT q = key_of(v[u]);
-                    const u32 s = lower_bound_pow2(A, un, top, q);
-                    u32 e = s + 1;
-                    if (e < un && A[e] == q) e = upper_bound_pow2(A, un, top, q);
-                    const u64 add = (u64)s + (u64)e + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
-                    atomicAdd(&acc[cd[u]], add);
+                for (int u = 0; u < UL; ++u) {
+                    const long long k = kb + u * NT + tid;
+                    v[u] = k < k1 ? data[k] : (InT)0;
+                    cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    if (v[u] != (InT)0) {
+                        const KeyT q = key_of(v[u]);
+                        const u32 b = (u32)((KeyT)(q - kmin) >> shift);
+                        const u32 lo = b ? tab[b - 1] : 0u, hi = tab[b];
+                        u32 less = 0, eq = 0;
+                        for (u32 j = lo; j < hi; ++j) {
+                            const KeyT a = A[j];
+                            less += a < q ? 1u : 0u;
+                            eq += a == q ? 1u : 0u;
+                        }
+                        const u32 s = lo + less;
+                        const u64 add = 2ull * s + eq + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
+                        atomicAdd(&acc[cd[u]], add + CNT1);
+                        tie += (u64)eq * eq - 1ull;
+                    }
+                }
+            }
+        } else if (n > 0) {
+            // ---- sorted form: keys -> LDS, sort, tie blocks, two look-ups per entry ----
+            const int ncap = (ns + CH - 1) / CH * CH;
+            if (ncap > P.key_cap) { // uniform
+                if (tid == 0) P.fallback[gene] = 1u;
+                __syncthreads();
+                continue;
+            }
+            for (int i = ns + tid; i < ncap; i += NT) A[i] = MAXK;
+            for (long long kb = k0; kb < k1; kb += NT * UL) {
+                InT v[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const long long k = kb + u * NT + tid;
+                    v[u] = k < k1 ? data[k] : (InT)0;
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const long long k = kb + u * NT + tid;
+                    if (k < k1) A[k - k0] = v[u] != (InT)0 ? key_of(v[u]) : MAXK; // stored zeros sort past the n keys
+                }
+            }
+            __syncthreads();
+            block_sort_hybrid<KeyT, NT, CSCO_K>(A, ncap, tid);
+            const u32 un = (u32)n, top = top_pow2(un);
+            for (int i = tid; i < n; i += NT) {
+                const KeyT k = A[i];
+                if ((i == 0 || A[i - 1] != k) && i + 1 < n && A[i + 1] == k) {
+                    const u64 t = upper_bound_pow2(A, un, top, k) - (u32)i;
+                    tie += t * t * t - t;
+                }
+            }
+            for (long long kb = k0; kb < k1; kb += NT * UL) {
+                InT v[UL];
+                int cd[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const long long k = kb + u * NT + tid;
+                    v[u] = k < k1 ? data[k] : (InT)0;
+                    cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    if (v[u] != (InT)0) {
+                        const KeyT q = key_of(v[u]);
+                        const u32 s = lower_bound_pow2(A, un, top, q);
+                        u32 e = s + 1;
+                        if (e < un && A[e] == q) e = upper_bound_pow2(A, un, top, q);
+                        const u64 add = (u64)s + (u64)e + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
+                        atomicAdd(&acc[cd[u]], add + CNT1);
+                    }
                 }
             }
         }
+        tie = wave_sum(tie);
+        __syncthreads(); // (also: s_red's readers of step 2 are done)
+        if (lane == 0) s_red[wave] = tie;
         __syncthreads();
         u64 tie_total = 0;
         for (int w = 0; w < NW; ++w) tie_total += s_red[w];
         tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
-        const long long nneg = (long long)lower_bound_pow2(A, un, top, ZEROK);
         for (int g = tid; g < G; g += NT) {
             const long long n_g = P.counts[g];
-            const long long z = n_g - (long long)gcnt[g];
-            const u64 r2 = acc[g] + (u64)z * (u64)(2 * nneg + n0 + 1);
+            const u64 a = acc[g];
+            const long long z = n_g - (long long)(a >> CSCO_CNT_SHIFT);
+            const u64 r2 = (a & R2MASK) + (u64)z * (u64)(2 * nneg + n0 + 1);
             P.out_2u[(size_t)gene * G + g] = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;
             P.out_tie[(size_t)gene * G + g] = tie_total;
         }

@@ -189,16 +189,23 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
 // entries than the LDS key buffer, which go to the general route): statistics + gene totals + finalize per batch.
 template <typename InT, typename IdxT, typename KeyT>
 static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, const int *d_codes,
-                             int dtype, int64_t n_rows, int64_t col_lb, int flags, int alternative, const OutPlanes &o, std::vector<int64_t> &cols) {
+                             int dtype, int64_t n_rows, int64_t col_lb, int64_t max_nnz, int flags, int alternative, const OutPlanes &o,
+                             std::vector<int64_t> &cols) {
     const int G = (int)c->n_groups;
-    const int key_cap = csco_key_cap(G, sizeof(KeyT), kMaxLds);
-    if (key_cap <= 0 || n_rows >= (1ll << 31)) return ILLICO_OK; // every gene stays in `cols`
+    // the group's stored-entry count rides above bit 40 of its doubled rank sum
+    if (n_rows >= (1ll << 31) || (double)c->max_nonref * 2.0 * (double)n_rows >= (double)(1ull << CSCO_CNT_SHIFT) || c->max_nonref >= (1ll << 23))
+        return ILLICO_OK; // every gene stays in `cols`
+    // 8192 buckets when the largest gene still fits beside them, else 4096
+    int lg = 13;
+    if (csco_key_cap(G, lg, sizeof(KeyT), kMaxLds) < max_nnz) lg = 12;
+    const int key_cap = csco_key_cap(G, lg, sizeof(KeyT), kMaxLds);
+    if (key_cap <= 0) return ILLICO_OK;
     int rc;
     void *v;
     const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
     const int *d_cols = nullptr;
     if (!contiguous && (rc = upload_cols(c, cols, &d_cols))) return rc;
-    const size_t lds = csco_fixed_lds_bytes(G) + (size_t)key_cap * sizeof(KeyT);
+    const size_t lds = csco_fixed_lds_bytes(G, lg) + (size_t)key_cap * sizeof(KeyT);
     const int64_t n = (int64_t)cols.size();
     const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
     if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
@@ -217,7 +224,8 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
         CscOvrParams P;
         P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
         P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.counts = c->d_counts; P.G = G; P.dt = dtype;
-        P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.key_cap = key_cap; P.fallback = fb;
+        P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.key_cap = key_cap; P.lg_buckets = lg;
+        P.force_sorted = c->csc_ovr_sorted_form ? 1 : 0; P.fallback = fb;
         P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
         {
             ProfScope ps(c, KID_CSC_OVR);
@@ -482,7 +490,9 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     }
 
     if (!is_csr && ovr && !c->no_csc_ovr_gene_path) {
-        if ((rc = run_csc_ovr_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, d_codes, dtype, n_rows, col_lb, flags, alternative, o, cols)))
+        int64_t max_nnz = 0;
+        for (int64_t cc : cols) max_nnz = std::max(max_nnz, gene_nnz[cc - col_lb]);
+        if ((rc = run_csc_ovr_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, d_codes, dtype, n_rows, col_lb, max_nnz, flags, alternative, o, cols)))
             return rc;
         if (cols.empty()) return ILLICO_OK;
     }

@@ -30,16 +30,17 @@ def route(request, engine):
     (count-valued data), otherwise it is transposed to CSC on the device and takes the CSC routes; the older CSR route
     (regroup by (gene, group) with global atomics) is kept behind an option.  The params force each so that all are
     exercised on the same data.  CSC OVR with values the histogram kernel cannot take (and CSR OVR after the device
-    transposition) sorts each gene's stored values inside LDS (k_csc_ovr_gene); genes larger than its key buffer and
-    the two-kernel params use the general route (regroup in HBM, segmented radix sort, sweeps)."""
+    transposition) ranks each gene's stored values inside LDS (k_csc_ovr_gene: value buckets, or a sort of the keys for
+    tie-heavy columns); genes larger than its key buffer and the two-kernel params use the general route (regroup in
+    HBM, segmented radix sort, sweeps)."""
     opts = {"no_csc_gene_path": 0, "no_dense_window_path": 0, "no_counts_path": 0, "no_csr_transpose_path": 0,
             "no_csr_tile_gather": 0, "no_csc_counts_path": 0, "no_ovr_library_sort": 0,
-            "no_csc_regroup_lds": 0, "no_csc_ovr_gene_path": 0}
+            "no_csc_regroup_lds": 0, "no_csc_ovr_gene_path": 0, "csc_ovr_sorted_form": 0}
     if request.param.startswith("two-kernel"):
         opts.update(no_csc_gene_path=1, no_dense_window_path=1, no_csc_counts_path=1, no_csc_ovr_gene_path=1)
     if request.param == "ovr-lds-sort":
-        # count-valued data too through the single-kernel CSC OVR route (sort in LDS + look-ups): tie-heavy columns
-        opts.update(no_dense_window_path=1, no_csc_counts_path=1)
+        # count-valued data too through the single-kernel CSC OVR route, sorted form (sort in LDS + look-ups)
+        opts.update(no_dense_window_path=1, no_csc_counts_path=1, csc_ovr_sorted_form=1)
     if request.param == "two-kernel":
         opts.update(no_csr_tile_gather=1)   # CSR -> CSC by the scatter form (what unsorted rows get)
     if request.param.endswith("sort-only"):
@@ -326,11 +327,14 @@ def test_drop_in_csr_narrow_dtypes(engine):
 
 @pytest.mark.parametrize("fmt", ["csc", "csr"])
 @pytest.mark.parametrize("dtype,idx", [(np.float32, np.int32), (np.float64, np.int64), (np.int32, np.int32)])
-def test_csc_ovr_lds_sort_route(engine, fmt, dtype, idx):
-    """OVR, any values, single kernel per gene (k_csc_ovr_gene): columns whose stored entries fill 1, 3, 5 and 30 sort
-    chunks of 1024 keys (LDS merge levels over a chunk count that is not a power of two), negatives stored explicitly,
-    tie-heavy and all-distinct columns, explicit stored zeros, an empty column, a constant column, and columns with
-    more stored entries than the LDS key buffer holds (those fall back to the general route as a column list)."""
+@pytest.mark.parametrize("sorted_form", [0, 1])
+def test_csc_ovr_single_kernel_route(engine, fmt, dtype, idx, sorted_form):
+    """OVR, any values, single kernel per gene (k_csc_ovr_gene).  Spread-out values are ranked inside value buckets,
+    tie-heavy columns (and everything with sorted_form = 1) by sorting the keys in LDS: columns whose stored entries fill
+    1, 3, 5 and 30+ sort chunks of 1024 keys (LDS merge levels over a chunk count that is not a power of two), negatives
+    stored explicitly, tie-heavy and all-distinct columns, explicit stored zeros, an empty column, a constant column,
+    and columns with more stored entries than the LDS key buffer holds (those fall back to the general route as a
+    column list)."""
     rng = np.random.RandomState(401)
     n, m = 52000, 14
     sizes = [20000, 9000, 700, 300, 255, 40, 3, 1]
@@ -361,6 +365,7 @@ def test_csc_ovr_lds_sort_route(engine, fmt, dtype, idx):
     want = oracle.run(Xd, g)
     engine.set_option("no_dense_window_path", 1)
     engine.set_option("no_csc_counts_path", 1)
+    engine.set_option("csc_ovr_sorted_form", sorted_form)
     engine.set_option("profile", 1)
     engine.profile_reset()
     try:
@@ -369,9 +374,10 @@ def test_csc_ovr_lds_sort_route(engine, fmt, dtype, idx):
         got_w = _run(engine, M, g, col_lb=2, col_ub=13, alternative="greater", use_continuity=False)
     finally:
         engine.set_option("profile", 0)
+        engine.set_option("csc_ovr_sorted_form", 0)
         engine.set_option("no_dense_window_path", 0)
         engine.set_option("no_csc_counts_path", 0)
     assert "k_csc_ovr_gene" in prof and "k_ovr_gene" in prof, prof   # the new route ran, and the oversized columns fell back
-    assert_planes_match(got, want, fc_rtol=1e-9, what=f"csc ovr lds sort {fmt} {dtype.__name__}")
+    assert_planes_match(got, want, fc_rtol=1e-9, what=f"csc ovr single kernel {fmt} {dtype.__name__} sorted_form={sorted_form}")
     want_w = oracle.run(Xd, g, col_lb=2, col_ub=13, alternative="greater", use_continuity=False)
-    assert_planes_match(got_w, want_w, fc_rtol=1e-9, what=f"csc ovr lds sort window {fmt} {dtype.__name__}")
+    assert_planes_match(got_w, want_w, fc_rtol=1e-9, what=f"csc ovr single kernel window {fmt} {dtype.__name__}")
