@@ -1,6 +1,6 @@
 // CSC one-versus-rest for ANY values in ONE kernel per gene, without a sort.  A rank needs, for every stored entry, the
 // tie block [s, e) its value occupies in the sorted column.  The gene's stored non-zeros are dealt into LDS buckets by
-// value ((key - kmin) >> shift, 4096 or 8192 buckets: a counting pass, a scan, a scattering pass), and every entry then
+// value ((key - kmin) >> shift, 8192 or 16384 buckets with 16-bit offsets: a counting pass, a scan, a scattering pass), and every entry then
 // counts the smaller and the equal keys INSIDE ITS OWN BUCKET (a few keys): s = bucket start + #smaller, e = s + #equal,
 // 2 * avg_rank = s + e + 1 goes to its group's LDS accumulator and e - s (the tie block length t) gives the tie term as
 // sum over entries of (t^2 - 1) = sum over blocks of (t^3 - t).  Nothing but the CSC arrays is read and nothing but the
@@ -48,12 +48,13 @@ struct CscOvrParams {
 
 __host__ __device__ static inline size_t csco_fixed_lds_bytes(int G, int lg_buckets) {
     // acc (value sums in pass 1, packed rank sums / counts afterwards) | bucket table | reductions: a multiple of 16
-    return (size_t)((G + 1) & ~1) * 8 + ((size_t)4 << lg_buckets) + 256;
+    return (size_t)((G + 1) & ~1) * 8 + ((size_t)2 << lg_buckets) + 256;
 }
 static inline int csco_key_cap(int G, int lg_buckets, size_t key_size, size_t lds_max) {
     const size_t fixed = csco_fixed_lds_bytes(G, lg_buckets);
-    if (fixed + (size_t)CSCO_NT * 4 > lds_max) return 0; // the scan borrows NT words of the key buffer
-    return (int)((lds_max - fixed) / key_size);
+    if (fixed + (size_t)CSCO_NT * 4 + 64 > lds_max) return 0; // the scan borrows NT words of the key buffer
+    // bucket offsets are 16-bit; 4 slots stay free behind the keys (the bucket walk reads 4 keys at a time)
+    return (int)std::min<size_t>((lds_max - fixed) / key_size - 4, 65535 - 4);
 }
 
 template <typename KeyT> __device__ __forceinline__ KeyT wave_min_key(KeyT x) {
@@ -69,6 +70,24 @@ template <typename KeyT> __device__ __forceinline__ KeyT wave_max_key(KeyT x) {
 __device__ __forceinline__ int key_bits(u32 r) { return r ? 32 - __clz(r) : 0; }
 __device__ __forceinline__ int key_bits(u64 r) { return r ? 64 - __clzll((long long)r) : 0; }
 
+// exclusive scan of the 16-bit counters arr[0..n) in place (n a multiple of NT; totals below 2^16).  tmp: [NT] words.
+template <int NT> __device__ __forceinline__ void block_excl_scan_u16(u16 *arr, int n, u32 *tmp, int tid) {
+    const int per = n / NT, b = tid * per;
+    u32 s = 0;
+    for (int i = 0; i < per; ++i) s += arr[b + i];
+    tmp[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < NT; d <<= 1) {
+        const u32 v = (tid >= d) ? tmp[tid - d] : 0u;
+        __syncthreads();
+        tmp[tid] += v;
+        __syncthreads();
+    }
+    u32 run = tmp[tid] - s;
+    for (int i = 0; i < per; ++i) { const u32 cnt = arr[b + i]; arr[b + i] = (u16)run; run += cnt; }
+    __syncthreads();
+}
+
 template <typename InT, typename IdxT, typename KeyT>
 __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     constexpr int NT = CSCO_NT, NW = NT / 64, CH = 64 * CSCO_K;
@@ -78,8 +97,9 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int G = P.G, NBKT = 1 << P.lg_buckets;
     u64 *acc = (u64 *)smem;                                   // [G]
-    u32 *tab = (u32 *)(smem + (size_t)((G + 1) & ~1) * 8);    // [NBKT]
-    u64 *s_red = (u64 *)(tab + NBKT);                         // [NW]
+    u32 *tab = (u32 *)(smem + (size_t)((G + 1) & ~1) * 8);    // [NBKT / 2] two 16-bit bucket counters / offsets per word
+    u16 *tab16 = (u16 *)tab;
+    u64 *s_red = (u64 *)(tab + NBKT / 2);                     // [NW]
     KeyT *s_k = (KeyT *)(s_red + NW);                         // [2] smallest / largest non-zero key
     u32 *s_misc = (u32 *)(s_red + NW + 2);                    // [0] stored zeros  [1] negatives  [2] largest bucket
     KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G, P.lg_buckets));
@@ -101,7 +121,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         // ---- 1. per-group value sums, key range, stored zeros, negatives ----
         double *sums = (double *)acc;
         for (int g = tid; g < G; g += NT) sums[g] = 0.0;
-        for (int b = tid; b < NBKT; b += NT) tab[b] = 0u;
+        for (int b = tid; b < NBKT / 2; b += NT) tab[b] = 0u;
         if (tid == 0) { s_k[0] = MAXK; s_k[1] = (KeyT)0; s_misc[0] = 0u; s_misc[1] = 0u; s_misc[2] = 0u; }
         __syncthreads();
         {
@@ -163,12 +183,15 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                 }
 #pragma unroll
                 for (int u = 0; u < UL; ++u)
-                    if (v[u] != (InT)0) atomicAdd(&tab[(u32)((KeyT)(key_of(v[u]) - kmin) >> shift)], 1u);
+                    if (v[u] != (InT)0) {
+                        const u32 b = (u32)((KeyT)(key_of(v[u]) - kmin) >> shift);
+                        atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u); // no carry: a counter stays below 2^16
+                    }
             }
             __syncthreads();
             u64 sq = 0;
             u32 mx = 0;
-            for (int b = tid; b < NBKT; b += NT) { const u32 cb = tab[b]; sq += (u64)cb * cb; mx = max(mx, cb); }
+            for (int b = tid; b < NBKT; b += NT) { const u32 cb = tab16[b]; sq += (u64)cb * cb; mx = max(mx, cb); }
             sq = wave_sum(sq);
             mx = (u32)wave_incl_scan_max((int)mx);
             if (lane == 63) { s_red[wave] = sq; atomicMax(&s_misc[2], mx); }
@@ -180,7 +203,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         }
         if (n > 0 && !sorted_form) {
             // ---- 3. bucket offsets, keys into their buckets ----
-            block_excl_scan_inplace<NT>(tab, NBKT, (u32 *)A, tid); // the key buffer is still free: scan scratch
+            block_excl_scan_u16<NT>(tab16, NBKT, (u32 *)A, tid); // the key buffer is still free: scan scratch
             for (long long kb = k0; kb < k1; kb += NT * UL) {
                 InT v[UL];
 #pragma unroll
@@ -192,10 +215,13 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                 for (int u = 0; u < UL; ++u)
                     if (v[u] != (InT)0) {
                         const KeyT key = key_of(v[u]);
-                        A[atomicAdd(&tab[(u32)((KeyT)(key - kmin) >> shift)], 1u)] = key;
+                        const u32 b = (u32)((KeyT)(key - kmin) >> shift);
+                        const u32 old = atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u);
+                        A[(b & 1u) ? (old >> 16) : (old & 0xFFFFu)] = key;
                     }
             }
-            __syncthreads(); // now tab[b] = one past bucket b; it starts at tab[b - 1]
+            if (tid < 4) A[n + tid] = MAXK; // the bucket walk below reads up to 3 keys past a bucket's end
+            __syncthreads(); // now tab16[b] = one past bucket b; it starts at tab16[b - 1]
             // ---- 4. every stored entry against its own bucket ----
             for (long long kb = k0; kb < k1; kb += NT * UL) {
                 InT v[UL];
@@ -211,12 +237,14 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                     if (v[u] != (InT)0) {
                         const KeyT q = key_of(v[u]);
                         const u32 b = (u32)((KeyT)(q - kmin) >> shift);
-                        const u32 lo = b ? tab[b - 1] : 0u, hi = tab[b];
+                        const u32 lo = b ? tab16[b - 1] : 0u, hi = tab16[b];
                         u32 less = 0, eq = 0;
-                        for (u32 j = lo; j < hi; ++j) {
-                            const KeyT a = A[j];
-                            less += a < q ? 1u : 0u;
-                            eq += a == q ? 1u : 0u;
+                        // 4 keys per step; keys past the bucket's end belong to later buckets (larger than q) or are the
+                        // MAXK pad, so they count for neither sum
+                        for (u32 j = lo; j < hi; j += 4) {
+                            const KeyT a0 = A[j], a1 = A[j + 1], a2 = A[j + 2], a3 = A[j + 3];
+                            less += (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u) + (a3 < q ? 1u : 0u);
+                            eq += (a0 == q ? 1u : 0u) + (a1 == q ? 1u : 0u) + (a2 == q ? 1u : 0u) + (a3 == q ? 1u : 0u);
                         }
                         const u32 s = lo + less;
                         const u64 add = 2ull * s + eq + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);

@@ -195,9 +195,9 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
     // the group's stored-entry count rides above bit 40 of its doubled rank sum
     if (n_rows >= (1ll << 31) || (double)c->max_nonref * 2.0 * (double)n_rows >= (double)(1ull << CSCO_CNT_SHIFT) || c->max_nonref >= (1ll << 23))
         return ILLICO_OK; // every gene stays in `cols`
-    // 8192 buckets when the largest gene still fits beside them, else 4096
-    int lg = 13;
-    if (csco_key_cap(G, lg, sizeof(KeyT), kMaxLds) < max_nnz) lg = 12;
+    // 16384 buckets when the largest gene still fits beside them, else 8192
+    int lg = 14;
+    if (csco_key_cap(G, lg, sizeof(KeyT), kMaxLds) < max_nnz) lg = 13;
     const int key_cap = csco_key_cap(G, lg, sizeof(KeyT), kMaxLds);
     if (key_cap <= 0) return ILLICO_OK;
     int rc;
@@ -205,7 +205,7 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
     const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
     const int *d_cols = nullptr;
     if (!contiguous && (rc = upload_cols(c, cols, &d_cols))) return rc;
-    const size_t lds = csco_fixed_lds_bytes(G, lg) + (size_t)key_cap * sizeof(KeyT);
+    const size_t lds = csco_fixed_lds_bytes(G, lg) + (size_t)(key_cap + 4) * sizeof(KeyT);
     const int64_t n = (int64_t)cols.size();
     const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
     if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
