@@ -39,10 +39,12 @@ enum {
     KID_GENE_TOTALS,
     KID_CSC_COUNTS,
     KID_CSC_OVR,
+    KID_OVR_PART,
+    KID_OVR_RANK_PARTS,
     KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
-                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene"};
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts"};
 
 struct SampleKey {
     const void *ptr; int64_t n, ld, lb, ub; int dtype;
@@ -76,6 +78,7 @@ struct illico_ctx {
     bool no_fused_path = false;
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
+    bool no_ovr_parts_path = false;    // 1: dense OVR (any values) never takes the value-range parts route (k_ovr_partition + k_csc_ovr_gene)
     bool no_csc_ovr_gene_path = false; // 1: CSC OVR never takes the single-kernel LDS-sort route (k_csc_ovr_gene)
     bool csc_ovr_sorted_form = false;  // 1: k_csc_ovr_gene sorts every gene's keys in LDS (the form tie-heavy columns take) instead of bucketing them
     bool no_csc_counts_path = false;   // 1: count-valued CSC genes do not take the LDS-histogram kernel (k_csc_counts)
@@ -255,6 +258,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
     else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
+    else if (!strcmp(key, "no_ovr_parts_path")) c->no_ovr_parts_path = value != 0;
     else if (!strcmp(key, "no_csc_ovr_gene_path")) c->no_csc_ovr_gene_path = value != 0;
     else if (!strcmp(key, "csc_ovr_sorted_form")) c->csc_ovr_sorted_form = value != 0;
     else if (!strcmp(key, "no_ovr_one_pass")) c->no_ovr_one_pass = value != 0;
@@ -749,7 +753,9 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
             if ((rc = launch_ovo<KeyT>(c, P, c->h_counts[c->ref], c->max_nonref, gflags, &gb, false))) return rc;
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
         } else {
-            if ((rc = run_ovr_dense_batch<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot))) return rc;
+            bool done = false;
+            if ((rc = run_ovr_dense_parts<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot, &done))) return rc;
+            if (!done && (rc = run_ovr_dense_batch<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot))) return rc;
             if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
         }
     }

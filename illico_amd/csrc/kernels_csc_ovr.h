@@ -17,6 +17,13 @@
 //
 // A gene with more stored entries than the LDS key buffer sets fallback[gene]; the host sends those genes through the
 // general route.
+//
+// DENSE columns (and whatever else exceeds the LDS key buffer) take the same rank kernel in pieces: k_ovr_partition splits
+// a gene's non-zero keys by VALUE into parts of at most key_cap keys (histogram over 8192 value buckets, scan, part =
+// cumulative count / quota, (key, group code) records appended per part in HBM), k_csc_ovr_gene<..., PARTS = true> ranks
+// each part in LDS exactly as it ranks a CSC column -- a key's rank is the number of keys in lower parts plus its rank
+// inside its own part -- and adds the part's group sums to per-gene accumulators; k_ovr_parts_finish turns them into the
+// statistics.  Dense continuous OVR at C4 shape: 68 ms (segmented radix sort of (key, group) pairs in HBM) -> see DESIGN.
 #pragma once
 #include "common.h"
 #include "kernels_sparse.h"
@@ -26,14 +33,30 @@
 #define CSCO_MAX_BUCKET 192 // bucket form only while no bucket holds more keys than this ...
 #define CSCO_MAX_AVG 64     // ... and the average entry shares its bucket with at most this many
 #define CSCO_CNT_SHIFT 40   // acc word: doubled rank sum below, stored non-zeros of the group above
+#define OVRP_NT 512         // k_ovr_partition
+#define OVRP_LG 13          // its coarse buckets: (key - kmin) >> shift, 8192 of them over the gene's own key range
+#define OVRP_PMAX 32        // parts per gene at most
 
 struct CscOvrParams {
+    // CSC source (PARTS = false)
     const void *data, *indices, *indptr; // CSC arrays (device); stored entry k lives at data[k - kshift], indices[k - kshift]
     long long kshift;
     long long col0;                      // first gene of the batch (contiguous batches)
     const int *gene_cols;                // or: the batch's genes as a column list (absolute indices); nullptr = contiguous
-    int nb;
     const int *codes;                    // [n_cells] group code per cell; nullptr: `indices` already holds group codes
+    // part source (PARTS = true): records written by k_ovr_partition
+    const void *pkeys;                   // [nb][pstride] non-zero keys, part after part
+    const u16 *pcodes;                   // [nb][pstride] their group codes
+    long long pstride;
+    const u32 *part_start;               // [nb][OVRP_PMAX + 1] first record of each part, relative to the gene
+    const u32 *gene_info;                // [nb][4] non-zeros, negatives, parts, flag (1 = the gene left this route)
+    u64 *gacc;                           // [nb][G] packed rank sums / counts, accumulated over the parts
+    u64 *gtie;                           // [nb]
+    u32 *gflag;                          // [nb] set to 1 when a part cannot be ranked here
+    const u32 *unit_list;                // [*n_units] gene * OVRP_PMAX + part, the non-empty parts (k_ovr_partition)
+    const u32 *n_units;
+    u32 *unit_counter;                   // work queue head (zeroed by the host): resident workgroups draw units from it
+    int nb;
     const int *counts;                   // [G]
     int G, dt, is_log1p;
     long long n_cells;
@@ -43,15 +66,16 @@ struct CscOvrParams {
     u32 *fallback;                       // [nb] set to 1 for genes this kernel cannot take
     long long *out_2u;                   // [nb][G] 2 U (U of "the rest", dense_ovr.py:57-61)
     u64 *out_tie;                        // [nb][G] sum (t^3 - t), the same for every group of a gene
-    double *out_sum;                     // [nb][G] per-group value sums
+    double *out_sum;                     // [nb][G] per-group value sums (PARTS: accumulated with atomics, zeroed by the host)
 };
 
-__host__ __device__ static inline size_t csco_fixed_lds_bytes(int G, int lg_buckets) {
-    // acc (value sums in pass 1, packed rank sums / counts afterwards) | bucket table | reductions: a multiple of 16
-    return (size_t)((G + 1) & ~1) * 8 + ((size_t)2 << lg_buckets) + 256;
+__host__ __device__ static inline size_t csco_fixed_lds_bytes(int G, int lg_buckets, bool parts) {
+    // acc (CSC: value sums in pass 1, packed rank sums / counts afterwards; parts: both live to the end) | bucket table |
+    // reductions: a multiple of 16
+    return (size_t)((G + 1) & ~1) * 8 * (parts ? 2 : 1) + ((size_t)2 << lg_buckets) + 256;
 }
-static inline int csco_key_cap(int G, int lg_buckets, size_t key_size, size_t lds_max) {
-    const size_t fixed = csco_fixed_lds_bytes(G, lg_buckets);
+static inline int csco_key_cap(int G, int lg_buckets, size_t key_size, size_t lds_max, bool parts = false) {
+    const size_t fixed = csco_fixed_lds_bytes(G, lg_buckets, parts);
     if (fixed + (size_t)CSCO_NT * 4 + 64 > lds_max) return 0; // the scan borrows NT words of the key buffer
     // bucket offsets are 16-bit; 4 slots stay free behind the keys (the bucket walk reads 4 keys at a time)
     return (int)std::min<size_t>((lds_max - fixed) / key_size - 4, 65535 - 4);
@@ -88,7 +112,31 @@ template <int NT> __device__ __forceinline__ void block_excl_scan_u16(u16 *arr, 
     __syncthreads();
 }
 
-template <typename InT, typename IdxT, typename KeyT>
+// One source entry: CSC stored entry k of the column, or record k of the part.
+template <typename InT, typename IdxT, typename KeyT, bool PARTS> struct OvrSource {
+    const InT *data;
+    const IdxT *indices;
+    const int *codes;
+    const KeyT *pkeys;
+    const u16 *pcodes;
+    // key of entry k; nz = it takes part in the ranking (a stored zero is an implicit zero)
+    __device__ __forceinline__ KeyT key(long long k, bool in, bool &nz) const {
+        if constexpr (PARTS) {
+            nz = in;
+            return in ? pkeys[k] : (KeyT)0;
+        } else {
+            const InT v = in ? data[k] : (InT)0;
+            nz = v != (InT)0;
+            return key_of(v);
+        }
+    }
+    __device__ __forceinline__ int code(long long k, bool in) const {
+        if constexpr (PARTS) return in ? (int)pcodes[k] : 0;
+        else return in ? (codes ? codes[(long long)indices[k]] : (int)indices[k]) : 0;
+    }
+};
+
+template <typename InT, typename IdxT, typename KeyT, bool PARTS>
 __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     constexpr int NT = CSCO_NT, NW = NT / 64, CH = 64 * CSCO_K;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
@@ -96,31 +144,64 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     constexpr u64 CNT1 = 1ull << CSCO_CNT_SHIFT, R2MASK = CNT1 - 1ull;
     extern __shared__ __align__(16) unsigned char smem[];
     const int G = P.G, NBKT = 1 << P.lg_buckets;
+    const size_t accb = (size_t)((G + 1) & ~1) * 8;
     u64 *acc = (u64 *)smem;                                   // [G]
-    u32 *tab = (u32 *)(smem + (size_t)((G + 1) & ~1) * 8);    // [NBKT / 2] two 16-bit bucket counters / offsets per word
+    double *sums = PARTS ? (double *)(smem + accb) : (double *)smem; // [G]; CSC: aliases acc (done before acc is used)
+    u32 *tab = (u32 *)(smem + accb * (PARTS ? 2 : 1));        // [NBKT / 2] two 16-bit bucket counters / offsets per word
     u16 *tab16 = (u16 *)tab;
     u64 *s_red = (u64 *)(tab + NBKT / 2);                     // [NW]
     KeyT *s_k = (KeyT *)(s_red + NW);                         // [2] smallest / largest non-zero key
     u32 *s_misc = (u32 *)(s_red + NW + 2);                    // [0] stored zeros  [1] negatives  [2] largest bucket
-    KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G, P.lg_buckets));
+    KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G, P.lg_buckets, PARTS));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const InT *data = (const InT *)P.data;
-    const IdxT *indices = (const IdxT *)P.indices, *indptr = (const IdxT *)P.indptr;
+    const IdxT *indptr = (const IdxT *)P.indptr;
     constexpr int UL = 8; // independent entries per thread in flight
-
-    for (int gene = blockIdx.x; gene < P.nb; gene += gridDim.x) {
-        const long long col = P.gene_cols ? (long long)P.gene_cols[gene] : P.col0 + gene;
-        const long long k0 = (long long)indptr[col] - P.kshift, k1 = (long long)indptr[col + 1] - P.kshift;
+    // CSC: one gene per workgroup.  Parts: a launch of one workgroup per (gene, part slot) would be mostly empty slots, and
+    // every workgroup holds a whole CU's LDS; resident workgroups draw the non-empty parts from a queue instead (every
+    // wave leaves once the queue is empty).
+    for (int it = blockIdx.x;; it += gridDim.x) {
+        int unit;
+        if constexpr (PARTS) {
+            if (tid == 0) s_misc[3] = atomicAdd(P.unit_counter, 1u);
+            __syncthreads();
+            const u32 q = s_misc[3];
+            __syncthreads();
+            if (q >= *P.n_units) break;
+            unit = (int)P.unit_list[q];
+        } else {
+            if (it >= P.nb) break;
+            unit = it;
+        }
+        const int gene = PARTS ? unit / OVRP_PMAX : unit;
+        OvrSource<InT, IdxT, KeyT, PARTS> src;
+        long long k0, k1;
+        long long n0 = 0, nneg = 0, base = 0; // PARTS: column-level numbers come from k_ovr_partition
+        if constexpr (PARTS) {
+            const int part = unit % OVRP_PMAX;
+            const u32 *gi = P.gene_info + (size_t)gene * 4;
+            if (gi[3] != 0u || part >= (int)gi[2]) continue; // uniform
+            const u32 *ps = P.part_start + (size_t)gene * (OVRP_PMAX + 1);
+            base = ps[part];
+            k0 = (long long)gene * P.pstride + ps[part];
+            k1 = (long long)gene * P.pstride + ps[part + 1];
+            n0 = P.n_cells - (long long)gi[0];
+            nneg = gi[1];
+            src.pkeys = (const KeyT *)P.pkeys; src.pcodes = P.pcodes;
+            if (k1 == k0) continue;
+        } else {
+            const long long col = P.gene_cols ? (long long)P.gene_cols[gene] : P.col0 + gene;
+            k0 = (long long)indptr[col] - P.kshift; k1 = (long long)indptr[col + 1] - P.kshift;
+            src.data = (const InT *)P.data; src.indices = (const IdxT *)P.indices; src.codes = P.codes;
+        }
         const long long ns_ll = k1 - k0;
         if (ns_ll > (long long)P.key_cap) { // uniform: this gene takes the general route
-            if (tid == 0) P.fallback[gene] = 1u;
+            if (tid == 0) { if constexpr (PARTS) { P.gflag[gene] = 1u; } else { P.fallback[gene] = 1u; } }
             continue;
         }
         const int ns = (int)ns_ll;
         // ---- 1. per-group value sums, key range, stored zeros, negatives ----
-        double *sums = (double *)acc;
-        for (int g = tid; g < G; g += NT) sums[g] = 0.0;
+        for (int g = tid; g < G; g += NT) { sums[g] = 0.0; if constexpr (PARTS) acc[g] = 0ull; }
         for (int b = tid; b < NBKT / 2; b += NT) tab[b] = 0u;
         if (tid == 0) { s_k[0] = MAXK; s_k[1] = (KeyT)0; s_misc[0] = 0u; s_misc[1] = 0u; s_misc[2] = 0u; }
         __syncthreads();
@@ -128,24 +209,24 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
             u32 my_zero = 0, my_neg = 0;
             KeyT tmin = MAXK, tmax = (KeyT)0;
             for (long long kb = k0; kb < k1; kb += NT * UL) {
-                InT v[UL];
+                KeyT key[UL];
+                bool nz[UL];
                 int cd[UL];
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
                     const long long k = kb + u * NT + tid;
-                    v[u] = k < k1 ? data[k] : (InT)0;
-                    cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
+                    key[u] = src.key(k, k < k1, nz[u]);
+                    cd[u] = src.code(k, k < k1);
                 }
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
                     const long long k = kb + u * NT + tid;
                     if (k < k1) {
-                        if (v[u] != (InT)0) {
-                            const KeyT key = key_of(v[u]);
-                            atomicAdd(&sums[cd[u]], P.is_log1p ? key_to_expm1(key, P.dt) : key_to_double(key, P.dt));
-                            tmin = key < tmin ? key : tmin;
-                            tmax = key > tmax ? key : tmax;
-                            my_neg += key < ZEROK ? 1u : 0u;
+                        if (nz[u]) {
+                            atomicAdd(&sums[cd[u]], P.is_log1p ? key_to_expm1(key[u], P.dt) : key_to_double(key[u], P.dt));
+                            tmin = key[u] < tmin ? key[u] : tmin;
+                            tmax = key[u] > tmax ? key[u] : tmax;
+                            my_neg += key[u] < ZEROK ? 1u : 0u;
                         } else ++my_zero; // a stored zero is an implicit zero
                     }
                 }
@@ -163,28 +244,33 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         }
         __syncthreads();
         const int n = ns - (int)s_misc[0];                   // stored non-zeros
-        const long long n0 = P.n_cells - n;                  // zeros of the column
-        const long long nneg = (long long)s_misc[1];
+        if constexpr (!PARTS) {
+            n0 = P.n_cells - n;                              // zeros of the column
+            nneg = (long long)s_misc[1];
+        }
         const KeyT kmin = s_k[0], kmax = s_k[1];
-        for (int g = tid; g < G; g += NT) P.out_sum[(size_t)gene * G + g] = sums[g];
-        __syncthreads();
-        for (int g = tid; g < G; g += NT) acc[g] = 0ull;
+        if constexpr (!PARTS) {
+            for (int g = tid; g < G; g += NT) P.out_sum[(size_t)gene * G + g] = sums[g];
+            __syncthreads();
+            for (int g = tid; g < G; g += NT) acc[g] = 0ull;
+        }
         u64 tie = 0;
         bool sorted_form = P.force_sorted != 0;
         const int shift = n > 0 ? max(0, key_bits((KeyT)(kmax - kmin)) - P.lg_buckets) : 0;
         if (n > 0 && !sorted_form) {
             // ---- 2. bucket sizes ----
             for (long long kb = k0; kb < k1; kb += NT * UL) {
-                InT v[UL];
+                KeyT key[UL];
+                bool nz[UL];
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
                     const long long k = kb + u * NT + tid;
-                    v[u] = k < k1 ? data[k] : (InT)0;
+                    key[u] = src.key(k, k < k1, nz[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < UL; ++u)
-                    if (v[u] != (InT)0) {
-                        const u32 b = (u32)((KeyT)(key_of(v[u]) - kmin) >> shift);
+                    if (nz[u]) {
+                        const u32 b = (u32)((KeyT)(key[u] - kmin) >> shift);
                         atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u); // no carry: a counter stays below 2^16
                     }
             }
@@ -205,37 +291,38 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
             // ---- 3. bucket offsets, keys into their buckets ----
             block_excl_scan_u16<NT>(tab16, NBKT, (u32 *)A, tid); // the key buffer is still free: scan scratch
             for (long long kb = k0; kb < k1; kb += NT * UL) {
-                InT v[UL];
+                KeyT key[UL];
+                bool nz[UL];
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
                     const long long k = kb + u * NT + tid;
-                    v[u] = k < k1 ? data[k] : (InT)0;
+                    key[u] = src.key(k, k < k1, nz[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < UL; ++u)
-                    if (v[u] != (InT)0) {
-                        const KeyT key = key_of(v[u]);
-                        const u32 b = (u32)((KeyT)(key - kmin) >> shift);
+                    if (nz[u]) {
+                        const u32 b = (u32)((KeyT)(key[u] - kmin) >> shift);
                         const u32 old = atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u);
-                        A[(b & 1u) ? (old >> 16) : (old & 0xFFFFu)] = key;
+                        A[(b & 1u) ? (old >> 16) : (old & 0xFFFFu)] = key[u];
                     }
             }
             if (tid < 4) A[n + tid] = MAXK; // the bucket walk below reads up to 3 keys past a bucket's end
             __syncthreads(); // now tab16[b] = one past bucket b; it starts at tab16[b - 1]
             // ---- 4. every stored entry against its own bucket ----
             for (long long kb = k0; kb < k1; kb += NT * UL) {
-                InT v[UL];
+                KeyT key[UL];
+                bool nz[UL];
                 int cd[UL];
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
                     const long long k = kb + u * NT + tid;
-                    v[u] = k < k1 ? data[k] : (InT)0;
-                    cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
+                    key[u] = src.key(k, k < k1, nz[u]);
+                    cd[u] = src.code(k, k < k1);
                 }
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
-                    if (v[u] != (InT)0) {
-                        const KeyT q = key_of(v[u]);
+                    if (nz[u]) {
+                        const KeyT q = key[u];
                         const u32 b = (u32)((KeyT)(q - kmin) >> shift);
                         const u32 lo = b ? tab16[b - 1] : 0u, hi = tab16[b];
                         u32 less = 0, eq = 0;
@@ -246,7 +333,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                             less += (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u) + (a3 < q ? 1u : 0u);
                             eq += (a0 == q ? 1u : 0u) + (a1 == q ? 1u : 0u) + (a2 == q ? 1u : 0u) + (a3 == q ? 1u : 0u);
                         }
-                        const u32 s = lo + less;
+                        const u64 s = (u64)base + lo + less;
                         const u64 add = 2ull * s + eq + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
                         atomicAdd(&acc[cd[u]], add + CNT1);
                         tie += (u64)eq * eq - 1ull;
@@ -257,22 +344,23 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
             // ---- sorted form: keys -> LDS, sort, tie blocks, two look-ups per entry ----
             const int ncap = (ns + CH - 1) / CH * CH;
             if (ncap > P.key_cap) { // uniform
-                if (tid == 0) P.fallback[gene] = 1u;
+                if (tid == 0) { if constexpr (PARTS) { P.gflag[gene] = 1u; } else { P.fallback[gene] = 1u; } }
                 __syncthreads();
                 continue;
             }
             for (int i = ns + tid; i < ncap; i += NT) A[i] = MAXK;
             for (long long kb = k0; kb < k1; kb += NT * UL) {
-                InT v[UL];
+                KeyT key[UL];
+                bool nz[UL];
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
                     const long long k = kb + u * NT + tid;
-                    v[u] = k < k1 ? data[k] : (InT)0;
+                    key[u] = src.key(k, k < k1, nz[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
                     const long long k = kb + u * NT + tid;
-                    if (k < k1) A[k - k0] = v[u] != (InT)0 ? key_of(v[u]) : MAXK; // stored zeros sort past the n keys
+                    if (k < k1) A[k - k0] = nz[u] ? key[u] : MAXK; // stored zeros sort past the n keys
                 }
             }
             __syncthreads();
@@ -286,22 +374,23 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                 }
             }
             for (long long kb = k0; kb < k1; kb += NT * UL) {
-                InT v[UL];
+                KeyT key[UL];
+                bool nz[UL];
                 int cd[UL];
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
                     const long long k = kb + u * NT + tid;
-                    v[u] = k < k1 ? data[k] : (InT)0;
-                    cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
+                    key[u] = src.key(k, k < k1, nz[u]);
+                    cd[u] = src.code(k, k < k1);
                 }
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
-                    if (v[u] != (InT)0) {
-                        const KeyT q = key_of(v[u]);
+                    if (nz[u]) {
+                        const KeyT q = key[u];
                         const u32 s = lower_bound_pow2(A, un, top, q);
                         u32 e = s + 1;
                         if (e < un && A[e] == q) e = upper_bound_pow2(A, un, top, q);
-                        const u64 add = (u64)s + (u64)e + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
+                        const u64 add = 2ull * (u64)base + (u64)s + (u64)e + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
                         atomicAdd(&acc[cd[u]], add + CNT1);
                     }
                 }
@@ -313,15 +402,202 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         __syncthreads();
         u64 tie_total = 0;
         for (int w = 0; w < NW; ++w) tie_total += s_red[w];
-        tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
-        for (int g = tid; g < G; g += NT) {
-            const long long n_g = P.counts[g];
-            const u64 a = acc[g];
-            const long long z = n_g - (long long)(a >> CSCO_CNT_SHIFT);
-            const u64 r2 = (a & R2MASK) + (u64)z * (u64)(2 * nneg + n0 + 1);
-            P.out_2u[(size_t)gene * G + g] = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;
-            P.out_tie[(size_t)gene * G + g] = tie_total;
+        if constexpr (PARTS) {
+            // this part's share of the gene's accumulators
+            for (int g = tid; g < G; g += NT) {
+                const u64 a = acc[g];
+                if (a) {
+                    atomicAdd(&P.gacc[(size_t)gene * G + g], a);
+                    atomicAdd(&P.out_sum[(size_t)gene * G + g], sums[g]);
+                }
+            }
+            if (tid == 0 && tie_total) atomicAdd(&P.gtie[gene], tie_total);
+        } else {
+            tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
+            for (int g = tid; g < G; g += NT) {
+                const long long n_g = P.counts[g];
+                const u64 a = acc[g];
+                const long long z = n_g - (long long)(a >> CSCO_CNT_SHIFT);
+                const u64 r2 = (a & R2MASK) + (u64)z * (u64)(2 * nneg + n0 + 1);
+                P.out_2u[(size_t)gene * G + g] = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;
+                P.out_tie[(size_t)gene * G + g] = tie_total;
+            }
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Dense (gene-major key rows, group-contiguous positions: what k_transpose_permute writes): split a gene's non-zero keys
+// by value into parts of at most `cap` keys.
+// ---------------------------------------------------------------------------------------------------------------------
+struct OvrPartParams {
+    const void *Xt;            // [n_genes][stride] keys
+    long long stride;
+    int n_genes, n_cells;
+    const int *code_by_pos;    // [n_cells]
+    int cap;                   // keys per part at most
+    void *out_keys;            // [n_genes][stride]
+    u16 *out_codes;            // [n_genes][stride]
+    u32 *part_start;           // [n_genes][OVRP_PMAX + 1]
+    u32 *gene_info;            // [n_genes][4]: non-zeros, negatives, parts, flag
+    u32 *unit_list, *n_units;  // out: gene * OVRP_PMAX + part for every part, appended; counter zeroed by the host
+};
+
+static inline size_t ovrp_lds_bytes() { return ((size_t)4 << OVRP_LG) + OVRP_NT * 4 + (2 * OVRP_PMAX + 4) * 4 + 16 + ((size_t)1 << OVRP_LG); }
+
+template <typename KeyT>
+__global__ __launch_bounds__(OVRP_NT) void k_ovr_partition(OvrPartParams P) {
+    constexpr int NT = OVRP_NT, NB = 1 << OVRP_LG;
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
+    constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
+    extern __shared__ __align__(16) unsigned char smem[];
+    u32 *hist = (u32 *)smem;                         // [NB] counts, then exclusive offsets in value order
+    u32 *tmp = hist + NB;                            // [NT]
+    u32 *pstart = tmp + NT;                          // [OVRP_PMAX + 1]
+    u32 *pfill = pstart + OVRP_PMAX + 1;             // [OVRP_PMAX]
+    u32 *s_mx = pfill + OVRP_PMAX;                   // [0] largest bucket  [1] negatives
+    KeyT *s_k = (KeyT *)(s_mx + 2 + ((2 * OVRP_PMAX + 1) & 1)); // [2] smallest / largest non-zero key (8-byte aligned)
+    unsigned char *part_of = (unsigned char *)(s_k + 2); // [NB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = P.n_cells;
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    constexpr int UL = 8;
+    for (int gene = blockIdx.x; gene < P.n_genes; gene += gridDim.x) {
+        const KeyT *row = (const KeyT *)P.Xt + (size_t)gene * P.stride;
+        for (int b = tid; b < NB; b += NT) hist[b] = 0u;
+        if (tid < OVRP_PMAX) pfill[tid] = 0u;
+        if (tid == 0) { s_mx[0] = 0u; s_mx[1] = 0u; s_k[0] = MAXK; s_k[1] = (KeyT)0; }
+        __syncthreads();
+        { // key range of the non-zeros, negatives
+            KeyT tmin = MAXK, tmax = (KeyT)0;
+            u32 neg = 0;
+            for (int i0 = 0; i0 < N; i0 += NT * UL) {
+                KeyT k[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) { const int i = i0 + u * NT + tid; k[u] = i < N ? row[i] : ZEROK; }
+#pragma unroll
+                for (int u = 0; u < UL; ++u)
+                    if (k[u] != ZEROK) {
+                        tmin = k[u] < tmin ? k[u] : tmin;
+                        tmax = k[u] > tmax ? k[u] : tmax;
+                        neg += k[u] < ZEROK ? 1u : 0u;
+                    }
+            }
+            tmin = wave_min_key(tmin);
+            tmax = wave_max_key(tmax);
+            neg = (u32)wave_sum((int)neg);
+            if (lane == 0) {
+                atomicMin(&s_k[0], tmin);
+                atomicMax(&s_k[1], tmax);
+                if (neg) atomicAdd(&s_mx[1], neg);
+            }
+        }
+        __syncthreads();
+        const KeyT kmin = s_k[0], kmax = s_k[1];
+        const int shift = kmax >= kmin ? max(0, key_bits((KeyT)(kmax - kmin)) - OVRP_LG) : 0;
+        for (int i0 = 0; i0 < N; i0 += NT * UL) {
+            KeyT k[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) { const int i = i0 + u * NT + tid; k[u] = i < N ? row[i] : ZEROK; }
+#pragma unroll
+            for (int u = 0; u < UL; ++u)
+                if (k[u] != ZEROK) atomicAdd(&hist[(u32)((KeyT)(k[u] - kmin) >> shift)], 1u);
+        }
+        __syncthreads();
+        u32 mx = 0;
+        for (int b = tid; b < NB; b += NT) mx = max(mx, hist[b]);
+        mx = (u32)wave_incl_scan_max((int)mx);
+        if (lane == 63) atomicMax(&s_mx[0], mx);
+        __syncthreads();
+        mx = s_mx[0];
+        const u32 n = block_excl_scan_inplace<NT>(hist, NB, tmp, tid);
+        const u32 nneg = s_mx[1];
+        // part of a bucket = keys before it / quota; no bucket is larger than a quarter of cap, so every part gets a bucket
+        // boundary and holds fewer than quota + mx = cap keys
+        const bool skew = (unsigned long long)mx * 4ull > (unsigned long long)P.cap;
+        const u32 quota = skew ? 1u : (u32)P.cap - mx;
+        const u32 n_parts = n ? (n - 1) / quota + 1 : 0u;
+        const bool bad = skew || n_parts > (u32)OVRP_PMAX;
+        u32 *gi = P.gene_info + (size_t)gene * 4;
+        u32 *ps_out = P.part_start + (size_t)gene * (OVRP_PMAX + 1);
+        if (bad) { // uniform: this gene goes to the general route
+            if (tid == 0) { gi[0] = n; gi[1] = nneg; gi[2] = 0u; gi[3] = 1u; }
+            __syncthreads();
+            continue;
+        }
+        for (int b = tid; b < NB; b += NT) {
+            const u32 p = hist[b] / quota;
+            part_of[b] = (unsigned char)min(p, (u32)OVRP_PMAX - 1); // (empty buckets past the last key may overshoot)
+            if (p < n_parts && (b == 0 || hist[b - 1] / quota != p)) pstart[p] = hist[b];
+        }
+        if (tid == 0) pstart[n_parts] = n;
+        __syncthreads();
+        for (int i0 = 0; i0 < N; i0 += NT * UL) {
+            KeyT k[UL];
+            int cd[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int i = i0 + u * NT + tid;
+                k[u] = i < N ? row[i] : ZEROK;
+                cd[u] = i < N ? P.code_by_pos[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const bool nz = k[u] != ZEROK;
+                const int p = nz ? (int)part_of[(u32)((KeyT)(k[u] - kmin) >> shift)] : -1;
+                u64 rem = __ballot(nz);
+                u32 slot = 0;
+                while (rem) { // one LDS atomic per (wavefront, part present in it)
+                    const int leader = __ffsll((long long)rem) - 1;
+                    const int pl = __builtin_amdgcn_readlane(p, leader);
+                    const u64 m = __ballot(p == pl);
+                    u32 b0 = 0;
+                    if (lane == leader) b0 = atomicAdd(&pfill[pl], (u32)__popcll(m));
+                    b0 = (u32)__builtin_amdgcn_readlane((int)b0, leader);
+                    if (p == pl) slot = pstart[pl] + b0 + (u32)__popcll(m & lt_mask);
+                    rem &= ~m;
+                }
+                if (nz) {
+                    const size_t o = (size_t)gene * P.stride + slot;
+                    ((KeyT *)P.out_keys)[o] = k[u];
+                    P.out_codes[o] = (u16)cd[u];
+                }
+            }
+        }
+        if (tid <= (int)n_parts) ps_out[tid] = pstart[tid];
+        if (tid == 0) {
+            gi[0] = n; gi[1] = nneg; gi[2] = n_parts; gi[3] = 0u;
+            s_mx[0] = n_parts ? atomicAdd(P.n_units, n_parts) : 0u;
+        }
+        __syncthreads();
+        if (tid < (int)n_parts) P.unit_list[s_mx[0] + tid] = (u32)gene * OVRP_PMAX + tid;
+        __syncthreads();
+    }
+}
+
+// per (gene, group): the accumulated parts -> 2 U and the tie term (the CSC epilogue of k_csc_ovr_gene)
+struct OvrPartsFinishParams {
+    u64 *gacc;               // in: packed rank sums / counts   (aliases out_2u: same element, read before written)
+    const u64 *gtie;
+    const u32 *gene_info, *gflag;
+    const int *counts;
+    int G, nb;
+    long long n_cells;
+    long long *out_2u;
+    u64 *out_tie;
+};
+__global__ __launch_bounds__(256) void k_ovr_parts_finish(OvrPartsFinishParams P) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)P.nb * P.G) return;
+    const int gene = (int)(i / P.G), g = (int)(i % P.G);
+    const u32 *gi = P.gene_info + (size_t)gene * 4;
+    if (gi[3] != 0u || P.gflag[gene] != 0u) return; // the general route recomputes this gene
+    const long long n0 = P.n_cells - (long long)gi[0], nneg = gi[1];
+    const u64 a = P.gacc[i];
+    const long long n_g = P.counts[g];
+    const long long z = n_g - (long long)(a >> CSCO_CNT_SHIFT);
+    const u64 r2 = (a & ((1ull << CSCO_CNT_SHIFT) - 1ull)) + (u64)z * (u64)(2 * nneg + n0 + 1);
+    P.out_2u[i] = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;
+    P.out_tie[i] = P.gtie[gene] + ((u64)n0 * (u64)n0 * (u64)n0 - (u64)n0);
 }

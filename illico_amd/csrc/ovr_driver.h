@@ -102,3 +102,97 @@ static int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     if ((rc = launch_ovr_gene<KeyT, false>(c, P))) return rc;
     return launch_gene_totals(c, ssum, (int)c->n_groups, nb, gtot);
 }
+
+// Dense OVR, any values, in value-range parts (kernels_csc_ovr.h): partition each gene's non-zero keys into parts that
+// fit the LDS key buffer, rank every part with the bucket / sorted forms of k_csc_ovr_gene, sum the parts up.  Genes whose
+// values crowd into one coarse bucket (heavy ties) are recomputed by the general route over the gene range that covers
+// them (run by run).  *done = false: the route does not apply (nothing was launched).
+template <typename KeyT>
+static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags,
+                               long long *s2u, u64 *stie, double *ssum, double *gtot, bool *done) {
+    *done = false;
+    const int G = (int)c->n_groups;
+    if (c->no_ovr_parts_path || G > 65535 || c->max_nonref >= (1ll << 23) ||
+        (double)c->max_nonref * 2.0 * (double)N >= (double)(1ull << CSCO_CNT_SHIFT))
+        return ILLICO_OK;
+    int lg = 14;
+    if (csco_key_cap(G, lg, sizeof(KeyT), kMaxLds, true) < 12288) lg = 13;
+    const int key_cap = csco_key_cap(G, lg, sizeof(KeyT), kMaxLds, true);
+    const int cap = key_cap & ~1023; // any part can also take the sorted form (1024-key chunks)
+    if (cap < 4096 || (int64_t)cap * OVRP_PMAX < N) return ILLICO_OK;
+    int rc;
+    void *v;
+    if ((rc = get_scratch(c, "ovr_kb", (size_t)nb * stride * sizeof(KeyT), &v))) return rc;
+    void *pkeys = v;
+    if ((rc = get_scratch(c, "ovr_va", (size_t)nb * stride * 4, &v))) return rc;
+    u16 *pcodes = (u16 *)v;
+    const size_t meta = (size_t)nb * ((OVRP_PMAX + 1) * 4 + 16 + 8 + 4 + OVRP_PMAX * 4) + 64;
+    if ((rc = get_scratch(c, "ovr_parts_meta", meta, &v))) return rc;
+    u64 *gtie = (u64 *)v;
+    u32 *part_start = (u32 *)(gtie + nb);
+    u32 *gene_info = part_start + (size_t)nb * (OVRP_PMAX + 1);
+    u32 *gflag = gene_info + (size_t)nb * 4;
+    u32 *unit_list = gflag + nb;
+    u32 *unit_ctr = unit_list + (size_t)nb * OVRP_PMAX; // [0] units written  [1] queue head
+    HIPCHK(c, hipMemsetAsync(gtie, 0, (size_t)nb * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(gflag, 0, (size_t)nb * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(unit_ctr, 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(s2u, 0, (size_t)nb * G * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(ssum, 0, (size_t)nb * G * 8, c->stream));
+    {
+        OvrPartParams Q;
+        Q.Xt = Xt; Q.stride = stride; Q.n_genes = nb; Q.n_cells = N; Q.code_by_pos = c->d_code_by_pos; Q.cap = cap;
+        Q.out_keys = pkeys; Q.out_codes = pcodes; Q.part_start = part_start; Q.gene_info = gene_info; Q.unit_list = unit_list; Q.n_units = unit_ctr;
+        ProfScope ps(c, KID_OVR_PART);
+        auto kern = k_ovr_partition<KeyT>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovrp_lds_bytes()));
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(OVRP_NT), ovrp_lds_bytes(), c->stream, Q);
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        CscOvrParams P;
+        memset(&P, 0, sizeof P);
+        P.pkeys = pkeys; P.pcodes = pcodes; P.pstride = stride; P.part_start = part_start; P.gene_info = gene_info;
+        P.gacc = (u64 *)s2u; P.gtie = gtie; P.gflag = gflag; P.unit_list = unit_list; P.n_units = unit_ctr; P.unit_counter = unit_ctr + 1; P.nb = nb; P.counts = c->d_counts; P.G = G; P.dt = dtype;
+        P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = N; P.key_cap = key_cap; P.lg_buckets = lg;
+        P.force_sorted = c->csc_ovr_sorted_form ? 1 : 0; P.out_sum = ssum;
+        const size_t lds = csco_fixed_lds_bytes(G, lg, true) + (size_t)(key_cap + 4) * sizeof(KeyT);
+        ProfScope ps(c, KID_OVR_RANK_PARTS);
+        auto kern = k_csc_ovr_gene<KeyT, int, KeyT, true>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int n_cu = 256;
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+        const unsigned grid = (unsigned)std::min<long long>((long long)nb * OVRP_PMAX, std::max(n_cu, 1)); // one resident workgroup per CU (LDS)
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(CSCO_NT), lds, c->stream, P);
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        OvrPartsFinishParams F;
+        F.gacc = (u64 *)s2u; F.gtie = gtie; F.gene_info = gene_info; F.gflag = gflag; F.counts = c->d_counts; F.G = G; F.nb = nb;
+        F.n_cells = N; F.out_2u = s2u; F.out_tie = stie;
+        ProfScope ps(c, KID_OVR_RANK_PARTS);
+        const long long tot = (long long)nb * G;
+        hipLaunchKernelGGL(k_ovr_parts_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, F);
+        HIPCHK(c, hipGetLastError());
+    }
+    // genes that left the route (a coarse bucket too full, a part that fits neither form): the general route, over the
+    // gene range that covers them
+    std::vector<u32> h((size_t)nb * 5);
+    HIPCHK(c, hipMemcpyAsync(h.data(), gene_info, (size_t)nb * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h.data() + (size_t)nb * 4, gflag, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // (runs of flagged genes closer than 16 genes are merged: the genes in between are recomputed, identically)
+    for (int j = 0; j < nb;) {
+        if (!(h[(size_t)j * 4 + 3] || h[(size_t)nb * 4 + j])) { ++j; continue; }
+        int first = j, last = j;
+        for (int e = j + 1; e < nb && e - last <= 16; ++e)
+            if (h[(size_t)e * 4 + 3] || h[(size_t)nb * 4 + e]) last = e;
+        const int sub = last - first + 1;
+        if ((rc = run_ovr_dense_batch<KeyT>(c, Xt + (size_t)first * stride, stride, sub, N, dtype, flags, s2u + (size_t)first * G,
+                                            stie + (size_t)first * G, ssum + (size_t)first * G, gtot + first)))
+            return rc;
+        j = last + 1;
+    }
+    *done = true;
+    return launch_gene_totals(c, ssum, G, nb, gtot);
+}

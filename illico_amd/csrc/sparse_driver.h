@@ -205,7 +205,7 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
     const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
     const int *d_cols = nullptr;
     if (!contiguous && (rc = upload_cols(c, cols, &d_cols))) return rc;
-    const size_t lds = csco_fixed_lds_bytes(G, lg) + (size_t)(key_cap + 4) * sizeof(KeyT);
+    const size_t lds = csco_fixed_lds_bytes(G, lg, false) + (size_t)(key_cap + 4) * sizeof(KeyT);
     const int64_t n = (int64_t)cols.size();
     const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
     if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
@@ -215,13 +215,14 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
     double *gtot = ssum + (size_t)nb_max * G;
     if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
     u32 *fb = (u32 *)v;
-    auto kern = k_csc_ovr_gene<InT, IdxT, KeyT>;
+    auto kern = k_csc_ovr_gene<InT, IdxT, KeyT, false>;
     HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<int64_t> left;
     for (int64_t b0 = 0; b0 < n; b0 += nb_max) {
         const int nb = (int)std::min<int64_t>(nb_max, n - b0);
         HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)nb * 4, c->stream));
         CscOvrParams P;
+        memset(&P, 0, sizeof P);
         P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
         P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.counts = c->d_counts; P.G = G; P.dt = dtype;
         P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.key_cap = key_cap; P.lg_buckets = lg;

@@ -47,7 +47,11 @@ def route(request, engine):
     engine.set_option("no_ovr_one_pass", 1 if request.param.startswith("fused-host") else 0)
     # the general OVR route sorts with rocPRIM's segmented radix sort; "sort-only" keeps the in-kernel LSD passes alive
     engine.set_option("no_ovr_library_sort", 1 if request.param == "sort-only" else 0)
+    # ... and is itself the fallback of the value-range parts route (k_ovr_partition + k_csc_ovr_gene), which the fused
+    # params leave on
+    engine.set_option("no_ovr_parts_path", 0 if request.param.startswith("fused") else 1)
     yield request.param
+    engine.set_option("no_ovr_parts_path", 0)
     engine.set_option("no_ovr_library_sort", 0)
     engine.set_option("no_counts_path", 0)
     engine.set_option("no_fused_path", 0)
@@ -184,6 +188,54 @@ def test_ovr_ragged(engine):
     got = _run(engine, X, g)
     want = oracle.run(X, g)
     assert_planes_match(got, want, what="ovr ragged")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("sorted_form", [0, 1])
+def test_ovr_dense_value_range_parts_route(engine, dtype, sorted_form):
+    """Dense OVR, any values: each gene's non-zero keys are split by value into parts that fit LDS and ranked part by
+    part (k_ovr_partition + k_csc_ovr_gene<PARTS>; bucket form, and the sorted form when forced).  70 000 cells: fully
+    dense columns need 3+ parts (5+ for float64 keys); half-empty and nearly empty columns, negatives, exact repeats
+    among continuous values, a tie-heavy column and a constant column (one coarse bucket holds everything: those genes
+    leave the route and the general route recomputes the gene range covering them), an all-zero column."""
+    rng = np.random.RandomState(509)
+    n, m = 70000, 12
+    sizes = [30000, 20000, 9000, 700, 300, 255, 40, 3, 1]
+    sizes.append(n - sum(sizes))
+    labels = np.concatenate([[f"s{i:02d}"] * sz for i, sz in enumerate(sizes)])
+    rng.shuffle(labels)
+    X = np.zeros((n, m))
+    X[:, 0] = np.log1p(rng.poisson(3.0, size=n) * rng.uniform(0.5, 1.5, size=n))      # ~5 % exact zeros, rest spread
+    X[:, 1] = rng.randn(n)                                                            # fully dense, negatives
+    X[:, 2] = np.where(rng.rand(n) < 0.5, 0.0, rng.lognormal(0.0, 1.0, size=n))       # half empty
+    X[:, 3] = np.where(rng.rand(n) < 0.999, 0.0, rng.rand(n))                         # nearly empty
+    X[:, 4] = rng.poisson(2.0, size=n)                                                # tie-heavy -> general route
+    X[:, 5] = rng.rand(n) * 1e-3 + 5.0                                                # narrow range: one coarse bucket
+    X[:, 6] = 0.0                                                                     # all zero
+    X[:, 7] = np.round(rng.lognormal(0.0, 1.0, size=n), 2)                            # many exact repeats, wide range
+    X[:, 8] = rng.exponential(1.0, size=n) * (rng.rand(n) < 0.9)
+    X[:, 9] = 3.25                                                                    # constant
+    X[:, 10] = rng.standard_cauchy(size=n)                                            # heavy tails both ways
+    X[:, 11] = np.where(rng.rand(n) < 0.3, -rng.rand(n), rng.rand(n) * 100)
+    X = X.astype(dtype)
+    _, g = oracle.encode_and_count_groups(labels, None)
+    want = oracle.run(X.astype(np.float64), g)
+    engine.set_option("no_fused_path", 1)
+    engine.set_option("csc_ovr_sorted_form", sorted_form)
+    engine.set_option("profile", 1)
+    engine.profile_reset()
+    try:
+        got = _run(engine, X, g)
+        prof = engine.profile_get()
+        got_w = _run(engine, X, g, col_lb=1, col_ub=4, alternative="less", tie_correct=False)
+    finally:
+        engine.set_option("profile", 0)
+        engine.set_option("csc_ovr_sorted_form", 0)
+        engine.set_option("no_fused_path", 0)
+    assert "k_ovr_partition" in prof and "k_ovr_rank_parts" in prof and "k_ovr_gene" in prof, prof
+    assert_planes_match(got, want, fc_rtol=1e-9, what=f"dense ovr parts {dtype.__name__} sorted_form={sorted_form}")
+    want_w = oracle.run(X.astype(np.float64), g, col_lb=1, col_ub=4, alternative="less", tie_correct=False)
+    assert_planes_match(got_w, want_w, fc_rtol=1e-9, what=f"dense ovr parts window {dtype.__name__}")
 
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
