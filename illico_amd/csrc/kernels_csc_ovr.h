@@ -200,14 +200,38 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
             continue;
         }
         const int ns = (int)ns_ll;
-        // ---- 1. per-group value sums, key range, stored zeros, negatives ----
+        // ---- 0. key range of the bucket function, from every 8th row of NT entries.  Any monotone bucket function ranks
+        // correctly (keys outside the sampled range are clamped into the first / last bucket); the range only balances
+        // the buckets. ----
         for (int g = tid; g < G; g += NT) { sums[g] = 0.0; if constexpr (PARTS) acc[g] = 0ull; }
         for (int b = tid; b < NBKT / 2; b += NT) tab[b] = 0u;
         if (tid == 0) { s_k[0] = MAXK; s_k[1] = (KeyT)0; s_misc[0] = 0u; s_misc[1] = 0u; s_misc[2] = 0u; }
         __syncthreads();
         {
-            u32 my_zero = 0, my_neg = 0;
             KeyT tmin = MAXK, tmax = (KeyT)0;
+            const int row_step = ns > 8 * NT ? 8 : 1;
+            for (long long k = k0 + tid; k < k1; k += (long long)NT * row_step) {
+                bool nz;
+                const KeyT key = src.key(k, true, nz);
+                if (nz) { tmin = key < tmin ? key : tmin; tmax = key > tmax ? key : tmax; }
+            }
+            tmin = wave_min_key(tmin);
+            tmax = wave_max_key(tmax);
+            if (lane == 0) { atomicMin(&s_k[0], tmin); atomicMax(&s_k[1], tmax); }
+        }
+        __syncthreads();
+        const bool have_range = s_k[1] >= s_k[0];
+        const KeyT kmin = have_range ? s_k[0] : (KeyT)0, kmax = have_range ? s_k[1] : (KeyT)0;
+        const int shift = max(0, key_bits((KeyT)(kmax - kmin)) - P.lg_buckets);
+        const KeyT last_bucket = (KeyT)(NBKT - 1);
+        auto bucket_of = [&](KeyT key) -> u32 {
+            const KeyT d = key > kmin ? (KeyT)((KeyT)(key - kmin) >> shift) : (KeyT)0;
+            return (u32)(d < last_bucket ? d : last_bucket);
+        };
+        bool sorted_form = P.force_sorted != 0;
+        // ---- 1. per-group value sums, stored zeros, negatives, bucket sizes ----
+        {
+            u32 my_zero = 0, my_neg = 0;
             for (long long kb = k0; kb < k1; kb += NT * UL) {
                 KeyT key[UL];
                 bool nz[UL];
@@ -224,20 +248,18 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                     if (k < k1) {
                         if (nz[u]) {
                             atomicAdd(&sums[cd[u]], P.is_log1p ? key_to_expm1(key[u], P.dt) : key_to_double(key[u], P.dt));
-                            tmin = key[u] < tmin ? key[u] : tmin;
-                            tmax = key[u] > tmax ? key[u] : tmax;
                             my_neg += key[u] < ZEROK ? 1u : 0u;
+                            if (!sorted_form) {
+                                const u32 b = bucket_of(key[u]);
+                                atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u); // no carry: a counter stays below 2^16
+                            }
                         } else ++my_zero; // a stored zero is an implicit zero
                     }
                 }
             }
-            tmin = wave_min_key(tmin);
-            tmax = wave_max_key(tmax);
             my_zero = (u32)wave_sum((int)my_zero);
             my_neg = (u32)wave_sum((int)my_neg);
             if (lane == 0) {
-                atomicMin(&s_k[0], tmin);
-                atomicMax(&s_k[1], tmax);
                 if (my_zero) atomicAdd(&s_misc[0], my_zero);
                 if (my_neg) atomicAdd(&s_misc[1], my_neg);
             }
@@ -247,33 +269,13 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         if constexpr (!PARTS) {
             n0 = P.n_cells - n;                              // zeros of the column
             nneg = (long long)s_misc[1];
-        }
-        const KeyT kmin = s_k[0], kmax = s_k[1];
-        if constexpr (!PARTS) {
             for (int g = tid; g < G; g += NT) P.out_sum[(size_t)gene * G + g] = sums[g];
             __syncthreads();
             for (int g = tid; g < G; g += NT) acc[g] = 0ull;
         }
         u64 tie = 0;
-        bool sorted_form = P.force_sorted != 0;
-        const int shift = n > 0 ? max(0, key_bits((KeyT)(kmax - kmin)) - P.lg_buckets) : 0;
         if (n > 0 && !sorted_form) {
-            // ---- 2. bucket sizes ----
-            for (long long kb = k0; kb < k1; kb += NT * UL) {
-                KeyT key[UL];
-                bool nz[UL];
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const long long k = kb + u * NT + tid;
-                    key[u] = src.key(k, k < k1, nz[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < UL; ++u)
-                    if (nz[u]) {
-                        const u32 b = (u32)((KeyT)(key[u] - kmin) >> shift);
-                        atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u); // no carry: a counter stays below 2^16
-                    }
-            }
+            // ---- 2. how crowded are the buckets? ----
             __syncthreads();
             u64 sq = 0;
             u32 mx = 0;
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
 #pragma unroll
                 for (int u = 0; u < UL; ++u)
                     if (nz[u]) {
-                        const u32 b = (u32)((KeyT)(key[u] - kmin) >> shift);
+                        const u32 b = bucket_of(key[u]);
                         const u32 old = atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u);
                         A[(b & 1u) ? (old >> 16) : (old & 0xFFFFu)] = key[u];
                     }
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                 for (int u = 0; u < UL; ++u) {
                     if (nz[u]) {
                         const KeyT q = key[u];
-                        const u32 b = (u32)((KeyT)(q - kmin) >> shift);
+                        const u32 b = bucket_of(q);
                         const u32 lo = b ? tab16[b - 1] : 0u, hi = tab16[b];
                         u32 less = 0, eq = 0;
                         // 4 keys per step; keys past the bucket's end belong to later buckets (larger than q) or are the
@@ -469,8 +471,26 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition(OvrPartParams P) {
         if (tid < OVRP_PMAX) pfill[tid] = 0u;
         if (tid == 0) { s_mx[0] = 0u; s_mx[1] = 0u; s_k[0] = MAXK; s_k[1] = (KeyT)0; }
         __syncthreads();
-        { // key range of the non-zeros, negatives
+        { // key range for the bucket function, from every 8th row of NT keys (any monotone function partitions correctly:
+          // keys outside the sampled range are clamped into the first / last bucket)
             KeyT tmin = MAXK, tmax = (KeyT)0;
+            for (int i = tid; i < N; i += NT * 8) {
+                const KeyT k = row[i];
+                if (k != ZEROK) { tmin = k < tmin ? k : tmin; tmax = k > tmax ? k : tmax; }
+            }
+            tmin = wave_min_key(tmin);
+            tmax = wave_max_key(tmax);
+            if (lane == 0) { atomicMin(&s_k[0], tmin); atomicMax(&s_k[1], tmax); }
+        }
+        __syncthreads();
+        const bool have_range = s_k[1] >= s_k[0];
+        const KeyT kmin = have_range ? s_k[0] : (KeyT)0, kmax = have_range ? s_k[1] : (KeyT)0;
+        const int shift = max(0, key_bits((KeyT)(kmax - kmin)) - OVRP_LG);
+        auto bucket_of = [&](KeyT key) -> u32 {
+            const KeyT d = key > kmin ? (KeyT)((KeyT)(key - kmin) >> shift) : (KeyT)0;
+            return (u32)(d < (KeyT)(NB - 1) ? d : (KeyT)(NB - 1));
+        };
+        {
             u32 neg = 0;
             for (int i0 = 0; i0 < N; i0 += NT * UL) {
                 KeyT k[UL];
@@ -479,30 +499,12 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition(OvrPartParams P) {
 #pragma unroll
                 for (int u = 0; u < UL; ++u)
                     if (k[u] != ZEROK) {
-                        tmin = k[u] < tmin ? k[u] : tmin;
-                        tmax = k[u] > tmax ? k[u] : tmax;
+                        atomicAdd(&hist[bucket_of(k[u])], 1u);
                         neg += k[u] < ZEROK ? 1u : 0u;
                     }
             }
-            tmin = wave_min_key(tmin);
-            tmax = wave_max_key(tmax);
             neg = (u32)wave_sum((int)neg);
-            if (lane == 0) {
-                atomicMin(&s_k[0], tmin);
-                atomicMax(&s_k[1], tmax);
-                if (neg) atomicAdd(&s_mx[1], neg);
-            }
-        }
-        __syncthreads();
-        const KeyT kmin = s_k[0], kmax = s_k[1];
-        const int shift = kmax >= kmin ? max(0, key_bits((KeyT)(kmax - kmin)) - OVRP_LG) : 0;
-        for (int i0 = 0; i0 < N; i0 += NT * UL) {
-            KeyT k[UL];
-#pragma unroll
-            for (int u = 0; u < UL; ++u) { const int i = i0 + u * NT + tid; k[u] = i < N ? row[i] : ZEROK; }
-#pragma unroll
-            for (int u = 0; u < UL; ++u)
-                if (k[u] != ZEROK) atomicAdd(&hist[(u32)((KeyT)(k[u] - kmin) >> shift)], 1u);
+            if (lane == 0 && neg) atomicAdd(&s_mx[1], neg);
         }
         __syncthreads();
         u32 mx = 0;
@@ -545,18 +547,22 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition(OvrPartParams P) {
 #pragma unroll
             for (int u = 0; u < UL; ++u) {
                 const bool nz = k[u] != ZEROK;
-                const int p = nz ? (int)part_of[(u32)((KeyT)(k[u] - kmin) >> shift)] : -1;
-                u64 rem = __ballot(nz);
+                const int p = nz ? (int)part_of[bucket_of(k[u])] : OVRP_PMAX; // 6 bits: slot 32 = not a record
+                // lanes with the same part, without a loop: match the 6 bits of p through ballots
+                u64 m = ~0ull;
+#pragma unroll
+                for (int bit = 0; bit < 6; ++bit) {
+                    const bool on = (p >> bit) & 1;
+                    const u64 bl = __ballot(on);
+                    m &= on ? bl : ~bl;
+                }
                 u32 slot = 0;
-                while (rem) { // one LDS atomic per (wavefront, part present in it)
-                    const int leader = __ffsll((long long)rem) - 1;
-                    const int pl = __builtin_amdgcn_readlane(p, leader);
-                    const u64 m = __ballot(p == pl);
+                if (nz) { // one LDS atomic per (wavefront, part present in it): the lowest lane of each match set
+                    const int leader = __ffsll((long long)m) - 1;
                     u32 b0 = 0;
-                    if (lane == leader) b0 = atomicAdd(&pfill[pl], (u32)__popcll(m));
-                    b0 = (u32)__builtin_amdgcn_readlane((int)b0, leader);
-                    if (p == pl) slot = pstart[pl] + b0 + (u32)__popcll(m & lt_mask);
-                    rem &= ~m;
+                    if (lane == leader) b0 = atomicAdd(&pfill[p], (u32)__popcll(m));
+                    b0 = (u32)__shfl((int)b0, leader);
+                    slot = pstart[p] + b0 + (u32)__popcll(m & lt_mask);
                 }
                 if (nz) {
                     const size_t o = (size_t)gene * P.stride + slot;
