@@ -78,6 +78,7 @@ struct illico_ctx {
     bool no_fused_path = false;
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
+    int64_t ovr_parts_cap = 0;         // > 0: keys per part at most in the value-range parts route (tests: many small parts)
     bool no_ovr_parts_path = false;    // 1: dense OVR (any values) never takes the value-range parts route (k_ovr_partition + k_csc_ovr_gene)
     bool no_csc_ovr_gene_path = false; // 1: CSC OVR never takes the single-kernel LDS-sort route (k_csc_ovr_gene)
     bool csc_ovr_sorted_form = false;  // 1: k_csc_ovr_gene sorts every gene's keys in LDS (the form tie-heavy columns take) instead of bucketing them
@@ -258,6 +259,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
     else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
+    else if (!strcmp(key, "ovr_parts_cap")) c->ovr_parts_cap = value;
     else if (!strcmp(key, "no_ovr_parts_path")) c->no_ovr_parts_path = value != 0;
     else if (!strcmp(key, "no_csc_ovr_gene_path")) c->no_csc_ovr_gene_path = value != 0;
     else if (!strcmp(key, "csc_ovr_sorted_form")) c->csc_ovr_sorted_form = value != 0;

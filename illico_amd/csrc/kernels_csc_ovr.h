@@ -35,7 +35,7 @@
 #define CSCO_CNT_SHIFT 40   // acc word: doubled rank sum below, stored non-zeros of the group above
 #define OVRP_NT 512         // k_ovr_partition
 #define OVRP_LG 13          // its coarse buckets: (key - kmin) >> shift, 8192 of them over the gene's own key range
-#define OVRP_PMAX 32        // parts per gene at most
+#define OVRP_PMAX 128       // parts per gene at most (8-bit part ids)
 
 struct CscOvrParams {
     // CSC source (PARTS = false)
@@ -547,11 +547,11 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition(OvrPartParams P) {
 #pragma unroll
             for (int u = 0; u < UL; ++u) {
                 const bool nz = k[u] != ZEROK;
-                const int p = nz ? (int)part_of[bucket_of(k[u])] : OVRP_PMAX; // 6 bits: slot 32 = not a record
-                // lanes with the same part, without a loop: match the 6 bits of p through ballots
+                const int p = nz ? (int)part_of[bucket_of(k[u])] : OVRP_PMAX; // 8 bits: OVRP_PMAX = not a record
+                // lanes with the same part, without a loop: match the 8 bits of p through ballots
                 u64 m = ~0ull;
 #pragma unroll
-                for (int bit = 0; bit < 6; ++bit) {
+                for (int bit = 0; bit < 8; ++bit) {
                     const bool on = (p >> bit) & 1;
                     const u64 bl = __ballot(on);
                     m &= on ? bl : ~bl;

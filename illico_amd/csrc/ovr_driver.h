@@ -118,8 +118,10 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     int lg = 14;
     if (csco_key_cap(G, lg, sizeof(KeyT), kMaxLds, true) < 12288) lg = 13;
     const int key_cap = csco_key_cap(G, lg, sizeof(KeyT), kMaxLds, true);
-    const int cap = key_cap & ~1023; // any part can also take the sorted form (1024-key chunks)
-    if (cap < 4096 || (int64_t)cap * OVRP_PMAX < N) return ILLICO_OK;
+    int cap = key_cap & ~1023; // any part can also take the sorted form (1024-key chunks)
+    if (cap < 4096) return ILLICO_OK;
+    if (c->ovr_parts_cap > 0) cap = (int)std::min<int64_t>(cap, std::max<int64_t>(1024, c->ovr_parts_cap & ~1023ll)); // tests: many small parts
+    if ((int64_t)cap * OVRP_PMAX < N) return ILLICO_OK;
     int rc;
     void *v;
     if ((rc = get_scratch(c, "ovr_kb", (size_t)nb * stride * sizeof(KeyT), &v))) return rc;

@@ -191,13 +191,14 @@ def test_ovr_ragged(engine):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("sorted_form", [0, 1])
-def test_ovr_dense_value_range_parts_route(engine, dtype, sorted_form):
+@pytest.mark.parametrize("sorted_form,parts_cap", [(0, 0), (1, 0), (0, 1024)])
+def test_ovr_dense_value_range_parts_route(engine, dtype, sorted_form, parts_cap):
     """Dense OVR, any values: each gene's non-zero keys are split by value into parts that fit LDS and ranked part by
     part (k_ovr_partition + k_csc_ovr_gene<PARTS>; bucket form, and the sorted form when forced).  70 000 cells: fully
     dense columns need 3+ parts (5+ for float64 keys); half-empty and nearly empty columns, negatives, exact repeats
     among continuous values, a tie-heavy column and a constant column (one coarse bucket holds everything: those genes
-    leave the route and the general route recomputes the gene range covering them), an all-zero column."""
+    leave the route and the general route recomputes the gene range covering them), an all-zero column.  parts_cap =
+    1024 makes ~90 parts per dense column (more than 64: all 8 bits of the part id in play)."""
     rng = np.random.RandomState(509)
     n, m = 70000, 12
     sizes = [30000, 20000, 9000, 700, 300, 255, 40, 3, 1]
@@ -222,6 +223,7 @@ def test_ovr_dense_value_range_parts_route(engine, dtype, sorted_form):
     want = oracle.run(X.astype(np.float64), g)
     engine.set_option("no_fused_path", 1)
     engine.set_option("csc_ovr_sorted_form", sorted_form)
+    engine.set_option("ovr_parts_cap", parts_cap)
     engine.set_option("profile", 1)
     engine.profile_reset()
     try:
@@ -231,6 +233,7 @@ def test_ovr_dense_value_range_parts_route(engine, dtype, sorted_form):
     finally:
         engine.set_option("profile", 0)
         engine.set_option("csc_ovr_sorted_form", 0)
+        engine.set_option("ovr_parts_cap", 0)
         engine.set_option("no_fused_path", 0)
     assert "k_ovr_partition" in prof and "k_ovr_rank_parts" in prof and "k_ovr_gene" in prof, prof
     assert_planes_match(got, want, fc_rtol=1e-9, what=f"dense ovr parts {dtype.__name__} sorted_form={sorted_form}")
