@@ -79,6 +79,7 @@ struct illico_ctx {
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
     int64_t ovr_parts_cap = 0;         // > 0: keys per part at most in the value-range parts route (tests: many small parts)
+    bool no_ovo_ref_buckets = false;   // 1: the OVO sort route always sorts the reference column (no value-bucket form)
     bool no_ovr_parts_path = false;    // 1: dense OVR (any values) never takes the value-range parts route (k_ovr_partition + k_csc_ovr_gene)
     bool no_csc_ovr_gene_path = false; // 1: CSC OVR never takes the single-kernel LDS-sort route (k_csc_ovr_gene)
     bool csc_ovr_sorted_form = false;  // 1: k_csc_ovr_gene sorts every gene's keys in LDS (the form tie-heavy columns take) instead of bucketing them
@@ -260,6 +261,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
     else if (!strcmp(key, "ovr_parts_cap")) c->ovr_parts_cap = value;
+    else if (!strcmp(key, "no_ovo_ref_buckets")) c->no_ovo_ref_buckets = value != 0;
     else if (!strcmp(key, "no_ovr_parts_path")) c->no_ovr_parts_path = value != 0;
     else if (!strcmp(key, "no_csc_ovr_gene_path")) c->no_csc_ovr_gene_path = value != 0;
     else if (!strcmp(key, "csc_ovr_sorted_form")) c->csc_ovr_sorted_form = value != 0;
@@ -361,12 +363,12 @@ static const size_t kMaxLds = 160 * 1024;
 static const int kOvoThreads = 512;
 #include "ovr_driver.h"
 
-template <typename KeyT> static size_t ovo_lds_bytes(int ref_cap, bool runend, int nt) {
+template <typename KeyT> static size_t ovo_lds_bytes(int ref_cap, bool runend, int nt, bool buckets = false) {
     size_t nw = nt / 64;
-    size_t b = (((size_t)ref_cap * sizeof(KeyT)) + 15) & ~(size_t)15;
-    if (runend) b += (((size_t)ref_cap * 2) + 15) & ~(size_t)15;
+    size_t b = ((((size_t)ref_cap + 4) * sizeof(KeyT)) + 15) & ~(size_t)15;
+    if (runend) b += ovo_runend_bytes(ref_cap, buckets);
     b += nw * 256 * sizeof(KeyT) + nw * 256 * 4;
-    b += nw * 8 * 2 + 16;
+    b += nw * 8 * 2 + 16 + 48;
     return b;
 }
 
@@ -416,8 +418,11 @@ static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t m
     }
     int ref_cap = (int)std::max<int64_t>(max_ref_nnz, 1);
     bool runend = ref_cap <= 65535 && ovo_lds_bytes<KeyT>(ref_cap, true, kOvoThreads) <= kMaxLds;
-    size_t lds = ovo_lds_bytes<KeyT>(ref_cap, runend, kOvoThreads);
+    // bucket form of the reference column (no sort, short look-ups): needs the 16-bit table beside the keys
+    const bool buckets = runend && !c->no_ovo_ref_buckets && ref_cap <= 65531 && ovo_lds_bytes<KeyT>(ref_cap, true, kOvoThreads, true) <= kMaxLds;
+    size_t lds = ovo_lds_bytes<KeyT>(ref_cap, runend, kOvoThreads, buckets);
     P.ref_cap = ref_cap;
+    P.ref_buckets = buckets ? 1 : 0;
     bool big = max_grp_nnz > 256;
     if (sparse) { // sparse layouts get the lane-per-group form as well
         if (big) return runend ? launch_ovo_t<KeyT, 16, true, true>(c, P, lds, flags) : launch_ovo_t<KeyT, 16, false, true>(c, P, lds, flags);

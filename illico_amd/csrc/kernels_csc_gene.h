@@ -31,16 +31,17 @@ struct CscGeneParams {
     int G, ref, dt, is_log1p;
     int key_cap;                         // LDS key slots
     int runend_cap;                      // LDS run-end slots (reference run length limit)
+    int ref_buckets;                     // 1: the reference run may take the bucket form (run-end region >= 16 KB, runend_cap <= 8192)
     u32 *fallback;                       // [nb] set to 1 for genes this kernel cannot take
     long long *out_2u;
     u64 *out_tie;
     double *out_sum;
 };
 
-static inline size_t cscg_lds_bytes(int G, int key_cap, int runend_cap, size_t key_size) {
+static inline size_t cscg_lds_bytes(int G, int key_cap, int runend_cap, size_t key_size, bool buckets = false) {
     size_t b = (size_t)((G + 1 + 3) & ~3) * 4;          // ends
     b += (size_t)CSCG_NT * 4;                            // scan scratch
-    b += ((size_t)runend_cap * 2 + 15) & ~(size_t)15;    // run ends
+    b += ovo_runend_bytes(runend_cap, buckets);          // run ends / bucket table
     b += 256;                                            // reductions
     b += (size_t)key_cap * key_size;
     return b;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
     u32 *tmp = (u32 *)(smem + off);
     off += (size_t)NT * 4;
     u16 *runend = (u16 *)(smem + off);
-    off += ((size_t)P.runend_cap * 2 + 15) & ~(size_t)15;
+    off += ovo_runend_bytes(P.runend_cap, P.ref_buckets != 0);
     u64 *s_red = (u64 *)(smem + off);          // [NW]
     double *s_redd = (double *)(s_red + NW);   // [NW]
     u32 *s_misc = (u32 *)(s_redd + NW);        // [8]
@@ -132,25 +133,128 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
         rs = wave_sum(rs);
         if (lane == 0) s_redd[wave] = rs;
         __syncthreads();
-        block_bitonic_sort<KeyT, NT>(A, (int)nA, tid);
-        const u32 topA = top_pow2(nA);
-        u64 ta = 0;
-        for (u32 i = tid; i < nA; i += NT) {
-            const KeyT k = A[i];
-            if (i == 0 || A[i - 1] != k) {
-                const u32 e = upper_bound_pow2(A, nA, topA, k);
-                runend[i] = (u16)e;
-                const u64 t = e - i;
-                ta += t * t * t - t;
-            }
-        }
-        ta = wave_sum(ta);
-        if (lane == 0) s_red[wave] = ta;
-        __syncthreads();
+        RefBk<KeyT> bk;
+        bk.on = false; bk.tab = runend; bk.kmin = (KeyT)0; bk.last = (KeyT)((1u << OVO_REF_BUCKETS_LG) - 1u); bk.shift = 0; bk.zeros = 0u;
+        u32 topA = 0, nnegA = 0;
         u64 T_A = 0;
         double refsum = 0.0;
-        for (int w = 0; w < NW; ++w) { T_A += s_red[w]; refsum += s_redd[w]; }
-        const u32 nnegA = lower_bound_pow2(A, nA, topA, ZEROK);
+        if (P.ref_buckets && nA > 0) { // uniform
+            // ---- 4a. bucket form: the reference run's keys (no zeros among them) go through registers into value
+            // buckets, in place; nA <= runend_cap <= 8 * NT ----
+            constexpr int NBK = 1 << OVO_REF_BUCKETS_LG, RK = 8;
+            u32 *tab32 = (u32 *)runend;
+            u16 *tab16 = (u16 *)runend;
+            for (int w = 0; w < NW; ++w) refsum += s_redd[w];
+            KeyT rk[RK];
+            KeyT tmin = KeyInfo<KeyT>::MAXK, tmax = (KeyT)0;
+            u32 ng = 0;
+#pragma unroll
+            for (int r = 0; r < RK; ++r) {
+                const u32 i = (u32)r * NT + tid;
+                rk[r] = i < nA ? A[i] : KeyInfo<KeyT>::MAXK;
+                if (i < nA) { tmin = rk[r] < tmin ? rk[r] : tmin; tmax = rk[r] > tmax ? rk[r] : tmax; ng += rk[r] < ZEROK ? 1u : 0u; }
+            }
+            for (int b2 = tid; b2 < NBK / 2; b2 += NT) tab32[b2] = 0u;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const KeyT o1 = __shfl_xor(tmin, d), o2 = __shfl_xor(tmax, d);
+                tmin = o1 < tmin ? o1 : tmin;
+                tmax = o2 > tmax ? o2 : tmax;
+            }
+            ng = (u32)wave_sum((int)ng);
+            __syncthreads(); // (s_redd read above by everyone)
+            if (lane == 0) { s_red[wave] = (u64)tmin; s_redd[wave] = __longlong_as_double((long long)(u64)tmax); tmp[wave] = ng; }
+            __syncthreads();
+            KeyT kmin = KeyInfo<KeyT>::MAXK, kmax = (KeyT)0;
+            for (int w = 0; w < NW; ++w) {
+                const KeyT m1 = (KeyT)s_red[w], m2 = (KeyT)(u64)__double_as_longlong(s_redd[w]);
+                kmin = m1 < kmin ? m1 : kmin;
+                kmax = m2 > kmax ? m2 : kmax;
+                nnegA += tmp[w];
+            }
+            bk.kmin = kmin;
+            bk.shift = kmax == kmin ? 0 : max(0, (int)(sizeof(KeyT) * 8) - (int)(sizeof(KeyT) == 4 ? __clz((u32)(kmax - kmin)) : __clzll((long long)(u64)(kmax - kmin))) - OVO_REF_BUCKETS_LG);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RK; ++r) {
+                if ((u32)r * NT + tid < nA) {
+                    const u32 b2 = refbk_bucket(bk, rk[r]);
+                    atomicAdd(&tab32[b2 >> 1], (b2 & 1u) ? 0x10000u : 1u);
+                }
+            }
+            __syncthreads();
+            u32 mxb = 0;
+            for (int b2 = tid; b2 < NBK; b2 += NT) mxb = max(mxb, (u32)tab16[b2]);
+            mxb = (u32)wave_incl_scan_max((int)mxb);
+            if (lane == 63) tmp[wave] = mxb;
+            __syncthreads();
+            mxb = 0;
+            for (int w = 0; w < NW; ++w) mxb = max(mxb, tmp[w]);
+            __syncthreads();
+            if (mxb <= (u32)OVO_REF_MAX_BUCKET) { // uniform
+                const int per = NBK / NT, b0 = tid * per;
+                u32 sm = 0;
+                for (int i = 0; i < per; ++i) sm += tab16[b0 + i];
+                tmp[tid] = sm;
+                __syncthreads();
+                for (int d = 1; d < NT; d <<= 1) {
+                    const u32 v2 = (tid >= d) ? tmp[tid - d] : 0u;
+                    __syncthreads();
+                    tmp[tid] += v2;
+                    __syncthreads();
+                }
+                u32 run = tmp[tid] - sm;
+                for (int i = 0; i < per; ++i) { const u32 cnt = tab16[b0 + i]; tab16[b0 + i] = (u16)run; run += cnt; }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < RK; ++r) {
+                    if ((u32)r * NT + tid < nA) {
+                        const u32 b2 = refbk_bucket(bk, rk[r]);
+                        const u32 old = atomicAdd(&tab32[b2 >> 1], (b2 & 1u) ? 0x10000u : 1u);
+                        A[(b2 & 1u) ? (old >> 16) : (old & 0xFFFFu)] = rk[r];
+                    }
+                }
+                __syncthreads();
+                bk.on = true;
+                u64 ta = 0;
+#pragma unroll
+                for (int r = 0; r < RK; ++r) {
+                    if ((u32)r * NT + tid < nA) {
+                        u32 lb, a;
+                        ref_find<KeyT, true, false>(A, runend, nA, 0u, bk, rk[r], lb, a);
+                        ta += (u64)a * a - 1ull;
+                    }
+                }
+                ta = wave_sum(ta);
+                if (lane == 0) s_red[wave] = ta;
+                __syncthreads();
+                for (int w = 0; w < NW; ++w) T_A += s_red[w];
+            } else {
+                nnegA = 0;
+            }
+        }
+        if (!bk.on) {
+            if (!(P.ref_buckets && nA > 0))
+                for (int w = 0; w < NW; ++w) refsum += s_redd[w];
+            __syncthreads();
+            block_bitonic_sort<KeyT, NT>(A, (int)nA, tid);
+            topA = top_pow2(nA);
+            u64 ta = 0;
+            for (u32 i = tid; i < nA; i += NT) {
+                const KeyT k = A[i];
+                if (i == 0 || A[i - 1] != k) {
+                    const u32 e = upper_bound_pow2(A, nA, topA, k);
+                    runend[i] = (u16)e;
+                    const u64 t = e - i;
+                    ta += t * t * t - t;
+                }
+            }
+            ta = wave_sum(ta);
+            if (lane == 0) s_red[wave] = ta;
+            __syncthreads();
+            for (int w = 0; w < NW; ++w) T_A += s_red[w];
+            nnegA = lower_bound_pow2(A, nA, topA, ZEROK);
+        }
         // ---- 5. every other group: 64 runs per wavefront, one per lane ----
         for (int g0 = wave * 64; g0 < G; g0 += NW * 64) {
             const int gl = g0 + lane;
@@ -160,8 +264,8 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
             const int nmax = __builtin_amdgcn_readlane(wave_incl_scan_max(n), 63);
             u64 S2, TT;
             double sum;
-            if (nmax <= CSCG_SMALL) ovo_lane_groups<KeyT, CSCG_SMALL, true>(keybuf, (long long)start, n, nmax, A, runend, nA, topA, zA, P.dt, P.is_log1p, S2, TT, sum);
-            else ovo_lane_groups_mem<KeyT, true>(keybuf, (long long)start, n, nmax, A, runend, nA, topA, zA, P.dt, P.is_log1p, S2, TT, sum);
+            if (nmax <= CSCG_SMALL) ovo_lane_groups<KeyT, CSCG_SMALL, true, false>(keybuf, (long long)start, n, nmax, A, runend, nA, topA, zA, P.dt, P.is_log1p, S2, TT, sum, bk);
+            else ovo_lane_groups_mem<KeyT, true, false>(keybuf, (long long)start, n, nmax, A, runend, nA, topA, zA, P.dt, P.is_log1p, S2, TT, sum, bk);
             if (gl < G) {
                 const size_t o = (size_t)gene * G + gl;
                 if (gl == ref) {

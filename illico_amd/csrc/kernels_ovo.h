@@ -127,10 +127,72 @@ struct OvoParams {
     const int *counts;       // [G] cells per group
     int G, ref, n_genes, dt, is_log1p;
     int ref_cap;             // LDS slots reserved for the reference column
+    int ref_buckets;         // 1: the reference column may take the bucket form (LDS sized for it by the host)
     long long *out_2u;       // [n_genes][G]  2*U (U of the reference sample, as scipy's mannwhitneyu(ref, grp))
     u64 *out_tie;            // [n_genes][G]  sum_v (t^3 - t)
     double *out_sum;         // [n_genes][G]  sum of values (expm1'd if is_log1p)
 };
+
+// The reference column in LDS, looked up by every value of the other groups.  Two forms, chosen per gene:
+//  * sorted (A ascending, runend[i] = end of the run starting at i): lower bound by binary search, ~log2(nA) dependent
+//    LDS reads at random addresses;
+//  * bucketed (bk.on): the NON-ZERO reference keys are dealt into value buckets ((key - kmin) >> shift, clamped; order
+//    inside a bucket does not matter) and bk.tab[b] = one past bucket b; a look-up reads two table entries and the few
+//    keys of one bucket: #A<q = bucket start + smaller keys in the bucket, #A==q = equal keys in it.  The reference's
+//    zeros are not in the table: callers add them for q above zero (their zA argument counts ALL reference zeros then).
+// bytes of the run-end table / bucket table region
+__host__ __device__ static inline size_t ovo_runend_bytes(int ref_cap, bool buckets) {
+    size_t b = ((size_t)ref_cap * 2 + 15) & ~(size_t)15;
+    const size_t t = (size_t)2 << 13; // OVO_REF_BUCKETS_LG
+    return buckets && b < t ? t : b;
+}
+template <typename KeyT> struct RefBk {
+    bool on;
+    const u16 *tab;   // [n_buckets] (aliases the run-end table: one form per gene)
+    KeyT kmin, last;  // last = n_buckets - 1
+    int shift;
+    u32 zeros;        // reference cells stored as explicit zeros (dense layout): what a look-up of zero itself finds
+};
+#define OVO_REF_BUCKETS_LG 13
+#define OVO_REF_MAX_BUCKET 48 // bucket form only while no bucket holds more reference keys than this
+
+template <typename KeyT> __device__ __forceinline__ u32 refbk_bucket(const RefBk<KeyT> &bk, KeyT q) {
+    const KeyT d = q > bk.kmin ? (KeyT)((KeyT)(q - bk.kmin) >> bk.shift) : (KeyT)0;
+    return (u32)(d < bk.last ? d : bk.last);
+}
+// lb = #A < q, a = #A == q
+// PAD: 4 slots of the largest key follow the table's keys (the walk may read past the last bucket); without it the walk
+// checks every slot against the bucket's end (the reference run sits inside a larger buffer: k_csc_gene).
+template <typename KeyT, bool RUNEND, bool PAD = true>
+__device__ __forceinline__ void ref_find(const KeyT *A, const u16 *runend, u32 nA, u32 topA, const RefBk<KeyT> &bk, KeyT q, u32 &lb, u32 &a) {
+    if (RUNEND && bk.on) { // uniform
+        const u32 b = refbk_bucket(bk, q);
+        const u32 lo = b ? bk.tab[b - 1] : 0u, hi = bk.tab[b];
+        u32 less = 0, eq = 0;
+        for (u32 j = lo; j < hi; j += 4) { // keys past the bucket's end are larger than q (later buckets / the MAXK pad)
+            const KeyT a0 = A[j], a1 = A[j + 1], a2 = A[j + 2], a3 = A[j + 3];
+            if (PAD) {
+                less += (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u) + (a3 < q ? 1u : 0u);
+            } else { // later buckets still hold larger keys; only slots past the table's last key (j >= nA) are foreign
+                less += (a0 < q ? 1u : 0u) + ((j + 1 < nA && a1 < q) ? 1u : 0u) + ((j + 2 < nA && a2 < q) ? 1u : 0u) + ((j + 3 < nA && a3 < q) ? 1u : 0u);
+            }
+            if (PAD) {
+                eq += (a0 == q ? 1u : 0u) + (a1 == q ? 1u : 0u) + (a2 == q ? 1u : 0u) + (a3 == q ? 1u : 0u);
+            } else {
+                eq += (a0 == q ? 1u : 0u) + ((j + 1 < nA && a1 == q) ? 1u : 0u) + ((j + 2 < nA && a2 == q) ? 1u : 0u) + ((j + 3 < nA && a3 == q) ? 1u : 0u);
+            }
+        }
+        lb = lo + less;
+        a = q == KeyInfo<KeyT>::ZEROK ? bk.zeros : eq;
+    } else {
+        lb = lower_bound_pow2(A, nA, topA, q);
+        a = 0;
+        if (lb < nA && A[lb] == q) {
+            if (RUNEND) a = (u32)runend[lb] - lb;
+            else a = upper_bound_pow2(A, nA, topA, q) - lb;
+        }
+    }
+}
 
 // One group's values (nB <= 64*K keys) handled by one wavefront.  Returns PER-LANE partial sums
 // (S2, tie, value sum); the caller folds 64 groups' partials with a transpose-reduce.
@@ -145,7 +207,7 @@ template <typename KeyT, int K, int KIN, bool RUNEND>
 __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, const KeyT *A,
                                                const u16 *runend, u32 nA, u32 topA, u32 zA, u32 lbZ, u32 aZ, KeyT *sk, u32 *sb,
                                                int lane, int dt, int is_log1p, u64 &S2out, u64 &tieout,
-                                               double &sumout) {
+                                               double &sumout, const RefBk<KeyT> &bk) {
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     KeyT v[K];
@@ -205,12 +267,9 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, c
                 const int slot = j * 64 + lane;
                 if (slot < base) {
                     const KeyT q = sk[slot];
-                    const u32 lb = lower_bound_pow2(A, nA, topA, q);
-                    u64 a = 0;
-                    if (lb < nA && A[lb] == q) {
-                        if (RUNEND) a = (u32)runend[lb] - lb;
-                        else a = upper_bound_pow2(A, nA, topA, q) - lb;
-                    }
+                    u32 lb, a32;
+                    ref_find<KeyT, RUNEND>(A, runend, nA, topA, bk, q, lb, a32);
+                    const u64 a = a32;
                     const u64 lt = (u64)lb + ((q > ZEROK) ? (u64)zA : 0ull);
                     S2 += 2ull * lt + a;
                     TT += a * (a + 1ull); // run of length 1: tB (3 a (a+1) + 1 - 1) / 3
@@ -280,12 +339,9 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, c
             if (slot < cnt) {
                 KeyT q = sk[slot];
                 u64 b = sb[slot];
-                u32 lb = lower_bound_pow2(A, nA, topA, q);
-                u64 a = 0;
-                if (lb < nA && A[lb] == q) {
-                    if (RUNEND) a = (u32)runend[lb] - lb;
-                    else a = upper_bound_pow2(A, nA, topA, q) - lb;
-                }
+                u32 lb, a32;
+                ref_find<KeyT, RUNEND>(A, runend, nA, topA, bk, q, lb, a32);
+                const u64 a = a32;
                 u64 lt = (u64)lb + ((q > ZEROK) ? (u64)zA : 0ull);  // implicit zeros of A rank below positives
                 S2 += b * (2ull * lt + a);
                 tie += b * (3ull * a * (a + b) + b * b - 1ull);
@@ -305,10 +361,10 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, c
 // `o` is counted against the lane's own history in registers, and per element
 //     S2 += 2 #A<q + #A==q,      TT += t (t+1),  t = #A==q + o        (3 sum t(t+1) is the group's tie term)
 // -- the same integers as the run-based form of ovo_wave_group.  Returns per-lane (= per-group) totals.
-template <typename KeyT, int SMALL, bool RUNEND>
+template <typename KeyT, int SMALL, bool RUNEND, bool PAD = true>
 __device__ __forceinline__ void ovo_lane_groups(const KeyT *__restrict__ Xs, long long bstart, int n, int nmax, const KeyT *A,
                                                 const u16 *runend, u32 nA, u32 topA, u32 zA, int dt, int is_log1p,
-                                                u64 &S2out, u64 &TTout, double &sumout) {
+                                                u64 &S2out, u64 &TTout, double &sumout, const RefBk<KeyT> &bk) {
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     KeyT e[SMALL];
@@ -324,12 +380,8 @@ __device__ __forceinline__ void ovo_lane_groups(const KeyT *__restrict__ Xs, lon
             u32 o = 0;
 #pragma unroll
             for (int i = 0; i < j; ++i) o += (e[i] == q) ? 1u : 0u;
-            const u32 lb = lower_bound_pow2(A, nA, topA, q);
-            u32 a = 0;
-            if (lb < nA && A[lb] == q) {
-                if (RUNEND) a = (u32)runend[lb] - lb;
-                else a = upper_bound_pow2(A, nA, topA, q) - lb;
-            }
+            u32 lb, a;
+            ref_find<KeyT, RUNEND, PAD>(A, runend, nA, topA, bk, q, lb, a);
             if (valid) {
                 const u64 lt = (u64)lb + ((q > ZEROK) ? (u64)zA : 0ull);
                 const u64 t = (u64)a + o;
@@ -347,10 +399,10 @@ __device__ __forceinline__ void ovo_lane_groups(const KeyT *__restrict__ Xs, lon
 // Same as ovo_lane_groups for longer runs (up to a few hundred keys): the lane re-reads its own run from memory
 // (LDS in k_csc_gene) instead of keeping a register history.  O(n^2/2) reads per lane: meant for the rare block
 // whose longest run exceeds the register form's limit.
-template <typename KeyT, bool RUNEND>
+template <typename KeyT, bool RUNEND, bool PAD = true>
 __device__ __forceinline__ void ovo_lane_groups_mem(const KeyT *Xs, long long bstart, int n, int nmax, const KeyT *A,
                                                     const u16 *runend, u32 nA, u32 topA, u32 zA, int dt, int is_log1p,
-                                                    u64 &S2out, u64 &TTout, double &sumout) {
+                                                    u64 &S2out, u64 &TTout, double &sumout, const RefBk<KeyT> &bk) {
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     u64 S2 = 0, TT = 0;
@@ -360,12 +412,8 @@ __device__ __forceinline__ void ovo_lane_groups_mem(const KeyT *Xs, long long bs
         const KeyT q = valid ? Xs[bstart + j] : MAXK;
         u32 o = 0;
         for (int i = 0; i < j; ++i) o += (valid && Xs[bstart + i] == q) ? 1u : 0u;
-        const u32 lb = lower_bound_pow2(A, nA, topA, q);
-        u32 a = 0;
-        if (lb < nA && A[lb] == q) {
-            if (RUNEND) a = (u32)runend[lb] - lb;
-            else a = upper_bound_pow2(A, nA, topA, q) - lb;
-        }
+        u32 lb, a;
+        ref_find<KeyT, RUNEND, PAD>(A, runend, nA, topA, bk, q, lb, a);
         if (valid) {
             const u64 lt = (u64)lb + ((q > ZEROK) ? (u64)zA : 0ull);
             const u64 t = (u64)a + o;
@@ -388,9 +436,9 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     // LDS carve (all offsets multiples of 16 B): A | runend | per-wave compaction scratch | reduction words
     KeyT *A = (KeyT *)smem;
-    size_t off = ((size_t)P.ref_cap * sizeof(KeyT) + 15) & ~(size_t)15;
+    size_t off = (((size_t)P.ref_cap + 4) * sizeof(KeyT) + 15) & ~(size_t)15;
     u16 *runend = (u16 *)(smem + off);
-    if (RUNEND) off += ((size_t)P.ref_cap * sizeof(u16) + 15) & ~(size_t)15;
+    if (RUNEND) off += ovo_runend_bytes(P.ref_cap, P.ref_buckets != 0);
     KeyT *sk_all = (KeyT *)(smem + off);
     off += (size_t)NW * 256 * sizeof(KeyT);
     u32 *sb_all = (u32 *)(smem + off);
@@ -422,7 +470,128 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
             rstart = (long long)gene * P.gene_stride + P.pos_ptr[ref];
             nA = (u32)n_ref;
         }
-        const u32 zA = (u32)n_ref - nA;
+        const u32 zA_impl = (u32)n_ref - nA; // implicit zeros of the reference (sparse layout)
+        RefBk<KeyT> bk;
+        bk.on = false;
+        bk.tab = runend;
+        bk.kmin = (KeyT)0; bk.last = (KeyT)((1u << OVO_REF_BUCKETS_LG) - 1u); bk.shift = 0; bk.zeros = 0u;
+        u32 nAs = nA;          // keys held in A: all of the run (sorted form) / its non-zeros (bucket form)
+        u32 topA = 0, nnegA = 0, lbZ = 0, aZ = 0;
+        u64 T_A = 0;
+        double refsum = 0.0;
+        if (RUNEND && P.ref_buckets) { // uniform
+            // ---- reference column -> value buckets in LDS (no sort) ----
+            constexpr int NBK = 1 << OVO_REF_BUCKETS_LG;
+            u32 *tab32 = (u32 *)runend;
+            u16 *tab16 = (u16 *)runend;
+            KeyT *s_kr = (KeyT *)(s_refsum + 1);  // [2]
+            u32 *s_cnt = (u32 *)(s_kr + 2);       // [0] zeros  [1] negatives  [2] largest bucket
+            for (int b = tid; b < NBK / 2; b += NT) tab32[b] = 0u;
+            if (tid == 0) { s_kr[0] = KeyInfo<KeyT>::MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; }
+            __syncthreads();
+            {
+                KeyT tmin = KeyInfo<KeyT>::MAXK, tmax = (KeyT)0;
+                u32 nz0 = 0, ng = 0;
+                double rs = 0.0;
+                for (u32 i = tid; i < nA; i += NT) {
+                    const KeyT k = Xs[rstart + i];
+                    rs += P.is_log1p ? key_to_expm1(k, P.dt) : key_to_double(k, P.dt);
+                    if (k != ZEROK) { tmin = k < tmin ? k : tmin; tmax = k > tmax ? k : tmax; ng += k < ZEROK ? 1u : 0u; }
+                    else ++nz0;
+                }
+                rs = wave_sum(rs);
+                nz0 = (u32)wave_sum((int)nz0);
+                ng = (u32)wave_sum((int)ng);
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const KeyT o1 = __shfl_xor(tmin, d), o2 = __shfl_xor(tmax, d);
+                    tmin = o1 < tmin ? o1 : tmin;
+                    tmax = o2 > tmax ? o2 : tmax;
+                }
+                if (lane == 0) {
+                    s_redd[wave] = rs;
+                    atomicMin(&s_kr[0], tmin);
+                    atomicMax(&s_kr[1], tmax);
+                    if (nz0) atomicAdd(&s_cnt[0], nz0);
+                    if (ng) atomicAdd(&s_cnt[1], ng);
+                }
+            }
+            __syncthreads();
+            aZ = s_cnt[0];
+            bk.zeros = aZ;
+            nnegA = lbZ = s_cnt[1];
+            nAs = nA - aZ;
+            const bool have = s_kr[1] >= s_kr[0];
+            bk.kmin = have ? s_kr[0] : (KeyT)0;
+            const KeyT kmax = have ? s_kr[1] : (KeyT)0;
+            bk.shift = max(0, (int)(sizeof(KeyT) * 8) - (int)(sizeof(KeyT) == 4 ? __clz((u32)(kmax - bk.kmin)) : __clzll((long long)(u64)(kmax - bk.kmin))) - OVO_REF_BUCKETS_LG);
+            if (kmax == bk.kmin) bk.shift = 0;
+            for (u32 i = tid; i < nA; i += NT) {
+                const KeyT k = Xs[rstart + i];
+                if (k != ZEROK) {
+                    const u32 b = refbk_bucket(bk, k);
+                    atomicAdd(&tab32[b >> 1], (b & 1u) ? 0x10000u : 1u);
+                }
+            }
+            __syncthreads();
+            u32 mxb = 0;
+            for (int b = tid; b < NBK; b += NT) mxb = max(mxb, (u32)tab16[b]);
+            mxb = (u32)wave_incl_scan_max((int)mxb);
+            if (lane == 63) atomicMax(&s_cnt[2], mxb);
+            __syncthreads();
+            if (s_cnt[2] <= (u32)OVO_REF_MAX_BUCKET) { // uniform
+                { // exclusive scan of the 16-bit counters (scratch: the per-wave Bloom words, re-zeroed below)
+                    u32 *tmp = sb_all;
+                    const int per = NBK / NT, b0 = tid * per;
+                    u32 sm = 0;
+                    for (int i = 0; i < per; ++i) sm += tab16[b0 + i];
+                    tmp[tid] = sm;
+                    __syncthreads();
+                    for (int d = 1; d < NT; d <<= 1) {
+                        const u32 v = (tid >= d) ? tmp[tid - d] : 0u;
+                        __syncthreads();
+                        tmp[tid] += v;
+                        __syncthreads();
+                    }
+                    u32 run = tmp[tid] - sm;
+                    __syncthreads();
+                    tmp[tid] = 0u;
+                    for (int i = 0; i < per; ++i) { const u32 cnt = tab16[b0 + i]; tab16[b0 + i] = (u16)run; run += cnt; }
+                    __syncthreads();
+                }
+                for (u32 i = tid; i < nA; i += NT) {
+                    const KeyT k = Xs[rstart + i];
+                    if (k != ZEROK) {
+                        const u32 b = refbk_bucket(bk, k);
+                        const u32 old = atomicAdd(&tab32[b >> 1], (b & 1u) ? 0x10000u : 1u);
+                        A[(b & 1u) ? (old >> 16) : (old & 0xFFFFu)] = k;
+                    }
+                }
+                if (tid < 4) A[nAs + tid] = KeyInfo<KeyT>::MAXK; // the bucket walk reads up to 3 keys past a bucket's end
+                __syncthreads();
+                bk.on = true;
+                u64 ta = 0; // ties inside the reference: sum over its non-zero keys of (run length^2 - 1), plus its zero run
+                for (u32 i = tid; i < nAs; i += NT) {
+                    u32 lb, a;
+                    ref_find<KeyT, RUNEND>(A, runend, nAs, 0u, bk, A[i], lb, a);
+                    ta += (u64)a * a - 1ull;
+                }
+                ta = wave_sum(ta);
+                if (lane == 0) s_red[wave] = ta;
+                __syncthreads();
+                if (tid == 0) {
+                    u64 t = (u64)aZ * aZ * aZ - (u64)aZ;
+                    double d = 0.0;
+                    for (int w = 0; w < NW; ++w) { t += s_red[w]; d += s_redd[w]; }
+                    *s_TA = t;
+                    *s_refsum = d;
+                }
+                __syncthreads();
+                T_A = *s_TA;
+                refsum = *s_refsum;
+            }
+        }
+        if (!bk.on) {
         double rs = 0.0;
         for (u32 i = tid; i < nA; i += NT) {
             KeyT k = Xs[rstart + i];
@@ -433,7 +602,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
         if (lane == 0) s_redd[wave] = rs;
         __syncthreads();
         block_bitonic_sort<KeyT, NT>(A, (int)nA, tid);
-        const u32 topA = top_pow2(nA);
+        topA = top_pow2(nA);
         // run ends at run heads (the only slots a lower bound can land on) and T_A = sum (tA^3 - tA)
         u64 ta = 0;
         for (u32 i = tid; i < nA; i += NT) {
@@ -456,12 +625,16 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
             *s_refsum = d;
         }
         __syncthreads();
-        const u64 T_A = *s_TA;
-        const double refsum = *s_refsum;
-        const u32 nnegA = P.seg_ptr ? lower_bound_pow2(A, nA, topA, ZEROK) : 0u;
+        T_A = *s_TA;
+        refsum = *s_refsum;
+        nnegA = P.seg_ptr ? lower_bound_pow2(A, nA, topA, ZEROK) : 0u;
         // reference cells below zero / equal to zero (explicit zeros of the dense layout), for a group's zero run
-        const u32 lbZ = lower_bound_pow2(A, nA, topA, ZEROK);
-        const u32 aZ = upper_bound_pow2(A, nA, topA, ZEROK) - lbZ;
+        lbZ = lower_bound_pow2(A, nA, topA, ZEROK);
+        aZ = upper_bound_pow2(A, nA, topA, ZEROK) - lbZ;
+        }
+        // what a look-up adds for q above zero: the implicit zeros, plus (bucket form) the explicit ones, which are not
+        // in the table
+        const u32 zA = bk.on ? zA_impl + aZ : zA_impl;
 
         // ---- every other group: one wavefront each, 64 groups per output block ----
         KeyT *sk = sk_all + wave * 256;
@@ -477,7 +650,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                 if (nmax <= SMALL) {
                     u64 S2, TT;
                     double sum;
-                    ovo_lane_groups<KeyT, SMALL, RUNEND>(Xs, bs, n, nmax, A, runend, nA, topA, zA, P.dt, P.is_log1p, S2, TT, sum);
+                    ovo_lane_groups<KeyT, SMALL, RUNEND>(Xs, bs, n, nmax, A, runend, nA, topA, zA, P.dt, P.is_log1p, S2, TT, sum, bk);
                     if (gl < G) {
                         size_t o = (size_t)gene * G + gl;
                         if (gl == ref) {
@@ -487,8 +660,8 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                         } else {
                             const long long n_g = P.counts[gl];
                             const u64 zB = (u64)(n_g - n);
-                            S2 += zB * (2ull * nnegA + zA);
-                            const u64 t0 = (u64)zA + zB;
+                            S2 += zB * (2ull * nnegA + zA_impl);
+                            const u64 t0 = (u64)zA_impl + zB;
                             P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
                             P.out_tie[o] = T_A + 3ull * TT + (t0 * t0 * t0 - t0);
                             P.out_sum[o] = sum;
@@ -533,15 +706,15 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                 u64 S2 = 0, tie = 0;
                 double sum = 0.0;
                 if (g < G && g != ref) {
-                    if (nB <= 64) ovo_wave_group<KeyT, 1, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                    else if (nB <= 128) ovo_wave_group<KeyT, 2, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                    else if (nB <= 256) ovo_wave_group<KeyT, 4, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                    else if (KMAX >= 8 && nB <= 512) ovo_wave_group<KeyT, (KMAX >= 8 ? 8 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
-                    else if (KMAX >= 16 && nB <= 1024) ovo_wave_group<KeyT, (KMAX >= 16 ? 16 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum);
+                    if (nB <= 64) ovo_wave_group<KeyT, 1, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk);
+                    else if (nB <= 128) ovo_wave_group<KeyT, 2, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk);
+                    else if (nB <= 256) ovo_wave_group<KeyT, 4, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk);
+                    else if (KMAX >= 8 && nB <= 512) ovo_wave_group<KeyT, (KMAX >= 8 ? 8 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk);
+                    else if (KMAX >= 16 && nB <= 1024) ovo_wave_group<KeyT, (KMAX >= 16 ? 16 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk);
                     if (lane == 0) {
                         // implicit zeros of B (sparse layout): each ranks above A's negatives and ties with A's zeros
-                        S2 += (u64)zB * (2ull * nnegA + zA);
-                        const u64 t0 = (u64)zA + zB;
+                        S2 += (u64)zB * (2ull * nnegA + zA_impl);
+                        const u64 t0 = (u64)zA_impl + zB;
                         tie += T_A + (t0 * t0 * t0 - t0);
                     }
                 }

@@ -146,10 +146,12 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
     int rc;
     void *v;
     const int runend_cap = (int)std::max<int64_t>(1, std::min<int64_t>(c->h_counts[c->ref], 8192));
-    const size_t fixed = cscg_lds_bytes(G, 0, runend_cap, sizeof(KeyT));
+    // bucket form of the reference run (no sort, short look-ups): its 16-bit table takes the run-end region
+    const bool ref_buckets = !c->no_ovo_ref_buckets && cscg_lds_bytes(G, 0, runend_cap, sizeof(KeyT), true) + 16384 * sizeof(KeyT) <= kMaxLds;
+    const size_t fixed = cscg_lds_bytes(G, 0, runend_cap, sizeof(KeyT), ref_buckets);
     if (fixed + 1024 * sizeof(KeyT) > kMaxLds) return ILLICO_OK; // every gene stays in `cols` for the two-kernel route
     const int key_cap = (int)((kMaxLds - fixed) / sizeof(KeyT));
-    const size_t lds = cscg_lds_bytes(G, key_cap, runend_cap, sizeof(KeyT));
+    const size_t lds = cscg_lds_bytes(G, key_cap, runend_cap, sizeof(KeyT), ref_buckets);
     const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(g1 - g0, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
     if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
     long long *s2u = (long long *)v;
@@ -167,7 +169,7 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
         P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
         P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes;
         P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
-        P.key_cap = key_cap; P.runend_cap = runend_cap; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
+        P.key_cap = key_cap; P.runend_cap = runend_cap; P.ref_buckets = ref_buckets ? 1 : 0; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
         {
             ProfScope ps(c, KID_CSC_GENE);
             hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCG_NT), lds, c->stream, P);

@@ -50,7 +50,10 @@ def route(request, engine):
     # ... and is itself the fallback of the value-range parts route (k_ovr_partition + k_csc_ovr_gene), which the fused
     # params leave on
     engine.set_option("no_ovr_parts_path", 0 if request.param.startswith("fused") else 1)
+    # the OVO sort route keeps the reference column in value buckets (no sort) unless its values crowd; "sort-only" sorts it
+    engine.set_option("no_ovo_ref_buckets", 1 if request.param == "sort-only" else 0)
     yield request.param
+    engine.set_option("no_ovo_ref_buckets", 0)
     engine.set_option("no_ovr_parts_path", 0)
     engine.set_option("no_ovr_library_sort", 0)
     engine.set_option("no_counts_path", 0)
