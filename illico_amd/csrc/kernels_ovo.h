@@ -427,6 +427,121 @@ __device__ __forceinline__ void ovo_lane_groups_mem(const KeyT *Xs, long long bs
     sumout = s;
 }
 
+// The reference column -> value buckets in LDS (no sort): A = its non-zero keys in bucket order (+ 4 pad slots), the
+// run-end region = 16-bit bucket ends.  Returns false (uniform) when a bucket would hold more than OVO_REF_MAX_BUCKET
+// keys: the caller sorts the column instead.  Outputs through LDS: s_kr[0] = kmin, s_cnt[0] = explicit zeros, [1] =
+// negatives, [3] = shift, *s_TA = tie term of the column, *s_refsum = its value sum.  Kept out of line: it runs once per
+// gene and its registers must not weigh on the group loop.
+template <typename KeyT, int NT>
+__device__ __noinline__ bool ovo_build_ref_buckets(const KeyT *__restrict__ src, u32 nA, KeyT *A, u16 *runend, u32 *scan_tmp, u64 *s_red,
+                                                   double *s_redd, u64 *s_TA, double *s_refsum, KeyT *s_kr, u32 *s_cnt, int dt, int is_log1p) {
+    constexpr int NBK = 1 << OVO_REF_BUCKETS_LG, NW = NT / 64;
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 *tab32 = (u32 *)runend;
+    u16 *tab16 = (u16 *)runend;
+    RefBk<KeyT> bk;
+    bk.on = true; bk.tab = runend; bk.last = (KeyT)(NBK - 1); bk.zeros = 0u;
+    for (int b = tid; b < NBK / 2; b += NT) tab32[b] = 0u;
+    if (tid == 0) { s_kr[0] = KeyInfo<KeyT>::MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; }
+    __syncthreads();
+    {
+        KeyT tmin = KeyInfo<KeyT>::MAXK, tmax = (KeyT)0;
+        u32 nz0 = 0, ng = 0;
+        double rs = 0.0;
+        for (u32 i = tid; i < nA; i += NT) {
+            const KeyT k = src[i];
+            rs += is_log1p ? key_to_expm1(k, dt) : key_to_double(k, dt);
+            if (k != ZEROK) { tmin = k < tmin ? k : tmin; tmax = k > tmax ? k : tmax; ng += k < ZEROK ? 1u : 0u; }
+            else ++nz0;
+        }
+        rs = wave_sum(rs);
+        nz0 = (u32)wave_sum((int)nz0);
+        ng = (u32)wave_sum((int)ng);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const KeyT o1 = __shfl_xor(tmin, d), o2 = __shfl_xor(tmax, d);
+            tmin = o1 < tmin ? o1 : tmin;
+            tmax = o2 > tmax ? o2 : tmax;
+        }
+        if (lane == 0) {
+            s_redd[wave] = rs;
+            atomicMin(&s_kr[0], tmin);
+            atomicMax(&s_kr[1], tmax);
+            if (nz0) atomicAdd(&s_cnt[0], nz0);
+            if (ng) atomicAdd(&s_cnt[1], ng);
+        }
+    }
+    __syncthreads();
+    const u32 aZ = s_cnt[0], nAs = nA - aZ;
+    const bool have = s_kr[1] >= s_kr[0];
+    const KeyT kmax = have ? s_kr[1] : (KeyT)0;
+    bk.kmin = have ? s_kr[0] : (KeyT)0;
+    bk.shift = kmax == bk.kmin ? 0 : max(0, (int)(sizeof(KeyT) * 8) - (int)(sizeof(KeyT) == 4 ? __clz((u32)(kmax - bk.kmin)) : __clzll((long long)(u64)(kmax - bk.kmin))) - OVO_REF_BUCKETS_LG);
+    __syncthreads();
+    if (tid == 0) { s_kr[0] = bk.kmin; s_cnt[3] = (u32)bk.shift; }
+    for (u32 i = tid; i < nA; i += NT) {
+        const KeyT k = src[i];
+        if (k != ZEROK) {
+            const u32 b = refbk_bucket(bk, k);
+            atomicAdd(&tab32[b >> 1], (b & 1u) ? 0x10000u : 1u);
+        }
+    }
+    __syncthreads();
+    u32 mxb = 0;
+    for (int b = tid; b < NBK; b += NT) mxb = max(mxb, (u32)tab16[b]);
+    mxb = (u32)wave_incl_scan_max((int)mxb);
+    if (lane == 63) atomicMax(&s_cnt[2], mxb);
+    __syncthreads();
+    if (s_cnt[2] > (u32)OVO_REF_MAX_BUCKET) return false; // uniform
+    { // exclusive scan of the 16-bit counters (scratch: the per-wave Bloom words, left zeroed)
+        const int per = NBK / NT, b0 = tid * per;
+        u32 sm = 0;
+        for (int i = 0; i < per; ++i) sm += tab16[b0 + i];
+        scan_tmp[tid] = sm;
+        __syncthreads();
+        for (int d = 1; d < NT; d <<= 1) {
+            const u32 v = (tid >= d) ? scan_tmp[tid - d] : 0u;
+            __syncthreads();
+            scan_tmp[tid] += v;
+            __syncthreads();
+        }
+        u32 run = scan_tmp[tid] - sm;
+        __syncthreads();
+        scan_tmp[tid] = 0u;
+        for (int i = 0; i < per; ++i) { const u32 cnt = tab16[b0 + i]; tab16[b0 + i] = (u16)run; run += cnt; }
+        __syncthreads();
+    }
+    for (u32 i = tid; i < nA; i += NT) {
+        const KeyT k = src[i];
+        if (k != ZEROK) {
+            const u32 b = refbk_bucket(bk, k);
+            const u32 old = atomicAdd(&tab32[b >> 1], (b & 1u) ? 0x10000u : 1u);
+            A[(b & 1u) ? (old >> 16) : (old & 0xFFFFu)] = k;
+        }
+    }
+    if (tid < 4) A[nAs + tid] = KeyInfo<KeyT>::MAXK; // the bucket walk reads up to 3 keys past a bucket's end
+    __syncthreads();
+    u64 ta = 0; // ties inside the column: sum over its non-zero keys of (run length^2 - 1), plus its zero run
+    for (u32 i = tid; i < nAs; i += NT) {
+        u32 lb, a;
+        ref_find<KeyT, true>(A, runend, nAs, 0u, bk, A[i], lb, a);
+        ta += (u64)a * a - 1ull;
+    }
+    ta = wave_sum(ta);
+    if (lane == 0) s_red[wave] = ta;
+    __syncthreads();
+    if (tid == 0) {
+        u64 t = (u64)aZ * aZ * aZ - (u64)aZ;
+        double d = 0.0;
+        for (int w = 0; w < NW; ++w) { t += s_red[w]; d += s_redd[w]; }
+        *s_TA = t;
+        *s_refsum = d;
+    }
+    __syncthreads();
+    return true;
+}
+
 // LG: also compile the lane-per-group form for blocks of 64 short runs (sparse layouts); it needs more registers
 // (the lane's history), so the dense instantiations leave it out and keep 4 waves per SIMD.
 template <typename KeyT, int KMAX, bool RUNEND, int NT, bool LG>
@@ -480,113 +595,16 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
         u64 T_A = 0;
         double refsum = 0.0;
         if (RUNEND && P.ref_buckets) { // uniform
-            // ---- reference column -> value buckets in LDS (no sort) ----
-            constexpr int NBK = 1 << OVO_REF_BUCKETS_LG;
-            u32 *tab32 = (u32 *)runend;
-            u16 *tab16 = (u16 *)runend;
             KeyT *s_kr = (KeyT *)(s_refsum + 1);  // [2]
-            u32 *s_cnt = (u32 *)(s_kr + 2);       // [0] zeros  [1] negatives  [2] largest bucket
-            for (int b = tid; b < NBK / 2; b += NT) tab32[b] = 0u;
-            if (tid == 0) { s_kr[0] = KeyInfo<KeyT>::MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; }
-            __syncthreads();
-            {
-                KeyT tmin = KeyInfo<KeyT>::MAXK, tmax = (KeyT)0;
-                u32 nz0 = 0, ng = 0;
-                double rs = 0.0;
-                for (u32 i = tid; i < nA; i += NT) {
-                    const KeyT k = Xs[rstart + i];
-                    rs += P.is_log1p ? key_to_expm1(k, P.dt) : key_to_double(k, P.dt);
-                    if (k != ZEROK) { tmin = k < tmin ? k : tmin; tmax = k > tmax ? k : tmax; ng += k < ZEROK ? 1u : 0u; }
-                    else ++nz0;
-                }
-                rs = wave_sum(rs);
-                nz0 = (u32)wave_sum((int)nz0);
-                ng = (u32)wave_sum((int)ng);
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) {
-                    const KeyT o1 = __shfl_xor(tmin, d), o2 = __shfl_xor(tmax, d);
-                    tmin = o1 < tmin ? o1 : tmin;
-                    tmax = o2 > tmax ? o2 : tmax;
-                }
-                if (lane == 0) {
-                    s_redd[wave] = rs;
-                    atomicMin(&s_kr[0], tmin);
-                    atomicMax(&s_kr[1], tmax);
-                    if (nz0) atomicAdd(&s_cnt[0], nz0);
-                    if (ng) atomicAdd(&s_cnt[1], ng);
-                }
-            }
-            __syncthreads();
-            aZ = s_cnt[0];
-            bk.zeros = aZ;
-            nnegA = lbZ = s_cnt[1];
-            nAs = nA - aZ;
-            const bool have = s_kr[1] >= s_kr[0];
-            bk.kmin = have ? s_kr[0] : (KeyT)0;
-            const KeyT kmax = have ? s_kr[1] : (KeyT)0;
-            bk.shift = max(0, (int)(sizeof(KeyT) * 8) - (int)(sizeof(KeyT) == 4 ? __clz((u32)(kmax - bk.kmin)) : __clzll((long long)(u64)(kmax - bk.kmin))) - OVO_REF_BUCKETS_LG);
-            if (kmax == bk.kmin) bk.shift = 0;
-            for (u32 i = tid; i < nA; i += NT) {
-                const KeyT k = Xs[rstart + i];
-                if (k != ZEROK) {
-                    const u32 b = refbk_bucket(bk, k);
-                    atomicAdd(&tab32[b >> 1], (b & 1u) ? 0x10000u : 1u);
-                }
-            }
-            __syncthreads();
-            u32 mxb = 0;
-            for (int b = tid; b < NBK; b += NT) mxb = max(mxb, (u32)tab16[b]);
-            mxb = (u32)wave_incl_scan_max((int)mxb);
-            if (lane == 63) atomicMax(&s_cnt[2], mxb);
-            __syncthreads();
-            if (s_cnt[2] <= (u32)OVO_REF_MAX_BUCKET) { // uniform
-                { // exclusive scan of the 16-bit counters (scratch: the per-wave Bloom words, re-zeroed below)
-                    u32 *tmp = sb_all;
-                    const int per = NBK / NT, b0 = tid * per;
-                    u32 sm = 0;
-                    for (int i = 0; i < per; ++i) sm += tab16[b0 + i];
-                    tmp[tid] = sm;
-                    __syncthreads();
-                    for (int d = 1; d < NT; d <<= 1) {
-                        const u32 v = (tid >= d) ? tmp[tid - d] : 0u;
-                        __syncthreads();
-                        tmp[tid] += v;
-                        __syncthreads();
-                    }
-                    u32 run = tmp[tid] - sm;
-                    __syncthreads();
-                    tmp[tid] = 0u;
-                    for (int i = 0; i < per; ++i) { const u32 cnt = tab16[b0 + i]; tab16[b0 + i] = (u16)run; run += cnt; }
-                    __syncthreads();
-                }
-                for (u32 i = tid; i < nA; i += NT) {
-                    const KeyT k = Xs[rstart + i];
-                    if (k != ZEROK) {
-                        const u32 b = refbk_bucket(bk, k);
-                        const u32 old = atomicAdd(&tab32[b >> 1], (b & 1u) ? 0x10000u : 1u);
-                        A[(b & 1u) ? (old >> 16) : (old & 0xFFFFu)] = k;
-                    }
-                }
-                if (tid < 4) A[nAs + tid] = KeyInfo<KeyT>::MAXK; // the bucket walk reads up to 3 keys past a bucket's end
-                __syncthreads();
+            u32 *s_cnt = (u32 *)(s_kr + 2);       // [0] zeros  [1] negatives  [2] largest bucket  [3] shift
+            if (ovo_build_ref_buckets<KeyT, NT>(Xs + rstart, nA, A, runend, sb_all, s_red, s_redd, s_TA, s_refsum, s_kr, s_cnt, P.dt, P.is_log1p)) {
                 bk.on = true;
-                u64 ta = 0; // ties inside the reference: sum over its non-zero keys of (run length^2 - 1), plus its zero run
-                for (u32 i = tid; i < nAs; i += NT) {
-                    u32 lb, a;
-                    ref_find<KeyT, RUNEND>(A, runend, nAs, 0u, bk, A[i], lb, a);
-                    ta += (u64)a * a - 1ull;
-                }
-                ta = wave_sum(ta);
-                if (lane == 0) s_red[wave] = ta;
-                __syncthreads();
-                if (tid == 0) {
-                    u64 t = (u64)aZ * aZ * aZ - (u64)aZ;
-                    double d = 0.0;
-                    for (int w = 0; w < NW; ++w) { t += s_red[w]; d += s_redd[w]; }
-                    *s_TA = t;
-                    *s_refsum = d;
-                }
-                __syncthreads();
+                aZ = s_cnt[0];
+                bk.zeros = aZ;
+                nnegA = lbZ = s_cnt[1];
+                nAs = nA - aZ;
+                bk.kmin = s_kr[0];
+                bk.shift = (int)s_cnt[3];
                 T_A = *s_TA;
                 refsum = *s_refsum;
             }
