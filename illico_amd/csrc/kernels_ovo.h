@@ -203,7 +203,7 @@ __device__ __forceinline__ u32 bloom_fold(u64 k) { return (u32)(k ^ (k >> 32)); 
 
 // sk / sb (256 entries each, per wavefront) must be all-zero on entry and are all-zero again on exit: they serve
 // first as two 8192-bit Bloom tables, then as compaction scratch.
-template <typename KeyT, int K, int KIN, bool RUNEND>
+template <typename KeyT, int K, int KIN, bool RUNEND, int KB = K>
 __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, const KeyT *A,
                                                const u16 *runend, u32 nA, u32 topA, u32 zA, u32 lbZ, u32 aZ, KeyT *sk, u32 *sb,
                                                int lane, int dt, int is_log1p, u64 &S2out, u64 &tieout,
@@ -215,7 +215,7 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, c
 #pragma unroll
     for (int r = 0; r < K; ++r) { // vin[r] holds element r*64 + lane of the group (MAXK beyond nB)
         v[r] = vin[r];
-        if (r * 64 + lane < nB) s += is_log1p ? key_to_expm1(v[r], dt) : key_to_double(v[r], dt);
+        if (r < KB && r * 64 + lane < nB) s += is_log1p ? key_to_expm1(v[r], dt) : key_to_double(v[r], dt); // nB <= 64 * KB
     }
 
     // ---- distinct-values fast path (normalised / continuous data) ----
@@ -229,7 +229,7 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, c
         bool maybe_dup = false;
         u32 zc = 0;
 #pragma unroll
-        for (int r = 0; r < K; ++r) {
+        for (int r = 0; r < KB; ++r) {
             const bool valid = r * 64 + lane < nB;
             const bool nz = valid && v[r] != ZEROK;
             zc += (u32)__popcll(__ballot(valid && v[r] == ZEROK));
@@ -243,7 +243,7 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, c
         }
         const bool any_dup = __ballot(maybe_dup) != 0ull;
 #pragma unroll
-        for (int r = 0; r < K; ++r) { // wipe the words this lane touched (LDS is in order within a wavefront)
+        for (int r = 0; r < KB; ++r) { // wipe the words this lane touched (LDS is in order within a wavefront)
             if (r * 64 + lane < nB && v[r] != ZEROK) {
                 const u32 f = bloom_fold(v[r]);
                 bm1[bloom_hash1(f) >> 5] = 0u;
@@ -255,7 +255,7 @@ __device__ __forceinline__ void ovo_wave_group(const KeyT (&vin)[KIN], int nB, c
             // compact the non-zero keys through sk, then one lookup per key
             int base = 0;
 #pragma unroll
-            for (int r = 0; r < K; ++r) {
+            for (int r = 0; r < KB; ++r) {
                 const bool nz = (r * 64 + lane < nB) && v[r] != ZEROK;
                 const u64 m = __ballot(nz);
                 if (nz) sk[base + __popcll(m & lt_mask)] = v[r];
@@ -726,6 +726,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                 if (g < G && g != ref) {
                     if (nB <= 64) ovo_wave_group<KeyT, 1, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk);
                     else if (nB <= 128) ovo_wave_group<KeyT, 2, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk);
+                    else if (nB <= 192) ovo_wave_group<KeyT, 4, KMAX, RUNEND, 3>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk); // 3 rounds of the distinct-values path
                     else if (nB <= 256) ovo_wave_group<KeyT, 4, KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk);
                     else if (KMAX >= 8 && nB <= 512) ovo_wave_group<KeyT, (KMAX >= 8 ? 8 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk);
                     else if (KMAX >= 16 && nB <= 1024) ovo_wave_group<KeyT, (KMAX >= 16 ? 16 : 4), KMAX, RUNEND>(cur, nB, A, runend, nA, topA, zA, lbZ, aZ, sk, sb, lane, P.dt, P.is_log1p, S2, tie, sum, bk);
