@@ -117,3 +117,89 @@ def test_c3_sparse_formats_equal_dense_on_a_gene_slice(c2):
             got = eng.run_sparse(fmt, Ms.data, Ms.indices, Ms.indptr, Ms.shape, 0, Ms.shape[1])
             for a, b in zip(got, dense):
                 np.testing.assert_array_equal(a, b, err_msg=f"{fmt} ovr={ovr}")
+
+
+def _continuous_slice(c2, lb, ub):
+    """Normalised-like values on a gene slice of the C2 matrix: log1p(counts * U(0.5, 1.5)), zeros kept (bench.py recipe)."""
+    torch = c2["torch"]
+    gen = torch.Generator(device=c2["X"].device)
+    gen.manual_seed(1234)
+    blk = c2["X"][:, lb:ub]
+    return torch.log1p(blk * torch.empty_like(blk).uniform_(0.5, 1.5, generator=gen)).contiguous()
+
+
+def test_c2_continuous_ovo_bucketed_reference_equals_sorted_reference(c2):
+    """Full-size groups (300k cells, 2000 groups, 10 000 reference cells), continuous values: the sort route with the
+    reference column in value buckets gives the same planes, bit for bit, as with the sorted reference column; sampled
+    genes against the CPU oracle."""
+    Xc = _continuous_slice(c2, 2048, 2048 + 192)
+    grpc = c2["gc"](c2["codes"], G, False)
+    eng = c2["eng"]
+    got = [a.cpu().numpy() for a in _planes(c2, grpc, X=Xc)]
+    eng.set_option("no_ovo_ref_buckets", 1)
+    try:
+        want = [a.cpu().numpy() for a in _planes(c2, grpc, X=Xc)]
+    finally:
+        eng.set_option("no_ovo_ref_buckets", 0)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    cols = [0, 77, 191]
+    ora = oracle.run(Xc[:, cols].contiguous().cpu().numpy(), grpc, batch_size=1, n_threads=len(cols))
+    assert_planes_match(tuple(a[:, cols] for a in got), ora, ref_row=0, fc_rtol=1e-9, what="continuous OVO spot check")
+
+
+def test_c4_continuous_ovr_parts_route_equals_general_route(c2):
+    """Full-size OVR on continuous values: the value-range parts route (6 parts per gene here) gives the same U and p,
+    bit for bit, as the general route (segmented radix sort + sweeps); rank sums add up to N(N+1)/2 per gene; sampled
+    genes against the CPU oracle.  Fold changes are compared at 1e-12 (value sums are accumulated in a different order)."""
+    torch = c2["torch"]
+    Xc = _continuous_slice(c2, 4096, 4096 + 192)
+    grpc = c2["gc"](c2["codes"], G, True)
+    eng = c2["eng"]
+    eng.set_option("profile", 1)
+    eng.profile_reset()
+    try:
+        gp, gu, gfc = _planes(c2, grpc, X=Xc)
+        prof = eng.profile_get()
+    finally:
+        eng.set_option("profile", 0)
+    assert "k_ovr_partition" in prof and "k_ovr_gene" not in prof, prof
+    n_g = torch.from_numpy(grpc.counts).cuda().double().unsqueeze(1)
+    ranksum = (N - n_g) * n_g + n_g * (n_g + 1) / 2 - gu
+    assert bool((ranksum.sum(0) == N * (N + 1) / 2).all())
+    eng.set_option("no_ovr_parts_path", 1)
+    try:
+        wp, wu, wfc = _planes(c2, grpc, X=Xc)
+    finally:
+        eng.set_option("no_ovr_parts_path", 0)
+    np.testing.assert_array_equal(gu.cpu().numpy(), wu.cpu().numpy())
+    np.testing.assert_array_equal(gp.cpu().numpy(), wp.cpu().numpy())
+    np.testing.assert_allclose(gfc.cpu().numpy(), wfc.cpu().numpy(), rtol=1e-12, atol=0)
+    cols = [5, 100]
+    ora = oracle.run(Xc[:, cols].contiguous().cpu().numpy(), grpc, batch_size=1, n_threads=len(cols))
+    got = tuple(a[:, cols].cpu().numpy() for a in (gp, gu, gfc))
+    assert_planes_match(got, ora, fc_rtol=1e-9, what="continuous OVR spot check")
+
+
+def test_c3_continuous_csc_ovr_single_kernel_equals_general_route(c2):
+    """C3-shaped CSC slice (90 % zeros, continuous values, ~30 000 stored entries per gene): k_csc_ovr_gene (value
+    buckets in LDS) == the general route, bit for bit on U and p; the sorted form of the same kernel as well."""
+    torch = c2["torch"]
+    from scipy import sparse
+    Xc = _continuous_slice(c2, 6000, 6000 + 96)
+    Xc = Xc * (torch.rand(Xc.shape, device=Xc.device) < 0.2)
+    Ms = sparse.csc_matrix(Xc.cpu().numpy())
+    grpc = c2["gc"](c2["codes"], G, True)
+    eng = c2["eng"]
+    eng.set_groups(grpc)
+    run = lambda: eng.run_sparse("csc", Ms.data, Ms.indices, Ms.indptr, Ms.shape, 0, Ms.shape[1])
+    got = run()
+    for opt in ("no_csc_ovr_gene_path", "csc_ovr_sorted_form"):
+        eng.set_option(opt, 1)
+        try:
+            want = run()
+        finally:
+            eng.set_option(opt, 0)
+        np.testing.assert_array_equal(got[1], want[1], err_msg=opt)
+        np.testing.assert_array_equal(got[0], want[0], err_msg=opt)
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-12, atol=0, err_msg=opt)
