@@ -688,7 +688,8 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                     continue;
                 }
             }
-            TrReduce<u64> rS2, rTie;
+            TrReduce<u64> rS2;
+            u64 tie_out = 0; // lane j: tie term of group g0 + j
             TrReduce<double> rSum;
             // The next group's keys are fetched into registers while the current group is processed: one
             // wavefront walks ~G/NW groups back to back and would otherwise expose a full HBM round trip each.
@@ -738,7 +739,18 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                     }
                 }
                 rS2.push(S2, j, lane);
-                rTie.push(tie, j, lane);
+                { // tie partials are zero in most lanes (continuous data: all but lane 0's zero-run / T_A terms): reduce only
+                  // what is there instead of carrying a third 64-bit transpose-reduce
+                    const u64 m = __ballot(tie != 0ull);
+                    u64 tot = 0;
+                    if (m) {
+                        if ((m & (m - 1ull)) == 0ull) {
+                            const int src = __ffsll((long long)m) - 1;
+                            tot = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(tie >> 32), src) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)tie, src);
+                        } else tot = wave_sum(tie);
+                    }
+                    if (lane == j) tie_out = tot;
+                }
                 rSum.push(sum, j, lane);
             }
             const int g = g0 + lane; // lane j now holds the totals of group g0 + j
@@ -750,7 +762,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                     P.out_sum[o] = refsum;
                 } else {
                     P.out_2u[o] = 2ll * (long long)n_ref * (long long)P.counts[g] - (long long)rS2.result;
-                    P.out_tie[o] = rTie.result;
+                    P.out_tie[o] = tie_out;
                     P.out_sum[o] = rSum.result;
                 }
             }
