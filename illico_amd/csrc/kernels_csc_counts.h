@@ -57,6 +57,16 @@ __global__ __launch_bounds__(CSCC_NT) void k_csc_counts(CscCountsParams P) {
     for (int gene = blockIdx.x; gene < P.nb; gene += gridDim.x) {
         const long long col = P.gene_cols ? (long long)P.gene_cols[gene] : P.col0 + gene;
         const long long k0 = (long long)indptr[col] - P.kshift, k1 = (long long)indptr[col + 1] - P.kshift;
+        constexpr int UL = 8; // independent entries per thread in flight
+        // (the first round's loads are in flight while the tables are zeroed)
+        InT vn[UL];
+        IdxT in[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const long long k = k0 + u * NT + tid;
+            vn[u] = k < k1 ? data[k] : (InT)0;
+            in[u] = k < k1 ? indices[k] : (IdxT)0;
+        }
         for (int i = tid; i < G * WPG; i += NT) cscc_h[i] = 0;
         if (tid < RT) hsel[tid] = 0;
         if (HAS_BIG) {
@@ -66,15 +76,24 @@ __global__ __launch_bounds__(CSCC_NT) void k_csc_counts(CscCountsParams P) {
         if (tid == 0) s_bad = 0;
         __syncthreads();
         bool bad = false;
-        constexpr int UL = 8; // independent entries per thread in flight
+        // two-stage pipeline over the gene's entries: the values / row indices of round i + 1 are requested before round
+        // i's group codes (a dependent gather) and LDS atomics, so one HBM round trip per round is off the critical path
         for (long long kb = k0; kb < k1; kb += NT * UL) {
             InT v[UL];
             int cd[UL];
 #pragma unroll
             for (int u = 0; u < UL; ++u) {
-                const long long k = kb + u * NT + tid;
-                v[u] = k < k1 ? data[k] : (InT)0;
-                cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
+                v[u] = vn[u];
+                cd[u] = P.codes ? P.codes[(long long)in[u]] : (int)in[u]; // (entries past k1: row 0, value 0 -> ignored)
+            }
+            const long long kn = kb + (long long)NT * UL;
+            if (kn < k1) { // uniform
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const long long k = kn + u * NT + tid;
+                    vn[u] = k < k1 ? data[k] : (InT)0;
+                    in[u] = k < k1 ? indices[k] : (IdxT)0;
+                }
             }
 #pragma unroll
             for (int u = 0; u < UL; ++u)
