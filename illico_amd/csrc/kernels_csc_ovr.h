@@ -112,29 +112,74 @@ template <int NT> __device__ __forceinline__ void block_excl_scan_u16(u16 *arr, 
     __syncthreads();
 }
 
-// One source entry: CSC stored entry k of the column, or record k of the part.
+// One source entry: CSC stored entry k of the column, or record k of the part.  Raw loads (value / row index or group
+// code) are split from what is derived from them (key; group code through the codes[row] gather) so that the entry
+// loops can request round i + 1's raw loads before round i's gather and LDS work.
 template <typename InT, typename IdxT, typename KeyT, bool PARTS> struct OvrSource {
+    typedef typename std::conditional<PARTS, KeyT, InT>::type RawV;
+    typedef typename std::conditional<PARTS, u16, IdxT>::type RawI;
     const InT *data;
     const IdxT *indices;
     const int *codes;
     const KeyT *pkeys;
     const u16 *pcodes;
-    // key of entry k; nz = it takes part in the ranking (a stored zero is an implicit zero)
-    __device__ __forceinline__ KeyT key(long long k, bool in, bool &nz) const {
-        if constexpr (PARTS) {
-            nz = in;
-            return in ? pkeys[k] : (KeyT)0;
-        } else {
-            const InT v = in ? data[k] : (InT)0;
-            nz = v != (InT)0;
-            return key_of(v);
-        }
+    __device__ __forceinline__ RawV raw_v(long long k, bool in) const {
+        if constexpr (PARTS) return in ? pkeys[k] : (KeyT)0;
+        else return in ? data[k] : (InT)0;
     }
-    __device__ __forceinline__ int code(long long k, bool in) const {
-        if constexpr (PARTS) return in ? (int)pcodes[k] : 0;
-        else return in ? (codes ? codes[(long long)indices[k]] : (int)indices[k]) : 0;
+    __device__ __forceinline__ RawI raw_i(long long k, bool in) const {
+        if constexpr (PARTS) return in ? pcodes[k] : (u16)0;
+        else return in ? indices[k] : (IdxT)0;
+    }
+    // key of an entry; nz = it takes part in the ranking (a stored zero is an implicit zero)
+    __device__ __forceinline__ KeyT key_from(RawV v, bool in, bool &nz) const {
+        if constexpr (PARTS) { nz = in; return v; }
+        else { nz = v != (InT)0; return key_of(v); }
+    }
+    __device__ __forceinline__ int code_from(RawI i) const {
+        if constexpr (PARTS) return (int)i;
+        else return codes ? codes[(long long)i] : (int)i; // (entries past the end carry row 0: a valid, ignored look-up)
     }
 };
+
+// for every entry k in [k0, k1), 8 per thread and round: body(u, k, key, nz, code).  Two-stage pipeline: the raw loads of
+// the next round are issued before this round's code gather and body.
+template <bool WANT_CODE, int NT, int UL, typename Src, typename KeyT, typename Body>
+__device__ __forceinline__ void ovr_for_entries(const Src &src, long long k0, long long k1, int tid, Body &&body) {
+    typename Src::RawV vn[UL];
+    typename Src::RawI in[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+        const long long k = k0 + u * NT + tid;
+        vn[u] = src.raw_v(k, k < k1);
+        if (WANT_CODE) in[u] = src.raw_i(k, k < k1);
+    }
+    for (long long kb = k0; kb < k1; kb += (long long)NT * UL) {
+        KeyT key[UL];
+        bool nz[UL];
+        int cd[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const long long k = kb + u * NT + tid;
+            key[u] = src.key_from(vn[u], k < k1, nz[u]);
+            cd[u] = WANT_CODE ? src.code_from(in[u]) : 0;
+        }
+        const long long kn = kb + (long long)NT * UL;
+        if (kn < k1) { // uniform
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const long long k = kn + u * NT + tid;
+                vn[u] = src.raw_v(k, k < k1);
+                if (WANT_CODE) in[u] = src.raw_i(k, k < k1);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const long long k = kb + u * NT + tid;
+            if (k < k1) body(u, k, key[u], nz[u], cd[u]);
+        }
+    }
+}
 
 template <typename InT, typename IdxT, typename KeyT, bool PARTS>
 __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
@@ -212,7 +257,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
             const int row_step = ns > 8 * NT ? 8 : 1;
             for (long long k = k0 + tid; k < k1; k += (long long)NT * row_step) {
                 bool nz;
-                const KeyT key = src.key(k, true, nz);
+                const KeyT key = src.key_from(src.raw_v(k, true), true, nz);
                 if (nz) { tmin = key < tmin ? key : tmin; tmax = key > tmax ? key : tmax; }
             }
             tmin = wave_min_key(tmin);
@@ -232,31 +277,16 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         // ---- 1. per-group value sums, stored zeros, negatives, bucket sizes ----
         {
             u32 my_zero = 0, my_neg = 0;
-            for (long long kb = k0; kb < k1; kb += NT * UL) {
-                KeyT key[UL];
-                bool nz[UL];
-                int cd[UL];
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const long long k = kb + u * NT + tid;
-                    key[u] = src.key(k, k < k1, nz[u]);
-                    cd[u] = src.code(k, k < k1);
-                }
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const long long k = kb + u * NT + tid;
-                    if (k < k1) {
-                        if (nz[u]) {
-                            atomicAdd(&sums[cd[u]], P.is_log1p ? key_to_expm1(key[u], P.dt) : key_to_double(key[u], P.dt));
-                            my_neg += key[u] < ZEROK ? 1u : 0u;
-                            if (!sorted_form) {
-                                const u32 b = bucket_of(key[u]);
-                                atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u); // no carry: a counter stays below 2^16
-                            }
-                        } else ++my_zero; // a stored zero is an implicit zero
+            ovr_for_entries<true, NT, UL, decltype(src), KeyT>(src, k0, k1, tid, [&](int, long long, KeyT key, bool nz, int cd) {
+                if (nz) {
+                    atomicAdd(&sums[cd], P.is_log1p ? key_to_expm1(key, P.dt) : key_to_double(key, P.dt));
+                    my_neg += key < ZEROK ? 1u : 0u;
+                    if (!sorted_form) {
+                        const u32 b = bucket_of(key);
+                        atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u); // no carry: a counter stays below 2^16
                     }
-                }
-            }
+                } else ++my_zero; // a stored zero is an implicit zero
+            });
             my_zero = (u32)wave_sum((int)my_zero);
             my_neg = (u32)wave_sum((int)my_neg);
             if (lane == 0) {
@@ -292,56 +322,34 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         if (n > 0 && !sorted_form) {
             // ---- 3. bucket offsets, keys into their buckets ----
             block_excl_scan_u16<NT>(tab16, NBKT, (u32 *)A, tid); // the key buffer is still free: scan scratch
-            for (long long kb = k0; kb < k1; kb += NT * UL) {
-                KeyT key[UL];
-                bool nz[UL];
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const long long k = kb + u * NT + tid;
-                    key[u] = src.key(k, k < k1, nz[u]);
+            ovr_for_entries<false, NT, UL, decltype(src), KeyT>(src, k0, k1, tid, [&](int, long long, KeyT key, bool nz, int) {
+                if (nz) {
+                    const u32 b = bucket_of(key);
+                    const u32 old = atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u);
+                    A[(b & 1u) ? (old >> 16) : (old & 0xFFFFu)] = key;
                 }
-#pragma unroll
-                for (int u = 0; u < UL; ++u)
-                    if (nz[u]) {
-                        const u32 b = bucket_of(key[u]);
-                        const u32 old = atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u);
-                        A[(b & 1u) ? (old >> 16) : (old & 0xFFFFu)] = key[u];
-                    }
-            }
+            });
             if (tid < 4) A[n + tid] = MAXK; // the bucket walk below reads up to 3 keys past a bucket's end
             __syncthreads(); // now tab16[b] = one past bucket b; it starts at tab16[b - 1]
             // ---- 4. every stored entry against its own bucket ----
-            for (long long kb = k0; kb < k1; kb += NT * UL) {
-                KeyT key[UL];
-                bool nz[UL];
-                int cd[UL];
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const long long k = kb + u * NT + tid;
-                    key[u] = src.key(k, k < k1, nz[u]);
-                    cd[u] = src.code(k, k < k1);
-                }
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    if (nz[u]) {
-                        const KeyT q = key[u];
-                        const u32 b = bucket_of(q);
-                        const u32 lo = b ? tab16[b - 1] : 0u, hi = tab16[b];
-                        u32 less = 0, eq = 0;
-                        // 4 keys per step; keys past the bucket's end belong to later buckets (larger than q) or are the
-                        // MAXK pad, so they count for neither sum
-                        for (u32 j = lo; j < hi; j += 4) {
-                            const KeyT a0 = A[j], a1 = A[j + 1], a2 = A[j + 2], a3 = A[j + 3];
-                            less += (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u) + (a3 < q ? 1u : 0u);
-                            eq += (a0 == q ? 1u : 0u) + (a1 == q ? 1u : 0u) + (a2 == q ? 1u : 0u) + (a3 == q ? 1u : 0u);
-                        }
-                        const u64 s = (u64)base + lo + less;
-                        const u64 add = 2ull * s + eq + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
-                        atomicAdd(&acc[cd[u]], add + CNT1);
-                        tie += (u64)eq * eq - 1ull;
+            ovr_for_entries<true, NT, UL, decltype(src), KeyT>(src, k0, k1, tid, [&](int, long long, KeyT q, bool nz, int cd) {
+                if (nz) {
+                    const u32 b = bucket_of(q);
+                    const u32 lo = b ? tab16[b - 1] : 0u, hi = tab16[b];
+                    u32 less = 0, eq = 0;
+                    // 4 keys per step; keys past the bucket's end belong to later buckets (larger than q) or are the MAXK
+                    // pad, so they count for neither sum
+                    for (u32 j = lo; j < hi; j += 4) {
+                        const KeyT a0 = A[j], a1 = A[j + 1], a2 = A[j + 2], a3 = A[j + 3];
+                        less += (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u) + (a3 < q ? 1u : 0u);
+                        eq += (a0 == q ? 1u : 0u) + (a1 == q ? 1u : 0u) + (a2 == q ? 1u : 0u) + (a3 == q ? 1u : 0u);
                     }
+                    const u64 s = (u64)base + lo + less;
+                    const u64 add = 2ull * s + eq + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
+                    atomicAdd(&acc[cd], add + CNT1);
+                    tie += (u64)eq * eq - 1ull;
                 }
-            }
+            });
         } else if (n > 0) {
             // ---- sorted form: keys -> LDS, sort, tie blocks, two look-ups per entry ----
             const int ncap = (ns + CH - 1) / CH * CH;
@@ -351,20 +359,9 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                 continue;
             }
             for (int i = ns + tid; i < ncap; i += NT) A[i] = MAXK;
-            for (long long kb = k0; kb < k1; kb += NT * UL) {
-                KeyT key[UL];
-                bool nz[UL];
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const long long k = kb + u * NT + tid;
-                    key[u] = src.key(k, k < k1, nz[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const long long k = kb + u * NT + tid;
-                    if (k < k1) A[k - k0] = nz[u] ? key[u] : MAXK; // stored zeros sort past the n keys
-                }
-            }
+            ovr_for_entries<false, NT, UL, decltype(src), KeyT>(src, k0, k1, tid, [&](int, long long k, KeyT key, bool nz, int) {
+                A[k - k0] = nz ? key : MAXK; // stored zeros sort past the n keys
+            });
             __syncthreads();
             block_sort_hybrid<KeyT, NT, CSCO_K>(A, ncap, tid);
             const u32 un = (u32)n, top = top_pow2(un);
@@ -375,28 +372,15 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                     tie += t * t * t - t;
                 }
             }
-            for (long long kb = k0; kb < k1; kb += NT * UL) {
-                KeyT key[UL];
-                bool nz[UL];
-                int cd[UL];
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const long long k = kb + u * NT + tid;
-                    key[u] = src.key(k, k < k1, nz[u]);
-                    cd[u] = src.code(k, k < k1);
+            ovr_for_entries<true, NT, UL, decltype(src), KeyT>(src, k0, k1, tid, [&](int, long long, KeyT q, bool nz, int cd) {
+                if (nz) {
+                    const u32 s = lower_bound_pow2(A, un, top, q);
+                    u32 e = s + 1;
+                    if (e < un && A[e] == q) e = upper_bound_pow2(A, un, top, q);
+                    const u64 add = 2ull * (u64)base + (u64)s + (u64)e + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
+                    atomicAdd(&acc[cd], add + CNT1);
                 }
-#pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    if (nz[u]) {
-                        const KeyT q = key[u];
-                        const u32 s = lower_bound_pow2(A, un, top, q);
-                        u32 e = s + 1;
-                        if (e < un && A[e] == q) e = upper_bound_pow2(A, un, top, q);
-                        const u64 add = 2ull * (u64)base + (u64)s + (u64)e + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
-                        atomicAdd(&acc[cd[u]], add + CNT1);
-                    }
-                }
-            }
+            });
         }
         tie = wave_sum(tie);
         __syncthreads(); // (also: s_red's readers of step 2 are done)
