@@ -47,6 +47,43 @@ static inline size_t cscg_lds_bytes(int G, int key_cap, int runend_cap, size_t k
     return b;
 }
 
+// for every stored entry of [k0, k1), UL per thread and round: body(value, group code).  Two-stage pipeline: the values / row
+// indices of round i + 1 are requested before round i's codes[row] gather and LDS work (one workgroup per CU holds the
+// LDS, so nothing else hides that round trip).
+template <int NT, int UL, typename InT, typename IdxT, typename Body>
+__device__ __forceinline__ void csc_for_entries(const InT *__restrict__ data, const IdxT *__restrict__ indices, const int *__restrict__ codes,
+                                                long long k0, long long k1, int tid, Body &&body) {
+    InT vn[UL];
+    IdxT in[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+        const long long k = k0 + u * NT + tid;
+        vn[u] = k < k1 ? data[k] : (InT)0;
+        in[u] = k < k1 ? indices[k] : (IdxT)0;
+    }
+    for (long long kb = k0; kb < k1; kb += (long long)NT * UL) {
+        InT v[UL];
+        int cd[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            v[u] = vn[u];
+            cd[u] = codes ? codes[(long long)in[u]] : (int)in[u]; // (entries past k1: row 0, value 0 -> ignored by the bodies)
+        }
+        const long long kn = kb + (long long)NT * UL;
+        if (kn < k1) { // uniform
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const long long k = kn + u * NT + tid;
+                vn[u] = k < k1 ? data[k] : (InT)0;
+                in[u] = k < k1 ? indices[k] : (IdxT)0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u)
+            if (v[u] != (InT)0) body(v[u], cd[u]);
+    }
+}
+
 template <typename InT, typename IdxT, typename KeyT>
 __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
     constexpr int NT = CSCG_NT, NW = NT / 64;
@@ -77,19 +114,7 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
         for (int g = tid; g <= G; g += NT) ends[g] = 0;
         __syncthreads();
         constexpr int UL = 8; // independent entries per thread in flight
-        for (long long kb = k0; kb < k1; kb += NT * UL) {
-            InT v[UL];
-            int cd[UL];
-#pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                const long long k = kb + u * NT + tid;
-                v[u] = k < k1 ? data[k] : (InT)0;
-                cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < UL; ++u)
-                if (v[u] != (InT)0) atomicAdd(&ends[cd[u]], 1u);
-        }
+        csc_for_entries<NT, UL>(data, indices, P.codes, k0, k1, tid, [&](InT, int cd) { atomicAdd(&ends[cd], 1u); });
         __syncthreads();
         const u32 nA = ends[ref];
         u32 mx = 0;
@@ -109,19 +134,7 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
             continue;
         }
         // ---- 3. regroup the keys in LDS ----
-        for (long long kb = k0; kb < k1; kb += NT * UL) {
-            InT v[UL];
-            int cd[UL];
-#pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                const long long k = kb + u * NT + tid;
-                v[u] = k < k1 ? data[k] : (InT)0;
-                cd[u] = k < k1 ? (P.codes ? P.codes[(long long)indices[k]] : (int)indices[k]) : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < UL; ++u)
-                if (v[u] != (InT)0) keybuf[atomicAdd(&ends[cd[u]], 1u)] = key_of(v[u]);
-        }
+        csc_for_entries<NT, UL>(data, indices, P.codes, k0, k1, tid, [&](InT v, int cd) { keybuf[atomicAdd(&ends[cd], 1u)] = key_of(v); });
         __syncthreads();
         // now ends[g] = one past the last key of group g; its run starts at ends[g-1] (0 for g = 0)
         // ---- 4. reference run: sort in place, run ends, T_A, sum ----
