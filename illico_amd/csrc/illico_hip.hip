@@ -88,6 +88,7 @@ struct illico_ctx {
     bool no_ovr_library_sort = false;   // 1: the general OVR route sorts inside k_ovr_gene (LSD radix passes) instead of rocPRIM's segmented sort
     bool no_csr_tile_gather = false;    // 1: CSR -> CSC always by the scatter form (k_csr_block_scatter), as for unsorted rows
     bool no_csr_transpose_path = false; // 1: CSR is regrouped by (gene, group) with global atomics instead of being transposed to CSC
+    bool dense_window_f32 = false;      // 1: CSR dense windows hold float32 cells instead of bytes
     bool no_dense_window_path = false; // 1: CSR never goes through dense float32 windows + the fused kernels
     int fused_groups_per_wg = 0; // 0 = auto
     int ovr_hist_groups_per_wg = 0; // k_ovr_from_hists; 0 = auto
@@ -269,6 +270,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_ovr_library_sort")) c->no_ovr_library_sort = value != 0;
     else if (!strcmp(key, "no_csr_tile_gather")) c->no_csr_tile_gather = value != 0;
     else if (!strcmp(key, "no_csr_transpose_path")) c->no_csr_transpose_path = value != 0;
+    else if (!strcmp(key, "dense_window_f32")) c->dense_window_f32 = value != 0;
     else if (!strcmp(key, "no_dense_window_path")) c->no_dense_window_path = value != 0;
     else if (!strcmp(key, "ovr_hist_groups_per_wg")) c->ovr_hist_groups_per_wg = (int)std::max<int64_t>(0, value);
     else if (!strcmp(key, "fused_groups_per_wg")) c->fused_groups_per_wg = (int)std::max<int64_t>(0, value);

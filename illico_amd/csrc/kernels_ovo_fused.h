@@ -76,6 +76,13 @@ template <> __device__ __forceinline__ u32 clamp_count<int64_t, 64>(int64_t v, b
     return c;
 }
 
+// (byte windows written by k_csr_densify: 255 marks a value the window cannot hold)
+template <> __device__ __forceinline__ u32 clamp_count<uint8_t, 64>(uint8_t v, bool &exact) {
+    const u32 c = min((u32)v, 63u);
+    exact = c == (u32)v;
+    return c;
+}
+
 // One chunk = UU rows of one group for the wavefront's 64 genes, in two straight-line halves: gather_rows requests
 // the UU row segments back to back, consume_* works through them in order behind counted vmcnt waits.
 //  * row indices come from scalar loads (the perm array is read through the constant address space, so a uniform

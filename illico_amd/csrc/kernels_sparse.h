@@ -441,12 +441,25 @@ __global__ __launch_bounds__(TR_NT) void k_csr_tile_gather(const InT *__restrict
 // (value, row) pairs with scattered stores.
 #define DENS_NT 256
 #define DENS_WB 8192 // columns per LDS row block
-template <typename InT, typename IdxT>
+// OutT = float (the window holds any float32-exact value) or uint8_t (count windows for the fused kernels, which only take
+// integers below 64 anyway: a quarter of the bytes written here and read there; 255 = not an integer in [0, 255)).
+template <typename OutT, typename InT> __device__ __forceinline__ OutT dens_cell(InT v);
+template <> __device__ __forceinline__ float dens_cell<float, float>(float v) { return v; }
+template <> __device__ __forceinline__ float dens_cell<float, double>(double v) { float f = (float)v; return (double)f == v ? f : __int_as_float(0x7FC00000); }
+template <> __device__ __forceinline__ float dens_cell<float, int32_t>(int32_t v) { float f = (float)v; return (v > -(1 << 24) && v < (1 << 24)) ? f : __int_as_float(0x7FC00000); }
+template <> __device__ __forceinline__ float dens_cell<float, int64_t>(int64_t v) { float f = (float)v; return (v > -(1ll << 24) && v < (1ll << 24)) ? f : __int_as_float(0x7FC00000); }
+template <> __device__ __forceinline__ uint8_t dens_cell<uint8_t, float>(float v) { const float m = __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f); const u32 c = (u32)m; return ((float)c == v && c < 255u) ? (uint8_t)c : (uint8_t)255; }
+template <> __device__ __forceinline__ uint8_t dens_cell<uint8_t, double>(double v) { const double m = fmin(fmax(v, 0.0), 255.0); const u32 c = (u32)m; return ((double)c == v && c < 255u) ? (uint8_t)c : (uint8_t)255; }
+template <> __device__ __forceinline__ uint8_t dens_cell<uint8_t, int32_t>(int32_t v) { return (v >= 0 && v < 255) ? (uint8_t)v : (uint8_t)255; }
+template <> __device__ __forceinline__ uint8_t dens_cell<uint8_t, int64_t>(int64_t v) { return (v >= 0 && v < 255) ? (uint8_t)v : (uint8_t)255; }
+
+template <typename InT, typename IdxT, typename OutT>
 __global__ __launch_bounds__(DENS_NT) void k_csr_densify(const InT *__restrict__ data, const IdxT *__restrict__ indices,
                                                          const IdxT *__restrict__ indptr, int n_rows, long long c0, int W,
-                                                         float *__restrict__ D, long long ldD) {
-    __shared__ __align__(16) float row[DENS_WB];
+                                                         OutT *__restrict__ D, long long ldD) {
+    __shared__ __align__(16) OutT row[DENS_WB];
     constexpr int UL = 4; // stored entries per thread requested together (column and value loads are independent)
+    constexpr int VW = 16 / (int)sizeof(OutT); // cells per 16-byte store
     const int tid = threadIdx.x;
     long long col[UL]; // column (relative to c0) of the entries in flight; < 0: none
     InT v[UL];
@@ -462,11 +475,7 @@ __global__ __launch_bounds__(DENS_NT) void k_csr_densify(const InT *__restrict__
 #pragma unroll
         for (int j = 0; j < UL; ++j) {
             const long long cj = col[j] - cb;
-            if (col[j] >= 0 && cj >= 0 && cj < wb) {
-                float f = (float)v[j];
-                if (!((InT)f == v[j])) f = __int_as_float(0x7FC00000); // not representable (or NaN): send the gene elsewhere
-                row[cj] = f;
-            }
+            if (col[j] >= 0 && cj >= 0 && cj < wb) row[cj] = dens_cell<OutT, InT>(v[j]); // not representable: sends the gene elsewhere
         }
     };
     int r = blockIdx.x;
@@ -477,8 +486,8 @@ __global__ __launch_bounds__(DENS_NT) void k_csr_densify(const InT *__restrict__
         long long sn = 0, en = 0;
         if (rn < n_rows) { sn = (long long)indptr[rn]; en = (long long)indptr[rn + 1]; }
         for (int cb = 0; cb < W; cb += DENS_WB) {
-            const int wb = min(DENS_WB, W - cb), wb4 = (wb + 3) & ~3;
-            for (int i = tid * 4; i < wb4; i += DENS_NT * 4) *(float4 *)&row[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int wb = min(DENS_WB, W - cb), wbv = (wb + VW - 1) / VW * VW;
+            for (int i = tid * VW; i < wbv; i += DENS_NT * VW) *(uint4 *)&row[i] = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
             if (cb > 0) fetch(s, e); // wide windows: the row is walked once per column block
             scatter(cb, wb);
@@ -486,9 +495,9 @@ __global__ __launch_bounds__(DENS_NT) void k_csr_densify(const InT *__restrict__
             __syncthreads();
             // the next row's first entries are requested before this row is copied out: their latency hides behind the stores
             if (cb + DENS_WB >= W) fetch(sn, en);
-            float *dst = D + (long long)r * ldD + cb; // ldD and cb are multiples of 4: 16-byte aligned
-            for (int i = tid * 4; i < wb4; i += DENS_NT * 4) {
-                if (i + 4 <= wb) *(float4 *)&dst[i] = *(const float4 *)&row[i];
+            OutT *dst = D + (long long)r * ldD + cb; // ldD and cb are multiples of 64 cells: 16-byte aligned
+            for (int i = tid * VW; i < wbv; i += DENS_NT * VW) {
+                if (i + VW <= wb) *(uint4 *)&dst[i] = *(const uint4 *)&row[i];
                 else for (int j = i; j < wb; ++j) dst[j] = row[j];
             }
             __syncthreads();

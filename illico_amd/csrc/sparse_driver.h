@@ -301,7 +301,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     // ---- CSR, count-valued, not too sparse: dense float32 windows + the fused single-pass kernels (k_csr_densify) ----
     const double density = (double)total_nnz / ((double)std::max<int64_t>(n_rows, 1) * (double)std::max<int64_t>(n_cols, 1));
     bool dense_window = is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) && density >= 0.015 &&
-                        (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes && total_nnz > 0;
+                        (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes && total_nnz > 0 && n_rows * 64 < (1ll << 32);
     if (dense_window) { // worth it only for count-valued data: look at 64k evenly spaced stored values first
         const int n_samples = (int)std::min<int64_t>(total_nnz, 1 << 16);
         if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
@@ -318,22 +318,31 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         dense_window = (double)n_bad[0] <= 0.02 * (double)n_samples && (double)n_bad[1] <= 0.005 * (double)n_samples;
     }
     if (dense_window) {
-        int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * 4)) & ~63ll;
+        // byte cells (the fused kernels only take integers below 64): a quarter of the window's traffic both ways;
+        // float32 cells behind "dense_window_f32"
+        const bool bytes = !c->dense_window_f32;
+        const size_t cell = bytes ? 1 : 4;
+        int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * cell)) & ~63ll;
         wmax = std::min<int64_t>(wmax, (1ll << 29));
         if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, (c->gene_batch + 63) & ~63ll);
         int64_t bad_lo = -1, bad_hi = -1;
         std::vector<u32> hf;
         for (int64_t w0 = col_lb; w0 < col_ub; w0 += wmax) {
             const int64_t wn = std::min<int64_t>(wmax, col_ub - w0), ldD = (wn + 63) & ~63ll;
-            if ((rc = get_scratch(c, "dense_window", (size_t)n_rows * ldD * 4, &v))) return rc;
-            float *D = (float *)v;
+            if ((rc = get_scratch(c, "dense_window", (size_t)n_rows * ldD * cell, &v))) return rc;
             {
                 ProfScope ps(c, KID_SPARSE_SEG);
-                hipLaunchKernelGGL((k_csr_densify<InT, IdxT>), dim3((unsigned)std::min<int64_t>(n_rows, 1 << 16)), dim3(DENS_NT), 0, c->stream,
-                                   d_data, d_indices, d_indptr, (int)n_rows, (long long)w0, (int)wn, D, (long long)ldD);
+                const dim3 grid((unsigned)std::min<int64_t>(n_rows, 1 << 16));
+                if (bytes)
+                    hipLaunchKernelGGL((k_csr_densify<InT, IdxT, uint8_t>), grid, dim3(DENS_NT), 0, c->stream, d_data, d_indices, d_indptr,
+                                       (int)n_rows, (long long)w0, (int)wn, (uint8_t *)v, (long long)ldD);
+                else
+                    hipLaunchKernelGGL((k_csr_densify<InT, IdxT, float>), grid, dim3(DENS_NT), 0, c->stream, d_data, d_indices, d_indptr,
+                                       (int)n_rows, (long long)w0, (int)wn, (float *)v, (long long)ldD);
                 HIPCHK(c, hipGetLastError());
             }
-            if ((rc = run_fused_ovo<float>(c, D, ldD, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc;
+            if (bytes) { if ((rc = run_fused_ovo<uint8_t>(c, v, ldD, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc; }
+            else if ((rc = run_fused_ovo<float>(c, v, ldD, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc;
             for (int64_t j = 0; j < wn; ++j)
                 if (hf[j]) {
                     if (bad_lo < 0) bad_lo = w0 + j;

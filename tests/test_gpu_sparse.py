@@ -204,8 +204,9 @@ def test_csc_interleaved_dense_and_sparse_genes(engine, test):
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64])
-def test_csr_dense_window_route(engine, test, dtype):
-    """CSR through dense float32 windows + the fused kernels: a window wider than one LDS row block (8192 columns),
+@pytest.mark.parametrize("f32_cells", [0, 1])
+def test_csr_dense_window_route(engine, test, dtype, f32_cells):
+    """CSR through dense windows (byte cells by default, float32 cells behind an option) + the fused kernels: a window wider than one LDS row block (8192 columns),
     windows split by gene_batch, and genes the fused kernels must hand back to the exact sparse route
     (fractional values, a value float32 cannot hold, values beyond the small-integer table, negatives)."""
     rng = np.random.RandomState(101)
@@ -224,6 +225,7 @@ def test_csr_dense_window_route(engine, test, dtype):
     X = X.astype(dtype).astype(np.float64)   # the values the engine sees (float32 rounds the fractional gene)
     M = sparse.csr_matrix(X.astype(dtype))
     want = oracle.run(X, g)
+    engine.set_option("dense_window_f32", f32_cells)
     engine.set_option("profile", 1)
     engine.profile_reset()
     try:
@@ -231,6 +233,7 @@ def test_csr_dense_window_route(engine, test, dtype):
         prof = engine.profile_get()
     finally:
         engine.set_option("profile", 0)
+        engine.set_option("dense_window_f32", 0)
     assert "k_ovo_fused" in prof or "k_ovr_fused" in prof, prof   # the dense-window route ran
     assert_planes_match(got, want, fc_rtol=1e-9, what=f"csr dense window {test} {dtype.__name__}")
     engine.set_option("gene_batch", 3000)
