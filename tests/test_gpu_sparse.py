@@ -26,7 +26,7 @@ def _run(engine, M, grpc, **kw):
 def route(request, engine):
     """Count-valued CSC genes with groups of at most 255 cells take the LDS-histogram kernel (OVO and OVR); otherwise
     CSC OVO has a single-kernel route (regroup + rank in LDS) with the two-kernel route (regroup into HBM, then
-    histogram / sort rank kernels) as fallback.  CSR first tries dense float32 windows + the fused dense kernels
+    histogram / sort rank kernels) as fallback.  CSR first tries dense byte windows + the fused dense kernels
     (count-valued data), otherwise it is transposed to CSC on the device and takes the CSC routes; the older CSR route
     (regroup by (gene, group) with global atomics) is kept behind an option.  The params force each so that all are
     exercised on the same data.  CSC OVR with values the histogram kernel cannot take (and CSR OVR after the device
