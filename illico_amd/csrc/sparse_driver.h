@@ -666,6 +666,7 @@ static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, c
     if (W == 0) return ILLICO_OK;
     OutPlanes o;
     if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) return rc;
+#ifndef ILLICO_DEV_F32_ONLY
 #define SP_CALL(InT, KeyT)                                                                                                 \
     (idx_dtype == ILLICO_IDX_I32                                                                                           \
          ? run_sparse_t<InT, int32_t, KeyT>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o) \
@@ -677,6 +678,11 @@ static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, c
     default: rc = SP_CALL(int64_t, u64); break;
     }
 #undef SP_CALL
+#else // development build: float32 values, int32 indices only
+    if (dtype == ILLICO_F32 && idx_dtype == ILLICO_IDX_I32)
+        rc = run_sparse_t<float, int32_t, u32>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o);
+    else rc = fail(c, ILLICO_ERR_DTYPE, "this development build holds the float32 / int32-index kernels only");
+#endif
     if (rc) return rc;
     return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
 }
