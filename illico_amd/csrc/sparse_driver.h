@@ -301,7 +301,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     // ---- CSR, count-valued, not too sparse: dense float32 windows + the fused single-pass kernels (k_csr_densify) ----
     const double density = (double)total_nnz / ((double)std::max<int64_t>(n_rows, 1) * (double)std::max<int64_t>(n_cols, 1));
     bool dense_window = is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) && density >= 0.015 &&
-                        (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes && total_nnz > 0 && n_rows * 64 < (1ll << 32);
+                        (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes && total_nnz > 0;
     if (dense_window) { // worth it only for count-valued data: look at 64k evenly spaced stored values first
         const int n_samples = (int)std::min<int64_t>(total_nnz, 1 << 16);
         if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
