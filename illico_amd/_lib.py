@@ -28,7 +28,7 @@ _DTYPES = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.int
 SYMBOLS = [
     "illico_ctx_create", "illico_ctx_destroy", "illico_ctx_set_stream", "illico_ctx_set_option",
     "illico_last_error", "illico_ctx_synchronize", "illico_set_groups", "illico_run_dense", "illico_run_csc",
-    "illico_run_csr", "illico_csr_indices_sorted", "illico_profile_num_kernels", "illico_profile_kernel_name",
+    "illico_run_csr", "illico_csr_indices_sorted", "illico_rank_statistics", "illico_profile_num_kernels", "illico_profile_kernel_name",
     "illico_profile_get", "illico_profile_reset", "illico_version",
 ]
 
@@ -60,6 +60,7 @@ def load() -> ctypes.CDLL:
         for f in (lib.illico_run_csc, lib.illico_run_csr):
             f.argtypes = [vp, vp, ci, vp, vp, ci, i64, i64, i64, i64, ci, ci, vp, vp, vp, i64]
         lib.illico_csr_indices_sorted.argtypes = [vp, vp, vp, ci, i64, ci, ctypes.POINTER(ci)]
+        lib.illico_rank_statistics.argtypes = [vp, vp, ci, i64, i64, i64, i64, i64, ci, vp, vp, vp]
         lib.illico_profile_num_kernels.argtypes = []
         lib.illico_profile_kernel_name.argtypes = [ci]
         lib.illico_profile_kernel_name.restype = ctypes.c_char_p
@@ -149,6 +150,7 @@ class Engine:
         self.h = h
         self._groups_key = None
         self._groups_keep = None
+        self._stream = None  # None = the context's own non-blocking stream; else the hipStream_t it was bound to
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
@@ -170,6 +172,21 @@ class Engine:
 
     def set_stream(self, stream_ptr: int):
         self._check(self.lib.illico_ctx_set_stream(self.h, ctypes.c_void_p(stream_ptr)))
+        self._stream = int(stream_ptr)
+
+    def _bind_torch_stream(self, *tensors):
+        """Device tensors as inputs or outputs: run this call on torch's CURRENT stream of the engine's device.
+
+        The engine's kernels are then ordered after whatever produced the inputs on that stream (``X = torch.log1p(Y)``
+        just before the call) and before whatever consumes device-resident output planes on it -- the same contract
+        every torch op gives.  Host arrays need nothing: the C side synchronises before it returns them.
+        """
+        if not any(_is_torch_tensor(t) and t.is_cuda for t in tensors):
+            return
+        import torch
+        s = int(torch.cuda.current_stream(self.device).cuda_stream)
+        if s != self._stream:
+            self.set_stream(s)
 
     def synchronize(self):
         self._check(self.lib.illico_ctx_synchronize(self.h))
@@ -256,6 +273,7 @@ class Engine:
         if ptrs is None:
             return planes
         flags = self._flags(is_log1p, use_continuity, tie_correct) | (FLAG_INPUT_DEVICE if on_dev else 0) | oflag
+        self._bind_torch_stream(keep, *planes)
         self._check(self.lib.illico_run_dense(self.h, buf_ptr, dt, n_rows, n_cols, ld, col_lb, col_ub, flags, alt,
                                               ptrs[0], ptrs[1], ptrs[2], out_ld))
         del keep
@@ -283,15 +301,39 @@ class Engine:
             return planes
         flags = self._flags(is_log1p, use_continuity, tie_correct) | (FLAG_INPUT_DEVICE if d.on_device else 0) | oflag
         fn = self.lib.illico_run_csc if fmt == "csc" else self.lib.illico_run_csr
+        self._bind_torch_stream(d.keep, i.keep, p.keep, *planes)
         self._check(fn(self.h, d.ptr, dtype_code(d.np_dtype), i.ptr, p.ptr, IDX_I32 if i.np_dtype == np.int32 else IDX_I64,
                        n_rows, n_cols, col_lb, col_ub, flags, alt, ptrs[0], ptrs[1], ptrs[2], out_ld))
         return planes
+
+    def rank_statistics(self, X, col_lb, col_ub, *, is_log1p=False):
+        """The ranking primitives before finalisation (include/illico_hip.h: illico_rank_statistics):
+        ``(two_u int64 [W, G], tie_sum uint64 [W, G], value_sum float64 [W, G])`` for the dense columns [col_lb, col_ub)."""
+        if _is_torch_tensor(X):
+            if X.dim() != 2 or X.stride(1) != 1:
+                raise ValueError("X must be row-major 2-D")
+            ptr, on_dev, keep = X.data_ptr(), X.is_cuda, X
+            n_rows, n_cols, ld = X.shape[0], X.shape[1], X.stride(0)
+            dt = dtype_code(str(X.dtype).replace("torch.", ""))
+        else:
+            X = np.ascontiguousarray(normalize_values(np.asarray(X)))
+            ptr, on_dev, keep = X.ctypes.data, False, X
+            (n_rows, n_cols), ld, dt = X.shape, X.shape[1], dtype_code(X.dtype)
+        W, G = col_ub - col_lb, self.n_groups
+        two_u, tie, vsum = np.zeros((W, G), np.int64), np.zeros((W, G), np.uint64), np.zeros((W, G), np.float64)
+        self._bind_torch_stream(keep)
+        flags = (FLAG_LOG1P if is_log1p else 0) | (FLAG_INPUT_DEVICE if on_dev else 0)
+        self._check(self.lib.illico_rank_statistics(self.h, ptr, dt, n_rows, n_cols, ld, col_lb, col_ub, flags,
+                                                    two_u.ctypes.data, tie.ctypes.data, vsum.ctypes.data))
+        del keep
+        return two_u, tie, vsum
 
     def csr_indices_sorted(self, indices, indptr, n_rows) -> bool:
         i, p = _Buf(indices), _Buf(indptr)
         if i.np_dtype != p.np_dtype:
             i, p = _Buf(np.asarray(indices), np.int64), _Buf(np.asarray(indptr), np.int64)
         res = ctypes.c_int(0)
+        self._bind_torch_stream(i.keep, p.keep)
         self._check(self.lib.illico_csr_indices_sorted(self.h, i.ptr, p.ptr, IDX_I32 if i.np_dtype == np.int32 else IDX_I64,
                                                        int(n_rows), FLAG_INPUT_DEVICE if i.on_device else 0,
                                                        ctypes.byref(res)))

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,7 @@
 #include "kernels_csc_gene.h"
 #include "kernels_csc_counts.h"
 #include "kernels_csc_ovr.h"
+#include "kernels_sums.h"
 
 // ---- profiled kernel ids ---------------------------------------------------------------------
 enum {
@@ -41,10 +43,11 @@ enum {
     KID_CSC_OVR,
     KID_OVR_PART,
     KID_OVR_RANK_PARTS,
+    KID_VALUE_SUMS,
     KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
-                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts"};
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums"};
 
 struct SampleKey {
     const void *ptr; int64_t n, ld, lb, ub; int dtype;
@@ -57,6 +60,9 @@ struct ProfEvent {
 };
 
 struct illico_ctx {
+    // Every entry point that takes the context holds this lock for the whole call: two host threads driving ONE context
+    // (the reference's joblib threads share one dispatcher, asymptotic_wilcoxon.py:236-241) are serialised, not raced.
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -104,7 +110,17 @@ struct illico_ctx {
     int64_t prof_n[KID_COUNT] = {0};
     // grow-only scratch
     std::map<std::string, std::pair<void *, size_t>> scratch;
+    // illico_rank_statistics: host arrays that receive the integer rank statistics of the two-pass routes instead of the
+    // finalisation ([W][G] each, W = the call's column window)
+    struct StatsTap { long long *two_u; u64 *tie; double *sum; } *tap = nullptr;
 };
+
+#define CTX_LOCK(c) std::lock_guard<std::recursive_mutex> ctx_lock__((c)->mu)
+
+// The message of a failed call is kept per calling thread (and in the context, for single-threaded callers): a second
+// thread's failure must not replace the text the first is about to read through illico_last_error.
+static thread_local std::string t_err;
+static thread_local const illico_ctx *t_err_ctx = nullptr;
 
 static int fail(illico_ctx *c, int code, const char *fmt, ...) {
     if (c) {
@@ -113,7 +129,10 @@ static int fail(illico_ctx *c, int code, const char *fmt, ...) {
         va_start(ap, fmt);
         vsnprintf(buf, sizeof buf, fmt, ap);
         va_end(ap);
+        CTX_LOCK(c);
         c->err = buf;
+        t_err = buf;
+        t_err_ctx = c;
     }
     return code;
 }
@@ -241,6 +260,7 @@ int illico_ctx_destroy(illico_ctx *c) {
 
 int illico_ctx_set_stream(illico_ctx *c, void *hip_stream) {
     if (!c) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     drain_events(c);
@@ -252,6 +272,7 @@ int illico_ctx_set_stream(illico_ctx *c, void *hip_stream) {
 
 int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
     if (!strcmp(key, "gene_batch")) c->gene_batch = value;
     else if (!strcmp(key, "scratch_bytes")) c->scratch_bytes = value;
     else if (!strcmp(key, "profile")) c->profile = value != 0;
@@ -278,10 +299,14 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     return ILLICO_OK;
 }
 
-const char *illico_last_error(const illico_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *illico_last_error(const illico_ctx *c) {
+    if (!c) return "null context";
+    return t_err_ctx == c ? t_err.c_str() : c->err.c_str();
+}
 
 int illico_ctx_synchronize(illico_ctx *c) {
     if (!c) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ILLICO_OK;
@@ -291,6 +316,7 @@ int illico_profile_num_kernels(void) { return KID_COUNT; }
 const char *illico_profile_kernel_name(int k) { return (k >= 0 && k < KID_COUNT) ? kKernelNames[k] : ""; }
 int illico_profile_get(illico_ctx *c, int k, double *total_ms, int64_t *launches) {
     if (!c || k < 0 || k >= KID_COUNT) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
     hipSetDevice(c->device);
     drain_events(c);
     if (total_ms) *total_ms = c->prof_ms[k];
@@ -299,6 +325,7 @@ int illico_profile_get(illico_ctx *c, int k, double *total_ms, int64_t *launches
 }
 int illico_profile_reset(illico_ctx *c) {
     if (!c) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
     hipSetDevice(c->device);
     drain_events(c);
     for (int k = 0; k < KID_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
@@ -308,7 +335,9 @@ int illico_profile_reset(illico_ctx *c) {
 // ---- groups ---------------------------------------------------------------------------------
 int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_t *counts, const int64_t *indices,
                       const int64_t *indptr, int64_t n_cells, int64_t n_groups, int64_t ref) {
-    if (!c || !encoded_groups || !counts || !indices || !indptr) return fail(c, ILLICO_ERR_ARG, "null group array");
+    if (!c) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
+    if (!encoded_groups || !counts || !indices || !indptr) return fail(c, ILLICO_ERR_ARG, "null group array");
     if (n_cells <= 0 || n_groups <= 0 || n_cells > 0x7FFFFFF0ll) return fail(c, ILLICO_ERR_ARG, "bad n_cells/n_groups");
     if (ref < -1 || ref >= n_groups) return fail(c, ILLICO_ERR_ARG, "encoded_ref_group out of range");
     HIPCHK(c, hipSetDevice(c->device));
@@ -325,6 +354,13 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
         if (g != ref) max_nonref = std::max<int64_t>(max_nonref, counts[g]);
     }
     if (tot != n_cells || indptr[n_groups] != n_cells) return fail(c, ILLICO_ERR_ARG, "counts do not sum to n_cells");
+    {   // n (n-1) (n+1) and the t^3 tie terms are 64-bit integer products, as in the reference (utils/math.py:95,
+        // ranking.py:107): they hold up to n = 2^21 - 1 cells per test (n = n_ref + n_tgt for OVO, every cell for OVR).
+        // Beyond that the reference's int64 wraps silently; this build refuses instead of returning wrapped values.
+        const int64_t n_test = ref < 0 ? n_cells : counts[ref] + max_nonref;
+        if (n_test > 2097151)
+            return fail(c, ILLICO_ERR_UNSUPPORTED, "%lld cells in one test: n(n-1)(n+1) and the tie sums overflow 64-bit integers beyond 2097151 cells (the reference's int64 arithmetic wraps there, utils/math.py:95)", (long long)n_test);
+    }
     posptr[n_groups] = (int)n_cells;
     for (int64_t i = 0; i < n_cells; ++i) {
         int64_t g = encoded_groups[i];
@@ -363,6 +399,52 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
 // ============================================================================================
 static const size_t kMaxLds = 160 * 1024;
 static const int kOvoThreads = 512;
+
+// ---- order-independent value sums (kernels_sums.h) ----
+template <typename InT, typename IdxT>
+static int launch_csc_value_sums(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, int64_t col0,
+                                 const int *d_cols, const int *d_codes, int nb, int dtype, int flags, double *ssum) {
+    CscSumsParams P;
+    P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = col0; P.gene_cols = d_cols; P.codes = d_codes;
+    P.nb = nb; P.G = (int)c->n_groups; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.acc_global = nullptr; P.out_sum = ssum;
+    const bool accg = csc_sums_lds_bytes(P.G, false) > kMaxLds / 2; // two workgroups per CU at least
+    const size_t lds = csc_sums_lds_bytes(P.G, accg);
+    if (accg) {
+        void *v;
+        int rc = get_scratch(c, "sums_acc", (size_t)nb * 2 * P.G * 8, &v);
+        if (rc) return rc;
+        P.acc_global = (long long *)v;
+        HIPCHK(c, hipMemsetAsync(v, 0, (size_t)nb * 2 * P.G * 8, c->stream));
+    }
+    ProfScope ps(c, KID_VALUE_SUMS);
+    if (accg) {
+        auto kern = k_csc_value_sums<InT, IdxT, true>;
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(SUMS_NT), lds, c->stream, P);
+    } else {
+        auto kern = k_csc_value_sums<InT, IdxT, false>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(SUMS_NT), lds, c->stream, P);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+template <typename KeyT>
+static int launch_seg_value_sums(illico_ctx *c, const KeyT *Xs, const u32 *seg, int nb, int dtype, int flags, double *ssum) {
+    SegSumsParams P;
+    P.Xs = Xs; P.seg_ptr = seg; P.nb = nb; P.G = (int)c->n_groups; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.out_sum = ssum;
+    ProfScope ps(c, KID_VALUE_SUMS);
+    hipLaunchKernelGGL((k_seg_value_sums<KeyT>), dim3(nb), dim3(SUMS_NT), 0, c->stream, P);
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+template <typename KeyT>
+static int launch_group_sums_rows(illico_ctx *c, const KeyT *Xt, int64_t stride, int nb, int dtype, int flags, double *ssum) {
+    ProfScope ps(c, KID_VALUE_SUMS);
+    hipLaunchKernelGGL((k_group_sums_rows<KeyT>), dim3(nb), dim3(SUMS_NT), 0, c->stream, Xt, (long long)stride, nb, (const int *)c->d_posptr,
+                       (int)c->n_groups, dtype, (flags & ILLICO_FLAG_LOG1P) ? 1 : 0, ssum);
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
 #include "ovr_driver.h"
 
 template <typename KeyT> static size_t ovo_lds_bytes(int ref_cap, bool runend, int nt, bool buckets = false) {
@@ -637,6 +719,7 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
     // ---- route 1 (device-resident dense OVO): fused single pass; it reports the genes it could not take ----
     std::vector<std::pair<int64_t, int64_t>> runs; // column ranges still to be computed by the two-pass routes
     bool try_fused = fused_path_allowed(c, flags) && (uint64_t)ld * sizeof(InT) < (1ull << 32); // row pitch: 32-bit byte offsets
+    if (c->tap) try_fused = false; // the fused kernels go from values to p-values without leaving statistics behind
     if (try_fused && in_dev && N > 0 && W > 0) { // count-valued at all?  64k evenly spaced cells of the window decide
         // The answer only picks the route (every route is exact), so it is remembered per (pointer, shape, window):
         // repeated calls on the same matrix skip the sampling kernel and its host round trip.
@@ -760,20 +843,52 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
             P.G = G; P.ref = (int)c->ref; P.n_genes = nb; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
             P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
             if ((rc = launch_ovo<KeyT>(c, P, c->h_counts[c->ref], c->max_nonref, gflags, &gb, false))) return rc;
+            if (c->tap) {
+                const size_t off = (size_t)(b0 - col_lb) * G, cnt = (size_t)nb * G;
+                HIPCHK(c, hipMemcpyAsync(c->tap->two_u + off, s2u, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->tap->tie + off, stie, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->tap->sum + off, ssum, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                continue;
+            }
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
         } else {
             bool done = false;
             if ((rc = run_ovr_dense_parts<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot, &done))) return rc;
             if (!done && (rc = run_ovr_dense_batch<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot))) return rc;
+            if (c->tap) {
+                const size_t off = (size_t)(b0 - col_lb) * G, cnt = (size_t)nb * G;
+                HIPCHK(c, hipMemcpyAsync(c->tap->two_u + off, s2u, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->tap->tie + off, stie, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->tap->sum + off, ssum, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                continue;
+            }
             if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
         }
     }
     return ILLICO_OK;
 }
 
+static int run_dense_any(illico_ctx *c, const void *X, int dtype, int64_t n_rows, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
+                         int alternative, const OutPlanes &o) {
+    switch (dtype) {
+    case ILLICO_F32: return run_dense_t<float, u32>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o);
+#ifndef ILLICO_DEV_F32_ONLY // development builds (ILLICO_DEV_F32_ONLY=1 python build.py) compile the float32 kernels only: 4x faster to build
+    case ILLICO_F64: return run_dense_t<double, u64>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o);
+    case ILLICO_I32: return run_dense_t<int32_t, u32>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o);
+    default: return run_dense_t<int64_t, u64>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o);
+#else
+    default: return fail(c, ILLICO_ERR_DTYPE, "this development build holds the float32 kernels only");
+#endif
+    }
+}
+
 extern "C" int illico_run_dense(illico_ctx *c, const void *X, int dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
                                 int64_t col_lb, int64_t col_ub, int flags, int alternative, double *out_p, double *out_u,
                                 double *out_fc, int64_t out_ld) {
+    if (!c) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
     int rc = check_common(c, n_rows, n_cols, col_lb, col_ub, alternative, out_p, out_u, out_fc, out_ld);
     if (rc) return rc;
     if (!X) return fail(c, ILLICO_ERR_ARG, "null X");
@@ -784,18 +899,27 @@ extern "C" int illico_run_dense(illico_ctx *c, const void *X, int dtype, int64_t
     if (W == 0) return ILLICO_OK;
     OutPlanes o;
     if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) return rc;
-    switch (dtype) {
-    case ILLICO_F32: rc = run_dense_t<float, u32>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o); break;
-#ifndef ILLICO_DEV_F32_ONLY // development builds (ILLICO_DEV_F32_ONLY=1 python build.py) compile the float32 kernels only: 4x faster to build
-    case ILLICO_F64: rc = run_dense_t<double, u64>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o); break;
-    case ILLICO_I32: rc = run_dense_t<int32_t, u32>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o); break;
-    default: rc = run_dense_t<int64_t, u64>(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o); break;
-#else
-    default: rc = fail(c, ILLICO_ERR_DTYPE, "this development build holds the float32 kernels only"); break;
-#endif
-    }
-    if (rc) return rc;
+    if ((rc = run_dense_any(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o))) return rc;
     return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
+}
+
+extern "C" int illico_rank_statistics(illico_ctx *c, const void *X, int dtype, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t col_lb,
+                                      int64_t col_ub, int flags, int64_t *out_two_u, uint64_t *out_tie_sum, double *out_value_sum) {
+    if (!c) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
+    int rc = check_common(c, n_rows, n_cols, col_lb, col_ub, 0, out_two_u, out_tie_sum, out_value_sum, col_ub - col_lb);
+    if (rc) return rc;
+    if (!X) return fail(c, ILLICO_ERR_ARG, "null X");
+    if (ld < n_cols) return fail(c, ILLICO_ERR_ARG, "ld smaller than n_cols");
+    if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (col_ub == col_lb) return ILLICO_OK;
+    illico_ctx::StatsTap tap{(long long *)out_two_u, (u64 *)out_tie_sum, out_value_sum};
+    c->tap = &tap;
+    OutPlanes none{nullptr, nullptr, nullptr, 0, false};
+    rc = run_dense_any(c, X, dtype, n_rows, ld, col_lb, col_ub, flags & (ILLICO_FLAG_LOG1P | ILLICO_FLAG_INPUT_DEVICE), 0, none);
+    c->tap = nullptr;
+    return rc;
 }
 
 #include "sparse_driver.h"

@@ -66,13 +66,14 @@ struct CscOvrParams {
     u32 *fallback;                       // [nb] set to 1 for genes this kernel cannot take
     long long *out_2u;                   // [nb][G] 2 U (U of "the rest", dense_ovr.py:57-61)
     u64 *out_tie;                        // [nb][G] sum (t^3 - t), the same for every group of a gene
-    double *out_sum;                     // [nb][G] per-group value sums (PARTS: accumulated with atomics, zeroed by the host)
+    // (per-group value sums are not formed here: they would be order-dependent float64 atomics.  The host launches
+    //  k_csc_value_sums / k_group_sums_rows, kernels_sums.h, whose results do not depend on the order of arrival.)
 };
 
 __host__ __device__ static inline size_t csco_fixed_lds_bytes(int G, int lg_buckets, bool parts) {
-    // acc (CSC: value sums in pass 1, packed rank sums / counts afterwards; parts: both live to the end) | bucket table |
-    // reductions: a multiple of 16
-    return (size_t)((G + 1) & ~1) * 8 * (parts ? 2 : 1) + ((size_t)2 << lg_buckets) + 256;
+    // acc (packed rank sums / counts) | bucket table | reductions: a multiple of 16
+    (void)parts;
+    return (size_t)((G + 1) & ~1) * 8 + ((size_t)2 << lg_buckets) + 256;
 }
 static inline int csco_key_cap(int G, int lg_buckets, size_t key_size, size_t lds_max, bool parts = false) {
     const size_t fixed = csco_fixed_lds_bytes(G, lg_buckets, parts);
@@ -191,8 +192,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     const int G = P.G, NBKT = 1 << P.lg_buckets;
     const size_t accb = (size_t)((G + 1) & ~1) * 8;
     u64 *acc = (u64 *)smem;                                   // [G]
-    double *sums = PARTS ? (double *)(smem + accb) : (double *)smem; // [G]; CSC: aliases acc (done before acc is used)
-    u32 *tab = (u32 *)(smem + accb * (PARTS ? 2 : 1));        // [NBKT / 2] two 16-bit bucket counters / offsets per word
+    u32 *tab = (u32 *)(smem + accb);                          // [NBKT / 2] two 16-bit bucket counters / offsets per word
     u16 *tab16 = (u16 *)tab;
     u64 *s_red = (u64 *)(tab + NBKT / 2);                     // [NW]
     KeyT *s_k = (KeyT *)(s_red + NW);                         // [2] smallest / largest non-zero key
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         // ---- 0. key range of the bucket function, from every 8th row of NT entries.  Any monotone bucket function ranks
         // correctly (keys outside the sampled range are clamped into the first / last bucket); the range only balances
         // the buckets. ----
-        for (int g = tid; g < G; g += NT) { sums[g] = 0.0; if constexpr (PARTS) acc[g] = 0ull; }
+        for (int g = tid; g < G; g += NT) acc[g] = 0ull;
         for (int b = tid; b < NBKT / 2; b += NT) tab[b] = 0u;
         if (tid == 0) { s_k[0] = MAXK; s_k[1] = (KeyT)0; s_misc[0] = 0u; s_misc[1] = 0u; s_misc[2] = 0u; }
         __syncthreads();
@@ -274,12 +274,11 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
             return (u32)(d < last_bucket ? d : last_bucket);
         };
         bool sorted_form = P.force_sorted != 0;
-        // ---- 1. per-group value sums, stored zeros, negatives, bucket sizes ----
+        // ---- 1. stored zeros, negatives, bucket sizes ----
         {
             u32 my_zero = 0, my_neg = 0;
-            ovr_for_entries<true, NT, UL, decltype(src), KeyT>(src, k0, k1, tid, [&](int, long long, KeyT key, bool nz, int cd) {
+            ovr_for_entries<false, NT, UL, decltype(src), KeyT>(src, k0, k1, tid, [&](int, long long, KeyT key, bool nz, int) {
                 if (nz) {
-                    atomicAdd(&sums[cd], P.is_log1p ? key_to_expm1(key, P.dt) : key_to_double(key, P.dt));
                     my_neg += key < ZEROK ? 1u : 0u;
                     if (!sorted_form) {
                         const u32 b = bucket_of(key);
@@ -299,9 +298,6 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         if constexpr (!PARTS) {
             n0 = P.n_cells - n;                              // zeros of the column
             nneg = (long long)s_misc[1];
-            for (int g = tid; g < G; g += NT) P.out_sum[(size_t)gene * G + g] = sums[g];
-            __syncthreads();
-            for (int g = tid; g < G; g += NT) acc[g] = 0ull;
         }
         u64 tie = 0;
         if (n > 0 && !sorted_form) {
@@ -344,6 +340,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                         less += (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u) + (a3 < q ? 1u : 0u);
                         eq += (a0 == q ? 1u : 0u) + (a1 == q ? 1u : 0u) + (a2 == q ? 1u : 0u) + (a3 == q ? 1u : 0u);
                     }
+                    if (q == MAXK) eq = (hi - lo) - less; // the largest key also matches the pad slots
                     const u64 s = (u64)base + lo + less;
                     const u64 add = 2ull * s + eq + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
                     atomicAdd(&acc[cd], add + CNT1);
@@ -392,10 +389,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
             // this part's share of the gene's accumulators
             for (int g = tid; g < G; g += NT) {
                 const u64 a = acc[g];
-                if (a) {
-                    atomicAdd(&P.gacc[(size_t)gene * G + g], a);
-                    atomicAdd(&P.out_sum[(size_t)gene * G + g], sums[g]);
-                }
+                if (a) atomicAdd(&P.gacc[(size_t)gene * G + g], a);
             }
             if (tid == 0 && tie_total) atomicAdd(&P.gtie[gene], tie_total);
         } else {

@@ -182,6 +182,9 @@ __device__ __forceinline__ void ref_find(const KeyT *A, const u16 *runend, u32 n
                 eq += (a0 == q ? 1u : 0u) + ((j + 1 < nA && a1 == q) ? 1u : 0u) + ((j + 2 < nA && a2 == q) ? 1u : 0u) + ((j + 3 < nA && a3 == q) ? 1u : 0u);
             }
         }
+        // a query equal to the largest key (INT_MAX, an all-ones NaN) also matches the MAXK pad slots past the last bucket:
+        // there every key of the bucket that is not smaller is equal
+        if (PAD && q == KeyInfo<KeyT>::MAXK) eq = (hi - lo) - less;
         lb = lo + less;
         a = q == KeyInfo<KeyT>::ZEROK ? bk.zeros : eq;
     } else {
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                         if (gl == ref) {
                             P.out_2u[o] = -2;
                             P.out_tie[o] = 0;
-                            P.out_sum[o] = refsum;
+                            if (P.out_sum) P.out_sum[o] = refsum;
                         } else {
                             const long long n_g = P.counts[gl];
                             const u64 zB = (u64)(n_g - n);
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                             const u64 t0 = (u64)zA_impl + zB;
                             P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
                             P.out_tie[o] = T_A + 3ull * TT + (t0 * t0 * t0 - t0);
-                            P.out_sum[o] = sum;
+                            if (P.out_sum) P.out_sum[o] = sum;
                         }
                     }
                     continue;
@@ -759,11 +762,11 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                 if (g == ref) {
                     P.out_2u[o] = -2;
                     P.out_tie[o] = 0;
-                    P.out_sum[o] = refsum;
+                    if (P.out_sum) P.out_sum[o] = refsum;
                 } else {
                     P.out_2u[o] = 2ll * (long long)n_ref * (long long)P.counts[g] - (long long)rS2.result;
                     P.out_tie[o] = tie_out;
-                    P.out_sum[o] = rSum.result;
+                    if (P.out_sum) P.out_sum[o] = rSum.result;
                 }
             }
         }

@@ -209,11 +209,11 @@ __global__ __launch_bounds__(COUNTS_NT, 4) void k_ovo_counts(OvoParams P, const 
                 if (g == ref) {
                     P.out_2u[o] = -2;
                     P.out_tie[o] = 0;
-                    P.out_sum[o] = (double)refsum_i;
+                    if (P.out_sum) P.out_sum[o] = (double)refsum_i;
                 } else {
                     P.out_2u[o] = 2ll * (long long)n_ref * (long long)P.counts[g] - (long long)rS2.result;
                     P.out_tie[o] = rTie.result;
-                    P.out_sum[o] = (double)rSum.result;
+                    if (P.out_sum) P.out_sum[o] = (double)rSum.result;
                 }
             }
         }

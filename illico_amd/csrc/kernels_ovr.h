@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
                     }
                     for (int i = p0[j] + RR * 64 + lane; i < p1[j]; i += 64) s += P.is_log1p ? key_to_expm1(ka[i], P.dt) : key_to_double(ka[i], P.dt);
                     s = wave_sum(s);
-                    if (lane == 0) P.out_sum[(size_t)gene * G + g] = s;
+                    if (lane == 0 && P.out_sum) P.out_sum[(size_t)gene * G + g] = s;
                 }
             }
         }

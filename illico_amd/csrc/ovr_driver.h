@@ -140,7 +140,9 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     HIPCHK(c, hipMemsetAsync(gflag, 0, (size_t)nb * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(unit_ctr, 0, 8, c->stream));
     HIPCHK(c, hipMemsetAsync(s2u, 0, (size_t)nb * G * 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(ssum, 0, (size_t)nb * G * 8, c->stream));
+    // per-group value sums from the group-contiguous key rows, in a fixed order (the parts see a group's values in an order
+    // that depends on timing)
+    if ((rc = launch_group_sums_rows<KeyT>(c, Xt, stride, nb, dtype, flags, ssum))) return rc;
     {
         OvrPartParams Q;
         Q.Xt = Xt; Q.stride = stride; Q.n_genes = nb; Q.n_cells = N; Q.code_by_pos = c->d_code_by_pos; Q.cap = cap;
@@ -157,7 +159,7 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
         P.pkeys = pkeys; P.pcodes = pcodes; P.pstride = stride; P.part_start = part_start; P.gene_info = gene_info;
         P.gacc = (u64 *)s2u; P.gtie = gtie; P.gflag = gflag; P.unit_list = unit_list; P.n_units = unit_ctr; P.unit_counter = unit_ctr + 1; P.nb = nb; P.counts = c->d_counts; P.G = G; P.dt = dtype;
         P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = N; P.key_cap = key_cap; P.lg_buckets = lg;
-        P.force_sorted = c->csc_ovr_sorted_form ? 1 : 0; P.out_sum = ssum;
+        P.force_sorted = c->csc_ovr_sorted_form ? 1 : 0;
         const size_t lds = csco_fixed_lds_bytes(G, lg, true) + (size_t)(key_cap + 4) * sizeof(KeyT);
         ProfScope ps(c, KID_OVR_RANK_PARTS);
         auto kern = k_csc_ovr_gene<KeyT, int, KeyT, true>;

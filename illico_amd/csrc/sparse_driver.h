@@ -175,6 +175,9 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
             hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCG_NT), lds, c->stream, P);
             HIPCHK(c, hipGetLastError());
         }
+        // the kernel adds a group's values in the order its LDS regroup happened to leave them: replace its sums by the
+        // order-independent ones
+        if ((rc = launch_csc_value_sums<InT, IdxT>(c, d_data, d_indices, d_indptr, kshift, cols[b0], d_cols ? d_cols + b0 : nullptr, d_codes, nb, dtype, flags, ssum))) return rc;
         if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0))) return rc; }
         else if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb))) return rc;
         h_fb.resize(nb);
@@ -229,12 +232,13 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
         P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.counts = c->d_counts; P.G = G; P.dt = dtype;
         P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.key_cap = key_cap; P.lg_buckets = lg;
         P.force_sorted = c->csc_ovr_sorted_form ? 1 : 0; P.fallback = fb;
-        P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
+        P.out_2u = s2u; P.out_tie = stie;
         {
             ProfScope ps(c, KID_CSC_OVR);
             hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCO_NT), lds, c->stream, P);
             HIPCHK(c, hipGetLastError());
         }
+        if ((rc = launch_csc_value_sums<InT, IdxT>(c, d_data, d_indices, d_indptr, kshift, cols[b0], d_cols ? d_cols + b0 : nullptr, d_codes, nb, dtype, flags, ssum))) return rc;
         if ((rc = launch_gene_totals(c, ssum, G, nb, gtot))) return rc;
         if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0))) return rc; }
         else if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb))) return rc;
@@ -272,7 +276,11 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
 
     // host copy of indptr (batch planning for CSC; total nnz for CSR)
     std::vector<IdxT> h_indptr(n_ptr);
-    if (in_dev) HIPCHK(c, hipMemcpy(h_indptr.data(), indptr, n_ptr * sizeof(IdxT), hipMemcpyDeviceToHost));
+    if (in_dev) { // on the context's stream: ordered after whatever produced indptr on it (a blocking hipMemcpy runs on the
+        // null stream, which non-blocking streams -- torch's side streams -- do not synchronise with)
+        HIPCHK(c, hipMemcpyAsync(h_indptr.data(), indptr, n_ptr * sizeof(IdxT), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     else memcpy(h_indptr.data(), indptr, n_ptr * sizeof(IdxT));
     const int64_t total_nnz = (int64_t)h_indptr[n_ptr - 1];
     if (h_indptr[0] != 0) return fail(c, ILLICO_ERR_ARG, "indptr[0] must be 0");
@@ -629,7 +637,10 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             OvoParams P;
             P.Xs = Xs; P.gene_stride = 0; P.pos_ptr = c->d_posptr; P.seg_ptr = seg; P.counts = c->d_counts;
             P.G = G; P.ref = (int)c->ref; P.n_genes = nb; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
-            P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
+            // value sums first (the global-sort fallback permutes Xs), exact whatever order the regroup left the runs in; the
+            // rank kernels then leave out_sum alone
+            if ((rc = launch_seg_value_sums<KeyT>(c, Xs, seg, nb, dtype, flags, ssum))) return rc;
+            P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = nullptr;
             OvoGlobalBufs gb;
             gb.kb = kb; gb.va = va; gb.vb = vb;
             // When the in-LDS sort route holds this batch it serves every gene (its lane-per-group form makes the
@@ -643,7 +654,8 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             P.keys_a = Xs; P.keys_b = kb; P.vals_a = va; P.vals_b = vb; P.code_by_pos = nullptr; P.seg_ptr = seg;
             P.stride = 0; P.pos_ptr = nullptr; P.counts = c->d_counts; P.G = G; P.n_genes = nb; P.dt = dtype;
             P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.ref = -1; P.gene_flags = nullptr;
-            P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
+            P.out_2u = s2u; P.out_tie = stie; P.out_sum = nullptr; // (the sort below permutes Xs: the sums come first)
+            if ((rc = launch_seg_value_sums<KeyT>(c, Xs, seg, nb, dtype, flags, ssum))) return rc;
             if ((rc = launch_ovr_gene<KeyT, true>(c, P))) return rc;
             if ((rc = launch_gene_totals(c, ssum, G, nb, gtot))) return rc;
             if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, fin_off, d_cols))) return rc;
@@ -656,6 +668,8 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
 static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr,
                       int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
                       double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
+    if (!c) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
     int rc = check_common(c, n_rows, n_cols, col_lb, col_ub, alternative, out_p, out_u, out_fc, out_ld);
     if (rc) return rc;
     if (!data || !indices || !indptr) return fail(c, ILLICO_ERR_ARG, "null sparse array");
@@ -709,7 +723,9 @@ template <typename IdxT> static int csr_sorted_host(const IdxT *indices, const I
 
 extern "C" int illico_csr_indices_sorted(illico_ctx *c, const void *indices, const void *indptr, int idx_dtype,
                                          int64_t n_rows, int flags, int *out_sorted) {
-    if (!c || !indices || !indptr || !out_sorted || n_rows < 0) return fail(c, ILLICO_ERR_ARG, "bad argument");
+    if (!c) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
+    if (!indices || !indptr || !out_sorted || n_rows < 0) return fail(c, ILLICO_ERR_ARG, "bad argument");
     if (idx_dtype != ILLICO_IDX_I32 && idx_dtype != ILLICO_IDX_I64) return fail(c, ILLICO_ERR_DTYPE, "unsupported index dtype code %d", idx_dtype);
     if (!(flags & ILLICO_FLAG_INPUT_DEVICE)) {
         *out_sorted = idx_dtype == ILLICO_IDX_I32 ? csr_sorted_host((const int32_t *)indices, (const int32_t *)indptr, n_rows)

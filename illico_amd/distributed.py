@@ -11,8 +11,9 @@ import numpy as np
 
 
 def shard_bounds(n: int, parts: int) -> list[tuple[int, int]]:
-    """Contiguous, balanced (+-1) split of range(n) into `parts` non-empty-if-possible windows."""
-    parts = max(1, min(int(parts), max(int(n), 1)))
+    """Contiguous, balanced (+-1) split of range(n) into EXACTLY `parts` windows (empty ones when n < parts: every
+    rank must issue the same number of gathers whatever its own width)."""
+    parts = max(1, int(parts))
     edges = [(n * i) // parts for i in range(parts + 1)]
     return [(edges[i], edges[i + 1]) for i in range(parts)]
 

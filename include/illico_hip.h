@@ -14,9 +14,11 @@
  * Ownership: the caller owns X, the group arrays and the three output planes; the library owns
  * only device scratch inside the context and never writes to X (the reference's tests assert the
  * input is not mutated, tests/test_asymptotic_wilcoxon.py:187-194).
- * Threading: one context = one HIP stream = one host thread at a time; different contexts may be
- * driven from different host threads (the reference's "threads, never processes" model,
- * illico/asymptotic_wilcoxon.py:236-241).
+ * Threading: one context = one HIP stream.  Every entry point that takes a context locks it for the
+ * duration of the call, so host threads sharing ONE context (the reference's joblib threads share one
+ * dispatcher, illico/asymptotic_wilcoxon.py:236-241) are serialised, never raced; illico_last_error
+ * returns the calling thread's own last message.  Threads that want overlap use one context each.
+ * illico_ctx_destroy must not race with other calls on the same context.
  */
 #ifndef ILLICO_HIP_H
 #define ILLICO_HIP_H
@@ -112,6 +114,21 @@ int illico_run_csr(illico_ctx *ctx, const void *data, int dtype, const void *ind
 /* replaces check_indices_sorted_per_parcel (utils/ranking.py:245-273); *out_sorted = 1/0. */
 int illico_csr_indices_sorted(illico_ctx *ctx, const void *indices, const void *indptr, int idx_dtype,
                               int64_t n_rows, int flags, int *out_sorted);
+
+/* ---- the ranking primitives, before finalisation -----------------------------------------
+ * Device counterpart of rank_sum_and_ties_from_sorted (utils/ranking.py:52-158; OVO) and
+ * _accumulate_group_ranksums_from_argsort (utils/ranking.py:7-49; OVR) for the dense columns [col_lb, col_ub): the integer
+ * statistics the dispatchers feed to compute_pval, as the reference's own primitive tests look at them
+ * (tests/utils/test_ranking.py:13-56).  Host arrays [col_ub - col_lb][n_groups]:
+ *   out_two_u[j][g]     2 * U1,  U1 = n_ref n_tgt + n_tgt (n_tgt + 1) / 2 - ranksum_g   (dense_ovo.py:48, dense_ovr.py:57-61;
+ *                       n_ref = reference-group size, or every other cell for OVR) -- ranksum_g follows exactly;
+ *   out_tie_sum[j][g]   sum over tie blocks of t^3 - t  (of reference + group g for OVO, of the whole column for OVR);
+ *   out_value_sum[j][g] the group's value sum (expm1'd under ILLICO_FLAG_LOG1P).
+ * The reference group's own entries are unspecified in OVO.  Runs the two-pass routes (the fused single-pass kernels
+ * never materialise these numbers).  flags: ILLICO_FLAG_LOG1P, ILLICO_FLAG_INPUT_DEVICE. */
+int illico_rank_statistics(illico_ctx *ctx, const void *X, int dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                           int64_t col_lb, int64_t col_ub, int flags, int64_t *out_two_u, uint64_t *out_tie_sum,
+                           double *out_value_sum);
 
 /* ---- measurement hooks (bench.py roofline leg) ------------------------------------------- */
 int illico_profile_num_kernels(void);

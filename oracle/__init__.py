@@ -36,14 +36,42 @@ def build(force: bool = False) -> Path:
     return _SO
 
 
+def build_native() -> Path:
+    """``-O3 -march=native`` build for the timed CPU baseline, compiled ON the machine that runs it (the portable ``-O2``
+    library above travels between machines; a native one built elsewhere could use instructions this CPU lacks).  One file
+    per CPU model, so a stale one from another box is never loaded."""
+    import hashlib
+    try:
+        model = next(l for l in Path("/proc/cpuinfo").read_text().splitlines() if l.startswith(("model name", "flags")))
+        flags = next(l for l in Path("/proc/cpuinfo").read_text().splitlines() if l.startswith("flags"))
+    except Exception:
+        model, flags = "unknown", ""
+    tag = hashlib.sha1((model + flags).encode()).hexdigest()[:10]
+    so = _HERE / "_build" / f"libillico_oracle.native.{tag}.so"
+    srcs = [_HERE / "illico_oracle.c", _HERE / "oracle_impl.inc"]
+    if not so.exists() or any(f.stat().st_mtime > so.stat().st_mtime for f in srcs):
+        so.parent.mkdir(exist_ok=True)
+        subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-shared",
+                        "-o", str(so), str(srcs[0]), "-lm"], check=True, capture_output=True)
+    return so
+
+
 _lib = None
+_native = False
+
+
+def use_native(on: bool = True) -> None:
+    """Switch the loaded library to the ``-O3 -march=native`` build (bench.py's cpu_baseline leg) or back."""
+    global _lib, _native
+    if on != _native:
+        _lib, _native = None, on
 
 
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        build()
-        _lib = ctypes.CDLL(str(_SO))
+        so = build_native() if _native else build()
+        _lib = ctypes.CDLL(str(so))
         i64, dbl, p = ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
         _lib.oracle_run.restype = ctypes.c_int
         _lib.oracle_run.argtypes = [ctypes.c_int, ctypes.c_int, p, p, p, i64, i64, i64, i64, i64,
@@ -61,7 +89,37 @@ def lib() -> ctypes.CDLL:
         _lib.oracle_check_indices_sorted_per_parcel.restype = ctypes.c_int
         _lib.oracle_check_indices_sorted_per_parcel.argtypes = [p, p, i64]
         _lib.oracle_max_threads.restype = ctypes.c_int
+        _lib.oracle_set_cpu_list.restype = None
+        _lib.oracle_set_cpu_list.argtypes = [p, ctypes.c_int]
     return _lib
+
+
+def physical_cpus() -> tuple[list[int], list[int]]:
+    """CPUs this process may run on, split into (one per physical core, their SMT siblings), from sysfs topology."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen, primary, siblings = set(), [], []
+    for c in allowed:
+        try:
+            txt = Path(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read_text().strip()
+            core = tuple(sorted(int(x) for part in txt.split(",") for x in
+                                (range(int(part.split("-")[0]), int(part.split("-")[-1]) + 1))))
+        except Exception:
+            core = (c,)
+        if core in seen:
+            siblings.append(c)
+        else:
+            seen.add(core)
+            primary.append(c)
+    return primary, siblings
+
+
+def pin_threads(on: bool = True) -> int:
+    """bench.py's cpu_baseline leg: pin OpenMP worker t to the t-th CPU of (physical cores first, SMT siblings after).
+    Returns the number of physical cores available."""
+    primary, siblings = physical_cpus()
+    order = np.ascontiguousarray((primary + siblings) if on else [], dtype=np.int32)
+    lib().oracle_set_cpu_list(_ptr(order) if order.size else None, int(order.size))
+    return len(primary)
 
 
 def _ptr(a):

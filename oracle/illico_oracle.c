@@ -17,7 +17,9 @@
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp; strict IEEE, no fast-math).
  */
+#define _GNU_SOURCE
 #include <math.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -127,6 +129,19 @@ int oracle_check_indices_sorted_per_parcel(const int64_t *indices, const int64_t
  * fmt: 0 dense, 1 csc, 2 csr.  dtype: 0 f32, 1 f64.  test is OVR iff encoded_ref_group == -1
  * (asymptotic_wilcoxon.py:41-44).
  * ====================================================================================== */
+/* Thread placement for the timed CPU baseline (bench.py): worker t is pinned to cpus[t % n].  Without it the kernel's
+ * scheduler may leave freshly created OpenMP threads stacked on one CPU for hundreds of milliseconds (measured: 4
+ * threads, 3 of them on the same CPU, 4x the single-thread wall time), which would understate the baseline.  The list
+ * comes from the Python side (one CPU per physical core first, SMT siblings after).  n = 0 (default): no pinning. */
+static int g_cpus[4096];
+static int g_ncpus = 0;
+void oracle_set_cpu_list(const int *cpus, int n) {
+    if (n < 0) n = 0;
+    if (n > 4096) n = 4096;
+    for (int i = 0; i < n; ++i) g_cpus[i] = cpus[i];
+    g_ncpus = n;
+}
+
 int oracle_run(int fmt, int dtype, const void *data, const int64_t *indices, const int64_t *indptr,
                int64_t n_rows, int64_t n_cols, int64_t ld, int64_t col_lb, int64_t col_ub,
                const int64_t *encoded_groups, const int64_t *counts, const int64_t *grp_indices,
@@ -142,6 +157,20 @@ int oracle_run(int fmt, int dtype, const void *data, const int64_t *indices, con
     int64_t n_chunks = (W + batch_size - 1) / batch_size;
     int rc_all = 0;
     if (n_threads < 1) n_threads = 1;
+    cpu_set_t saved_mask;
+    int pinned = 0;
+#ifdef _OPENMP
+    if (g_ncpus > 0 && n_threads > 1 && sched_getaffinity(0, sizeof saved_mask, &saved_mask) == 0) {
+        pinned = 1;
+#pragma omp parallel num_threads(n_threads)
+        {
+            cpu_set_t m;
+            CPU_ZERO(&m);
+            CPU_SET(g_cpus[omp_get_thread_num() % g_ncpus], &m);
+            sched_setaffinity(0, sizeof m, &m);
+        }
+    }
+#endif
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
     for (int64_t c = 0; c < n_chunks; ++c) {
         int64_t lb = col_lb + c * batch_size;
@@ -180,6 +209,7 @@ int oracle_run(int fmt, int dtype, const void *data, const int64_t *indices, con
         }
         free(p); free(u); free(fc);
     }
+    if (pinned) sched_setaffinity(0, sizeof saved_mask, &saved_mask); /* the caller's thread gets its mask back */
     return rc_all;
 }
 

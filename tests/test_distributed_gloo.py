@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fmt, test, out_path):
+def _worker(rank, world, port, fmt, test, out_path, n_genes=37, n_blocks=3):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,7 +35,7 @@ def _worker(rank, world, port, fmt, test, out_path):
     from illico_amd import AnnDataLite
     from illico_amd.distributed import asymptotic_wilcoxon_sharded
 
-    X, rng = make_counts(3, 600, 37, 0.6)
+    X, rng = make_counts(3, 600, n_genes, 0.6)
     labels = make_labels(rng, 600, 6, n_ref=60)
     M = {"dense": X, "csc": sparse.csc_matrix(X), "csr": sparse.csr_matrix(X)}[fmt]
     adata = AnnDataLite(M, obs=pd.DataFrame({"pert": labels}))
@@ -43,7 +43,7 @@ def _worker(rank, world, port, fmt, test, out_path):
     def compute(Xm, grpc, lb, ub, **o):
         return oracle.run(Xm, grpc, col_lb=lb, col_ub=ub, **o)
 
-    df = asymptotic_wilcoxon_sharded(adata, False, "pert", "non-targeting" if test == "ovo" else None, n_blocks=3,
+    df = asymptotic_wilcoxon_sharded(adata, False, "pert", "non-targeting" if test == "ovo" else None, n_blocks=n_blocks,
                                      compute_planes=compute)
     if rank == 0:
         df.to_pickle(out_path)
@@ -70,3 +70,21 @@ def test_sharded_gather_world2(tmp_path, fmt, test):
     np.testing.assert_array_equal(got[:, :, 2], fc)
     assert list(df.index.get_level_values(0).unique()) == list(uniq)
     assert df.index.names == ["pert", "feature"]
+
+
+@pytest.mark.parametrize("world,n_genes,n_blocks", [(2, 5, 4), (3, 7, 4), (2, 1, 2)])
+def test_sharded_gather_fewer_genes_than_blocks(tmp_path, world, n_genes, n_blocks):
+    """A rank that owns fewer genes than gather blocks (or none) still issues every gather: no IndexError, no hang."""
+    import oracle
+    from conftest import make_counts, make_labels
+    out = tmp_path / "df.pkl"
+    mp.spawn(_worker, args=(world, _free_port(), "dense", "ovo", str(out), n_genes, n_blocks), nprocs=world, join=True)
+    df = pd.read_pickle(out)
+    X, rng = make_counts(3, 600, n_genes, 0.6)
+    labels = make_labels(rng, 600, 6, n_ref=60)
+    uniq, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    p, u, fc = oracle.run(X, g)
+    got = df.values.reshape(len(uniq), n_genes, 3)
+    np.testing.assert_array_equal(got[:, :, 0], p)
+    np.testing.assert_array_equal(got[:, :, 1], u)
+    np.testing.assert_array_equal(got[:, :, 2], fc)

@@ -239,9 +239,9 @@ def test_ovr_dense_value_range_parts_route(engine, dtype, sorted_form, parts_cap
         engine.set_option("ovr_parts_cap", 0)
         engine.set_option("no_fused_path", 0)
     assert "k_ovr_partition" in prof and "k_ovr_rank_parts" in prof and "k_ovr_gene" in prof, prof
-    assert_planes_match(got, want, fc_rtol=1e-9, what=f"dense ovr parts {dtype.__name__} sorted_form={sorted_form}")
+    assert_planes_match(got, want, what=f"dense ovr parts {dtype.__name__} sorted_form={sorted_form}")
     want_w = oracle.run(X.astype(np.float64), g, col_lb=1, col_ub=4, alternative="less", tie_correct=False)
-    assert_planes_match(got_w, want_w, fc_rtol=1e-9, what=f"dense ovr parts window {dtype.__name__}")
+    assert_planes_match(got_w, want_w, what=f"dense ovr parts window {dtype.__name__}")
 
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])

@@ -31,7 +31,7 @@ def _check(engine, X, labels, ref, what, **kw):
     engine.set_groups(g)
     for name, fn in _all_inputs(X):
         got = fn(engine, 0, X.shape[1], **kw)
-        assert_planes_match(got, want, ref_row=g.encoded_ref_group if ref is not None else None, fc_rtol=1e-9,
+        assert_planes_match(got, want, ref_row=g.encoded_ref_group if ref is not None else None,
                             what=f"{what} [{name}]")
 
 
@@ -121,10 +121,10 @@ def test_many_groups_beyond_lds_accumulators(engine, ref):
     want = oracle.run(X, g)
     engine.set_groups(g)
     got = engine.run_dense(X, 0, 3)
-    assert_planes_match(got, want, ref_row=g.encoded_ref_group if ref else None, fc_rtol=1e-9, what="20k groups dense")
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group if ref else None, what="20k groups dense")
     M = sparse.csc_matrix(X)
     got = engine.run_sparse("csc", M.data, M.indices, M.indptr, M.shape, 0, 3)
-    assert_planes_match(got, want, ref_row=g.encoded_ref_group if ref else None, fc_rtol=1e-9, what="20k groups csc")
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group if ref else None, what="20k groups csc")
 
 
 @pytest.mark.parametrize("ref", ["s017", "s300", None])

@@ -59,7 +59,9 @@ def test_random_case_all_input_paths(engine, seed):
     engine.set_groups(g)
     Xt = np.ascontiguousarray(X.astype(dtype))
     rr = g.encoded_ref_group if ref is not None else None
-    fc = 1e-6 if opts["is_log1p"] else 1e-9   # expm1 in the input dtype: the reference's own tolerance
+    # expm1 is taken in the input dtype (math.py:212): for float32 input the device's expm1f and libm's may differ in the
+    # last float32 bit, so that case is held to the reference's own tolerance; everything else to 1e-12
+    fc = 1e-6 if (opts["is_log1p"] and np.dtype(dtype) == np.float32) else 1e-12
     what = f"seed {seed} {kind} {np.dtype(dtype).name} {X.shape} ref={ref} [{lb},{ub}) {opts}"
     got = engine.run_dense(Xt, lb, ub, **opts)
     assert_planes_match(got, want, ref_row=rr, fc_rtol=fc, what="dense-host " + what)

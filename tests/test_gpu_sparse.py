@@ -173,7 +173,7 @@ def test_sparse_ovo_big_groups_any_values(engine, fmt):
         _, g = oracle.encode_and_count_groups(labels, ref)
         want = oracle.run(X, g)     # dense semantics (negatives rank below the zero block)
         got = _run(engine, M, g)
-        assert_planes_match(got, want, fc_rtol=1e-9, what=f"{fmt} ref={ref}")
+        assert_planes_match(got, want, what=f"{fmt} ref={ref}")
 
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
@@ -196,10 +196,10 @@ def test_csc_interleaved_dense_and_sparse_genes(engine, test):
     _, g = oracle.encode_and_count_groups(labels, "g00" if test == "ovo" else None)
     want = oracle.run(X, g)
     got = _run(engine, M, g)
-    assert_planes_match(got, want, fc_rtol=1e-9, what=f"interleaved {test}")
+    assert_planes_match(got, want, what=f"interleaved {test}")
     got = _run(engine, M, g, col_lb=3, col_ub=38)
     want = oracle.run(X, g, col_lb=3, col_ub=38)
-    assert_planes_match(got, want, fc_rtol=1e-9, what=f"interleaved window {test}")
+    assert_planes_match(got, want, what=f"interleaved window {test}")
 
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
@@ -235,13 +235,13 @@ def test_csr_dense_window_route(engine, test, dtype, f32_cells):
         engine.set_option("profile", 0)
         engine.set_option("dense_window_f32", 0)
     assert "k_ovo_fused" in prof or "k_ovr_fused" in prof, prof   # the dense-window route ran
-    assert_planes_match(got, want, fc_rtol=1e-9, what=f"csr dense window {test} {dtype.__name__}")
+    assert_planes_match(got, want, what=f"csr dense window {test} {dtype.__name__}")
     engine.set_option("gene_batch", 3000)
     try:
         got = _run(engine, M, g, col_lb=100, col_ub=8290)
     finally:
         engine.set_option("gene_batch", 0)
-    assert_planes_match(got, oracle.run(X, g, col_lb=100, col_ub=8290), fc_rtol=1e-9, what=f"csr dense window batches {test}")
+    assert_planes_match(got, oracle.run(X, g, col_lb=100, col_ub=8290), what=f"csr dense window batches {test}")
 
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
@@ -263,16 +263,16 @@ def test_csr_transposition_route(engine, test, dtype, idx):
     M.indptr = M.indptr.astype(idx)
     want = oracle.run(X, g)
     got = _run(engine, M, g)
-    assert_planes_match(got, want, fc_rtol=1e-9, what=f"csr transposition {test}")
+    assert_planes_match(got, want, what=f"csr transposition {test}")
     got = _run(engine, M, g, col_lb=777, col_ub=32999)
-    assert_planes_match(got, oracle.run(X, g, col_lb=777, col_ub=32999), fc_rtol=1e-9, what=f"csr transposition window {test}")
+    assert_planes_match(got, oracle.run(X, g, col_lb=777, col_ub=32999), what=f"csr transposition window {test}")
     for r in range(n):                             # shuffle inside every row
         s, e = M.indptr[r], M.indptr[r + 1]
         perm = rng.permutation(e - s)
         M.indices[s:e] = M.indices[s:e][perm]
         M.data[s:e] = M.data[s:e][perm]
     got = _run(engine, M, g)
-    assert_planes_match(got, want, fc_rtol=1e-9, what=f"csr transposition, unsorted rows {test}")
+    assert_planes_match(got, want, what=f"csr transposition, unsorted rows {test}")
 
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
@@ -308,9 +308,9 @@ def test_csc_counts_route(engine, test, many_groups):
         finally:
             engine.set_option("profile", 0)
         assert "k_csc_counts" in prof, prof
-        assert_planes_match(got, want, fc_rtol=1e-9, what=f"csc counts {test} ref={ref} many_groups={many_groups}")
+        assert_planes_match(got, want, what=f"csc counts {test} ref={ref} many_groups={many_groups}")
         got = _run(engine, M, g, col_lb=2, col_ub=31)
-        assert_planes_match(got, oracle.run(Xd, g, col_lb=2, col_ub=31), fc_rtol=1e-9, what=f"csc counts window {test}")
+        assert_planes_match(got, oracle.run(Xd, g, col_lb=2, col_ub=31), what=f"csc counts window {test}")
 
 
 def test_drop_in_csr_narrow_dtypes(engine):
@@ -381,6 +381,6 @@ def test_csc_ovr_single_kernel_route(engine, fmt, dtype, idx, sorted_form):
         engine.set_option("no_dense_window_path", 0)
         engine.set_option("no_csc_counts_path", 0)
     assert "k_csc_ovr_gene" in prof and "k_ovr_gene" in prof, prof   # the new route ran, and the oversized columns fell back
-    assert_planes_match(got, want, fc_rtol=1e-9, what=f"csc ovr single kernel {fmt} {dtype.__name__} sorted_form={sorted_form}")
+    assert_planes_match(got, want, what=f"csc ovr single kernel {fmt} {dtype.__name__} sorted_form={sorted_form}")
     want_w = oracle.run(Xd, g, col_lb=2, col_ub=13, alternative="greater", use_continuity=False)
-    assert_planes_match(got_w, want_w, fc_rtol=1e-9, what=f"csc ovr single kernel window {fmt} {dtype.__name__}")
+    assert_planes_match(got_w, want_w, what=f"csc ovr single kernel window {fmt} {dtype.__name__}")

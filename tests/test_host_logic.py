@@ -142,6 +142,7 @@ def test_shard_bounds():
     for n in (0, 1, 7, 8000, 30000):
         for parts in (1, 2, 3, 8):
             b = shard_bounds(n, parts)
+            assert len(b) == parts  # always `parts` windows (empty ones allowed): ranks issue the same number of gathers
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
             w = [u - l for l, u in b]
