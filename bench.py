@@ -238,8 +238,12 @@ def main():
     in_step = world > 1 and args.gather_in_step
     n_blocks = max(1, args.gather_batches) if in_step else 1
     blocks = [b for b in shard_bounds(M, n_blocks) if b[1] > b[0]]
-    # one contiguous (3, G, w) staging tensor per gene block: the engine writes its planes straight into it
-    stages = [torch.empty((3, G, ub - lb), dtype=torch.float64, device=device) for (lb, ub) in blocks]
+    # one contiguous (3, G, w) staging tensor per gene block: the engine writes its planes straight into it.  Two sets, used
+    # by alternate steps (a consumer reads step k's planes while step k + 1 computes): with ILLICO_FLAG_DEFER a dense pass is
+    # then enqueued before the previous one's route flags have been looked at -- no host round trip between passes.
+    stage_sets = [[torch.empty((3, G, ub - lb), dtype=torch.float64, device=device) for (lb, ub) in blocks] for _ in range(2)]
+    stages = stage_sets[0]
+    step_no = [0]
     recvs = None
     if world > 1 and rank == 0:
         recvs = [[torch.empty_like(st) for _ in range(world)] for st in stages]
@@ -248,9 +252,12 @@ def main():
         if sparse_fmt:
             eng.run_sparse(sparse_fmt, csx[0], csx[1], csx[2], (N, M), lb, ub, out=out)
         else:
-            eng.run_dense(X, lb, ub, out=out)
+            eng.run_dense(X, lb, ub, out=out, defer=not in_step)
 
     def step():
+        nonlocal stages
+        stages = stage_sets[step_no[0] & 1]
+        step_no[0] += 1
         handles = []
         for b, (lb, ub) in enumerate(blocks):
             st = stages[b]
@@ -267,6 +274,7 @@ def main():
             h.wait()
 
     def sync():
+        eng.synchronize()  # completes a deferred pass (genes the fused route could not take), then waits for the stream
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -276,7 +284,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     step()
-    torch.cuda.synchronize()
+    eng.synchronize()
     first_call_ms = (time.perf_counter() - t0) * 1e3
     # The first ~8 passes of a fresh process run up to 6 % slower than the steady state (tools/ramp.py): a few settling
     # passes before the W warm-up steps, so that a small W still measures the steady state.  Untimed, like the warm-up.
@@ -324,6 +332,19 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     tests_per_step = G * M_total
     value = tests_per_step / (dt / args.steps)
+
+    # what this box's HBM delivers to a plain streaming read (boxes of the pool differ by up to 15 %: 1.65 vs 1.90 ms for the
+    # same C2 kernel): torch's sum over the resident input
+    calib = None
+    if rank == 0:
+        src = X if X is not None else csx[0]
+        src.sum(); torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(5):
+            src.sum()
+        torch.cuda.synchronize()
+        calib = {"stream_read_GBs": round(src.numel() * src.element_size() * 5 / (time.perf_counter() - tc) / 1e9, 1),
+                 "what": "torch .sum() over the resident input, 5 passes: the box's own streaming-read rate, for comparing runs on different boxes"}
 
     if rank == 0:
         # ---- roofline of the dominant kernel (HIP events recorded on the engine's stream) ----
@@ -481,7 +502,7 @@ def main():
                        "workload_id": args.workload, "cells": N, "genes_per_gpu": M, "genes_total": M_total, "groups": G, "format": args.fmt,
                        "test": args.test, "sparsity": args.sparsity, "nnz_per_gpu": nnz, "settle_steps": settle,
                        "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "timing_scopes": scopes,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "timing_scopes": scopes, "box_calibration": calib,
         }
         if world > 1:
             plane_bytes = 24 * G * M

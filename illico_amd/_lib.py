@@ -20,7 +20,7 @@ ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = -10, -11, -12
 F32, F64, I32, I64 = 0, 1, 2, 3
 IDX_I32, IDX_I64 = 0, 1
 ALTERNATIVES = {"two-sided": 0, "less": 1, "greater": 2}
-FLAG_LOG1P, FLAG_CONTINUITY, FLAG_TIE_CORRECT, FLAG_INPUT_DEVICE, FLAG_OUTPUT_DEVICE = 1, 2, 4, 8, 16
+FLAG_LOG1P, FLAG_CONTINUITY, FLAG_TIE_CORRECT, FLAG_INPUT_DEVICE, FLAG_OUTPUT_DEVICE, FLAG_DEFER = 1, 2, 4, 8, 16, 32
 
 _DTYPES = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.int32): I32, np.dtype(np.int64): I64}
 
@@ -250,7 +250,9 @@ class Engine:
         return planes, ptrs, flag, int(ld if ld else max(W, 1))
 
     def run_dense(self, X, col_lb, col_ub, *, is_log1p=False, use_continuity=True, tie_correct=True,
-                  alternative="two-sided", out=None, device_out=False):
+                  alternative="two-sided", out=None, device_out=False, defer=False):
+        """``defer=True`` (device input and device planes only): return once the pass is enqueued; the planes are complete
+        after ``synchronize()`` or the next call on this engine (ILLICO_FLAG_DEFER, include/illico_hip.h)."""
         alt = self._alt(alternative)
         if _is_torch_tensor(X):
             if X.dim() != 2 or X.stride(1) != 1:
@@ -272,7 +274,8 @@ class Engine:
         planes, ptrs, oflag, out_ld = self._outputs(out, G, W, device_out)
         if ptrs is None:
             return planes
-        flags = self._flags(is_log1p, use_continuity, tie_correct) | (FLAG_INPUT_DEVICE if on_dev else 0) | oflag
+        flags = self._flags(is_log1p, use_continuity, tie_correct) | (FLAG_INPUT_DEVICE if on_dev else 0) | oflag | \
+            (FLAG_DEFER if defer else 0)
         self._bind_torch_stream(keep, *planes)
         self._check(self.lib.illico_run_dense(self.h, buf_ptr, dt, n_rows, n_cols, ld, col_lb, col_ub, flags, alt,
                                               ptrs[0], ptrs[1], ptrs[2], out_ld))

@@ -49,9 +49,14 @@ enum {
 static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
                                               "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums"};
 
-struct SampleKey {
-    const void *ptr; int64_t n, ld, lb, ub; int dtype;
-    bool operator==(const SampleKey &o) const { return ptr == o.ptr && n == o.n && ld == o.ld && lb == o.lb && ub == o.ub && dtype == o.dtype; }
+// A dense call made with ILLICO_FLAG_DEFER whose fused pass is in flight: which genes it could not take is known only once
+// its route flags have reached the host; they are then recomputed by the two-pass routes (resolve_pending).
+struct PendingDense {
+    bool on = false;
+    const void *X = nullptr;
+    int dtype = 0, flags = 0, alternative = 0, slot = 0;
+    int64_t N = 0, ld = 0, col_lb = 0, col_ub = 0, out_ld = 0;
+    double *p = nullptr, *u = nullptr, *fc = nullptr;
 };
 
 struct ProfEvent {
@@ -77,6 +82,7 @@ struct illico_ctx {
     int *d_posptr = nullptr;      // [G+1]
     int *d_counts = nullptr;      // [G]
     int *d_code_by_pos = nullptr; // [N] group code at position p
+    u16 *d_codes16 = nullptr;     // [N] d_codes as 16-bit values when G <= 65535 (half the cache lines per codes[row] gather), else null
     // options
     int64_t gene_batch = 0;
     int64_t scratch_bytes = 24ll << 30;
@@ -90,6 +96,7 @@ struct illico_ctx {
     bool no_csc_ovr_gene_path = false; // 1: CSC OVR never takes the single-kernel LDS-sort route (k_csc_ovr_gene)
     bool csc_ovr_sorted_form = false;  // 1: k_csc_ovr_gene sorts every gene's keys in LDS (the form tie-heavy columns take) instead of bucketing them
     bool no_csc_counts_path = false;   // 1: count-valued CSC genes do not take the LDS-histogram kernel (k_csc_counts)
+    bool no_csc_counts_mixed = false;  // 1: k_csc_counts with 8-bit cells for every value only (the form 4-bit overflows fall back to)
     bool no_ovr_one_pass = false;      // 1: dense OVR reads X twice (column histogram, then rank sums) instead of once
     bool no_ovr_library_sort = false;   // 1: the general OVR route sorts inside k_ovr_gene (LSD radix passes) instead of rocPRIM's segmented sort
     bool no_csr_tile_gather = false;    // 1: CSR -> CSC always by the scatter form (k_csr_block_scatter), as for unsorted rows
@@ -100,8 +107,11 @@ struct illico_ctx {
     int ovr_hist_groups_per_wg = 0; // k_ovr_from_hists; 0 = auto
     bool profile = false;
     int profile_only = -1;        // >= 0: time this kernel id only (the others run without events around them)
-    SampleKey sample_key{};       // last dense window whose values were sampled (count-valued or not: route choice only)
-    bool sample_valid = false, sample_counts = false;
+    PendingDense pend;            // deferred dense call (ILLICO_FLAG_DEFER), see resolve_pending
+    void *pend_pinned[2] = {nullptr, nullptr}; // its route flags arrive here (two buffers: the next call may be enqueued first)
+    size_t pend_pinned_bytes[2] = {0, 0};
+    hipEvent_t pend_event[2] = {nullptr, nullptr};
+    int pend_next = 0;
     void *pinned = nullptr;       // pinned host staging for small device -> host results
     size_t pinned_bytes = 0;
     std::vector<ProfEvent> events;
@@ -213,6 +223,8 @@ static void drain_events(illico_ctx *c) {
     c->events.clear();
 }
 
+static int resolve_pending(illico_ctx *c); // completes a deferred dense call (defined with the dense driver)
+
 // ============================================================================================
 extern "C" {
 
@@ -240,6 +252,8 @@ static void free_groups(illico_ctx *c) {
         if (*p) hipFree(*p);
         *p = nullptr;
     }
+    if (c->d_codes16) hipFree(c->d_codes16);
+    c->d_codes16 = nullptr;
     c->has_groups = false;
 }
 
@@ -250,6 +264,10 @@ int illico_ctx_destroy(illico_ctx *c) {
     drain_events(c);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     if (c->pinned) hipHostFree(c->pinned);
+    for (int k = 0; k < 2; ++k) {
+        if (c->pend_pinned[k]) hipHostFree(c->pend_pinned[k]);
+        if (c->pend_event[k]) hipEventDestroy(c->pend_event[k]);
+    }
     free_groups(c);
     for (auto &kv : c->scratch)
         if (kv.second.first) hipFree(kv.second.first);
@@ -262,6 +280,8 @@ int illico_ctx_set_stream(illico_ctx *c, void *hip_stream) {
     if (!c) return ILLICO_ERR_ARG;
     CTX_LOCK(c);
     hipSetDevice(c->device);
+    int rc = resolve_pending(c);
+    if (rc) return rc;
     hipStreamSynchronize(c->stream);
     drain_events(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -280,6 +300,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
+    else if (!strcmp(key, "no_csc_counts_mixed")) c->no_csc_counts_mixed = value != 0;
     else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
     else if (!strcmp(key, "ovr_parts_cap")) c->ovr_parts_cap = value;
@@ -308,6 +329,8 @@ int illico_ctx_synchronize(illico_ctx *c) {
     if (!c) return ILLICO_ERR_ARG;
     CTX_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
+    int rc = resolve_pending(c); // a deferred call's leftover genes are recomputed now
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ILLICO_OK;
 }
@@ -341,6 +364,7 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
     if (n_cells <= 0 || n_groups <= 0 || n_cells > 0x7FFFFFF0ll) return fail(c, ILLICO_ERR_ARG, "bad n_cells/n_groups");
     if (ref < -1 || ref >= n_groups) return fail(c, ILLICO_ERR_ARG, "encoded_ref_group out of range");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc0 = resolve_pending(c); if (rc0) return rc0; } // (its leftover genes need the groups it was made with)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_groups(c);
     // perm is padded with valid indices: tail chunks of k_ovo_fused read (and discard) up to 8 entries past a group's end
@@ -383,6 +407,11 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
     if ((rc = up(&c->d_codes, codes)) || (rc = up(&c->d_perm, perm)) || (rc = up(&c->d_posptr, posptr)) ||
         (rc = up(&c->d_counts, cnt)) || (rc = up(&c->d_code_by_pos, cbp)))
         return rc;
+    if (n_groups <= 65535) {
+        std::vector<u16> c16(codes.begin(), codes.end());
+        HIPCHK(c, hipMalloc((void **)&c->d_codes16, c16.size() * sizeof(u16)));
+        HIPCHK(c, hipMemcpy(c->d_codes16, c16.data(), c16.size() * sizeof(u16), hipMemcpyHostToDevice));
+    }
     c->h_counts = cnt;
     c->n_cells = n_cells;
     c->n_groups = n_groups;
@@ -405,7 +434,7 @@ template <typename InT, typename IdxT>
 static int launch_csc_value_sums(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, int64_t col0,
                                  const int *d_cols, const int *d_codes, int nb, int dtype, int flags, double *ssum) {
     CscSumsParams P;
-    P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = col0; P.gene_cols = d_cols; P.codes = d_codes;
+    P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = col0; P.gene_cols = d_cols; P.codes = d_codes; P.codes16 = d_codes ? c->d_codes16 : nullptr;
     P.nb = nb; P.G = (int)c->n_groups; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.acc_global = nullptr; P.out_sum = ssum;
     const bool accg = csc_sums_lds_bytes(P.G, false) > kMaxLds / 2; // two workgroups per CU at least
     const size_t lds = csc_sums_lds_bytes(P.G, accg);
@@ -419,11 +448,11 @@ static int launch_csc_value_sums(illico_ctx *c, const InT *d_data, const IdxT *d
     ProfScope ps(c, KID_VALUE_SUMS);
     if (accg) {
         auto kern = k_csc_value_sums<InT, IdxT, true>;
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(SUMS_NT), lds, c->stream, P);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(CSUM_NT), lds, c->stream, P);
     } else {
         auto kern = k_csc_value_sums<InT, IdxT, false>;
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(SUMS_NT), lds, c->stream, P);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(CSUM_NT), lds, c->stream, P);
     }
     HIPCHK(c, hipGetLastError());
     return ILLICO_OK;
@@ -610,7 +639,7 @@ static int check_common(illico_ctx *c, int64_t n_rows, int64_t n_cols, int64_t c
 // h_flags[j] != 0 for the others.
 template <typename InT>
 static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, int flags, int alternative,
-                         const OutPlanes &o, int64_t col_off, std::vector<u32> &h_flags) {
+                         const OutPlanes &o, int64_t col_off, std::vector<u32> &h_flags, int defer_slot = -1, bool probe = false) {
     constexpr int RT = FUSED_RT;
     const bool ovr = c->ref < 0;
     void *v;
@@ -642,6 +671,12 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     }
     P.groups_per_wg = gpw;
     HIPCHK(c, hipMemsetAsync(P.gene_flags, 0, (size_t)nb * 4, c->stream));
+    if (probe) { // OVR on device-resident input: which genes are count-valued at all is found on the device (the OVO pass has
+        // k_fused_ref, which reads every reference row first)
+        ProfScope ps(c, KID_FUSED_REF);
+        hipLaunchKernelGGL((k_fused_probe<InT, RT>), dim3(tiles), dim3(256), 0, c->stream, P);
+        HIPCHK(c, hipGetLastError());
+    }
     const dim3 main_grid(tiles, ((int)c->n_groups + P.groups_per_wg - 1) / P.groups_per_wg);
     if (!ovr) {
         {
@@ -692,6 +727,20 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
         }
     }
     // route flags back through a pinned staging buffer (a pageable destination makes the copy a blocking, staged one)
+    if (defer_slot >= 0) { // deferred: the copy is enqueued, an event marks it, nobody waits here (resolve_pending does)
+        void *&pin = c->pend_pinned[defer_slot];
+        if (c->pend_pinned_bytes[defer_slot] < (size_t)nb * 4) {
+            if (pin) hipHostFree(pin);
+            pin = nullptr;
+            c->pend_pinned_bytes[defer_slot] = 0;
+            HIPCHK(c, hipHostMalloc(&pin, (size_t)nb * 4 + 4096, hipHostMallocDefault));
+            c->pend_pinned_bytes[defer_slot] = (size_t)nb * 4 + 4096;
+        }
+        if (!c->pend_event[defer_slot]) HIPCHK(c, hipEventCreateWithFlags(&c->pend_event[defer_slot], hipEventDisableTiming));
+        HIPCHK(c, hipMemcpyAsync(pin, P.gene_flags, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->pend_event[defer_slot], c->stream));
+        return ILLICO_OK;
+    }
     if (c->pinned_bytes < (size_t)nb * 4) {
         if (c->pinned) hipHostFree(c->pinned);
         c->pinned = nullptr;
@@ -705,53 +754,69 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     return ILLICO_OK;
 }
 
+// column runs [first, second) of the flagged genes of a window starting at column w0
+static void flagged_runs(const u32 *hf, int64_t wn, int64_t w0, std::vector<std::pair<int64_t, int64_t>> &runs) {
+    for (int64_t j = 0; j < wn;) {
+        if (!hf[j]) { ++j; continue; }
+        int64_t e = j;
+        while (e < wn && hf[e]) ++e;
+        if (!runs.empty() && runs.back().second == w0 + j) runs.back().second = w0 + e;
+        else runs.push_back({w0 + j, w0 + e});
+        j = e;
+    }
+}
+
+// Of 64k evenly spaced cells of a HOST matrix window: is it count-valued at all?  (The fused route over a host matrix copies
+// the window up; on normalised data that copy would be made twice, once for nothing.)
+template <typename InT> static bool host_window_is_count_valued(const InT *X, int64_t ld, int64_t col_lb, int64_t N, int64_t W) {
+    const int64_t n_samples = std::min<int64_t>(N * W, 1 << 16);
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n_samples; ++i) {
+        const int64_t k = (int64_t)((double)i * (double)(N * W) / (double)n_samples);
+        const int64_t r = k / W, j = k - r * W;
+        const InT v = X[r * ld + col_lb + j];
+        if (!(v >= (InT)0 && v < (InT)(1 << 24) && (InT)(int)v == v)) ++bad;
+    }
+    return (double)bad <= 0.02 * (double)n_samples;
+}
+
+template <typename InT, typename KeyT>
+static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
+                             int alternative, const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> runs);
+
 template <typename InT, typename KeyT>
 static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
                        int alternative, const OutPlanes &o) {
     const int64_t W = col_ub - col_lb;
-    const int G = (int)c->n_groups;
     const bool ovr = c->ref < 0;
     const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
-    const int64_t stride = (N + 63) & ~63ll;
     int rc;
     void *v;
 
-    // ---- route 1 (device-resident dense OVO): fused single pass; it reports the genes it could not take ----
+    // ---- route 1 (dense, count-valued genes): fused single pass; it reports the genes it could not take ----
+    // Which genes are count-valued is found by the kernels themselves (k_fused_ref reads the reference rows first, k_fused_probe
+    // a few hundred rows of every gene): flagged tiles are skipped on the device, so there is no host-side route decision, no
+    // sampling round trip and nothing cached between calls.
     std::vector<std::pair<int64_t, int64_t>> runs; // column ranges still to be computed by the two-pass routes
     bool try_fused = fused_path_allowed(c, flags) && (uint64_t)ld * sizeof(InT) < (1ull << 32); // row pitch: 32-bit byte offsets
     if (c->tap) try_fused = false; // the fused kernels go from values to p-values without leaving statistics behind
-    if (try_fused && in_dev && N > 0 && W > 0) { // count-valued at all?  64k evenly spaced cells of the window decide
-        // The answer only picks the route (every route is exact), so it is remembered per (pointer, shape, window):
-        // repeated calls on the same matrix skip the sampling kernel and its host round trip.
-        SampleKey key{X, (int64_t)N, (int64_t)ld, col_lb, col_ub, dtype};
-        if (c->sample_valid && c->sample_key == key) try_fused = c->sample_counts;
-        else {
-            const int n_samples = (int)std::min<int64_t>(N * W, 1 << 16);
-            if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
-            u32 *d_cnt = (u32 *)v;
-            HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
-            hipLaunchKernelGGL((k_sample_noncount_dense<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, (const InT *)X, (long long)ld,
-                               (long long)col_lb, (long long)N, (long long)W, n_samples, 1 << 24, d_cnt); // integers of any size count as count-like: a gene with large counts leaves the route alone
-            HIPCHK(c, hipGetLastError());
-            u32 n_bad = 0;
-            HIPCHK(c, hipMemcpyAsync(&n_bad, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            try_fused = (double)n_bad <= 0.02 * (double)n_samples; // a few outlier values cost a few genes, not the route
-            c->sample_key = key; c->sample_counts = try_fused; c->sample_valid = true;
-        }
-    }
-    if (in_dev && try_fused) {
+    if (in_dev && try_fused && N > 0 && W > 0) {
+        // ILLICO_FLAG_DEFER (device planes only): enqueue and return; the flags are looked at by resolve_pending
+        const bool defer = (flags & ILLICO_FLAG_DEFER) && (flags & ILLICO_FLAG_OUTPUT_DEVICE) && !o.staged;
         std::vector<u32> hf;
-        if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf))) return rc;
-        for (int64_t j = 0; j < W;) {
-            if (!hf[j]) { ++j; continue; }
-            int64_t e = j;
-            while (e < W && hf[e]) ++e;
-            runs.push_back({col_lb + j, col_lb + e});
-            j = e;
+        if (defer) {
+            const int slot = c->pend_next;
+            if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf, slot, ovr))) return rc;
+            c->pend_next ^= 1;
+            PendingDense &q = c->pend;
+            q.on = true; q.X = X; q.dtype = dtype; q.flags = flags & ~ILLICO_FLAG_DEFER; q.alternative = alternative; q.slot = slot;
+            q.N = N; q.ld = ld; q.col_lb = col_lb; q.col_ub = col_ub; q.out_ld = o.ld; q.p = o.p; q.u = o.u; q.fc = o.fc;
+            return ILLICO_OK;
         }
+        if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf, -1, ovr))) return rc;
+        flagged_runs(hf.data(), W, col_lb, runs);
         if (runs.empty()) return ILLICO_OK;
-    } else if (!in_dev && try_fused) {
+    } else if (!in_dev && try_fused && N > 0 && W > 0 && host_window_is_count_valued<InT>((const InT *)X, ld, col_lb, N, W)) {
         // host matrix: column windows are copied up row-major (one 2-D copy each) and take the same fused pass
         int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)N * sizeof(InT))) & ~63ll;
         wmax = std::min<int64_t>(std::max<int64_t>(wmax, 64), (int64_t)((1ull << 32) / sizeof(InT)) - 64);
@@ -763,19 +828,25 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
             HIPCHK(c, hipMemcpy2DAsync(v, (size_t)wn * sizeof(InT), (const InT *)X + w0, (size_t)ld * sizeof(InT), (size_t)wn * sizeof(InT),
                                        (size_t)N, hipMemcpyHostToDevice, c->stream));
             if ((rc = run_fused_ovo<InT>(c, v, wn, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc;
-            for (int64_t j = 0; j < wn;) {
-                if (!hf[j]) { ++j; continue; }
-                int64_t e = j;
-                while (e < wn && hf[e]) ++e;
-                if (!runs.empty() && runs.back().second == w0 + j) runs.back().second = w0 + e;
-                else runs.push_back({w0 + j, w0 + e});
-                j = e;
-            }
+            flagged_runs(hf.data(), wn, w0, runs);
         }
         if (runs.empty()) return ILLICO_OK;
     } else {
         runs.push_back({col_lb, col_ub});
     }
+    return run_dense_twopass<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, runs);
+}
+
+// ---- routes 2-4 over the column runs the fused route left (or over everything) ----
+template <typename InT, typename KeyT>
+static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
+                             int alternative, const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> runs) {
+    const int G = (int)c->n_groups;
+    const bool ovr = c->ref < 0;
+    const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
+    const int64_t stride = (N + 63) & ~63ll;
+    int rc;
+    void *v;
     // Flagged genes scattered through the window would make one tiny launch sequence each: runs closer than 32 genes
     // are merged (the good genes in between are recomputed, identically, by the two-pass routes).
     if (runs.size() > 1) {
@@ -870,6 +941,34 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
     return ILLICO_OK;
 }
 
+// Completes a deferred dense call: waits for its route flags and sends the genes the fused pass could not take through the
+// two-pass routes.  Every entry point that takes the context runs this first (illico_run_dense may enqueue its own fused pass
+// before it, see there), so results are complete after illico_ctx_synchronize or any later call.
+static int resolve_pending(illico_ctx *c, PendingDense q) {
+    if (!q.on) return ILLICO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->pend_event[q.slot]));
+    std::vector<std::pair<int64_t, int64_t>> runs;
+    flagged_runs((const u32 *)c->pend_pinned[q.slot], q.col_ub - q.col_lb, q.col_lb, runs);
+    if (runs.empty()) return ILLICO_OK;
+    const OutPlanes o{q.p, q.u, q.fc, q.out_ld, false};
+    switch (q.dtype) {
+    case ILLICO_F32: return run_dense_twopass<float, u32>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, runs);
+#ifndef ILLICO_DEV_F32_ONLY
+    case ILLICO_F64: return run_dense_twopass<double, u64>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, runs);
+    case ILLICO_I32: return run_dense_twopass<int32_t, u32>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, runs);
+    default: return run_dense_twopass<int64_t, u64>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, runs);
+#else
+    default: return fail(c, ILLICO_ERR_DTYPE, "this development build holds the float32 kernels only");
+#endif
+    }
+}
+static int resolve_pending(illico_ctx *c) {
+    const PendingDense q = c->pend;
+    c->pend.on = false;
+    return resolve_pending(c, q);
+}
+
 static int run_dense_any(illico_ctx *c, const void *X, int dtype, int64_t n_rows, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
                          int alternative, const OutPlanes &o) {
     switch (dtype) {
@@ -896,10 +995,26 @@ extern "C" int illico_run_dense(illico_ctx *c, const void *X, int dtype, int64_t
     if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t W = col_ub - col_lb;
-    if (W == 0) return ILLICO_OK;
+    // A deferred call still in flight: when this call is deferred too and writes other planes, its fused pass is enqueued
+    // FIRST (the GPU goes from one pass to the next without waiting for the host) and the earlier call is completed after;
+    // otherwise the earlier call is completed before anything else happens.
+    PendingDense prev = c->pend;
+    c->pend.on = false;
+    bool later = false;
+    if (prev.on && (flags & ILLICO_FLAG_DEFER) && (flags & ILLICO_FLAG_OUTPUT_DEVICE) && (flags & ILLICO_FLAG_INPUT_DEVICE) && W > 0) {
+        const size_t span = (size_t)(c->n_groups - 1) * (size_t)out_ld + (size_t)W, pspan = (size_t)(c->n_groups - 1) * (size_t)prev.out_ld + (size_t)(prev.col_ub - prev.col_lb);
+        auto apart = [](const double *a, size_t na, const double *b, size_t nb) { return a + na <= b || b + nb <= a; };
+        later = true;
+        for (const double *a : {out_p, out_u, out_fc})
+            for (const double *b : {prev.p, prev.u, prev.fc}) later = later && apart(a, span, b, pspan);
+    }
+    if (!later && (rc = resolve_pending(c, prev))) return rc;
+    if (W == 0) return later ? resolve_pending(c, prev) : ILLICO_OK;
     OutPlanes o;
-    if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) return rc;
-    if ((rc = run_dense_any(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o))) return rc;
+    if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) { if (later) resolve_pending(c, prev); return rc; }
+    rc = run_dense_any(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o);
+    if (later) { const int rc2 = resolve_pending(c, prev); if (!rc) rc = rc2; }
+    if (rc) return rc;
     return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
 }
 
@@ -913,6 +1028,7 @@ extern "C" int illico_rank_statistics(illico_ctx *c, const void *X, int dtype, i
     if (ld < n_cols) return fail(c, ILLICO_ERR_ARG, "ld smaller than n_cols");
     if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
     HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = resolve_pending(c))) return rc;
     if (col_ub == col_lb) return ILLICO_OK;
     illico_ctx::StatsTap tap{(long long *)out_two_u, (u64 *)out_tie_sum, out_value_sum};
     c->tap = &tap;

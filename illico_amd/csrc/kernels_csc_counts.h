@@ -1,6 +1,6 @@
 // CSC, count-valued genes, small groups: one pass over a gene's stored entries builds the per-group value histograms in
-// LDS -- h[group][value], 8-bit cells, 64 (or 32) values: 64 bytes per group, 128 KB for 2000 groups -- with ONE non-returning
-// LDS atomic per entry; a sweep with one thread per group then turns histograms into the statistics:
+// LDS -- h[group][value] -- with ONE non-returning LDS atomic per entry; a sweep with one thread per group then turns
+// histograms into the statistics:
 //   OVO:  S2 = sum_{c>=1} tB[c] (2 zA + 2 cumA[c] + tA[c]) + zB zA,      tie = T_A + sum_{c>=1} tB (3 tA (tA+tB) + tB^2 - 1) + (t0^3 - t0)
 //   OVR:  r2 = sum_{c>=1} tB[c] (2 n0 + 2 cum[c] + t[c] + 1) + zB (n0 + 1),  tie = sum_{c>=1} (t^3 - t) + (n0^3 - n0)
 // (zA, zB, n0 = implicit zeros of the reference / the group / the column, t0 = zA + zB) -- the same integers the sort-based
@@ -8,12 +8,28 @@
 // regrouping or searching anything.  Nothing but the CSC arrays is read from HBM: 1.9 GB at C3.
 //
 // Takes a gene only if every stored value is an integer in [1, RT) (stored zeros are dropped: they are zeros) and
-// -- host-checked -- at most CSCC_MAX_BIG ranked groups have more than 255 cells (those get 32-bit cells; the others
-// 8-bit cells); other genes set fallback[gene] and go to the general CSC routes.
+// -- host-checked -- at most CSCC_MAX_BIG ranked groups have more than 255 cells (those get 32-bit cells); other genes set
+// fallback[gene] = 1 and go to the general CSC routes.
+//
+// Two cell layouts (word-major: word w of group g = h[w * G + g], so lanes = consecutive groups read consecutive words in
+// the sweep and the increments of random groups spread over all banks):
+//  * MIXED: 8 bits for the values 1 .. 7, 4 bits for 8 .. 63 -> 36 bytes per group, 72 KB for 2000 groups, so that TWO
+//    workgroups fit a CU and one gene's entry loop overlaps the other's zeroing / sweep / stores.  A 4-bit cell that
+//    overflows (16 or more cells of one group with the same value >= 8) carries into its neighbour: the cells of the gene then
+//    add up to fewer entries than were counted (a carry can only lose entries), the gene sets fallback[gene] = 2 and the host
+//    sends it through the 8-bit form.  words 0, 1: the 8-bit cells of values 0 .. 7; words 2 .. 8: eight 4-bit cells each.
+//  * 8-bit cells for every value: RT bytes per group (128 KB for 2000 groups at RT = 64: one workgroup per CU).
+//
+// What bounds the entry loop is the texture addresser: one codes[row] gather per entry.  A column's rows ascend, so the 64
+// gathers of a wavefront fall into a few cache lines -- half as many with 16-bit codes (codes16): 0.80 -> 0.65 ms at C3.
+// History at C3 (tools/micro/cscc_bench.hip, nnz 2.4e8): 8-bit cells, 1024 threads, sweep fully unrolled (43 spilled VGPRs)
+// 1.51 ms -> sweep rolled, no spills 1.05 -> 16 entries per thread in flight 1.01 -> mixed cells, 2 x 512 threads per CU 0.79
+// -> 16-bit codes 0.65 ms.  Phases of the 1.01 ms form: zeroing + launch 0.15, entry loop 0.64, sweep + stores 0.2.
 #pragma once
 #include "common.h"
 
-#define CSCC_NT 1024
+#define CSCC_NT 512
+#define CSCC_UL 16 // entries per thread and round
 #define CSCC_RT 64 // widest table (values 1 .. 63); the 32-value form is used when 64 bytes per group do not fit LDS
 
 struct CscCountsParams {
@@ -23,6 +39,7 @@ struct CscCountsParams {
     const int *gene_cols;                // or: the batch's genes as a column list (absolute indices); nullptr = contiguous
     int nb;
     const int *codes;                    // [n_cells] group code per cell; nullptr: `indices` already holds group codes
+    const u16 *codes16;                  // the same codes as 16-bit values (G <= 65535), or nullptr
     const int *counts;                   // [G]
     int G, ref;                          // ref == -1: OVR
     long long n_cells;
@@ -31,25 +48,27 @@ struct CscCountsParams {
     long long *out_2u;
     u64 *out_tie;
     double *out_sum;
+    double *gene_total;                  // OVR: [nb] the column's value sum (what k_gene_totals would add up from out_sum), or nullptr
 };
 
-static inline size_t cscc_lds_bytes(int G, int rt) { return (size_t)G * rt + (((size_t)G + 15) & ~(size_t)15); } // cells + slot bytes
+#define CSCM_WPG 9 // words per group of the mixed layout
+// cells + slot bytes; rt = 0: the mixed layout
+static inline size_t cscc_lds_bytes(int G, int rt) { return (size_t)G * (rt ? rt : CSCM_WPG * 4) + (((size_t)G + 15) & ~(size_t)15); }
 
 #define CSCC_MAX_BIG 8
-template <typename InT, typename IdxT, bool OVR, int RT, bool HAS_BIG>
-__global__ __launch_bounds__(CSCC_NT) void k_csc_counts(CscCountsParams P) {
-    constexpr int NT = CSCC_NT, WPG = RT / 4; // words per group
-    extern __shared__ __align__(16) u32 cscc_h[];             // [WPG][G] words: cell (g, c) = byte c % 4 of word [c / 4][g]
-    // (word-major: a group's words are G apart, so lanes = consecutive groups read consecutive words in the sweep and
-    //  the increments of random groups spread over all banks)
+template <typename InT, typename IdxT, bool OVR, int RT, bool HAS_BIG, bool MIXED>
+__global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCountsParams P) { // (waves per SIMD: two workgroups per CU for the mixed form)
+    static_assert(!MIXED || RT == 64, "the mixed layout holds the values 1 .. 63");
+    constexpr int NT = CSCC_NT, UL = CSCC_UL, WPG = MIXED ? CSCM_WPG : RT / 4; // words per group
+    extern __shared__ __align__(16) u32 cscc_h[];             // [WPG][G] words
     __shared__ u32 hsel[RT];   // OVO: histogram of the reference group's stored values; OVR: of the whole column
     __shared__ u32 hbig[HAS_BIG ? CSCC_MAX_BIG * RT : 1]; // 32-bit cells of the few groups with more than 255 cells
     signed char *slot = (signed char *)(cscc_h + (size_t)WPG * P.G); // [G] copy of big_slot (HAS_BIG)
     __shared__ u32 cum[RT + 1]; // cum[c] = # selected stored values < c (c >= 1)
     __shared__ u64 s_T, s_sum;
-    __shared__ u32 s_nnz;
+    __shared__ u32 s_nnz, s_entries, s_cells;
     __shared__ int s_bad;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int G = P.G, ref = P.ref;
     const InT *data = (const InT *)P.data;
     const IdxT *indices = (const IdxT *)P.indices, *indptr = (const IdxT *)P.indptr;
@@ -57,7 +76,6 @@ __global__ __launch_bounds__(CSCC_NT) void k_csc_counts(CscCountsParams P) {
     for (int gene = blockIdx.x; gene < P.nb; gene += gridDim.x) {
         const long long col = P.gene_cols ? (long long)P.gene_cols[gene] : P.col0 + gene;
         const long long k0 = (long long)indptr[col] - P.kshift, k1 = (long long)indptr[col + 1] - P.kshift;
-        constexpr int UL = 8; // independent entries per thread in flight
         // (the first round's loads are in flight while the tables are zeroed)
         InT vn[UL];
         IdxT in[UL];
@@ -67,46 +85,69 @@ __global__ __launch_bounds__(CSCC_NT) void k_csc_counts(CscCountsParams P) {
             vn[u] = k < k1 ? data[k] : (InT)0;
             in[u] = k < k1 ? indices[k] : (IdxT)0;
         }
-        for (int i = tid; i < G * WPG; i += NT) cscc_h[i] = 0;
+        {
+            uint4 *h4 = (uint4 *)cscc_h;
+            const int n4 = (G * WPG) >> 2;
+            for (int i = tid; i < n4; i += NT) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (int i = (n4 << 2) + tid; i < G * WPG; i += NT) cscc_h[i] = 0;
+        }
         if (tid < RT) hsel[tid] = 0;
         if (HAS_BIG) {
             for (int i = tid; i < CSCC_MAX_BIG * RT; i += NT) hbig[i] = 0;
             for (int i = tid; i < G; i += NT) slot[i] = P.big_slot[i];
         }
-        if (tid == 0) s_bad = 0;
+        if (tid == 0) { s_bad = 0; s_entries = 0; s_cells = 0; }
         __syncthreads();
         bool bad = false;
+        u32 n_ent = 0; // MIXED: entries this thread put into the packed group tables
         // two-stage pipeline over the gene's entries: the values / row indices of round i + 1 are requested before round
-        // i's group codes (a dependent gather) and LDS atomics, so one HBM round trip per round is off the critical path
-        for (long long kb = k0; kb < k1; kb += NT * UL) {
-            InT v[UL];
-            int cd[UL];
-#pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                v[u] = vn[u];
-                cd[u] = P.codes ? P.codes[(long long)in[u]] : (int)in[u]; // (entries past k1: row 0, value 0 -> ignored)
-            }
-            const long long kn = kb + (long long)NT * UL;
-            if (kn < k1) { // uniform
+        // i's group codes (a dependent gather) and LDS atomics, so one HBM round trip per round is off the critical path.
+        // (One copy of the loop per code source: with the choice inside, the 16 gathers of a round are not issued back to back.)
+        auto entry_loop = [&](auto code_of) {
+            for (long long kb = k0; kb < k1; kb += (long long)NT * UL) {
+                InT v[UL];
+                int cd[UL];
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
-                    const long long k = kn + u * NT + tid;
-                    vn[u] = k < k1 ? data[k] : (InT)0;
-                    in[u] = k < k1 ? indices[k] : (IdxT)0;
+                    v[u] = vn[u];
+                    cd[u] = code_of(in[u]); // (entries past k1: row 0, value 0 -> ignored)
                 }
-            }
+                const long long kn = kb + (long long)NT * UL;
+                if (kn < k1) { // uniform
 #pragma unroll
-            for (int u = 0; u < UL; ++u)
-                if (v[u] != (InT)0) {
-                    const int c = (v[u] > (InT)0 && v[u] < (InT)RT) ? (int)v[u] : 0;
-                    if (c == 0 || (InT)c != v[u]) bad = true; // negative, fractional, NaN or beyond the table
-                    else {
-                        const int bs = HAS_BIG ? (int)slot[cd[u]] : -1;
-                        if (bs >= 0) atomicAdd(&hbig[bs * RT + c], 1u);
-                        else if (OVR || cd[u] != ref) atomicAdd(&cscc_h[(c >> 2) * G + cd[u]], 1u << ((c & 3) * 8));
-                        if (OVR || cd[u] == ref) atomicAdd(&hsel[c], 1u);
+                    for (int u = 0; u < UL; ++u) {
+                        const long long k = kn + u * NT + tid;
+                        vn[u] = k < k1 ? data[k] : (InT)0;
+                        in[u] = k < k1 ? indices[k] : (IdxT)0;
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < UL; ++u)
+                    if (v[u] != (InT)0) {
+                        const int c = (v[u] > (InT)0 && v[u] < (InT)RT) ? (int)v[u] : 0;
+                        if (c == 0 || (InT)c != v[u]) bad = true; // negative, fractional, NaN or beyond the table
+                        else {
+                            const int bs = HAS_BIG ? (int)slot[cd[u]] : -1;
+                            if (bs >= 0) atomicAdd(&hbig[bs * RT + c], 1u);
+                            else if (OVR || cd[u] != ref) {
+                                if (MIXED) {
+                                    const int wi = c < 8 ? (c >> 2) : 2 + ((c - 8) >> 3);
+                                    const int sh = c < 8 ? (c & 3) * 8 : ((c - 8) & 7) * 4;
+                                    atomicAdd(&cscc_h[wi * G + cd[u]], 1u << sh);
+                                    ++n_ent;
+                                } else atomicAdd(&cscc_h[(c >> 2) * G + cd[u]], 1u << ((c & 3) * 8));
+                            }
+                            if (OVR || cd[u] == ref) atomicAdd(&hsel[c], 1u);
+                        }
+                    }
+            }
+        };
+        if (P.codes16) { const u16 *t = P.codes16; entry_loop([t](IdxT row) { return (int)t[(long long)row]; }); }
+        else if (P.codes) { const int *t = P.codes; entry_loop([t](IdxT row) { return t[(long long)row]; }); }
+        else entry_loop([](IdxT row) { return (int)row; });
+        if (MIXED) {
+            n_ent = (u32)wave_sum((int)n_ent);
+            if (lane == 0 && n_ent) atomicAdd(&s_entries, n_ent);
         }
         if (bad) s_bad = 1;
         __syncthreads();
@@ -130,11 +171,13 @@ __global__ __launch_bounds__(CSCC_NT) void k_csc_counts(CscCountsParams P) {
             s_nnz = run;
             s_T = T;
             s_sum = sum;
+            if (OVR && P.gene_total) P.gene_total[gene] = (double)sum; // integer sums: exact whatever the order of addition
         }
         __syncthreads();
         const u64 nnz_sel = s_nnz, T_sel = s_T;
         const long long n_ref = OVR ? 0 : P.counts[OVR ? 0 : ref];
         const u64 zsel = (u64)((OVR ? P.n_cells : n_ref) - (long long)nnz_sel); // zA (OVO) or n0 (OVR)
+        u32 cells_seen = 0;
         for (int g = tid; g < G; g += NT) {
             const size_t o = (size_t)gene * G + g;
             if (!OVR && g == ref) {
@@ -144,27 +187,49 @@ __global__ __launch_bounds__(CSCC_NT) void k_csc_counts(CscCountsParams P) {
                 continue;
             }
             // 32-bit inner terms (host-checked: n_ref < 30000 for OVO, n_cells < 2^30), one 32 x 32 -> 64 multiply-add each;
-            // a word whose four cells are empty for every lane of the wavefront (most of the table) is skipped
+            // a word whose cells are empty for every lane of the wavefront is skipped.  The word loop stays rolled: unrolled,
+            // the compiler hoists all 2 RT table reads into registers and spills 43 of them.
             u64 acc = 0, tie = 0;
             u32 nnz_g = 0, vsum = 0;
             const int bs = HAS_BIG ? (int)slot[g] : -1;
+            auto cell = [&](int c, u32 tB) {
+                const u32 tS = hsel[c], lo = cum[c];
+                nnz_g += tB;
+                vsum += tB * (u32)c;
+                if (OVR) acc += (u64)tB * (u32)(2u * (u32)zsel + 2u * lo + tS + 1u);
+                else {
+                    acc += (u64)tB * (u32)(2u * (u32)zsel + 2u * lo + tS);
+                    tie += (u64)tB * (u32)(3u * tS * (tS + tB) + tB * tB - 1u);
+                }
+            };
+            if (HAS_BIG && bs >= 0) {
+#pragma unroll 1
+                for (int c = 1; c < RT; ++c) cell(c, hbig[bs * RT + c]);
+            }
+            const bool packed = !HAS_BIG || bs < 0;
+            if (MIXED) {
 #pragma unroll
-            for (int i = 0; i < WPG; ++i) {
-                const u32 w = cscc_h[i * G + g];
-                if (__ballot(w != 0 || bs >= 0) == 0ull) continue;
+                for (int i = 0; i < 2; ++i) { // the 8-bit cells of the values 0 .. 7
+                    const u32 w = packed ? cscc_h[i * G + g] : 0u;
+                    if (__ballot(w != 0) == 0ull) continue;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int c = i * 4 + k;
-                    if (c == 0) continue;
-                    const u32 tB = bs >= 0 ? hbig[bs * RT + c] : ((w >> (k * 8)) & 0xFFu);
-                    const u32 tS = hsel[c], lo = cum[c];
-                    nnz_g += tB;
-                    vsum += tB * (u32)c;
-                    if (OVR) acc += (u64)tB * (u32)(2u * (u32)zsel + 2u * lo + tS + 1u);
-                    else {
-                        acc += (u64)tB * (u32)(2u * (u32)zsel + 2u * lo + tS);
-                        tie += (u64)tB * (u32)(3u * tS * (tS + tB) + tB * tB - 1u);
-                    }
+                    for (int k = 0; k < 4; ++k) cell(i * 4 + k, (w >> (k * 8)) & 0xFFu);
+                }
+#pragma unroll 1
+                for (int i = 2; i < WPG; ++i) { // eight 4-bit cells per word
+                    const u32 w = packed ? cscc_h[i * G + g] : 0u;
+                    if (__ballot(w != 0) == 0ull) continue;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) cell(8 + (i - 2) * 8 + k, (w >> (k * 4)) & 0xFu);
+                }
+                if (packed) cells_seen += nnz_g;
+            } else {
+#pragma unroll 1
+                for (int i = 0; i < WPG; ++i) {
+                    const u32 w = packed ? cscc_h[i * G + g] : 0u;
+                    if (__ballot(w != 0) == 0ull) continue;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) cell(i * 4 + k, (w >> (k * 8)) & 0xFFu);
                 }
             }
             const long long n_g = P.counts[g];
@@ -180,6 +245,12 @@ __global__ __launch_bounds__(CSCC_NT) void k_csc_counts(CscCountsParams P) {
                 P.out_tie[o] = T_sel + tie + (t0 * t0 * t0 - t0);
             }
             P.out_sum[o] = (double)vsum;
+        }
+        if (MIXED) {
+            cells_seen = (u32)wave_sum((int)cells_seen);
+            if (lane == 0 && cells_seen) atomicAdd(&s_cells, cells_seen);
+            __syncthreads();
+            if (tid == 0 && s_cells != s_entries) P.fallback[gene] = 2u; // a 4-bit cell overflowed: the 8-bit form redoes this gene
         }
         __syncthreads();
     }

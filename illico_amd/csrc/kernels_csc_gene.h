@@ -27,6 +27,7 @@ struct CscGeneParams {
     const int *gene_cols;                // or: the batch's genes as a column list (absolute indices); nullptr = contiguous
     int nb;
     const int *codes;                    // [n_cells] group code per cell; nullptr: `indices` already holds group codes
+    const u16 *codes16;                  // the same as 16-bit values (fewer cache lines per gather), or nullptr
     const int *counts;                   // [G]
     int G, ref, dt, is_log1p;
     int key_cap;                         // LDS key slots
@@ -52,7 +53,7 @@ static inline size_t cscg_lds_bytes(int G, int key_cap, int runend_cap, size_t k
 // LDS, so nothing else hides that round trip).
 template <int NT, int UL, typename InT, typename IdxT, typename Body>
 __device__ __forceinline__ void csc_for_entries(const InT *__restrict__ data, const IdxT *__restrict__ indices, const int *__restrict__ codes,
-                                                long long k0, long long k1, int tid, Body &&body) {
+                                                const u16 *__restrict__ codes16, long long k0, long long k1, int tid, Body &&body) {
     InT vn[UL];
     IdxT in[UL];
 #pragma unroll
@@ -67,7 +68,7 @@ __device__ __forceinline__ void csc_for_entries(const InT *__restrict__ data, co
 #pragma unroll
         for (int u = 0; u < UL; ++u) {
             v[u] = vn[u];
-            cd[u] = codes ? codes[(long long)in[u]] : (int)in[u]; // (entries past k1: row 0, value 0 -> ignored by the bodies)
+            cd[u] = codes16 ? (int)codes16[(long long)in[u]] : (codes ? codes[(long long)in[u]] : (int)in[u]); // (entries past k1: row 0, value 0 -> ignored by the bodies)
         }
         const long long kn = kb + (long long)NT * UL;
         if (kn < k1) { // uniform
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
         for (int g = tid; g <= G; g += NT) ends[g] = 0;
         __syncthreads();
         constexpr int UL = 8; // independent entries per thread in flight
-        csc_for_entries<NT, UL>(data, indices, P.codes, k0, k1, tid, [&](InT, int cd) { atomicAdd(&ends[cd], 1u); });
+        csc_for_entries<NT, UL>(data, indices, P.codes, P.codes16, k0, k1, tid, [&](InT, int cd) { atomicAdd(&ends[cd], 1u); });
         __syncthreads();
         const u32 nA = ends[ref];
         u32 mx = 0;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(CSCG_NT) void k_csc_gene(CscGeneParams P) {
             continue;
         }
         // ---- 3. regroup the keys in LDS ----
-        csc_for_entries<NT, UL>(data, indices, P.codes, k0, k1, tid, [&](InT v, int cd) { keybuf[atomicAdd(&ends[cd], 1u)] = key_of(v); });
+        csc_for_entries<NT, UL>(data, indices, P.codes, P.codes16, k0, k1, tid, [&](InT v, int cd) { keybuf[atomicAdd(&ends[cd], 1u)] = key_of(v); });
         __syncthreads();
         // now ends[g] = one past the last key of group g; its run starts at ends[g-1] (0 for g = 0)
         // ---- 4. reference run: sort in place, run ends, T_A, sum ----

@@ -44,6 +44,7 @@ struct CscOvrParams {
     long long col0;                      // first gene of the batch (contiguous batches)
     const int *gene_cols;                // or: the batch's genes as a column list (absolute indices); nullptr = contiguous
     const int *codes;                    // [n_cells] group code per cell; nullptr: `indices` already holds group codes
+    const u16 *codes16;                  // the same as 16-bit values (fewer cache lines per gather), or nullptr
     // part source (PARTS = true): records written by k_ovr_partition
     const void *pkeys;                   // [nb][pstride] non-zero keys, part after part
     const u16 *pcodes;                   // [nb][pstride] their group codes
@@ -122,6 +123,7 @@ template <typename InT, typename IdxT, typename KeyT, bool PARTS> struct OvrSour
     const InT *data;
     const IdxT *indices;
     const int *codes;
+    const u16 *codes16;
     const KeyT *pkeys;
     const u16 *pcodes;
     __device__ __forceinline__ RawV raw_v(long long k, bool in) const {
@@ -139,7 +141,7 @@ template <typename InT, typename IdxT, typename KeyT, bool PARTS> struct OvrSour
     }
     __device__ __forceinline__ int code_from(RawI i) const {
         if constexpr (PARTS) return (int)i;
-        else return codes ? codes[(long long)i] : (int)i; // (entries past the end carry row 0: a valid, ignored look-up)
+        else return codes16 ? (int)codes16[(long long)i] : (codes ? codes[(long long)i] : (int)i); // (entries past the end carry row 0: a valid, ignored look-up)
     }
 };
 
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         } else {
             const long long col = P.gene_cols ? (long long)P.gene_cols[gene] : P.col0 + gene;
             k0 = (long long)indptr[col] - P.kshift; k1 = (long long)indptr[col + 1] - P.kshift;
-            src.data = (const InT *)P.data; src.indices = (const IdxT *)P.indices; src.codes = P.codes;
+            src.data = (const InT *)P.data; src.indices = (const IdxT *)P.indices; src.codes = P.codes; src.codes16 = P.codes16;
         }
         const long long ns_ll = k1 - k0;
         if (ns_ll > (long long)P.key_cap) { // uniform: this gene takes the general route

@@ -97,12 +97,20 @@ __global__ __launch_bounds__(256) void k_gene_totals(const double *in_sum, int G
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // ty 0..3
     const int gene0 = blockIdx.x * 64;
     double t = 0.0;
-    for (int g0 = 0; g0 < G; g0 += 64) {
-        for (int r = ty; r < 64; r += 4) {
-            const int gene = gene0 + r, g = g0 + tx;
-            tile[r][tx] = (gene < nb && g < G) ? in_sum[(size_t)gene * G + g] : 0.0;
+    double nx[16]; // the next tile waits in registers while this one is added up (one load latency per tile, not two)
+    auto fetch = [&](int g0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int gene = gene0 + ty + 4 * i, g = g0 + tx;
+            nx[i] = (gene < nb && g < G) ? in_sum[(size_t)gene * G + g] : 0.0;
         }
+    };
+    fetch(0);
+    for (int g0 = 0; g0 < G; g0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tile[ty + 4 * i][tx] = nx[i];
         __syncthreads();
+        if (g0 + 64 < G) fetch(g0 + 64);
         if (ty == 0) {
             const int lim = min(64, G - g0);
             for (int k = 0; k < lim; ++k) t += tile[tx][k];

@@ -198,6 +198,36 @@ __global__ void k_sample_noncount_dense(const InT *__restrict__ X, long long ld,
     }
 }
 
+// Route probe, on the device and for the device: PROBE_ROWS evenly spaced rows of every gene of the window; a gene that shows
+// a value outside the table is flagged here, before the main pass, whose workgroups leave at once when every gene of their
+// tile is flagged.  On normalised (continuous) data that is every gene, so the pass over X costs nothing and no host round
+// trip is needed to choose the route; a gene this probe misses is flagged by the main pass itself.
+#define FUSED_PROBE_ROWS 256
+template <typename InT, int RT>
+__global__ __launch_bounds__(256) void k_fused_probe(FusedParams P) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gene = blockIdx.x * 64 + lane;
+    if (gene >= P.ncols) return;
+    const InT *Xg = (const InT *)P.X + P.col0 + gene;
+    bool bad = false;
+    constexpr int PER = FUSED_PROBE_ROWS / 4;
+    InT v[8];
+    for (int i0 = 0; i0 < PER; i0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long r = ((long long)(wave * PER + i0 + u) * P.n_cells) / FUSED_PROBE_ROWS;
+            v[u] = Xg[r * P.ld];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            bool exact;
+            clamp_count<InT, RT>(v[u], exact);
+            bad |= !exact;
+        }
+    }
+    if (bad) P.gene_flags[gene] = 1u;
+}
+
 // ---- reference tables: one 1024-thread workgroup per 64-gene tile; lane = gene.  All 16 wavefronts add into one
 // LDS histogram (columns are lane-private, so the only contention is between wavefronts), then wavefront 0 scans
 // each gene's bins into the cumulative table, T_A and the reference sum, and writes the reference group's row.
@@ -457,9 +487,16 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_ovr_group_hists(FusedParams P) 
     const u32 row_bytes = (u32)P.ld * (u32)sizeof(InT), col_bytes = (u32)lane_c * (u32)sizeof(InT);
     const const_int_p permc = (const_int_p)P.perm;
     u32 *cbw = cntB[wave];
+    __shared__ int s_skip;
+    if (wave == 0) { // every gene of this tile already sent to the slower routes (k_fused_probe)? then there is nothing to do here
+        const bool flagged = !act || P.gene_flags[gene] != 0;
+        const bool all = __all(flagged);
+        if (lane == 0) s_skip = all ? 1 : 0;
+    }
     for (int i = tid; i < RT * 64; i += NT) hcol[i] = 0;
     for (int i = 0; i < BW; ++i) cbw[i * 64 + lane] = 0;
     __syncthreads();
+    if (s_skip) return;
     cell_t *cells = (cell_t *)cbw + lane * PW; // cell c: cells[(c / PW) * 64 * PW + c % PW]
     u32 *hl = hcol + lane;
     bool bad = false;

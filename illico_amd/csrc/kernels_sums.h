@@ -22,28 +22,34 @@
 // 2^k with k in [-1022, 1023]
 __device__ __forceinline__ double exs_pow2(int k) { return __longlong_as_double((long long)(k + 1023) << 52); }
 
-// scale of a gene whose largest magnitude is vmax (finite, > 0): vmax * sc lies in [2^83, 2^84).  The scaling is done in two
-// exact power-of-two steps so that neither factor leaves the normal range whatever vmax is.
+// scale of a gene whose largest magnitude is vmax (finite, > 0): vmax * 2^k lies in [2^83, 2^84).
 struct ExsScale {
-    double s1, s2; // v * s1 * s2, both powers of two
-    double u1, u2; // inverse: x * u1 * u2
+    int k;         // v -> trunc(v * 2^k)
+    double u1, u2; // inverse: x * u1 * u2 (two exact power-of-two steps, so that neither factor leaves the normal range)
 };
 __device__ __forceinline__ ExsScale exs_scale(double vmax) {
-    const int e = (int)((__double_as_longlong(vmax) >> 52) & 0x7FF) - 1023; // floor(log2(vmax)) for normal vmax; -1023 for subnormals
-    const int k = 2 * EXS_LIMB - 1 - e;                                    // in [-940, 1106]
-    const int k1 = k / 2, k2 = k - k1;
+    int e = (int)((__double_as_longlong(vmax) >> 52) & 0x7FF);
+    e = (e ? e : 1) - 1023;                       // floor(log2(vmax)) for normal vmax; subnormals count as 2^-1022
     ExsScale S;
-    S.s1 = exs_pow2(k1); S.s2 = exs_pow2(k2);
+    S.k = 2 * EXS_LIMB - 1 - e;                   // in [-940, 1105]
+    const int k1 = S.k / 2, k2 = S.k - k1;
     S.u1 = exs_pow2(-k1); S.u2 = exs_pow2(-k2);
     return S;
 }
-// v -> (l1, l0): trunc(v * sc) = l1 * 2^42 + l0, both limbs carry v's sign
+// v -> (l1, l0): trunc(v * 2^k) = l1 * 2^42 + l0, both limbs carry v's sign.  Integer arithmetic on the bits of v (a 53-bit
+// significand shifted into place): the float64 form of the same split (multiply, trunc, subtract, two f64 -> i64 conversions)
+// made the sums kernels VALU-bound.
 __device__ __forceinline__ void exs_split(double v, const ExsScale &S, long long &l0, long long &l1) {
-    const double y = v * S.s1 * S.s2;                              // exact unless it underflows (then it is below one unit anyway)
-    const double hi = trunc(y * 0x1p-42);                          // |hi| < 2^42
-    const double lo = y - hi * 0x1p42;                             // exact: the low bits of y
-    l1 = (long long)hi;
-    l0 = (long long)lo;                                            // truncation toward zero: the one inexact step
+    const u64 b = (u64)__double_as_longlong(v);
+    const int ef = (int)((b >> 52) & 0x7FF);
+    u64 m = (b & 0x000FFFFFFFFFFFFFull) | (ef ? 0x0010000000000000ull : 0ull); // |v| = m * 2^(max(ef, 1) - 1075)
+    int p = (ef ? ef : 1) - 1075 + S.k;                                        // trunc(|v| 2^k) = m * 2^p; p <= 31 as |v| <= vmax
+    if (p < 0) { m = p > -64 ? m >> (-p) : 0ull; p = 0; }                      // truncation toward zero: the one inexact step
+    const int cut = EXS_LIMB - p;                                              // bits of m that stay in the low limb (11 .. 42)
+    u64 hi = m >> cut, lo = (m & ((1ull << cut) - 1ull)) << p;
+    const bool neg = (long long)b < 0;
+    l1 = neg ? -(long long)hi : (long long)hi;
+    l0 = neg ? -(long long)lo : (long long)lo;
 }
 // (L1 * 2^42 + L0) / sc, rounded to float64 once
 __device__ __forceinline__ double exs_combine(long long L0, long long L1, const ExsScale &S) {
@@ -96,13 +102,15 @@ struct CscSumsParams {
     long long col0;                      // first gene of the batch (contiguous batches)
     const int *gene_cols;                // or the batch's genes as a column list; nullptr = contiguous
     const int *codes;                    // [n_cells] group code per cell; nullptr: `indices` already holds group codes
+    const u16 *codes16;                  // the same as 16-bit values (fewer cache lines per gather), or nullptr
     int nb, G, dt, is_log1p;
     long long *acc_global;               // ACCG: [nb][2][G] limb totals in HBM (zeroed by the host) when 16 G bytes exceed LDS
     double *out_sum;                     // [nb][G]
 };
+#define CSUM_NT 512
 template <typename InT, typename IdxT, bool ACCG>
-__global__ __launch_bounds__(SUMS_NT) void k_csc_value_sums(CscSumsParams P) {
-    constexpr int NT = SUMS_NT, UL = 4;
+__global__ __launch_bounds__(CSUM_NT, 4) void k_csc_value_sums(CscSumsParams P) {
+    constexpr int NT = CSUM_NT, UL = 8, NW = NT / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     double *s_red = (double *)smem;                 // [NW]
     long long *L0 = (long long *)(smem + 64);       // [G]
@@ -115,12 +123,28 @@ __global__ __launch_bounds__(SUMS_NT) void k_csc_value_sums(CscSumsParams P) {
         const long long k0 = (long long)indptr[col] - P.kshift, k1 = (long long)indptr[col + 1] - P.kshift;
         if constexpr (ACCG) { L0 = P.acc_global + (size_t)gene * 2 * G; L1 = L0 + G; }
         else for (int g = tid; g < G; g += NT) { L0[g] = 0; L1[g] = 0; }
+        // ---- the gene's largest magnitude (UL independent loads per thread and round) ----
         double vmax = 0.0;
-        for (long long k = k0 + tid; k < k1; k += NT) {
-            const double a = fabs(sums_value(data[k], P.dt, P.is_log1p));
-            vmax = (a > vmax || a != a) ? a : vmax;
+        for (long long kb = k0; kb < k1; kb += (long long)NT * UL) {
+            InT v[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) { const long long k = kb + u * NT + tid; v[u] = k < k1 ? data[k] : (InT)0; }
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const double a = fabs(sums_value(v[u], P.dt, P.is_log1p));
+                vmax = (a > vmax || a != a) ? a : vmax;
+            }
         }
-        vmax = block_max_f64(vmax, s_red, tid); // (its barriers also order the zeroing above)
+        {   // block max, NaN-propagating (its barriers also order the zeroing above)
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { const double o = __shfl_xor(vmax, d); vmax = (o > vmax || o != o) ? o : vmax; }
+            __syncthreads();
+            if ((tid & 63) == 0) s_red[tid >> 6] = vmax;
+            __syncthreads();
+            vmax = s_red[0];
+            for (int w = 1; w < NW; ++w) { const double o = s_red[w]; vmax = (o > vmax || o != o) ? o : vmax; }
+            __syncthreads();
+        }
         const bool finite = vmax < __longlong_as_double(0x7FF0000000000000ll); // false for inf and NaN
         double *out = P.out_sum + (size_t)gene * G;
         if (vmax == 0.0) { // uniform: nothing but (stored) zeros
@@ -128,46 +152,55 @@ __global__ __launch_bounds__(SUMS_NT) void k_csc_value_sums(CscSumsParams P) {
             __syncthreads();
             continue;
         }
-        if (!finite) { // uniform: an inf or NaN among the values.  Its sums are inf / NaN whatever the order; plain float64 adds.
-            double *F = (double *)L0;
-            for (int g = tid; g < G; g += NT) F[g] = 0.0;
-            __syncthreads();
-            for (long long k = k0 + tid; k < k1; k += NT) {
-                const InT v = data[k];
-                if (v != (InT)0) {
-                    const int cd = P.codes ? P.codes[(long long)indices[k]] : (int)indices[k];
-                    atomicAdd(&F[cd], sums_value(v, P.dt, P.is_log1p));
-                }
-            }
-            __syncthreads();
-            for (int g = tid; g < G; g += NT) { out[g] = F[g]; if constexpr (ACCG) { L0[g] = 0; } }
-            __syncthreads();
-            continue;
-        }
-        const ExsScale S = exs_scale(vmax);
-        for (long long kb = k0; kb < k1; kb += (long long)NT * UL) {
-            InT v[UL];
-            IdxT ix[UL];
+        const bool exact = finite;
+        ExsScale S;
+        S.k = 0; S.u1 = S.u2 = 1.0;
+        if (exact) S = exs_scale(vmax);
+        double *F = (double *)L0; // inf / NaN among the values: the sums are inf / NaN whatever the order; plain float64 adds
+        // ---- two-stage pipeline over the entries (as k_csc_counts): the values / rows of round i + 1 are requested before
+        // round i's codes[row] gather and LDS atomics ----
+        auto entry_loop = [&](auto code_of) {
+            InT vn[UL];
+            IdxT in[UL];
 #pragma unroll
             for (int u = 0; u < UL; ++u) {
-                const long long k = kb + u * NT + tid;
-                v[u] = k < k1 ? data[k] : (InT)0;
-                ix[u] = k < k1 ? indices[k] : (IdxT)0;
+                const long long k = k0 + u * NT + tid;
+                vn[u] = k < k1 ? data[k] : (InT)0;
+                in[u] = k < k1 ? indices[k] : (IdxT)0;
             }
+            for (long long kb = k0; kb < k1; kb += (long long)NT * UL) {
+                InT v[UL];
+                int cd[UL];
 #pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                if (v[u] != (InT)0) {
-                    const int cd = P.codes ? P.codes[(long long)ix[u]] : (int)ix[u];
-                    long long l0, l1;
-                    exs_split(sums_value(v[u], P.dt, P.is_log1p), S, l0, l1);
-                    if (l1) atomicAdd((u64 *)&L1[cd], (u64)l1);
-                    if (l0) atomicAdd((u64 *)&L0[cd], (u64)l0);
+                for (int u = 0; u < UL; ++u) { v[u] = vn[u]; cd[u] = code_of(in[u]); }
+                const long long kn = kb + (long long)NT * UL;
+                if (kn < k1) { // uniform
+#pragma unroll
+                    for (int u = 0; u < UL; ++u) {
+                        const long long k = kn + u * NT + tid;
+                        vn[u] = k < k1 ? data[k] : (InT)0;
+                        in[u] = k < k1 ? indices[k] : (IdxT)0;
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < UL; ++u)
+                    if (v[u] != (InT)0) {
+                        const double x = sums_value(v[u], P.dt, P.is_log1p);
+                        if (exact) {
+                            long long l0, l1;
+                            exs_split(x, S, l0, l1);
+                            if (l1) atomicAdd((u64 *)&L1[cd[u]], (u64)l1);
+                            if (l0) atomicAdd((u64 *)&L0[cd[u]], (u64)l0);
+                        } else atomicAdd(&F[cd[u]], x);
+                    }
             }
-        }
+        };
+        if (P.codes16) { const u16 *t = P.codes16; entry_loop([t](IdxT row) { return (int)t[(long long)row]; }); }
+        else if (P.codes) { const int *t = P.codes; entry_loop([t](IdxT row) { return t[(long long)row]; }); }
+        else entry_loop([](IdxT row) { return (int)row; });
         if constexpr (ACCG) __threadfence();
         __syncthreads();
-        for (int g = tid; g < G; g += NT) out[g] = exs_combine(L0[g], L1[g], S);
+        for (int g = tid; g < G; g += NT) out[g] = exact ? exs_combine(L0[g], L1[g], S) : F[g];
         __syncthreads();
     }
 }

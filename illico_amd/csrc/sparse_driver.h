@@ -49,7 +49,27 @@ static int upload_cols(illico_ctx *c, const std::vector<int64_t> &cols, const in
 }
 
 // Count-valued CSC genes with small groups: per-group value histograms in LDS (k_csc_counts), OVO and OVR.  `cols` in:
-// the genes to compute; out: the genes it could not take.
+// the genes to compute; out: the genes it could not take.  First the mixed 8- / 4-bit cells (two workgroups per CU); the
+// genes where a 4-bit cell overflowed are redone with 8-bit cells; genes with values outside the table are left to the
+// general routes.
+template <typename InT, typename IdxT, bool MIXED>
+static int launch_csc_counts(illico_ctx *c, const CscCountsParams &P, int rt, bool has_big, bool ovr, size_t lds) {
+    ProfScope ps(c, KID_CSC_COUNTS);
+#define CSCC_LAUNCH(OVRF, RTV, BIG)                                                                                        \
+    do {                                                                                                                   \
+        auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, BIG, MIXED && RTV == 64>;                                           \
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+        hipLaunchKernelGGL(kern, dim3(P.nb), dim3(CSCC_NT), lds, c->stream, P);                                            \
+    } while (0)
+#define CSCC_LAUNCH2(OVRF, RTV) do { if (has_big) CSCC_LAUNCH(OVRF, RTV, true); else CSCC_LAUNCH(OVRF, RTV, false); } while (0)
+    if (ovr) { if (rt == 64) CSCC_LAUNCH2(true, 64); else CSCC_LAUNCH2(true, 32); }
+    else { if (rt == 64) CSCC_LAUNCH2(false, 64); else CSCC_LAUNCH2(false, 32); }
+#undef CSCC_LAUNCH2
+#undef CSCC_LAUNCH
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+
 template <typename InT, typename IdxT>
 static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, const int *d_codes,
                                 int64_t n_rows, int64_t col_lb, int flags, int alternative, const OutPlanes &o, std::vector<int64_t> &cols) {
@@ -57,9 +77,6 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
     const bool ovr = c->ref < 0;
     int rc;
     void *v;
-    const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
-    const int *d_cols = nullptr;
-    if (!contiguous && (rc = upload_cols(c, cols, &d_cols))) return rc;
     // groups of more than 255 cells (other than the OVO reference, which has its own table) get 32-bit rows
     std::vector<signed char> h_slot(G, (signed char)-1);
     int n_big = 0;
@@ -72,59 +89,62 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
         HIPCHK(c, hipStreamSynchronize(c->stream));
         d_slot = (const signed char *)v;
     }
-    const int rt = cscc_lds_bytes(G, 64) + 8192 <= kMaxLds ? 64 : 32;
-    const size_t lds = cscc_lds_bytes(G, rt);
-    const int64_t n = (int64_t)cols.size();
-    const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
-    if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
-    long long *s2u = (long long *)v;
-    u64 *stie = (u64 *)(s2u + (size_t)nb_max * G);
-    double *ssum = (double *)(stie + (size_t)nb_max * G);
-    double *gtot = ssum + (size_t)nb_max * G;
-    if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
-    u32 *fb = (u32 *)v;
+    const int rt8 = cscc_lds_bytes(G, 64) + 8192 <= kMaxLds ? 64 : 32;
+    // the mixed layout pays when two workgroups fit a CU
+    // (... or when 64 bytes per group do not fit at all: the mixed table still holds all 63 values where the 8-bit form
+    //  would drop to 31)
+    const bool try_mixed = !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(G, 0) + 4096) <= kMaxLds ||
+                                                       (rt8 == 32 && cscc_lds_bytes(G, 0) + 8192 <= kMaxLds));
+    const u16 *codes16 = d_codes ? c->d_codes16 : nullptr;
     std::vector<int64_t> left;
-    for (int64_t b0 = 0; b0 < n; b0 += nb_max) {
-        const int nb = (int)std::min<int64_t>(nb_max, n - b0);
-        HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)nb * 4, c->stream));
-        CscCountsParams P;
-        P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
-        P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref;
-        P.n_cells = n_rows; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot;
-        {
-            ProfScope ps(c, KID_CSC_COUNTS);
-#define CSCC_LAUNCH(OVRF, RTV)                                                                                              \
-    do {                                                                                                                   \
-        if (n_big) {                                                                                                       \
-            auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, true>;                                                          \
-            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-            hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCC_NT), lds, c->stream, P);                                          \
-        } else {                                                                                                           \
-            auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, false>;                                                         \
-            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-            hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCC_NT), lds, c->stream, P);                                          \
-        }                                                                                                                  \
-    } while (0)
-            if (ovr) { if (rt == 64) CSCC_LAUNCH(true, 64); else CSCC_LAUNCH(true, 32); }
-            else { if (rt == 64) CSCC_LAUNCH(false, 64); else CSCC_LAUNCH(false, 32); }
-#undef CSCC_LAUNCH
-            HIPCHK(c, hipGetLastError());
+    // pass 0: mixed cells over every gene; pass 1: 8-bit cells over the genes whose 4-bit cells overflowed (or over every
+    // gene when the mixed form is not used)
+    for (int pass = try_mixed ? 0 : 1; pass < 2 && !cols.empty(); ++pass) {
+        const bool mixed = pass == 0;
+        const int rt = mixed ? 64 : rt8;
+        const size_t lds = cscc_lds_bytes(G, mixed ? 0 : rt);
+        const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
+        const int *d_cols = nullptr;
+        if (!contiguous && (rc = upload_cols(c, cols, &d_cols))) return rc;
+        const int64_t n = (int64_t)cols.size();
+        const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
+        if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
+        long long *s2u = (long long *)v;
+        u64 *stie = (u64 *)(s2u + (size_t)nb_max * G);
+        double *ssum = (double *)(stie + (size_t)nb_max * G);
+        double *gtot = ssum + (size_t)nb_max * G;
+        if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
+        u32 *fb = (u32 *)v;
+        std::vector<int64_t> redo;
+        for (int64_t b0 = 0; b0 < n; b0 += nb_max) {
+            const int nb = (int)std::min<int64_t>(nb_max, n - b0);
+            HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)nb * 4, c->stream));
+            CscCountsParams P;
+            P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
+            P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.codes16 = codes16; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref;
+            P.n_cells = n_rows; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot;
+            P.gene_total = ovr ? gtot : nullptr;
+            if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
+            else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds))) return rc;
+            if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0))) return rc; }
+            else if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb))) return rc;
+            if (c->pinned_bytes < (size_t)nb * 4) {
+                if (c->pinned) hipHostFree(c->pinned);
+                c->pinned = nullptr; c->pinned_bytes = 0;
+                HIPCHK(c, hipHostMalloc(&c->pinned, (size_t)nb * 4 + 4096, hipHostMallocDefault));
+                c->pinned_bytes = (size_t)nb * 4 + 4096;
+            }
+            HIPCHK(c, hipMemcpyAsync(c->pinned, fb, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const u32 *h_fb = (const u32 *)c->pinned;
+            for (int64_t j = 0; j < nb; ++j) {
+                if (h_fb[j] == 2u) redo.push_back(cols[b0 + j]);
+                else if (h_fb[j]) left.push_back(cols[b0 + j]);
+            }
         }
-        if (ovr && (rc = launch_gene_totals(c, ssum, G, nb, gtot))) return rc;
-        if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0))) return rc; }
-        else if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb))) return rc;
-        if (c->pinned_bytes < (size_t)nb * 4) {
-            if (c->pinned) hipHostFree(c->pinned);
-            c->pinned = nullptr; c->pinned_bytes = 0;
-            HIPCHK(c, hipHostMalloc(&c->pinned, (size_t)nb * 4 + 4096, hipHostMallocDefault));
-            c->pinned_bytes = (size_t)nb * 4 + 4096;
-        }
-        HIPCHK(c, hipMemcpyAsync(c->pinned, fb, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const u32 *h_fb = (const u32 *)c->pinned;
-        for (int64_t j = 0; j < nb; ++j)
-            if (h_fb[j]) left.push_back(cols[b0 + j]);
+        cols.swap(redo);
     }
+    std::sort(left.begin(), left.end());
     cols.swap(left);
     return ILLICO_OK;
 }
@@ -167,7 +187,7 @@ static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_in
         HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)nb * 4, c->stream));
         CscGeneParams P;
         P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
-        P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes;
+        P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.codes16 = d_codes ? c->d_codes16 : nullptr;
         P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
         P.key_cap = key_cap; P.runend_cap = runend_cap; P.ref_buckets = ref_buckets ? 1 : 0; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
         {
@@ -229,7 +249,7 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
         CscOvrParams P;
         memset(&P, 0, sizeof P);
         P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
-        P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.counts = c->d_counts; P.G = G; P.dt = dtype;
+        P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.codes16 = d_codes ? c->d_codes16 : nullptr; P.counts = c->d_counts; P.G = G; P.dt = dtype;
         P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.key_cap = key_cap; P.lg_buckets = lg;
         P.force_sorted = c->csc_ovr_sorted_form ? 1 : 0; P.fallback = fb;
         P.out_2u = s2u; P.out_tie = stie;
@@ -676,6 +696,7 @@ static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, c
     if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
     if (idx_dtype != ILLICO_IDX_I32 && idx_dtype != ILLICO_IDX_I64) return fail(c, ILLICO_ERR_DTYPE, "unsupported index dtype code %d", idx_dtype);
     HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = resolve_pending(c))) return rc;
     const int64_t W = col_ub - col_lb;
     if (W == 0) return ILLICO_OK;
     OutPlanes o;

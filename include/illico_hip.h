@@ -57,7 +57,13 @@ enum {
     ILLICO_FLAG_CONTINUITY = 2,     /* use_continuity  (ovo/dense_ovo.py:58)      */
     ILLICO_FLAG_TIE_CORRECT = 4,    /* tie_correct     (ovo/dense_ovo.py:54)      */
     ILLICO_FLAG_INPUT_DEVICE = 8,   /* X / data / indices / indptr are device pointers on ctx's device */
-    ILLICO_FLAG_OUTPUT_DEVICE = 16  /* out_p / out_u / out_fc are device pointers                       */
+    ILLICO_FLAG_OUTPUT_DEVICE = 16, /* out_p / out_u / out_fc are device pointers                       */
+    /* illico_run_dense with device-resident input AND device planes: enqueue the fused single-pass route and return without
+     * waiting for it.  The few genes that route cannot take (values outside its table) are recomputed when their flags have
+     * arrived -- by the next call on the context or by illico_ctx_synchronize, after which the planes are complete.  X and
+     * the planes must stay valid until then.  A following deferred call that writes OTHER planes is enqueued before the
+     * earlier one is completed, so back-to-back passes run without a host round trip in between.  Ignored elsewhere. */
+    ILLICO_FLAG_DEFER = 32
 };
 
 /* ---- context ---------------------------------------------------------------------------- */

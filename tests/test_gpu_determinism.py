@@ -217,3 +217,63 @@ def test_engine_follows_torch_current_stream(engine):
     got = engine.run_dense(base, 0, 256, device_out=True)  # back on the default stream
     torch.cuda.synchronize()
     assert_planes_match(tuple(t.cpu().numpy() for t in got), want, ref_row=g.encoded_ref_group, what="default stream")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_deferred_dense_calls_complete_their_leftover_genes(engine, test):
+    """ILLICO_FLAG_DEFER: device input + device planes, no host round trip inside the call.  Genes the fused single-pass route
+    cannot take (values of 64 and more, fractional values) are recomputed when the NEXT call or synchronize() looks at the
+    route flags: alternating planes (the next pass is enqueued first), the same planes twice (completed before), a change of
+    groups in between, and a sparse call in between -- every variant ends with the planes of the plain call, byte for byte."""
+    import torch
+    X, rng = make_counts(41, 6000, 320, 0.5)
+    X[:, 7] = rng.poisson(70.0, size=6000)                       # beyond the 64-value table
+    X[:, 100] = np.log1p(X[:, 100] * rng.uniform(0.5, 1.5, 6000))  # continuous
+    X[5, 200] = 0.5
+    X2 = X[:, ::-1].copy()
+    labels = make_labels(rng, 6000, 30, n_ref=500)
+    ref = "non-targeting" if test == "ovo" else None
+    _, g = oracle.encode_and_count_groups(labels, ref)
+    _, g2 = oracle.encode_and_count_groups(labels, "pert_00003" if test == "ovo" else None)
+    Xd, X2d = torch.from_numpy(X).cuda(), torch.from_numpy(X2).cuda()
+    engine.set_groups(g)
+    want = [t.cpu().numpy() for t in engine.run_dense(Xd, 0, 320, device_out=True)]
+    want2 = [t.cpu().numpy() for t in engine.run_dense(X2d, 0, 320, device_out=True)]
+    assert_planes_match(want, oracle.run(X, g), ref_row=g.encoded_ref_group if ref else None, what="plain call")
+
+    def planes():
+        return tuple(torch.full((len(g.counts), 320), -7.0, dtype=torch.float64, device="cuda") for _ in range(3))
+
+    def same(got, w):
+        for a, b in zip(got, w):
+            assert a.cpu().numpy().tobytes() == b.tobytes()
+
+    # alternating planes: call 2 is enqueued before call 1 is completed
+    A, B = planes(), planes()
+    engine.run_dense(Xd, 0, 320, out=A, defer=True)
+    engine.run_dense(X2d, 0, 320, out=B, defer=True)
+    engine.run_dense(Xd, 0, 320, out=A, defer=True)
+    engine.synchronize()
+    same(A, want); same(B, want2)
+    # the same planes again: the earlier call is completed first, then overwritten
+    engine.run_dense(X2d, 0, 320, out=A, defer=True)
+    engine.run_dense(Xd, 0, 320, out=A, defer=True)
+    engine.synchronize()
+    same(A, want)
+    # a window, then new groups while a deferred call is pending (its leftovers need the old groups), then a sparse call
+    C = planes()
+    engine.run_dense(Xd, 64, 256, out=tuple(t[:, 64:256] for t in C), defer=True)
+    engine.set_groups(g2)
+    w3 = [t.cpu().numpy() for t in engine.run_dense(Xd, 0, 320, device_out=True)]
+    engine.set_groups(g)
+    for a, b in zip(C, want):
+        assert a[:, 64:256].cpu().numpy().tobytes() == np.ascontiguousarray(b[:, 64:256]).tobytes()
+        assert bool((a[:, :64] == -7.0).all()) and bool((a[:, 256:] == -7.0).all())
+    assert_planes_match(w3, oracle.run(X, g2), ref_row=g2.encoded_ref_group if ref else None, what="other groups")
+    D = planes()
+    engine.run_dense(Xd, 0, 320, out=D, defer=True)
+    M = sparse.csc_matrix(X[:, :40])
+    sp = engine.run_sparse("csc", M.data, M.indices, M.indptr, M.shape, 0, 40)
+    same(D, want)
+    for a, b in zip(sp, want):
+        np.testing.assert_array_equal(a, b[:, :40])

@@ -313,6 +313,47 @@ def test_csc_counts_route(engine, test, many_groups):
         assert_planes_match(got, oracle.run(Xd, g, col_lb=2, col_ub=31), what=f"csc counts window {test}")
 
 
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_csc_counts_mixed_cells_overflow_is_redone_with_8bit_cells(engine, test):
+    """k_csc_counts first runs with 8-bit cells for the values 1..7 and 4-bit cells for 8..63 (two workgroups per CU).  Here
+    most groups hold 16 or more cells with the same value >= 8 in several genes: those 4-bit cells overflow, the gene is
+    flagged (the cells no longer add up to the entries counted) and redone with 8-bit cells.  Genes without an overflow
+    stay on the mixed form; the planes equal the 8-bit-only run byte for byte and match the oracle."""
+    rng = np.random.RandomState(311)
+    sizes = [250] * 40 + [254, 255, 17, 16, 15, 1]
+    labels = np.concatenate([[f"s{i:03d}"] * sz for i, sz in enumerate(sizes)])
+    rng.shuffle(labels)
+    n, m = labels.size, 24
+    X = np.zeros((n, m), np.float32)
+    for j in range(m):
+        if j % 3 == 0:     # narrow distribution around 9..11, dense: 4-bit cells overflow in most groups
+            X[:, j] = rng.randint(9, 12, size=n) * (rng.rand(n) < 0.7)
+        elif j % 3 == 1:   # small values only: the 8-bit cells of the mixed layout take them (up to 255 per cell)
+            X[:, j] = rng.randint(1, 4, size=n) * (rng.rand(n) < 0.9)
+        else:              # spread-out values, sparse: no cell reaches 16
+            X[:, j] = rng.randint(1, 64, size=n) * (rng.rand(n) < 0.1)
+    X[:, 5] = 15.0          # exactly 15 / 16 / 17 copies in the groups of 15 / 16 / 17 cells: the overflow boundary
+    X[:, 8] = 63.0          # the last 4-bit cell of the last word: its carry leaves the word
+    M = sparse.csc_matrix(X)
+    _, g = oracle.encode_and_count_groups(labels, "s000" if test == "ovo" else None)
+    want = oracle.run(X, g)
+    engine.set_option("profile", 1)
+    engine.profile_reset()
+    try:
+        got = _run(engine, M, g)
+        prof = engine.profile_get()
+        engine.set_option("no_csc_counts_mixed", 1)
+        only8 = _run(engine, M, g)
+    finally:
+        engine.set_option("no_csc_counts_mixed", 0)
+        engine.set_option("profile", 0)
+    assert prof["k_csc_counts"]["launches"] == 2, prof   # the mixed pass, then the 8-bit pass over the flagged genes
+    assert set(prof) <= {"k_csc_counts", "k_finalize", "k_gene_totals"}, prof   # no gene left the histogram route
+    for a, b in zip(got, only8):
+        assert a.tobytes() == b.tobytes()
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group if test == "ovo" else None, what=f"mixed cells {test}")
+
+
 def test_drop_in_csr_narrow_dtypes(engine):
     """In-RAM CSR goes to the device inside the drop-in call: value / index dtypes the kernels do not take natively
     (uint16 counts, int64 indptr with int32 indices) are widened on the way like on the host path."""
