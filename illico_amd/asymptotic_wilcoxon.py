@@ -19,32 +19,9 @@ from illico_amd.utils.registry import DataHandler, Test, data_handler_registry, 
 
 __all__ = ["asymptotic_wilcoxon", "operator"]
 
-#: host bytes of one streamed gene chunk of a backed input (two chunks are alive at any time)
+#: host bytes of one streamed gene chunk of a backed input (illico_amd/streaming.py: the chunk being read plus two pinned
+#: staging slots are alive at any time)
 STREAM_CHUNK_BYTES = 256 << 20
-
-
-def _run_streaming(data_handler, iterator, group_container, is_log1p, use_continuity, alternative, tie_correct, planes):
-    """Backed inputs: chunk k+1 is read from storage by a prefetch thread while chunk k is copied to the GPU and
-    computed (file reads and the ctypes engine call both release the GIL).  At most two chunks live on the host."""
-    from concurrent.futures import ThreadPoolExecutor
-
-    test = Test.OVR if group_container.encoded_ref_group == -1 else Test.OVO
-    dispatcher = dispatcher_registry.get(test, data_handler.kernel_data_format())
-
-    def fetch(bounds):
-        lb, ub = bounds
-        data, local = data_handler.fetch(lb, ub)
-        return data_handler.to_nb(data), local
-
-    with ThreadPoolExecutor(max_workers=1) as pool:
-        nxt = pool.submit(fetch, iterator[0])
-        for k, (lb, ub) in enumerate(iterator):
-            X, local = nxt.result()
-            if k + 1 < len(iterator):
-                nxt = pool.submit(fetch, iterator[k + 1])
-            out = tuple(planes[j][:, lb:ub] for j in range(3))
-            dispatcher(X, *local, group_container, is_log1p, use_continuity, tie_correct, alternative, out=out)
-            del X
 
 
 def _csr_to_device(X, data_handler, check=True):
@@ -160,7 +137,8 @@ def asymptotic_wilcoxon(
     planes = np.empty((3, n_groups, n_genes), dtype=np.float64)
     iterator = [(lb, ub) for lb, ub in iterator if ub > lb]
     if streams and len(iterator) > 1:
-        _run_streaming(data_handler, iterator, group_container, is_log1p, use_continuity, alternative, tie_correct, planes)
+        from illico_amd.streaming import run_streaming
+        run_streaming(data_handler, iterator, group_container, is_log1p, use_continuity, alternative, tie_correct, planes)
     else:
         for lb, ub in iterator:
             out = tuple(planes[k][:, lb:ub] for k in range(3))

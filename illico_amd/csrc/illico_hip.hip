@@ -2,7 +2,6 @@
 // Host side: context, device scratch, gene batching, kernel launches, measurement hooks.
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cstdarg>
@@ -98,7 +97,6 @@ struct illico_ctx {
     bool no_csc_counts_path = false;   // 1: count-valued CSC genes do not take the LDS-histogram kernel (k_csc_counts)
     bool no_csc_counts_mixed = false;  // 1: k_csc_counts with 8-bit cells for every value only (the form 4-bit overflows fall back to)
     bool no_ovr_one_pass = false;      // 1: dense OVR reads X twice (column histogram, then rank sums) instead of once
-    bool no_ovr_library_sort = false;   // 1: the general OVR route sorts inside k_ovr_gene (LSD radix passes) instead of rocPRIM's segmented sort
     bool no_csr_tile_gather = false;    // 1: CSR -> CSC always by the scatter form (k_csr_block_scatter), as for unsorted rows
     bool no_csr_transpose_path = false; // 1: CSR is regrouped by (gene, group) with global atomics instead of being transposed to CSC
     bool dense_window_f32 = false;      // 1: CSR dense windows hold float32 cells instead of bytes
@@ -309,7 +307,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_csc_ovr_gene_path")) c->no_csc_ovr_gene_path = value != 0;
     else if (!strcmp(key, "csc_ovr_sorted_form")) c->csc_ovr_sorted_form = value != 0;
     else if (!strcmp(key, "no_ovr_one_pass")) c->no_ovr_one_pass = value != 0;
-    else if (!strcmp(key, "no_ovr_library_sort")) c->no_ovr_library_sort = value != 0;
+    else if (!strcmp(key, "no_ovr_library_sort")) (void)value; // accepted and ignored: there is no library sort any more
     else if (!strcmp(key, "no_csr_tile_gather")) c->no_csr_tile_gather = value != 0;
     else if (!strcmp(key, "no_csr_transpose_path")) c->no_csr_transpose_path = value != 0;
     else if (!strcmp(key, "dense_window_f32")) c->dense_window_f32 = value != 0;

@@ -18,49 +18,11 @@ static int launch_ovr_gene(illico_ctx *c, OvrParams P) {
         if (rc) return rc;
         P.acc_global = (u64 *)v;
     }
-    // OVR: sums / compaction and the rank sweeps stay here; the sort in between is rocPRIM's segmented radix sort (29 G
-    // pairs/s on 1024 x 150k segments against 12 for the in-kernel LSD passes, whose one-workgroup-per-gene structure
-    // spends 71 % of its wave-cycles waiting).  The global-sort OVO fallback keeps the all-in-one kernel.
-    if constexpr (!OVO)
-    if (!c->no_ovr_library_sort && (long long)P.n_genes * std::max<long long>(P.stride, 1) < (1ll << 31)) {
-        void *v;
-        int rc;
-        if ((rc = get_scratch(c, "ovr_seg", (size_t)P.n_genes * 12, &v))) return rc;
-        P.seg_begin = (u32 *)v;
-        P.seg_end = P.seg_begin + P.n_genes;
-        P.seg_n = (int *)(P.seg_end + P.n_genes);
-        ProfScope ps(c, KID_OVR_SCAN);
-#define OVR_LAUNCH(ACCGF, MODEV)                                                                                          \
-    do {                                                                                                                   \
-        auto kern = k_ovr_gene<KeyT, SPARSE, OVO, kOvrThreads, ACCGF, DC, MODEV>;                                          \
-        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
-        hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(kOvrThreads), lds, c->stream, P);                                   \
-    } while (0)
-        if (accg) OVR_LAUNCH(true, 1); else OVR_LAUNCH(false, 1);
-        HIPCHK(c, hipGetLastError());
-        // unsorted pairs: compacted dense layout in the B buffers (-> A), sparse layout in the A buffers (-> B)
-        KeyT *kin = (KeyT *)(DC ? P.keys_b : P.keys_a), *kout = (KeyT *)(DC ? P.keys_a : P.keys_b);
-        u32 *vin = DC ? P.vals_b : P.vals_a, *vout = DC ? P.vals_a : P.vals_b;
-        long long span;
-        if (SPARSE) {
-            u32 last = 0; // the batch's pairs are contiguous: [seg_ptr[0], seg_ptr[n_genes * (G+1) - 1])
-            HIPCHK(c, hipMemcpyAsync(&last, P.seg_ptr + (size_t)P.n_genes * (P.G + 1) - 1, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            span = last;
-        } else span = (long long)P.n_genes * P.stride;
-        size_t tmp_bytes = 0;
-        hipError_t e = rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, (unsigned int)span, (unsigned int)P.n_genes,
-                                                           P.seg_begin, P.seg_end, 0u, (unsigned int)(sizeof(KeyT) * 8), c->stream);
-        if (e != hipSuccess) return fail(c, ILLICO_ERR_HIP, "rocprim::segmented_radix_sort_pairs (size query) failed: %s", hipGetErrorString(e));
-        if ((rc = get_scratch(c, "ovr_sort_tmp", std::max<size_t>(tmp_bytes, 16), &v))) return rc;
-        e = rocprim::segmented_radix_sort_pairs(v, tmp_bytes, kin, kout, vin, vout, (unsigned int)span, (unsigned int)P.n_genes, P.seg_begin,
-                                                P.seg_end, 0u, (unsigned int)(sizeof(KeyT) * 8), c->stream);
-        if (e != hipSuccess) return fail(c, ILLICO_ERR_HIP, "rocprim::segmented_radix_sort_pairs failed: %s", hipGetErrorString(e));
-        if (accg) OVR_LAUNCH(true, 2); else OVR_LAUNCH(false, 2);
-#undef OVR_LAUNCH
-        HIPCHK(c, hipGetLastError());
-        return ILLICO_OK;
-    }
+    // One kernel per gene does everything: per-group sums, zero compaction, a stable LSD radix sort of the (key, group)
+    // pairs in HBM (2048-element rounds, one 256-thread workgroup per gene) and the rank sweeps.  (Round 1 sorted with
+    // rocPRIM's segmented radix sort here -- 29 G pairs/s against this kernel's 12 -- ; the library is gone from the build:
+    // this route only takes what the LDS routes leave -- tie-heavy dense columns outside the 64-value table, CSC genes larger
+    // than the LDS key buffer -- and no BASELINE configuration reaches it.)
     ProfScope ps(c, KID_OVR_SCAN);
     if (accg) {
         auto kern = k_ovr_gene<KeyT, SPARSE, OVO, kOvrThreads, true, DC>;

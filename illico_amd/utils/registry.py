@@ -129,7 +129,7 @@ class MemmapDenseDataHandler(DenseDataHandler):
     streams = True
 
     def fetch(self, lb: int, ub: int) -> tuple:
-        return np.ascontiguousarray(self.data[:, lb:ub]), (0, ub - lb)
+        return self.data[:, lb:ub], (0, ub - lb)  # a lazy view: the pages are read when the chunk is staged
 
     @classmethod
     def to_nb(cls, X):
@@ -178,32 +178,45 @@ try:  # device-resident dense input (a torch.Tensor on the MI355X): no H2D copy 
 except Exception:  # pragma: no cover
     pass
 
-try:  # out-of-core handlers of the reference (registry.py:162-188), when h5py / anndata are importable
-    import h5py as _h5py
+# ---- out-of-core handlers of the reference (registry.py:162-188) ------------------------------------------------------
+# Duck-typed: anything with ``.shape``, ``.dtype`` and ``[:, lb:ub]`` returning an ndarray (h5py.Dataset) / a scipy CSC matrix
+# (anndata's backed ``_CSCDataset``) can be registered under these handlers -- the tests do that with file-backed stand-ins,
+# since neither package ships in this image.  ``fetch`` reads ONE gene chunk from storage; the chunk pipeline of
+# illico_amd/streaming.py overlaps that read, the upload and the compute of neighbouring chunks.
+class H5pyDatasetDataHandler(DenseDataHandler):
+    streams = True
 
-    @data_handler_registry.register(_h5py.Dataset)
-    class H5pyDatasetDataHandler(DenseDataHandler):
-        streams = True
+    def fetch(self, lb: int, ub: int) -> tuple:
+        return self.data[:, lb:ub], (0, ub - lb)
 
-        def fetch(self, lb: int, ub: int) -> tuple:
-            return self.data[:, lb:ub], (0, ub - lb)
-except Exception:  # pragma: no cover
-    pass
+    def footprint(self) -> int:
+        return int(np.prod(self.data.shape)) * int(np.dtype(self.data.dtype).itemsize)
+
+    @classmethod
+    def to_nb(cls, X):
+        return np.asarray(X)
+
+
+class H5pyBackedCSCDataHandler(CSCDataHandler):
+    streams = True
+
+    def footprint(self) -> int:
+        d = self.data
+        return int(d._data.nbytes + d._indptr.nbytes + d._indices.nbytes)
+
+    def fetch(self, lb: int, ub: int) -> tuple:
+        return self.data[:, lb:ub], (0, ub - lb)  # a scipy CSC matrix of the chunk (registry.py:187-188)
+
 
 try:
+    import h5py as _h5py
+    data_handler_registry[_h5py.Dataset] = H5pyDatasetDataHandler
+except Exception:  # pragma: no cover  (h5py is not in this image)
+    pass
+try:
     import anndata as _ad
-
-    @data_handler_registry.register(_ad._core.sparse_dataset._CSCDataset)
-    class H5pyBackedCSCDataHandler(CSCDataHandler):
-        streams = True
-
-        def footprint(self) -> int:
-            d = self.data
-            return int(d._data.nbytes + d._indptr.nbytes + d._indices.nbytes)
-
-        def fetch(self, lb: int, ub: int) -> tuple:
-            return self.data[:, lb:ub], (0, ub - lb)
-except Exception:  # pragma: no cover
+    data_handler_registry[_ad._core.sparse_dataset._CSCDataset] = H5pyBackedCSCDataHandler
+except Exception:  # pragma: no cover  (anndata is not in this image)
     pass
 
 # importing the kernel modules registers the six dispatchers (the reference does the same, registry.py:193-202)

@@ -76,8 +76,8 @@ int illico_ctx_set_stream(illico_ctx *ctx, void *hip_stream);
  * that kernel only, -1 = all), "fused_groups_per_wg" / "ovr_hist_groups_per_wg" (launch geometry, 0 = auto).
  * Route switches, all 0 by default; every route produces the same integers, the switches exist so that tests and
  * A/B measurements can force each one: "no_fused_path", "no_counts_path" (dense / segmented histogram routes),
- * "no_ovr_one_pass" (dense OVR in two passes over X), "no_ovr_library_sort" (general OVR route: in-kernel LSD radix
- * passes instead of rocPRIM's segmented radix sort), "no_csc_counts_path" (count-valued CSC on LDS histograms),
+ * "no_ovr_one_pass" (dense OVR in two passes over X), "no_csc_counts_path" (count-valued CSC on LDS histograms;
+ * "no_csc_counts_mixed" = 1: its 8-bit cell form only),
  * "no_ovo_ref_buckets" (OVO sort route: reference column in value buckets instead of sorted), "no_ovr_parts_path" (dense OVR, any values: value-range parts ranked in LDS; "ovr_parts_cap" > 0 caps the keys per part), "no_csc_gene_path" (CSC OVO single-kernel route), "no_csc_ovr_gene_path" (CSC OVR single-kernel route; "csc_ovr_sorted_form" = 1 makes it sort every
  * gene in LDS, the form tie-heavy columns take, instead of bucketing the keys), "no_csc_regroup_lds" (two-kernel CSC route: regroup with scattered
  * stores only),

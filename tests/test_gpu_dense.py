@@ -45,8 +45,6 @@ def route(request, engine):
     engine.set_option("no_counts_path", 1 if request.param == "sort-only" else 0)
     # fused OVR has a one-pass form (per-group histograms) and a two-pass form: the host-input param runs the latter
     engine.set_option("no_ovr_one_pass", 1 if request.param.startswith("fused-host") else 0)
-    # the general OVR route sorts with rocPRIM's segmented radix sort; "sort-only" keeps the in-kernel LSD passes alive
-    engine.set_option("no_ovr_library_sort", 1 if request.param == "sort-only" else 0)
     # ... and is itself the fallback of the value-range parts route (k_ovr_partition + k_csc_ovr_gene), which the fused
     # params leave on
     engine.set_option("no_ovr_parts_path", 0 if request.param.startswith("fused") else 1)
@@ -55,7 +53,6 @@ def route(request, engine):
     yield request.param
     engine.set_option("no_ovo_ref_buckets", 0)
     engine.set_option("no_ovr_parts_path", 0)
-    engine.set_option("no_ovr_library_sort", 0)
     engine.set_option("no_counts_path", 0)
     engine.set_option("no_fused_path", 0)
     engine.set_option("no_ovr_one_pass", 0)

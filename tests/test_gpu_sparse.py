@@ -34,7 +34,7 @@ def route(request, engine):
     tie-heavy columns); genes larger than its key buffer and the two-kernel params use the general route (regroup in
     HBM, segmented radix sort, sweeps)."""
     opts = {"no_csc_gene_path": 0, "no_dense_window_path": 0, "no_counts_path": 0, "no_csr_transpose_path": 0,
-            "no_csr_tile_gather": 0, "no_csc_counts_path": 0, "no_ovr_library_sort": 0,
+            "no_csr_tile_gather": 0, "no_csc_counts_path": 0,
             "no_csc_regroup_lds": 0, "no_csc_ovr_gene_path": 0, "csc_ovr_sorted_form": 0, "no_ovo_ref_buckets": 0}
     if request.param.startswith("two-kernel"):
         opts.update(no_csc_gene_path=1, no_dense_window_path=1, no_csc_counts_path=1, no_csc_ovr_gene_path=1)
@@ -44,8 +44,8 @@ def route(request, engine):
     if request.param == "two-kernel":
         opts.update(no_csr_tile_gather=1)   # CSR -> CSC by the scatter form (what unsorted rows get)
     if request.param.endswith("sort-only"):
-        # OVR: the in-kernel LSD radix passes instead of rocPRIM's sort; regroup by k_csc_segment alone
-        opts.update(no_counts_path=1, no_ovr_library_sort=1, no_csc_regroup_lds=1, no_ovo_ref_buckets=1)
+        # regroup by k_csc_segment alone, sorted reference column
+        opts.update(no_counts_path=1, no_csc_regroup_lds=1, no_ovo_ref_buckets=1)
     if request.param == "csr-regroup":
         opts.update(no_dense_window_path=1, no_csr_transpose_path=1)
     for k, v in opts.items():

@@ -158,9 +158,10 @@ def test_memmap_handler_is_backed_and_fetches_chunks(tmp_path):
     mm = np.load(tmp_path / "x.npy", mmap_mode="r")
     h = data_handler_registry.get(mm)
     assert h.streams and h.kernel_data_format() == KernelDataFormat.DENSE
-    chunk, bounds = h.fetch(3, 9)
-    assert bounds == (0, 6) and type(chunk) is np.ndarray and chunk.flags.c_contiguous
-    np.testing.assert_array_equal(chunk, X[:, 3:9])
+    chunk, bounds = h.fetch(3, 9)   # a lazy column view: its pages are read when the chunk is staged (illico_amd/streaming.py)
+    assert bounds == (0, 6) and chunk.shape == (40, 6)
+    np.testing.assert_array_equal(np.asarray(chunk), X[:, 3:9])
+    assert type(h.to_nb(chunk)) is np.ndarray
     assert not data_handler_registry.get(X).streams
 
 
@@ -184,3 +185,26 @@ def test_categorical_group_column_encodes_like_strings():
     # a plain object / string Series takes the generic path
     u3, c = encode_and_count_groups(pd.Series(labels), "ctrl")
     np.testing.assert_array_equal(u3, np.unique(labels))
+
+
+def test_out_of_core_handlers_are_duck_typed():
+    """The reference's backed containers (h5py.Dataset, anndata's _CSCDataset; registry.py:162-188) are not in this image: any
+    container with the same duck type can be registered under the same handlers (tests/test_gpu_out_of_core.py runs them)."""
+    from illico_amd.utils.registry import (H5pyBackedCSCDataHandler, H5pyDatasetDataHandler, KernelDataFormat,
+                                           data_handler_registry)
+
+    class Dense:
+        shape, dtype = (5, 8), np.dtype(np.float32)
+
+        def __getitem__(self, key):
+            return np.arange(40, dtype=np.float32).reshape(5, 8)[key]
+
+    data_handler_registry[Dense] = H5pyDatasetDataHandler
+    try:
+        h = data_handler_registry.get(Dense())
+        assert h.streams and h.kernel_data_format() == KernelDataFormat.DENSE and h.footprint() == 160
+        chunk, bounds = h.fetch(2, 5)
+        assert bounds == (0, 3) and chunk.shape == (5, 3) and chunk[1, 0] == 10.0
+    finally:
+        data_handler_registry.pop(Dense)
+    assert H5pyBackedCSCDataHandler.streams and H5pyBackedCSCDataHandler(None).kernel_data_format() == KernelDataFormat.CSC
