@@ -74,6 +74,7 @@ def parse(argv=None):
     ap.add_argument("--format", choices=["dense", "csc", "csr"], default=None, dest="fmt")
     ap.add_argument("--values", choices=["counts", "continuous"], default="counts",
                     help="counts: the headline Poisson counts; continuous: log1p(counts * U(0.5,1.5)), the secondary stress of SURVEY.md 8d")
+    ap.add_argument("--mean-max", type=float, default=15.0, help="gene means ~ U(0.1, mean-max); 15 = the reference's fixture (SURVEY.md 8d)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--gene-batch", type=int, default=0, help="genes per engine pass (0 = auto)")
     ap.add_argument("--gather-batches", type=int, default=8, help="gene blocks per gather (N>1)")
@@ -113,12 +114,12 @@ def group_container(codes, n_groups, ovr):
     return GroupContainer(codes.astype(np.int64), counts, indices, indptr, -1 if ovr else 0)
 
 
-def make_matrix(torch, n_cells, n_genes, sparsity, seed, device, continuous=False):
+def make_matrix(torch, n_cells, n_genes, sparsity, seed, device, continuous=False, mean_max=15.0):
     """Poisson(gene mean ~ U(0.1, 15)) float32 with `sparsity` of the entries zeroed, generated on device."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     X = torch.empty((n_cells, n_genes), dtype=torch.float32, device=device)
-    means = torch.empty(n_genes, device=device).uniform_(0.1, 15.0, generator=gen)
+    means = torch.empty(n_genes, device=device).uniform_(0.1, mean_max, generator=gen)
     step = 256
     for j in range(0, n_genes, step):
         m = means[j:j + step]
@@ -217,7 +218,7 @@ def main():
     sparse_fmt = args.fmt if args.fmt != "dense" else None
     codes = make_labels(N, G, args.seed)
     grpc = group_container(codes, G, ovr)
-    X = make_matrix(torch, N, M, args.sparsity, args.seed + 1000 * rank, device, args.values == "continuous")  # this rank's gene shard
+    X = make_matrix(torch, N, M, args.sparsity, args.seed + 1000 * rank, device, args.values == "continuous", args.mean_max)  # this rank's gene shard
     csx, nnz = None, None
     if sparse_fmt:
         csx = compress(torch, X, sparse_fmt)
@@ -355,6 +356,8 @@ def main():
             alg_bytes_step = N * M * 4 + 4 * N + 24 * G * M
         wl_key = {"workload": args.workload, "cells": N, "genes_per_gpu": M, "groups": G, "test": args.test, "format": args.fmt,
                   "values": args.values, "sparsity": args.sparsity}
+        if args.mean_max != 15.0:
+            wl_key["mean_max"] = args.mean_max
         roofline = None
         if dom and dom in prof:
             launches = prof[dom]["launches"]
@@ -500,7 +503,7 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["label"].format(N=N, M=M, G=G) + ("" if args.values == "counts" else " [continuous values]"),
                        "workload_id": args.workload, "cells": N, "genes_per_gpu": M, "genes_total": M_total, "groups": G, "format": args.fmt,
-                       "test": args.test, "sparsity": args.sparsity, "nnz_per_gpu": nnz, "settle_steps": settle,
+                       "test": args.test, "sparsity": args.sparsity, "gene_mean_max": args.mean_max, "nnz_per_gpu": nnz, "settle_steps": settle,
                        "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "timing_scopes": scopes, "box_calibration": calib,
         }

@@ -43,10 +43,11 @@ enum {
     KID_OVR_PART,
     KID_OVR_RANK_PARTS,
     KID_VALUE_SUMS,
+    KID_OVO_FUSED_WIDE,
     KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
-                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums"};
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums", "k_ovo_fused_wide"};
 
 // A dense call made with ILLICO_FLAG_DEFER whose fused pass is in flight: which genes it could not take is known only once
 // its route flags have reached the host; they are then recomputed by the two-pass routes (resolve_pending).
@@ -87,6 +88,7 @@ struct illico_ctx {
     int64_t scratch_bytes = 24ll << 30;
     bool no_counts_path = false;
     bool no_fused_path = false;
+    bool no_fused_wide = false;        // 1: no second, 256-value pass of the fused OVO route (genes beyond 63 go to the two-pass routes)
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
     int64_t ovr_parts_cap = 0;         // > 0: keys per part at most in the value-range parts route (tests: many small parts)
@@ -297,6 +299,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "profile_only")) c->profile_only = (value >= 0 && value < KID_COUNT) ? (int)value : -1;
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
+    else if (!strcmp(key, "no_fused_wide")) c->no_fused_wide = value != 0;
     else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
     else if (!strcmp(key, "no_csc_counts_mixed")) c->no_csc_counts_mixed = value != 0;
     else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
@@ -654,6 +657,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.gene_flags = P.ref_cum + nb64 * (RT + 1);
     P.hist_all = ovr ? P.gene_flags + nb : nullptr;
     P.group_hist = nullptr;
+    P.wide_tiles = nullptr;
     P.n_cells = c->n_cells;
     P.rows_per_wg = (int)std::max<int64_t>(1024, (c->n_cells + 31) / 32);
     P.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;
@@ -676,17 +680,52 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
         HIPCHK(c, hipGetLastError());
     }
     const dim3 main_grid(tiles, ((int)c->n_groups + P.groups_per_wg - 1) / P.groups_per_wg);
+    const size_t lds8 = fused_main_lds_bytes<RT, false, 8>(), lds16 = fused_main_lds_bytes<RT, false, 16>(), lds_ovr = fused_main_lds_bytes<RT, true, 16>();
+    (void)lds8; (void)lds16; (void)lds_ovr;
     if (!ovr) {
         {
             ProfScope ps(c, KID_FUSED_REF);
-            hipLaunchKernelGGL((k_fused_ref<InT, RT>), dim3(tiles), dim3(FUSED_REF_NT), 0, c->stream, P);
+            auto kern = k_fused_ref<InT, RT>;
+            hipLaunchKernelGGL(kern, dim3(tiles), dim3(FUSED_REF_NT), fused_ref_lds_bytes(RT), c->stream, P);
             HIPCHK(c, hipGetLastError());
         }
-        ProfScope ps(c, KID_OVO_FUSED);
-        if (c->max_nonref <= 255) // 8-bit running multiplicities: 34 KB of LDS per workgroup instead of 50 KB
-            hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
-        else hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
-        HIPCHK(c, hipGetLastError());
+        {
+            ProfScope ps(c, KID_OVO_FUSED);
+            if (c->max_nonref <= 255) // 8-bit running multiplicities: 34 KB of LDS per workgroup instead of 50 KB
+                hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8>), main_grid, dim3(FUSED_NT), lds8, c->stream, P);
+            else hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16>), main_grid, dim3(FUSED_NT), lds16, c->stream, P);
+            HIPCHK(c, hipGetLastError());
+        }
+        // Second pass, 256-value tables, over the tiles that hold genes the first pass flagged (counts of 64 .. 255: highly
+        // expressed genes of real count matrices): same kernels, one workgroup per CU (130 KB of LDS), resident workgroups
+        // working through the list of such tiles that k_fused_ref<WIDE> builds on the device -- an empty list costs two
+        // near-empty launches (0.005 ms at C2).  Flags after it: 1 = the host's two-pass routes, 0 / 2 = done.
+        if (c->max_nonref <= 255 && !c->no_fused_wide) {
+            constexpr int WRT = FUSED_WIDE_RT;
+            const size_t wbytes = nb64 * (WRT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)(tiles + 1) * 4 + 64;
+            if ((rc = get_scratch(c, "fused_tables_wide", wbytes, &v))) return rc;
+            FusedParams Q = P;
+            Q.ref_TA = (u64 *)v;
+            Q.ref_sum = Q.ref_TA + nb;
+            Q.ref_cum = (u32 *)(Q.ref_sum + nb);
+            Q.wide_tiles = Q.ref_cum + nb64 * (WRT + 1);
+            HIPCHK(c, hipMemsetAsync(Q.wide_tiles, 0, 4, c->stream));
+            {
+                ProfScope ps(c, KID_FUSED_REF);
+                auto kern = k_fused_ref<InT, WRT, true>;
+                HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_ref_lds_bytes(WRT)));
+                hipLaunchKernelGGL(kern, dim3(tiles), dim3(FUSED_REF_NT), fused_ref_lds_bytes(WRT), c->stream, Q);
+                HIPCHK(c, hipGetLastError());
+            }
+            ProfScope ps(c, KID_OVO_FUSED_WIDE);
+            auto kern = k_ovo_fused<InT, WRT, false, 8, FUSED_U, true>;
+            const size_t lds = fused_main_lds_bytes<WRT, false, 8>();
+            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int n_cu = 256;
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+            hipLaunchKernelGGL(kern, dim3((unsigned)std::max(n_cu, 1)), dim3(FUSED_NT), lds, c->stream, Q); // resident workgroups over the listed tiles
+            HIPCHK(c, hipGetLastError());
+        }
     } else {
         HIPCHK(c, hipMemsetAsync(P.hist_all, 0, (size_t)nb * RT * 4, c->stream));
         // one pass over X when the per-(group, gene) histograms fit the scratch cap (64 or 128 bytes each)
@@ -720,7 +759,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
                 HIPCHK(c, hipGetLastError());
             }
             ProfScope ps(c, KID_OVR_FUSED);
-            hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+            hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16>), main_grid, dim3(FUSED_NT), lds_ovr, c->stream, P);
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -754,10 +793,11 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
 
 // column runs [first, second) of the flagged genes of a window starting at column w0
 static void flagged_runs(const u32 *hf, int64_t wn, int64_t w0, std::vector<std::pair<int64_t, int64_t>> &runs) {
+    // (1 = the gene left the fused route; 2 = taken by its second, wider pass: done)
     for (int64_t j = 0; j < wn;) {
-        if (!hf[j]) { ++j; continue; }
+        if (hf[j] != 1u) { ++j; continue; }
         int64_t e = j;
-        while (e < wn && hf[e]) ++e;
+        while (e < wn && hf[e] == 1u) ++e;
         if (!runs.empty() && runs.back().second == w0 + j) runs.back().second = w0 + e;
         else runs.push_back({w0 + j, w0 + e});
         j = e;

@@ -48,39 +48,31 @@ struct FusedParams {
     long long out_ld;
     int groups_per_wg;
     u32 *group_hist;          // OVR one-pass form: [G][tiles][RT * CB / 32][64] words, per-(group, gene) value histograms
+    u32 *wide_tiles;          // WIDE: [0] = number of tiles with candidates, [1 ..] = those tiles (k_fused_ref<WIDE> appends)
 };
 
 // Table index of a value, clamped into [0, RT-1], and whether the value IS that integer (else the gene leaves
 // this route).  One v_med3 replaces the range compares: out-of-range, fractional and NaN all fail `exact`.
-template <typename InT, int RT> __device__ __forceinline__ u32 clamp_count(InT v, bool &exact);
-template <> __device__ __forceinline__ u32 clamp_count<float, 64>(float v, bool &exact) {
-    const float m = __builtin_amdgcn_fmed3f(v, 0.0f, 63.0f);
-    const u32 c = (u32)m;
-    exact = (float)c == v;
-    return c;
-}
-template <> __device__ __forceinline__ u32 clamp_count<double, 64>(double v, bool &exact) {
-    const double m = fmin(fmax(v, 0.0), 63.0); // NaN -> 0
-    const u32 c = (u32)m;
-    exact = (double)c == v;
-    return c;
-}
-template <> __device__ __forceinline__ u32 clamp_count<int32_t, 64>(int32_t v, bool &exact) {
-    const u32 c = (u32)min(max(v, 0), 63);
-    exact = (int32_t)c == v;
-    return c;
-}
-template <> __device__ __forceinline__ u32 clamp_count<int64_t, 64>(int64_t v, bool &exact) {
-    const u32 c = (u32)min(max(v, (int64_t)0), (int64_t)63);
-    exact = (int64_t)c == v;
-    return c;
-}
-
-// (byte windows written by k_csr_densify: 255 marks a value the window cannot hold)
-template <> __device__ __forceinline__ u32 clamp_count<uint8_t, 64>(uint8_t v, bool &exact) {
-    const u32 c = min((u32)v, 63u);
-    exact = c == (u32)v;
-    return c;
+template <typename InT, int RT> __device__ __forceinline__ u32 clamp_count(InT v, bool &exact) {
+    if constexpr (std::is_same<InT, float>::value) {
+        const float m = __builtin_amdgcn_fmed3f(v, 0.0f, (float)(RT - 1));
+        const u32 c = (u32)m;
+        exact = (float)c == v;
+        return c;
+    } else if constexpr (std::is_same<InT, double>::value) {
+        const double m = fmin(fmax(v, 0.0), (double)(RT - 1)); // NaN -> 0
+        const u32 c = (u32)m;
+        exact = (double)c == v;
+        return c;
+    } else if constexpr (std::is_same<InT, uint8_t>::value) { // (byte windows written by k_csr_densify: 255 marks a value the window cannot hold)
+        const u32 c = min((u32)v, (u32)(RT - 1));
+        exact = c == (u32)v && (u32)v != 255u;
+        return c;
+    } else {
+        const InT cl = min(max(v, (InT)0), (InT)(RT - 1));
+        exact = cl == v;
+        return (u32)cl;
+    }
 }
 
 // One chunk = UU rows of one group for the wavefront's 64 genes, in two straight-line halves: gather_rows requests
@@ -231,15 +223,29 @@ __global__ __launch_bounds__(256) void k_fused_probe(FusedParams P) {
 // ---- reference tables: one 1024-thread workgroup per 64-gene tile; lane = gene.  All 16 wavefronts add into one
 // LDS histogram (columns are lane-private, so the only contention is between wavefronts), then wavefront 0 scans
 // each gene's bins into the cumulative table, T_A and the reference sum, and writes the reference group's row.
+// WIDE: the second, wider table (RT = 256) for the genes the 64-value pass flagged (gene_flags == 1): tiles without such a gene
+// leave at once; a flagged gene whose reference values all fit becomes a candidate (gene_flags = 2) for k_ovo_fused<WIDE>.
 #define FUSED_REF_NT 1024
-template <typename InT, int RT>
+#define FUSED_WIDE_RT 256
+static inline size_t fused_ref_lds_bytes(int rt) { return (size_t)64 * (rt + 1) * 4; }
+template <typename InT, int RT, bool WIDE = false>
 __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
     constexpr int NW = FUSED_REF_NT / 64, STR = RT + 1, UR = 16;
-    __shared__ u32 h[64 * STR];
+    extern __shared__ __align__(16) u32 h[]; // [64 * STR]
     __shared__ int s_bad[64];
+    __shared__ int s_skip;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
     const bool act = gene < P.ncols;
+    if (WIDE) {
+        if (wave == 0) {
+            const bool want = act && P.gene_flags[gene] == 1u;
+            const bool any = __any(want);
+            if (lane == 0) s_skip = any ? 0 : 1;
+        }
+        __syncthreads();
+        if (s_skip) return;
+    }
     for (int i = tid; i < 64 * STR; i += FUSED_REF_NT) h[i] = 0;
     if (tid < 64) s_bad[tid] = 0;
     __syncthreads();
@@ -274,10 +280,11 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
             sum += t * (u64)c;
         }
         hl[RT] = run;
-        if (act) {
+        if (act && (!WIDE || P.gene_flags[gene] == 1u)) {
         P.ref_TA[gene] = ta;
         P.ref_sum[gene] = sum;
-        if (s_bad[lane]) P.gene_flags[gene] = 1u;
+        if (WIDE) { if (!s_bad[lane]) { P.gene_flags[gene] = 2u; s_skip = 2; } } // candidate for the wide main pass (else it stays flagged); s_skip = 2: this tile has one
+        else if (s_bad[lane]) P.gene_flags[gene] = 1u;
         const size_t o = (size_t)P.ref * P.out_ld + gene;
         P.out_p[o] = 1.0;                                                            // sparse_ovo.py:140-143
         P.out_u[o] = -1.0;
@@ -285,6 +292,10 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
         }
     }
     __syncthreads();
+    if (WIDE) { // the tile joins the list the wide main pass works through (resident workgroups: nothing listed, nothing launched)
+        if (s_skip != 2) return; // uniform
+        if (tid == 0) P.wide_tiles[1 + atomicAdd(&P.wide_tiles[0], 1u)] = blockIdx.x;
+    }
     // copy-out as the [value][lane] image k_ovo_fused keeps in LDS: coalesced stores, conflict-free LDS reads
     u32 *dst = P.ref_cum + (size_t)blockIdx.x * (64 * STR);
     for (int i = tid; i < 64 * STR; i += FUSED_REF_NT) dst[i] = h[(i & 63) * STR + (i >> 6)];
@@ -356,37 +367,53 @@ template <int RT> __global__ void k_fused_tables_all(FusedParams P) {
 // ---- main pass: grid (tiles, group chunks); 4 wavefronts per workgroup, one group at a time per wavefront ----
 // (Building the reference tables inside this kernel, per workgroup, instead of reading k_fused_ref's was measured at
 // C2: no gain -- the 0.08 ms of k_fused_ref are matched by the redundant per-workgroup work.)
-template <typename InT, int RT, bool OVR, int CB, int U = FUSED_U>
-__global__ __launch_bounds__(FUSED_NT, (OVR || CB == 8) ? 4 : 3) void k_ovo_fused(FusedParams P) {
+// WIDE (RT = 256, OVO): the second pass over the tiles that hold candidates of the wider table (gene_flags == 2, set by
+// k_fused_ref<WIDE>); only those lanes are active, a candidate that shows a value beyond this table too goes back to
+// gene_flags = 1 (the host's two-pass routes).  130 KB of LDS: one workgroup per CU -- it only runs where the first pass left genes.
+template <int RT, bool OVR, int CB> static inline size_t fused_main_lds_bytes() {
+    return (size_t)(RT + 1) * 64 * 4 + (size_t)(FUSED_NT / 64) * (OVR ? 1 : RT * CB / 32) * 64 * 4;
+}
+template <typename InT, int RT, bool OVR, int CB, int U = FUSED_U, bool WIDE = false>
+__global__ __launch_bounds__(FUSED_NT, WIDE ? 1 : ((OVR || CB == 8) ? 4 : 3)) void k_ovo_fused(FusedParams P) {
     constexpr int NT = FUSED_NT, NW = NT / 64, CSTR = RT + 1, BW = OVR ? 1 : RT * CB / 32;
     // Both tables are laid out [value][lane]: the LDS bank of a lookup is set by the lane alone, whatever the values
     // (32-bit cells: conflict-free; 8- / 16-bit cells: four / two neighbouring lanes share a bank).  With [lane][value]
     // rows and an odd lane stride the data-dependent lookups collided at random (4.8 extra LDS cycles per instruction,
     // SQ_LDS_BANK_CONFLICT); same-process A/B: this layout 0.4 % faster.
     constexpr int LS = 64;                 // cell stride between consecutive values
-    __shared__ u32 cumA[CSTR * 64];        // cumA[c][lane] = # reference cells of gene `lane` with value < c
-    __shared__ u32 cntB[NW][BW * 64];      // per wavefront: running multiplicities [value][lane], CB bits each
+    extern __shared__ __align__(16) u32 fused_lds[];
+    u32 *cumA = fused_lds;                 // [CSTR * 64]: cumA[c][lane] = # reference cells of gene `lane` with value < c
+    u32 *cntB_all = fused_lds + CSTR * 64; // [NW][BW * 64] per wavefront: running multiplicities [value][lane], CB bits each
     __shared__ int s_skip;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
-    const bool act = gene < P.ncols;
+    // WIDE: resident workgroups (one per CU: 130 KB of LDS) work through (listed tile, group chunk) items; with nothing listed
+    // every workgroup leaves at once.  A grid of one workgroup per item cost 0.08 ms at C2 for nothing: 31 250 workgroups
+    // that each wait for a whole CU's LDS.
+    const int n_chunks = (P.G + P.groups_per_wg - 1) / P.groups_per_wg;
+    const int n_items = WIDE ? (int)P.wide_tiles[0] * n_chunks : 1;
+    for (int item = WIDE ? (int)blockIdx.x : 0; item < n_items; item += WIDE ? (int)gridDim.x : 1) {
+    const int tile = WIDE ? __builtin_amdgcn_readfirstlane((int)P.wide_tiles[1 + item / n_chunks]) : (int)blockIdx.x; // (uniform: scalar row bases below)
+    const int gchunk = WIDE ? item % n_chunks : (int)blockIdx.y;
+    if (WIDE) __syncthreads(); // the previous item's tables and s_skip are done with
+    const int gene0 = tile * 64, gene = gene0 + lane;
+    const bool act = gene < P.ncols && (!WIDE || P.gene_flags[gene] == 2u);
     const int lane_c = act ? lane : 0; // inactive lanes (tile wider than the batch) re-read a valid column
     const InT *Xg = (const InT *)P.X + P.col0 + gene0;
     const char *Xb = (const char *)Xg;
     const u32 row_bytes = (u32)P.ld * (u32)sizeof(InT), col_bytes = (u32)lane_c * (u32)sizeof(InT);
     const const_int_p permc = (const_int_p)P.perm;
     bool bad = false;
-    // every gene of this tile already sent to the slow routes? then there is nothing to do here
+    // every gene of this tile already sent to the slow routes (WIDE: no candidate in it)? then there is nothing to do here
     if (wave == 0) {
-        const bool flagged = !act || P.gene_flags[gene] != 0;
+        const bool flagged = !act || (!WIDE && P.gene_flags[gene] != 0);
         const bool all = __all(flagged);
         if (lane == 0) s_skip = all ? 1 : 0;
     }
-    u32 *cbw = cntB[wave];                 // the wavefront's counter block as words: lane zeroes words lane, lane + 64, ..
+    u32 *cbw = cntB_all + wave * (BW * 64); // the wavefront's counter block as words: lane zeroes words lane, lane + 64, ..
     for (int i = 0; i < BW; ++i) cbw[i * 64 + lane] = 0;
     __syncthreads();
-    if (s_skip) return;
-    for (int i = tid; i < 64 * CSTR; i += NT) cumA[i] = P.ref_cum[(size_t)blockIdx.x * (64 * CSTR) + i];
+    if (s_skip) { if (WIDE) continue; else return; }
+    for (int i = tid; i < 64 * CSTR; i += NT) cumA[i] = P.ref_cum[(size_t)tile * (64 * CSTR) + i];
     __syncthreads();
     const u64 T_A = act ? P.ref_TA[gene] : 0ull;
     const double ref_sum = act ? (double)P.ref_sum[gene] : 0.0;
@@ -396,7 +423,7 @@ __global__ __launch_bounds__(FUSED_NT, (OVR || CB == 8) ? 4 : 3) void k_ovo_fuse
     const long long n_ref = OVR ? 0 : P.counts[OVR ? 0 : P.ref];
     const double cc = P.use_continuity ? 0.5 : 0.0;
 
-    const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
+    const int gbeg = gchunk * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
 
     // ---- this lane's (group, gene) result from the group's integer statistics ----
     auto emit = [&](int g, long long n_tgt, u64 S2, u64 TT, u32 vsum) {
@@ -461,6 +488,7 @@ __global__ __launch_bounds__(FUSED_NT, (OVR || CB == 8) ? 4 : 3) void k_ovo_fuse
             for (int i = 0; i < BW; ++i) cbw[i * 64 + lane] = 0; // the wavefront's own block, in-order LDS: no barrier needed
     }
     if (act && bad) P.gene_flags[gene] = 1u;
+    } // items
 }
 
 // ============================================================================================

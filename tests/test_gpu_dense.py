@@ -336,3 +336,46 @@ def test_backed_memmap_input_streams_chunks(tmp_path, test, monkeypatch):
     want = asymptotic_wilcoxon(AnnDataLite(X, obs=obs), is_log1p=False, group_keys="pert", reference=ref)
     pd.testing.assert_frame_equal(got, want)
     np.testing.assert_array_equal(np.load(tmp_path / "x.npy"), X)
+
+
+def test_fused_route_second_pass_takes_counts_up_to_255(engine):
+    """Counts of 64 .. 255 (highly expressed genes of a real count matrix) stay on the single-pass fused route: its second,
+    256-value pass takes the genes the 64-value pass flags, on the device, without a host round trip.  Poisson(60) genes next
+    to Poisson(3) genes; one gene with a count of 300 (beyond the wider table too) and one fractional gene still go to the
+    two-pass routes.  Same bytes as with the second pass switched off; matches the oracle."""
+    import torch
+    rng = np.random.RandomState(67)
+    n, m = 9000, 200
+    means = np.where(np.arange(m) % 3 == 0, 60.0, 3.0)
+    X = (rng.poisson(means, size=(n, m)) * (rng.rand(n, m) < 0.6)).astype(np.float32)
+    X[17, 33] = 300.0
+    X[:, 34] = np.where(rng.rand(n) < 0.1, 0.5, X[:, 34])
+    X[:, 36] = 255.0 * (rng.rand(n) < 0.5)     # the last value of the wider table
+    labels = make_labels(rng, n, 40, n_ref=800)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    want = oracle.run(X, g)
+    Xd = torch.from_numpy(X).cuda()
+    engine.set_groups(g)
+    engine.set_option("profile", 1)
+    engine.profile_reset()
+    try:
+        got = engine.run_dense(Xd, 0, m)
+        prof = engine.profile_get()
+        engine.set_option("no_fused_wide", 1)
+        engine.profile_reset()
+        narrow_only = engine.run_dense(Xd, 0, m)
+        prof2 = engine.profile_get()
+    finally:
+        engine.set_option("no_fused_wide", 0)
+        engine.set_option("profile", 0)
+    assert "k_ovo_fused_wide" in prof and "k_ovo_fused_wide" not in prof2, (prof, prof2)
+    # with the second pass only genes 33 and 34 are left for the two-pass routes (one short run), without it a third of the matrix
+    assert prof["k_transpose_permute"]["launches"] < prof2["k_transpose_permute"]["launches"], (prof, prof2)
+    for a, b in zip(got, narrow_only):
+        assert a.tobytes() == b.tobytes()
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what="counts up to 255")
+    # the same through CSR byte windows (k_csr_densify writes bytes: values up to 254 fit)
+    from scipy import sparse
+    M = sparse.csr_matrix(X[:, :120])
+    got = engine.run_sparse("csr", M.data, M.indices, M.indptr, M.shape, 0, 120)
+    assert_planes_match(got, tuple(a[:, :120] for a in want), ref_row=g.encoded_ref_group, what="csr byte window, counts up to 254")
