@@ -38,8 +38,7 @@ struct CscCountsParams {
     long long col0;                      // first gene of the batch (contiguous batches)
     const int *gene_cols;                // or: the batch's genes as a column list (absolute indices); nullptr = contiguous
     int nb;
-    const int *codes;                    // [n_cells] group code per cell; nullptr: `indices` already holds group codes
-    const u16 *codes16;                  // the same codes as 16-bit values (G <= 65535), or nullptr
+    const u16 *codes16;                  // [n_cells] group code per cell as 16-bit values (C16); else `indices` already holds group codes
     const int *counts;                   // [G]
     int G, ref;                          // ref == -1: OVR
     long long n_cells;
@@ -56,10 +55,12 @@ struct CscCountsParams {
 static inline size_t cscc_lds_bytes(int G, int rt) { return (size_t)G * (rt ? rt : CSCM_WPG * 4) + (((size_t)G + 15) & ~(size_t)15); }
 
 #define CSCC_MAX_BIG 8
-template <typename InT, typename IdxT, bool OVR, int RT, bool HAS_BIG, bool MIXED>
+// C16: group codes come from codes16[row] (the host's case whenever a code table exists: sparse input is limited to fewer than
+// 65 536 groups); else `indices` already holds the codes (the device CSR -> CSC transposition writes them).
+template <typename InT, typename IdxT, bool OVR, int RT, bool HAS_BIG, bool MIXED, bool C16>
 __global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCountsParams P) { // (waves per SIMD: two workgroups per CU for the mixed form)
     static_assert(!MIXED || RT == 64, "the mixed layout holds the values 1 .. 63");
-    constexpr int NT = CSCC_NT, UL = CSCC_UL, WPG = MIXED ? CSCM_WPG : RT / 4; // words per group
+    constexpr int NT = CSCC_NT, UL = (HAS_BIG && MIXED) ? CSCC_UL / 2 : CSCC_UL, WPG = MIXED ? CSCM_WPG : RT / 4; // words per group (UL halved where 16 entries in flight would spill)
     extern __shared__ __align__(16) u32 cscc_h[];             // [WPG][G] words
     __shared__ u32 hsel[RT];   // OVO: histogram of the reference group's stored values; OVR: of the whole column
     __shared__ u32 hbig[HAS_BIG ? CSCC_MAX_BIG * RT : 1]; // 32-bit cells of the few groups with more than 255 cells
@@ -101,16 +102,15 @@ __global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCounts
         bool bad = false;
         u32 n_ent = 0; // MIXED: entries this thread put into the packed group tables
         // two-stage pipeline over the gene's entries: the values / row indices of round i + 1 are requested before round
-        // i's group codes (a dependent gather) and LDS atomics, so one HBM round trip per round is off the critical path.
-        // (One copy of the loop per code source: with the choice inside, the 16 gathers of a round are not issued back to back.)
-        auto entry_loop = [&](auto code_of) {
+        // i's group codes (a dependent gather) and LDS atomics, so one HBM round trip per round is off the critical path
+        {
             for (long long kb = k0; kb < k1; kb += (long long)NT * UL) {
                 InT v[UL];
                 int cd[UL];
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
                     v[u] = vn[u];
-                    cd[u] = code_of(in[u]); // (entries past k1: row 0, value 0 -> ignored)
+                    cd[u] = C16 ? (int)P.codes16[(long long)in[u]] : (int)in[u]; // (entries past k1: row 0, value 0 -> ignored)
                 }
                 const long long kn = kb + (long long)NT * UL;
                 if (kn < k1) { // uniform
@@ -141,10 +141,7 @@ __global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCounts
                         }
                     }
             }
-        };
-        if (P.codes16) { const u16 *t = P.codes16; entry_loop([t](IdxT row) { return (int)t[(long long)row]; }); }
-        else if (P.codes) { const int *t = P.codes; entry_loop([t](IdxT row) { return t[(long long)row]; }); }
-        else entry_loop([](IdxT row) { return (int)row; });
+        }
         if (MIXED) {
             n_ent = (u32)wave_sum((int)n_ent);
             if (lane == 0 && n_ent) atomicAdd(&s_entries, n_ent);

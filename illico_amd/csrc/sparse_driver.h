@@ -55,17 +55,19 @@ static int upload_cols(illico_ctx *c, const std::vector<int64_t> &cols, const in
 template <typename InT, typename IdxT, bool MIXED>
 static int launch_csc_counts(illico_ctx *c, const CscCountsParams &P, int rt, bool has_big, bool ovr, size_t lds) {
     ProfScope ps(c, KID_CSC_COUNTS);
-#define CSCC_LAUNCH(OVRF, RTV, BIG)                                                                                        \
+#define CSCC_LAUNCH1(OVRF, RTV, BIG, C16F)                                                                                 \
     do {                                                                                                                   \
-        auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, BIG, MIXED && RTV == 64>;                                           \
+        auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, BIG, MIXED && RTV == 64, C16F>;                                     \
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
         hipLaunchKernelGGL(kern, dim3(P.nb), dim3(CSCC_NT), lds, c->stream, P);                                            \
     } while (0)
+#define CSCC_LAUNCH(OVRF, RTV, BIG) do { if (P.codes16) CSCC_LAUNCH1(OVRF, RTV, BIG, true); else CSCC_LAUNCH1(OVRF, RTV, BIG, false); } while (0)
 #define CSCC_LAUNCH2(OVRF, RTV) do { if (has_big) CSCC_LAUNCH(OVRF, RTV, true); else CSCC_LAUNCH(OVRF, RTV, false); } while (0)
     if (ovr) { if (rt == 64) CSCC_LAUNCH2(true, 64); else CSCC_LAUNCH2(true, 32); }
     else { if (rt == 64) CSCC_LAUNCH2(false, 64); else CSCC_LAUNCH2(false, 32); }
 #undef CSCC_LAUNCH2
 #undef CSCC_LAUNCH
+#undef CSCC_LAUNCH1
     HIPCHK(c, hipGetLastError());
     return ILLICO_OK;
 }
@@ -95,7 +97,8 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
     //  would drop to 31)
     const bool try_mixed = !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(G, 0) + 4096) <= kMaxLds ||
                                                        (rt8 == 32 && cscc_lds_bytes(G, 0) + 8192 <= kMaxLds));
-    const u16 *codes16 = d_codes ? c->d_codes16 : nullptr;
+    const u16 *codes16 = d_codes ? c->d_codes16 : nullptr; // (sparse input holds fewer than 65 536 groups: the 16-bit table exists)
+    if (d_codes && !codes16) return ILLICO_OK; // every gene stays in `cols`
     std::vector<int64_t> left;
     // pass 0: mixed cells over every gene; pass 1: 8-bit cells over the genes whose 4-bit cells overflowed (or over every
     // gene when the mixed form is not used)
@@ -121,7 +124,7 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
             HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)nb * 4, c->stream));
             CscCountsParams P;
             P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = cols[b0];
-            P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.codes16 = codes16; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref;
+            P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes16 = codes16; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref;
             P.n_cells = n_rows; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot;
             P.gene_total = ovr ? gtot : nullptr;
             if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }

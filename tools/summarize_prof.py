@@ -5,7 +5,7 @@ import collections, csv, glob, json, os, sys
 out_dir = sys.argv[1]
 summary = {"kernels": {}}
 for f in glob.glob(os.path.join(out_dir, "kt", "*", "*_kernel_stats.csv")):
-    rows = [r for r in csv.DictReader(open(f)) if "k_" in r["Name"] and "at::" not in r["Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "k_" in r["Name"] and "at::" not in r["Name"] and "rocprim" not in r["Name"]]
     with open(os.path.join(out_dir, "kernel_stats.csv"), "w", newline="") as g:
         w = csv.DictWriter(g, fieldnames=rows[0].keys() if rows else ["Name"])
         w.writeheader()
@@ -20,7 +20,7 @@ for sub in ("fetch", "write", "sq", "sq2"):
         meta = {}
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "k_" not in k or "at::" in k:
+            if "k_" not in k or "at::" in k or "rocprim" in k:
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             n[k].add(r["Dispatch_Id"])
