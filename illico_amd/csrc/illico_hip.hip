@@ -82,6 +82,8 @@ struct illico_ctx {
     int *d_posptr = nullptr;      // [G+1]
     int *d_counts = nullptr;      // [G]
     int *d_code_by_pos = nullptr; // [N] group code at position p
+    u32 *d_hist_off = nullptr;    // [G+1] OVR one-pass histograms: words per lane before group g (16 per group of <= 255 cells, else 32)
+    size_t hist_words = 0;        // d_hist_off[G]
     u16 *d_codes16 = nullptr;     // [N] d_codes as 16-bit values when G <= 65535 (half the cache lines per codes[row] gather), else null
     // options
     int64_t gene_batch = 0;
@@ -254,6 +256,8 @@ static void free_groups(illico_ctx *c) {
     }
     if (c->d_codes16) hipFree(c->d_codes16);
     c->d_codes16 = nullptr;
+    if (c->d_hist_off) hipFree(c->d_hist_off);
+    c->d_hist_off = nullptr;
     c->has_groups = false;
 }
 
@@ -408,6 +412,13 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
     if ((rc = up(&c->d_codes, codes)) || (rc = up(&c->d_perm, perm)) || (rc = up(&c->d_posptr, posptr)) ||
         (rc = up(&c->d_counts, cnt)) || (rc = up(&c->d_code_by_pos, cbp)))
         return rc;
+    {
+        std::vector<u32> ho(n_groups + 1, 0u);
+        for (int64_t g = 0; g < n_groups; ++g) ho[g + 1] = ho[g] + (counts[g] <= 255 ? 16u : 32u);
+        HIPCHK(c, hipMalloc((void **)&c->d_hist_off, ho.size() * sizeof(u32)));
+        HIPCHK(c, hipMemcpy(c->d_hist_off, ho.data(), ho.size() * sizeof(u32), hipMemcpyHostToDevice));
+        c->hist_words = ho[n_groups];
+    }
     if (n_groups <= 65535) {
         std::vector<u16> c16(codes.begin(), codes.end());
         HIPCHK(c, hipMalloc((void **)&c->d_codes16, c16.size() * sizeof(u16)));
@@ -658,6 +669,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.hist_all = ovr ? P.gene_flags + nb : nullptr;
     P.group_hist = nullptr;
     P.wide_tiles = nullptr;
+    P.hist_off = nullptr;
     P.n_cells = c->n_cells;
     P.rows_per_wg = (int)std::max<int64_t>(1024, (c->n_cells + 31) / 32);
     P.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;
@@ -671,7 +683,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
         gpw = 8;
         while (gpw > 4 && (int64_t)tiles * ((c->n_groups + gpw - 1) / gpw) < 2048) gpw >>= 1;
     }
-    P.groups_per_wg = gpw;
+    P.groups_per_wg = gpw = std::min(gpw, 128); // (k_ovr_group_hists packs a workgroup's cells into 16-bit fields: 128 x 255 < 2^16)
     HIPCHK(c, hipMemsetAsync(P.gene_flags, 0, (size_t)nb * 4, c->stream));
     if (probe) { // OVR on device-resident input: which genes are count-valued at all is found on the device (the OVO pass has
         // k_fused_ref, which reads every reference row first)
@@ -729,15 +741,18 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     } else {
         HIPCHK(c, hipMemsetAsync(P.hist_all, 0, (size_t)nb * RT * 4, c->stream));
         // one pass over X when the per-(group, gene) histograms fit the scratch cap (64 or 128 bytes each)
-        const int cbits = c->max_nonref <= 255 ? 8 : 16;
-        const size_t hist_bytes = (size_t)c->n_groups * tiles * (RT * cbits / 32) * 64 * 4;
+        // 8-bit cells when no group is larger than 255 cells, else the width per group (0): a few large groups do not double
+        // the histogram bytes of all the small ones
+        const int cbits = c->max_nonref <= 255 ? 8 : 0;
+        const size_t hist_bytes = cbits ? (size_t)c->n_groups * tiles * (RT * cbits / 32) * 64 * 4 : (size_t)c->hist_words * tiles * 64 * 4;
         if (!c->no_ovr_one_pass && hist_bytes <= (size_t)c->scratch_bytes) {
             if ((rc = get_scratch(c, "group_hist", hist_bytes, &v))) return rc;
             P.group_hist = (u32 *)v;
+            P.hist_off = c->d_hist_off;
             {
                 ProfScope ps(c, KID_OVR_FUSED);
                 if (cbits == 8) hipLaunchKernelGGL((k_ovr_group_hists<InT, RT, 8>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
-                else hipLaunchKernelGGL((k_ovr_group_hists<InT, RT, 16>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
+                else hipLaunchKernelGGL((k_ovr_group_hists<InT, RT, 0>), main_grid, dim3(FUSED_NT), 0, c->stream, P);
                 HIPCHK(c, hipGetLastError());
             }
             ProfScope ps(c, KID_FUSED_REF);
@@ -748,7 +763,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             while (P2.groups_per_wg > 8 && (int64_t)tiles * ((c->n_groups + P2.groups_per_wg - 1) / P2.groups_per_wg) < 2048) P2.groups_per_wg >>= 1;
             const dim3 grid2(tiles, ((int)c->n_groups + P2.groups_per_wg - 1) / P2.groups_per_wg);
             if (cbits == 8) hipLaunchKernelGGL((k_ovr_from_hists<RT, 8>), grid2, dim3(FUSED_NT), 0, c->stream, P2);
-            else hipLaunchKernelGGL((k_ovr_from_hists<RT, 16>), grid2, dim3(FUSED_NT), 0, c->stream, P2);
+            else hipLaunchKernelGGL((k_ovr_from_hists<RT, 0>), grid2, dim3(FUSED_NT), 0, c->stream, P2);
             HIPCHK(c, hipGetLastError());
         } else {
             {

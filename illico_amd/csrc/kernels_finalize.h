@@ -52,25 +52,43 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     const bool ovr = P.ref < 0;
     const double cc = P.use_continuity ? 0.5 : 0.0;
     long long total_cells = P.n_cells;
-    for (int gy = ty; gy < 32; gy += 8) {
-        int gene = gene0 + gy, g = grp0 + tx;
-        if (gene < P.nb && g < P.G) {
-            size_t o = (size_t)gene * P.G + g;
-            long long n_tgt = P.counts[g];
-            long long n_ref = ovr ? (total_cells - n_tgt) : (long long)P.counts[P.ref];
+    // every load of this thread's four (gene, group) pairs is requested before any of the arithmetic: the kernel moves 48 bytes
+    // per test and does not compute much -- what it must not do is wait for memory four times in a row
+    const int g = grp0 + tx;
+    const bool gok = g < P.G;
+    const long long n_tgt = gok ? P.counts[g] : 1;
+    const long long n_refc = ovr ? 0 : (long long)P.counts[P.ref];
+    long long in2u[4];
+    u64 intie[4];
+    double insum[4], inref[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int gene = gene0 + ty + 8 * k;
+        const bool ok = gok && gene < P.nb;
+        const size_t o = ok ? (size_t)gene * P.G + g : 0;
+        in2u[k] = ok ? P.in_2u[o] : 0;
+        intie[k] = (ok && P.tie_correct) ? P.in_tie[o] : 0ull;
+        insum[k] = ok ? P.in_sum[o] : 0.0;
+        inref[k] = !ok ? 1.0 : (ovr ? P.gene_total[gene] : P.in_sum[(size_t)gene * P.G + P.ref]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int gy = ty + 8 * k, gene = gene0 + gy;
+        if (gene < P.nb && gok) {
+            long long n_ref = ovr ? (total_cells - n_tgt) : n_refc;
             long long n = ovr ? total_cells : (n_ref + n_tgt);
-            double U = 0.5 * (double)P.in_2u[o];
-            double tie = P.tie_correct ? (double)P.in_tie[o] : 0.0;
+            double U = 0.5 * (double)in2u[k];
+            double tie = P.tie_correct ? (double)intie[k] : 0.0;
             double mu = (double)(n_ref * n_tgt) / 2.0;
             double p;
             if (!ovr && g == P.ref) { p = 1.0; U = -1.0; }                         // sparse_ovo.py:140-143
             else p = pval_device(n_ref, n_tgt, n, tie, U, mu, cc, P.alternative);
             // fold change, math.py:181-192
-            double sum_g = P.in_sum[o];
+            double sum_g = insum[k];
             double mu_tgt = sum_g / (double)n_tgt;
             double mu_ref;
-            if (ovr) mu_ref = (P.gene_total[gene] - sum_g) / (double)(total_cells - n_tgt);
-            else mu_ref = P.in_sum[(size_t)gene * P.G + P.ref] / (double)P.counts[P.ref];
+            if (ovr) mu_ref = (inref[k] - sum_g) / (double)(total_cells - n_tgt);
+            else mu_ref = inref[k] / (double)n_refc;
             double fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
             tp[gy][tx] = p;
             tu[gy][tx] = U;

@@ -49,6 +49,7 @@ struct FusedParams {
     int groups_per_wg;
     u32 *group_hist;          // OVR one-pass form: [G][tiles][RT * CB / 32][64] words, per-(group, gene) value histograms
     u32 *wide_tiles;          // WIDE: [0] = number of tiles with candidates, [1 ..] = those tiles (k_fused_ref<WIDE> appends)
+    const u32 *hist_off;      // OVR one-pass form, mixed cell widths: [G + 1] words per lane before group g (16 for a group of <= 255 cells, else 32)
 };
 
 // Table index of a value, clamped into [0, RT-1], and whether the value IS that integer (else the gene leaves
@@ -501,12 +502,18 @@ __global__ __launch_bounds__(FUSED_NT, WIDE ? 1 : ((OVR || CB == 8) ? 4 : 3)) vo
 // Cell (value c, gene lane) lives in the lane-PRIVATE word (c / PW) * 64 + lane of the wavefront's block, PW = 32 / CB
 // cells per word: the dump to HBM is BW coalesced 256-B stores, the second kernel reads its genes' words the same
 // way, and the LDS bank of a cell is the lane (conflict-free).
+// CB = 0: the cell width is chosen per group -- 8 bits for a group of at most 255 cells, 16 bits above -- and a group's
+// block starts at hist_off[g] words per lane: one 10 000-cell group among 2000 no longer doubles the histogram bytes of the
+// 1999 small ones (C4: 2.05 GB of histograms written and read back -> 1.03 GB).
 template <typename InT, int RT, int CB>
 __global__ __launch_bounds__(FUSED_NT, 4) void k_ovr_group_hists(FusedParams P) {
-    constexpr int NT = FUSED_NT, NW = NT / 64, BW = RT * CB / 32, PW = 32 / CB, U = FUSED_U;
-    __shared__ u32 hcol[RT * 64];          // [value][lane]: histogram of every row this workgroup reads
-    __shared__ u32 cntB[NW][BW * 64];      // per wavefront: the current group's cells
-    typedef typename CntCell<CB>::type cell_t;
+    constexpr int NT = FUSED_NT, NW = NT / 64, BWMAX = RT * (CB ? CB : 16) / 32, U = FUSED_U;
+    // The column histogram (every cell, whatever its group) is not counted per element: when a group is done its 8-bit cells are
+    // added, two at a time as 16-bit fields, into hpack -- 32 LDS atomics per group and lane instead of one per cell (a
+    // workgroup sees at most 64 groups x 255 cells: the fields cannot overflow); a group with 16-bit cells (more than 255
+    // cells: a handful per data set) adds its cells to the global histogram directly.
+    __shared__ u32 hpack[(RT / 2) * 64];   // [pair][lane]: word 2 i -> values 4 i (low half), 4 i + 2 (high half); word 2 i + 1 -> 4 i + 1, 4 i + 3
+    __shared__ u32 cntB[NW][BWMAX * 64];   // per wavefront: the current group's cells
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
     const bool act = gene < P.ncols;
@@ -521,54 +528,73 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_ovr_group_hists(FusedParams P) 
         const bool all = __all(flagged);
         if (lane == 0) s_skip = all ? 1 : 0;
     }
-    for (int i = tid; i < RT * 64; i += NT) hcol[i] = 0;
-    for (int i = 0; i < BW; ++i) cbw[i * 64 + lane] = 0;
+    for (int i = tid; i < (RT / 2) * 64; i += NT) hpack[i] = 0;
+    for (int i = 0; i < BWMAX; ++i) cbw[i * 64 + lane] = 0;
     __syncthreads();
     if (s_skip) return;
-    cell_t *cells = (cell_t *)cbw + lane * PW; // cell c: cells[(c / PW) * 64 * PW + c % PW]
-    u32 *hl = hcol + lane;
     bool bad = false;
     const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
     const size_t tiles = gridDim.x;
     for (int g = gbeg + wave; g < gend; g += NW) {
         const int p0 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g]);
         const int p1 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g + 1]);
-        int p = p0;
-        InT v[U];
-        auto chunk = [&](auto uu, auto pred) {
-            constexpr int UU = decltype(uu)::value;
-            constexpr bool PRED = decltype(pred)::value;
-            gather_rows<InT, UU, PRED>(Xb, row_bytes, permc, p, p1, col_bytes, v);
+        auto one_group = [&](auto cbt) {
+            constexpr int CBG = decltype(cbt)::value, BW = RT * CBG / 32, PW = 32 / CBG;
+            typedef typename CntCell<CBG>::type cell_t;
+            cell_t *cells = (cell_t *)cbw + lane * PW; // cell c: cells[(c / PW) * 64 * PW + c % PW]
+            int p = p0;
+            InT v[U];
+            auto chunk = [&](auto uu, auto pred) {
+                constexpr int UU = decltype(uu)::value;
+                constexpr bool PRED = decltype(pred)::value;
+                gather_rows<InT, UU, PRED>(Xb, row_bytes, permc, p, p1, col_bytes, v);
 #pragma unroll
-            for (int u = 0; u < UU; ++u) {
-                const bool valid = !PRED || (p + u < p1);
-                bool exact;
-                const u32 c = clamp_count<InT, RT>(v[u], exact);
-                bad |= valid && !exact;
-                cell_t *cell = cells + (c / PW) * (64 * PW) + (c % PW);
-                *cell = (cell_t)(*cell + (valid ? 1u : 0u));
-                atomicAdd(&hl[c * 64], valid ? 1u : 0u);
+                for (int u = 0; u < UU; ++u) {
+                    const bool valid = !PRED || (p + u < p1);
+                    bool exact;
+                    const u32 c = clamp_count<InT, RT>(v[u], exact);
+                    bad |= valid && !exact;
+                    cell_t *cell = cells + (c / PW) * (64 * PW) + (c % PW);
+                    *cell = (cell_t)(*cell + (valid ? 1u : 0u));
+                }
+                p += UU;
+            };
+            typedef std::integral_constant<bool, false> full_t;
+            typedef std::integral_constant<bool, true> pred_t;
+            while (p + U <= p1) chunk(std::integral_constant<int, U>(), full_t());
+            if constexpr (U > 16) { if (p + 16 <= p1) chunk(std::integral_constant<int, 16>(), full_t()); }
+            if (p + 8 <= p1) chunk(std::integral_constant<int, 8>(), full_t());
+            if (p < p1) chunk(std::integral_constant<int, 8>(), pred_t());
+            const size_t base = CB ? ((size_t)g * tiles + blockIdx.x) * (BW * 64) : ((size_t)P.hist_off[g] * tiles + (size_t)blockIdx.x * BW) * 64;
+            u32 *dst = P.group_hist + base + lane;
+#pragma unroll
+            for (int i = 0; i < BW; ++i) {
+                const u32 w = cbw[i * 64 + lane];
+                dst[i * 64] = w;
+                cbw[i * 64 + lane] = 0;
+                if (CBG == 8) { // four 8-bit cells: values 4 i .. 4 i + 3
+                    const u32 x0 = w & 0x00FF00FFu, x1 = (w >> 8) & 0x00FF00FFu;
+                    if (x0) atomicAdd(&hpack[(2 * i) * 64 + lane], x0);
+                    if (x1) atomicAdd(&hpack[(2 * i + 1) * 64 + lane], x1);
+                } else if (act) { // two 16-bit cells: values 2 i, 2 i + 1 (a large group: straight to the global histogram)
+                    if (w & 0xFFFFu) atomicAdd(&P.hist_all[(size_t)gene * RT + 2 * i], w & 0xFFFFu);
+                    if (w >> 16) atomicAdd(&P.hist_all[(size_t)gene * RT + 2 * i + 1], w >> 16);
+                }
             }
-            p += UU;
         };
-        typedef std::integral_constant<bool, false> full_t;
-        typedef std::integral_constant<bool, true> pred_t;
-        while (p + U <= p1) chunk(std::integral_constant<int, U>(), full_t());
-        if constexpr (U > 16) { if (p + 16 <= p1) chunk(std::integral_constant<int, 16>(), full_t()); }
-        if (p + 8 <= p1) chunk(std::integral_constant<int, 8>(), full_t());
-        if (p < p1) chunk(std::integral_constant<int, 8>(), pred_t());
-        u32 *dst = P.group_hist + ((size_t)g * tiles + blockIdx.x) * (BW * 64) + lane;
-#pragma unroll
-        for (int i = 0; i < BW; ++i) {
-            dst[i * 64] = cbw[i * 64 + lane];
-            cbw[i * 64 + lane] = 0;
-        }
+        if constexpr (CB != 0) one_group(std::integral_constant<int, CB>());
+        else if (p1 - p0 <= 255) one_group(std::integral_constant<int, 8>()); // uniform
+        else one_group(std::integral_constant<int, 16>());
     }
     __syncthreads();
-    for (int i = tid; i < RT * 64; i += NT) {
-        const int c = i >> 6, l = i & 63;
-        const u32 cnt = hcol[i];
-        if (cnt && gene0 + l < P.ncols) atomicAdd(&P.hist_all[(size_t)(gene0 + l) * RT + c], cnt);
+    for (int i = tid; i < (RT / 2) * 64; i += NT) {
+        const int pr = i >> 6, l = i & 63;
+        const u32 wv = hpack[i];
+        const int c0 = (pr >> 1) * 4 + (pr & 1); // low half: value c0, high half: c0 + 2
+        if (gene0 + l < P.ncols) {
+            if (wv & 0xFFFFu) atomicAdd(&P.hist_all[(size_t)(gene0 + l) * RT + c0], wv & 0xFFFFu);
+            if (wv >> 16) atomicAdd(&P.hist_all[(size_t)(gene0 + l) * RT + c0 + 2], wv >> 16);
+        }
     }
     if (act && bad) P.gene_flags[gene] = 1u;
 }
@@ -577,7 +603,7 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_ovr_group_hists(FusedParams P) 
 // in registers for the workgroup's lifetime, a group costs BW coalesced word loads and RT multiply-adds per lane.
 template <int RT, int CB>
 __global__ __launch_bounds__(FUSED_NT) void k_ovr_from_hists(FusedParams P) {
-    constexpr int NW = FUSED_NT / 64, BW = RT * CB / 32, PW = 32 / CB, CSTR = RT + 1;
+    constexpr int NW = FUSED_NT / 64, CSTR = RT + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene = blockIdx.x * 64 + lane;
     const bool act = gene < P.ncols;
@@ -599,22 +625,30 @@ __global__ __launch_bounds__(FUSED_NT) void k_ovr_from_hists(FusedParams P) {
     const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
     const size_t tiles = gridDim.x;
     for (int g = gbeg + wave; g < gend; g += NW) {
-        const u32 *h = P.group_hist + ((size_t)g * tiles + blockIdx.x) * (BW * 64) + lane;
-        u32 w[BW];
-#pragma unroll
-        for (int i = 0; i < BW; ++i) w[i] = h[i * 64];
+        const long long n_tgt = P.counts[g];
         u64 R2 = 0;
         u32 vsum = 0;
+        auto one_group = [&](auto cbt) {
+            constexpr int CBG = decltype(cbt)::value, BW = RT * CBG / 32, PW = 32 / CBG;
+            const size_t base = CB ? ((size_t)g * tiles + blockIdx.x) * (BW * 64) : ((size_t)P.hist_off[g] * tiles + (size_t)blockIdx.x * BW) * 64;
+            const u32 *h = P.group_hist + base + lane;
+            u32 w[BW];
 #pragma unroll
-        for (int i = 0; i < BW; ++i)
+            for (int i = 0; i < BW; ++i) w[i] = h[i * 64];
 #pragma unroll
-            for (int k = 0; k < PW; ++k) {
-                const u32 cnt = __builtin_amdgcn_ubfe(w[i], k * CB, CB);
-                R2 += (u64)cnt * s[i * PW + k];
-                vsum += cnt * (u32)(i * PW + k);
-            }
+            for (int i = 0; i < BW; ++i)
+#pragma unroll
+                for (int k = 0; k < PW; ++k) {
+                    const u32 cnt = __builtin_amdgcn_ubfe(w[i], k * CBG, CBG);
+                    R2 += (u64)cnt * s[i * PW + k];
+                    vsum += cnt * (u32)(i * PW + k);
+                }
+        };
+        if constexpr (CB != 0) one_group(std::integral_constant<int, CB>());
+        else if (n_tgt <= 255) one_group(std::integral_constant<int, 8>()); // uniform
+        else one_group(std::integral_constant<int, 16>());
         // dense_ovr.py:57-75, as in k_ovo_fused<OVR>
-        const long long n_tgt = P.counts[g], n_rest = P.n_cells - n_tgt;
+        const long long n_rest = P.n_cells - n_tgt;
         const long long two_u = 2ll * n_rest * n_tgt + n_tgt * (n_tgt + 1) - ((long long)R2 + n_tgt);
         const double Ustat = 0.5 * (double)two_u;
         const double mu = (double)(n_rest * n_tgt) / 2.0;

@@ -257,39 +257,42 @@ __global__ __launch_bounds__(SUMS_NT) void k_seg_value_sums(SegSumsParams P) {
 }
 
 // ---- group-contiguous key rows -> out_sum[gene][G], fixed order ---------------------------------------------------------------
-// One wavefront per group: lane l adds elements l, l + 64, ... of the group's run, then a butterfly.  Four groups per
-// iteration, their first 256 keys each requested before any is summed (one load latency per four groups).
-template <typename KeyT, int GB = 4, int RR = 4>
+// One wavefront per 64 groups: for each group, lane l adds elements l, l + 64, ... of the group's run (the next group's first
+// 256 keys are requested before this group is summed); the 64 per-lane partial vectors are folded by a transpose-reduce
+// (common.h: TrReduce, 63 VALU combines for 64 groups instead of 64 six-step butterflies), after which lane j holds group j's
+// sum and the block is stored with one coalesced write.  The order of additions is fixed by the positions alone.
+template <typename KeyT, int RR = 4>
 __device__ __forceinline__ void group_sums_row(const KeyT *__restrict__ ka, const int *__restrict__ pos_ptr, int G, int dt, int is_log1p,
                                                double *__restrict__ out, int wave, int lane, int n_waves) {
-    for (int g0 = wave * GB; g0 < G; g0 += n_waves * GB) {
-        int p0[GB], p1[GB];
-        KeyT kk[GB][RR];
-#pragma unroll
-        for (int j = 0; j < GB; ++j) {
-            const int g = g0 + j;
-            p0[j] = p1[j] = 0;
-            if (g < G) { p0[j] = pos_ptr[g]; p1[j] = pos_ptr[g + 1]; }
+    auto val = [&](KeyT k) { return is_log1p ? key_to_expm1(k, dt) : key_to_double(k, dt); };
+    for (int g0 = wave * 64; g0 < G; g0 += n_waves * 64) {
+        TrReduce<double> red;
+        KeyT nxt[RR];
+        int np0 = 0, np1 = 0;
+        auto fetch = [&](int g) {
+            np0 = np1 = 0;
+            if (g < G) { np0 = pos_ptr[g]; np1 = pos_ptr[g + 1]; }
 #pragma unroll
             for (int r = 0; r < RR; ++r) {
-                const int i = p0[j] + r * 64 + lane;
-                kk[j][r] = i < p1[j] ? ka[i] : (KeyT)0;
+                const int i = np0 + r * 64 + lane;
+                nxt[r] = i < np1 ? ka[i] : (KeyT)0;
             }
-        }
+        };
+        fetch(g0);
+        for (int j = 0; j < 64; ++j) { // always 64 pushes so that the transpose-reduce completes
+            KeyT cur[RR];
 #pragma unroll
-        for (int j = 0; j < GB; ++j) {
-            const int g = g0 + j;
-            if (g >= G) break;
+            for (int r = 0; r < RR; ++r) cur[r] = nxt[r];
+            const int p0 = np0, p1 = np1;
+            fetch(g0 + j + 1 < g0 + 64 ? g0 + j + 1 : G);
             double s = 0.0;
 #pragma unroll
-            for (int r = 0; r < RR; ++r) {
-                const int i = p0[j] + r * 64 + lane;
-                if (i < p1[j]) s += is_log1p ? key_to_expm1(kk[j][r], dt) : key_to_double(kk[j][r], dt);
-            }
-            for (int i = p0[j] + RR * 64 + lane; i < p1[j]; i += 64) s += is_log1p ? key_to_expm1(ka[i], dt) : key_to_double(ka[i], dt);
-            s = wave_sum(s);
-            if (lane == 0) out[g] = s;
+            for (int r = 0; r < RR; ++r)
+                if (p0 + r * 64 + lane < p1) s += val(cur[r]);
+            for (int i = p0 + RR * 64 + lane; i < p1; i += 64) s += val(ka[i]);
+            red.push(s, j, lane);
         }
+        if (g0 + lane < G) out[g0 + lane] = red.result;
     }
 }
 template <typename KeyT>
