@@ -118,7 +118,11 @@ def make_matrix(torch, n_cells, n_genes, sparsity, seed, device, continuous=Fals
     """Poisson(gene mean ~ U(0.1, 15)) float32 with `sparsity` of the entries zeroed, generated on device."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    X = torch.empty((n_cells, n_genes), dtype=torch.float32, device=device)
+    # the row pitch is padded to a multiple of 128 bytes (the C-ABI takes any leading dimension): the fused kernels read
+    # 256-byte row segments, which then cover two 128-byte lines instead of straddling three (C5 shard, 3750 genes: a pitch
+    # of 15 000 bytes would misalign every row; C2's 32 000 bytes are aligned as they are)
+    ld = (n_genes + 31) // 32 * 32
+    X = torch.empty((n_cells, ld), dtype=torch.float32, device=device)[:, :n_genes]
     means = torch.empty(n_genes, device=device).uniform_(0.1, mean_max, generator=gen)
     step = 256
     for j in range(0, n_genes, step):
@@ -478,7 +482,7 @@ def main():
                     Xh = ctor((csx[0].cpu().numpy(), csx[1].cpu().numpy(), csx[2].cpu().numpy()), shape=(N, M))
                     run_host = lambda: eng.run_sparse(sparse_fmt, Xh.data, Xh.indices, Xh.indptr, (N, M), 0, M)
                 else:
-                    Xh = X.cpu().numpy()
+                    Xh = X.contiguous().cpu().numpy()
                     run_host = lambda: eng.run_dense(Xh, 0, M)
                 run_host()  # scratch for the staged route
                 t1 = time.perf_counter()
