@@ -657,7 +657,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     void *v;
     int rc;
     const size_t nb64 = ((size_t)nb + 63) & ~(size_t)63; // the cumulative tables are stored per 64-gene tile
-    size_t bytes = nb64 * (RT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * 4 + (ovr ? (size_t)nb * RT * 4 : 0) + 64;
+    size_t bytes = nb64 * (RT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * 4 + (size_t)nb * RT * 4 + 64;
     if ((rc = get_scratch(c, "fused_tables", bytes, &v))) return rc;
     FusedParams P;
     P.X = X; P.ld = ld; P.col0 = b0; P.ncols = nb; P.perm = c->d_perm; P.pos_ptr = c->d_posptr; P.counts = c->d_counts;
@@ -666,7 +666,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.ref_sum = P.ref_TA + nb;
     P.ref_cum = (u32 *)(P.ref_sum + nb);
     P.gene_flags = P.ref_cum + nb64 * (RT + 1);
-    P.hist_all = ovr ? P.gene_flags + nb : nullptr;
+    P.hist_all = P.gene_flags + nb; // OVR: the column histograms; OVO: the reference group's
     P.group_hist = nullptr;
     P.wide_tiles = nullptr;
     P.hist_off = nullptr;
@@ -695,10 +695,21 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     const size_t lds8 = fused_main_lds_bytes<RT, false, 8>(), lds16 = fused_main_lds_bytes<RT, false, 16>(), lds_ovr = fused_main_lds_bytes<RT, true, 16>();
     (void)lds8; (void)lds16; (void)lds_ovr;
     if (!ovr) {
-        {
+        if (tiles >= 100) { // one 1024-thread workgroup per tile builds the tables (C2: 125 tiles, 0.074 ms)
             ProfScope ps(c, KID_FUSED_REF);
             auto kern = k_fused_ref<InT, RT>;
             hipLaunchKernelGGL(kern, dim3(tiles), dim3(FUSED_REF_NT), fused_ref_lds_bytes(RT), c->stream, P);
+            HIPCHK(c, hipGetLastError());
+        } else { // few tiles (a C5 shard: 59): the reference rows split over (tiles, row chunks), then one thread per gene for
+            // the tables -- 0.20 -> 0.11 ms there, 0.074 -> 0.083 ms at C2, hence the switch
+            ProfScope ps(c, KID_FUSED_REF);
+            HIPCHK(c, hipMemsetAsync(P.hist_all, 0, (size_t)nb * RT * 4, c->stream));
+            const int64_t n_ref = c->h_counts[c->ref];
+            const int want_chunks = std::max(1, 768 / std::max(tiles, 1)); // enough workgroups for 256 CUs, few enough flushes
+            P.rows_per_wg = (int)std::max<int64_t>(FUSED_REF_ROWS, (n_ref + want_chunks - 1) / want_chunks);
+            const int chunks = (int)std::max<int64_t>(1, (n_ref + P.rows_per_wg - 1) / P.rows_per_wg);
+            hipLaunchKernelGGL((k_fused_ref_hist<InT, RT>), dim3(tiles, chunks), dim3(FUSED_NT), 0, c->stream, P);
+            hipLaunchKernelGGL((k_fused_tables_all<RT>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, P);
             HIPCHK(c, hipGetLastError());
         }
         {

@@ -302,6 +302,51 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
     for (int i = tid; i < 64 * STR; i += FUSED_REF_NT) dst[i] = h[(i & 63) * STR + (i >> 6)];
 }
 
+// ---- reference tables in two steps (the form the 64-value pass uses): k_fused_ref is one workgroup per tile -- 125 workgroups
+// at C2, 59 at a C5 shard, on 256 CUs.  Here the reference rows are split over grid (tiles, row chunks); every workgroup adds
+// its rows into an LDS histogram and flushes the non-empty bins with global integer atomics into hist_all;
+// k_fused_tables_all then forms the cumulative tables, T_A, the reference sums and the reference group's row.
+#define FUSED_REF_ROWS 1024 // reference rows per workgroup at least (the host aims at ~768 workgroups: FusedParams.rows_per_wg)
+template <typename InT, int RT>
+__global__ __launch_bounds__(FUSED_NT) void k_fused_ref_hist(FusedParams P) {
+    constexpr int NW = FUSED_NT / 64, STR = RT + 1, UR = 16;
+    __shared__ u32 h[64 * STR];
+    __shared__ int s_bad[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
+    const bool act = gene < P.ncols;
+    for (int i = tid; i < 64 * STR; i += FUSED_NT) h[i] = 0;
+    if (tid < 64) s_bad[tid] = 0;
+    __syncthreads();
+    const int pr0 = P.pos_ptr[P.ref], pr1 = P.pos_ptr[P.ref + 1];
+    const int p0 = pr0 + (int)blockIdx.y * P.rows_per_wg, p1 = min(p0 + P.rows_per_wg, pr1);
+    const InT *Xg = (const InT *)P.X + P.col0 + gene0;
+    const int lane_c = act ? lane : 0;
+    u32 *hl = h + lane * STR;
+    bool bad = false;
+    for (int p = p0 + wave * UR; p < p1; p += NW * UR) {
+        InT v[UR];
+        // rows past p1 are other cells' (or the padding's): valid memory, masked below
+        gather_rows<InT, UR, false>((const char *)Xg, (u32)P.ld * (u32)sizeof(InT), (const_int_p)P.perm, p, p1, (u32)lane_c * (u32)sizeof(InT), v);
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const bool valid = p + u < p1;
+            bool exact;
+            const u32 c = clamp_count<InT, RT>(v[u], exact);
+            bad |= valid && !exact;
+            atomicAdd(&hl[c], valid ? 1u : 0u);
+        }
+    }
+    if (bad) s_bad[lane] = 1;
+    __syncthreads();
+    for (int i = tid; i < 64 * RT; i += FUSED_NT) {
+        const int l = i / RT, c = i - l * RT;
+        const u32 cnt = h[l * STR + c];
+        if (cnt && gene0 + l < P.ncols) atomicAdd(&P.hist_all[(size_t)(gene0 + l) * RT + c], cnt);
+    }
+    if (tid < 64 && act && s_bad[tid]) P.gene_flags[gene] = 1u;
+}
+
 // ---- OVR tables.  For one-versus-rest every cell is ranked against the whole column, so the table is the
 // histogram of ALL cells: rank of value c = cum[c] + (cnt[c]+1)/2, and the tie term sum_v (t^3 - t) is a
 // property of the column alone (ranking.py:31-47) -- no per-group multiplicities are needed.
@@ -363,6 +408,12 @@ template <int RT> __global__ void k_fused_tables_all(FusedParams P) {
     }
     P.ref_TA[gene] = ta;
     P.ref_sum[gene] = sum;
+    if (P.ref >= 0) { // OVO (tables of the reference group, k_fused_ref_hist): the reference group's own row
+        const size_t o = (size_t)P.ref * P.out_ld + gene;
+        P.out_p[o] = 1.0;                                                            // sparse_ovo.py:140-143
+        P.out_u[o] = -1.0;
+        P.out_fc[o] = (sum == 0) ? __longlong_as_double(0x7FF0000000000000ll) : 1.0; // math.py:190-192 with mu_tgt == mu_ref
+    }
 }
 
 // ---- main pass: grid (tiles, group chunks); 4 wavefronts per workgroup, one group at a time per wavefront ----
