@@ -200,5 +200,43 @@ def main():
     print("wrote primitives", len(prim))
 
 
+def make_stored_zeros():
+    """Explicitly stored zeros (and negatives) in sparse input: the reference's SPARSE kernels treat every stored entry as a
+    value above the column's implicit zeros (illico/ovo/sparse_ovo.py:74, ovr/sparse_ovr.py:77), its DENSE kernels rank the
+    same numbers as the numbers they are.  Both outputs of the reference are recorded for the same matrix -- the sparse one
+    pins that behaviour, the dense one is what this repository returns for sparse input too."""
+    asymptotic_wilcoxon, anndata = import_reference()
+    rng = np.random.RandomState(11)
+    n_cells, n_genes, n_groups = 400, 12, 5
+    X = (rng.poisson(2.0, size=(n_cells, n_genes)) * (rng.rand(n_cells, n_genes) < 0.4)).astype(np.float32)
+    labels = make_labels(rng, n_cells, n_groups, 60)
+    out = {"X": X, "labels": labels, "reference": np.array("non-targeting")}
+    var = pd.DataFrame(index=[f"gene_{i}" for i in range(n_genes)])
+    obs = pd.DataFrame({"pert": labels})
+    M = sparse.csc_matrix(X)
+    stored_zero = np.zeros(M.nnz, dtype=bool)
+    stored_zero[::7] = True                      # every 7th stored entry becomes an explicit zero
+    M.data[stored_zero] = 0.0
+    Xz = M.toarray()                             # the same numbers, dense
+    out["Xz"] = Xz
+    out["csc_data"], out["csc_indices"], out["csc_indptr"] = M.data.copy(), M.indices.copy(), M.indptr.copy()
+    for test in ("ovo", "ovr"):
+        for fmt, A in (("dense", Xz), ("csc", M.copy()), ("csr", sparse.csr_matrix((M.data, M.indices, M.indptr), shape=M.shape[::-1]).T.tocsr()
+                                                          if False else None)):
+            if A is None:
+                continue
+            adata = anndata.AnnData(X=A, obs=obs.copy(), var=var.copy())
+            df = asymptotic_wilcoxon(adata, is_log1p=False, group_keys="pert", reference="non-targeting" if test == "ovo" else None,
+                                     n_threads=1, batch_size=16, precompile=False)
+            G = df.index.get_level_values(0).nunique()
+            out[f"{fmt}|{test}"] = df.values.reshape(G, n_genes, 3).astype(np.float64)
+    np.savez_compressed(HERE / "stored_zeros.npz", **out)
+    print("wrote stored_zeros", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if "--stored-zeros" in sys.argv:
+        make_stored_zeros()
+    else:
+        main()
+        make_stored_zeros()

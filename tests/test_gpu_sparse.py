@@ -425,3 +425,28 @@ def test_csc_ovr_single_kernel_route(engine, fmt, dtype, idx, sorted_form):
     assert_planes_match(got, want, what=f"csc ovr single kernel {fmt} {dtype.__name__} sorted_form={sorted_form}")
     want_w = oracle.run(Xd, g, col_lb=2, col_ub=13, alternative="greater", use_continuity=False)
     assert_planes_match(got_w, want_w, what=f"csc ovr single kernel window {fmt} {dtype.__name__}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+def test_explicitly_stored_zeros_are_ranked_as_zeros(engine, test, fmt):
+    """A deliberate difference from the reference, pinned on its own outputs (tests/golden/stored_zeros.npz): for sparse input
+    with explicitly stored zeros the engine returns what the reference's DENSE kernels return for the same numbers; the
+    reference's sparse kernels rank a stored zero above the implicit zeros and give different statistics throughout."""
+    z = load_golden("stored_zeros")
+    labels, ref = z["labels"], str(z["reference"])
+    from illico_amd.utils.groups import encode_and_count_groups
+    _, g = encode_and_count_groups(labels, ref if test == "ovo" else None)
+    M = sparse.csc_matrix((z["csc_data"], z["csc_indices"], z["csc_indptr"]), shape=z["X"].shape)
+    if fmt == "csr":
+        Mr = sparse.csr_matrix(z["Xz"])          # CSR with the same explicit zeros: rebuild from the CSC entries
+        coo = M.tocoo(copy=True)
+        Mr = sparse.csr_matrix((coo.data, (coo.row, coo.col)), shape=M.shape)
+        M = Mr
+    assert (M.data == 0).sum() > 50
+    got = _run(engine, M, g)
+    dense, sparse_ref = z[f"dense|{test}"], z[f"csc|{test}"]
+    assert_planes_match(got, (dense[:, :, 0], dense[:, :, 1], dense[:, :, 2]), ref_row=g.encoded_ref_group if test == "ovo" else None,
+                        what=f"stored zeros {fmt} {test}")
+    rows = np.arange(dense.shape[0]) != (g.encoded_ref_group if test == "ovo" else -1)
+    assert (got[1][rows] != sparse_ref[rows][:, :, 1]).all()

@@ -111,3 +111,30 @@ def test_oracle_errors():
         oracle.run(X, g, alternative="bigger")
     assert oracle.check_indices_sorted_per_parcel([0, 2, 1, 3], [0, 2, 4])
     assert not oracle.check_indices_sorted_per_parcel([2, 0, 1, 3], [0, 2, 4])
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_reference_behaviour_on_explicitly_stored_zeros_is_pinned(test):
+    """The reference's sparse kernels take every STORED entry for a value above the column's implicit zeros (sparse_ovo.py:74,
+    sparse_ovr.py:77); its dense kernels rank the same numbers as numbers.  tests/golden/stored_zeros.npz holds both outputs of
+    the reference for one matrix with explicit zeros: the oracle reproduces each with the matching input format, bit for bit --
+    and they differ in every statistic (the HIP engine returns the dense numbers for sparse input too: DESIGN.md section 1,
+    tests/test_gpu_sparse.py)."""
+    from scipy import sparse
+    z = load_golden("stored_zeros")
+    labels, ref = z["labels"], str(z["reference"])
+    _, g = oracle.encode_and_count_groups(labels, ref if test == "ovo" else None)
+    M = sparse.csc_matrix((z["csc_data"], z["csc_indices"], z["csc_indptr"]), shape=z["X"].shape)
+    assert (M.data == 0).sum() > 50
+    got_sparse = oracle.run(M, g)
+    got_dense = oracle.run(z["Xz"], g)
+    for got, key in ((got_sparse, f"csc|{test}"), (got_dense, f"dense|{test}")):
+        gold = z[key]
+        mask = np.ones(gold.shape[0], dtype=bool)
+        if test == "ovo" and key.startswith("dense"):
+            mask[g.encoded_ref_group] = False   # the reference leaves this row uninitialised in its dense path
+        np.testing.assert_array_equal(got[1][mask], gold[mask][:, :, 1], err_msg=key)
+        np.testing.assert_array_equal(got[0][mask], gold[mask][:, :, 0], err_msg=key)
+        np.testing.assert_array_equal(got[2], gold[:, :, 2], err_msg=key)
+    rows = np.arange(got_dense[1].shape[0]) != (g.encoded_ref_group if test == "ovo" else -1)
+    assert (got_sparse[1][rows] != got_dense[1][rows]).all()
