@@ -14,8 +14,18 @@ HEADERS = ["common.h", "kernels_ovo.h", "kernels_ovo_counts.h", "kernels_ovo_fus
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"]
 
 
+STAMP = HERE / "libillico_hip.stamp"  # the flags the library on disk was built with (a development build must not pass for a full one)
+
+
+def _flags() -> list[str]:
+    flags = list(FLAGS)
+    if os.environ.get("ILLICO_DEV_F32_ONLY") == "1":  # development: float32 / int32-index kernels only, ~4x faster to compile
+        flags.append("-DILLICO_DEV_F32_ONLY")
+    return flags
+
+
 def needs_build() -> bool:
-    if not SO.exists():
+    if not SO.exists() or not STAMP.exists() or STAMP.read_text() != " ".join(_flags()):
         return True
     t = SO.stat().st_mtime
     return any((HERE / f).stat().st_mtime > t for f in SOURCES + HEADERS)
@@ -25,15 +35,14 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = list(FLAGS)
-    if os.environ.get("ILLICO_DEV_F32_ONLY") == "1":  # development: float32 / int32-index kernels only, ~4x faster to compile
-        flags.append("-DILLICO_DEV_F32_ONLY")
+    flags = _flags()
     cmd = [hipcc, *flags, "-o", str(SO), *[str(HERE / s) for s in SOURCES]]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+    STAMP.write_text(" ".join(flags))
     return SO
 
 

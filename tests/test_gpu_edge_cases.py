@@ -140,3 +140,19 @@ def test_every_group_size_through_the_chunk_cascade(engine, ref):
     X[:, 3] = 0                      # an all-zero gene
     X[:, 9] = rng.randint(0, 64, size=labels.size)   # the whole table range
     _check(engine, X, labels, ref, "chunk cascade")
+
+
+def test_more_cells_per_test_than_the_64bit_products_hold_is_refused(engine):
+    """n (n-1)(n+1) and the t^3 tie terms are 64-bit integer products (utils/math.py:95): beyond 2^21 - 1 cells in one test the
+    reference's int64 wraps silently; illico_set_groups refuses instead (OVR: every cell is in every test; OVO: n_ref + n_tgt)."""
+    n = (1 << 21) + 5
+    labels = np.array(["a", "b", "c"])[np.arange(n) % 3]
+    _, g_ovr = oracle.encode_and_count_groups(labels, None)
+    with pytest.raises(NotImplementedError, match="overflow 64-bit"):
+        engine.set_groups(g_ovr)
+    _, g_ovo = oracle.encode_and_count_groups(labels, "a")     # 0.7M + 0.7M cells per test: fine
+    engine.set_groups(g_ovo)
+    big = np.where(np.arange(n) < n - 10, "a", "b")             # reference of 2^21 - 5 cells + a group of 10: 2^21 + 5 per test
+    _, g_big = oracle.encode_and_count_groups(big, "a")
+    with pytest.raises(NotImplementedError, match="overflow 64-bit"):
+        engine.set_groups(g_big)
