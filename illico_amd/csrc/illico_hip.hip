@@ -669,6 +669,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.hist_all = P.gene_flags + nb; // OVR: the column histograms; OVO: the reference group's
     P.group_hist = nullptr;
     P.wide_tiles = nullptr;
+    P.wide_bad = nullptr;
     P.hist_off = nullptr;
     P.n_cells = c->n_cells;
     P.rows_per_wg = (int)std::max<int64_t>(1024, (c->n_cells + 31) / 32);
@@ -780,7 +781,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             {
                 ProfScope ps(c, KID_FUSED_REF);
                 const int chunks = (int)((c->n_cells + P.rows_per_wg - 1) / P.rows_per_wg);
-                hipLaunchKernelGGL((k_fused_hist_all<InT, RT>), dim3(tiles, chunks), dim3(FUSED_NT), 0, c->stream, P);
+                hipLaunchKernelGGL((k_fused_hist_all<InT, RT>), dim3(tiles, chunks), dim3(FUSED_NT), fused_ref_lds_bytes(RT), c->stream, P);
                 hipLaunchKernelGGL((k_fused_tables_all<RT>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, P);
                 HIPCHK(c, hipGetLastError());
             }
@@ -788,6 +789,40 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             hipLaunchKernelGGL((k_ovo_fused<InT, RT, true, 16>), main_grid, dim3(FUSED_NT), lds_ovr, c->stream, P);
             HIPCHK(c, hipGetLastError());
         }
+    }
+    // OVR second stage, 256-value tables, over the tiles that hold genes the 64-value pass flagged (counts of 64 .. 255): the
+    // two-pass form -- column histograms of those tiles (k_fused_hist_all<WIDE>: every row, so a candidate is known to fit),
+    // tables, then k_ovo_fused<OVR, WIDE> with resident workgroups over the listed tiles.  No per-group state: 67 KB of LDS.
+    // C4 shape with gene means up to 40: 97 ms (those genes through the general sort route) -> see DESIGN.md.
+    if (ovr && !c->no_fused_wide) {
+        constexpr int WRT = FUSED_WIDE_RT;
+        const size_t wbytes = nb64 * (WRT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * WRT * 4 + (size_t)(nb + tiles) * 4 + (size_t)(tiles + 1) * 4 + 64;
+        if ((rc = get_scratch(c, "fused_tables_wide", wbytes, &v))) return rc;
+        FusedParams Q = P;
+        Q.ref_TA = (u64 *)v;
+        Q.ref_sum = Q.ref_TA + nb;
+        Q.ref_cum = (u32 *)(Q.ref_sum + nb);
+        Q.hist_all = Q.ref_cum + nb64 * (WRT + 1);
+        Q.wide_bad = Q.hist_all + (size_t)nb * WRT;          // [nb] + [tiles] tile marks
+        Q.wide_tiles = Q.wide_bad + nb + tiles;
+        HIPCHK(c, hipMemsetAsync(Q.hist_all, 0, ((size_t)nb * WRT + nb + tiles + 1) * 4, c->stream));
+        {
+            ProfScope ps(c, KID_FUSED_REF);
+            const int chunks = (int)((c->n_cells + P.rows_per_wg - 1) / P.rows_per_wg);
+            auto kh = k_fused_hist_all<InT, WRT, true>;
+            HIPCHK(c, hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_ref_lds_bytes(WRT)));
+            hipLaunchKernelGGL(kh, dim3(tiles, chunks), dim3(FUSED_NT), fused_ref_lds_bytes(WRT), c->stream, Q);
+            hipLaunchKernelGGL((k_fused_tables_all<WRT, true>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, Q);
+            HIPCHK(c, hipGetLastError());
+        }
+        ProfScope ps(c, KID_OVO_FUSED_WIDE);
+        auto kern = k_ovo_fused<InT, WRT, true, 16, FUSED_U, true>;
+        const size_t lds = fused_main_lds_bytes<WRT, true, 16>();
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int n_cu = 256;
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+        hipLaunchKernelGGL(kern, dim3((unsigned)std::max(2 * n_cu, 1)), dim3(FUSED_NT), lds, c->stream, Q); // resident workgroups over the listed tiles
+        HIPCHK(c, hipGetLastError());
     }
     // route flags back through a pinned staging buffer (a pageable destination makes the copy a blocking, staged one)
     if (defer_slot >= 0) { // deferred: the copy is enqueued, an event marks it, nobody waits here (resolve_pending does)

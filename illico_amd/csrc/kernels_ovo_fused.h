@@ -49,6 +49,7 @@ struct FusedParams {
     int groups_per_wg;
     u32 *group_hist;          // OVR one-pass form: [G][tiles][RT * CB / 32][64] words, per-(group, gene) value histograms
     u32 *wide_tiles;          // WIDE: [0] = number of tiles with candidates, [1 ..] = those tiles (k_fused_ref<WIDE> appends)
+    u32 *wide_bad;            // OVR second stage: [ncols] set when a column shows a value outside the 256-value table too
     const u32 *hist_off;      // OVR one-pass form, mixed cell widths: [G + 1] words per lane before group g (16 for a group of <= 255 cells, else 32)
 };
 
@@ -352,14 +353,26 @@ __global__ __launch_bounds__(FUSED_NT) void k_fused_ref_hist(FusedParams P) {
 // property of the column alone (ranking.py:31-47) -- no per-group multiplicities are needed.
 // Pass A: grid (tiles, row chunks); the workgroup's wavefronts add into one LDS histogram, flushed with global
 // integer atomics (non-empty bins only).
-template <typename InT, int RT>
+// WIDE (OVR second stage, RT = 256): only tiles that hold a gene the 64-value pass flagged (gene_flags == 1); a column that
+// leaves this table too is marked in wide_bad (every row chunk of a column must agree before it becomes a candidate).
+template <typename InT, int RT, bool WIDE = false>
 __global__ __launch_bounds__(FUSED_NT) void k_fused_hist_all(FusedParams P) {
     constexpr int NW = FUSED_NT / 64, STR = RT + 1, UR = 32;
-    __shared__ u32 h[64 * STR];
+    extern __shared__ __align__(16) u32 h[]; // [64 * STR]
     __shared__ int s_bad[64];
+    __shared__ int s_skip;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
     const bool act = gene < P.ncols;
+    if (WIDE) {
+        if (wave == 0) {
+            const bool want = act && P.gene_flags[gene] == 1u;
+            const bool any = __any(want);
+            if (lane == 0) s_skip = any ? 0 : 1;
+        }
+        __syncthreads();
+        if (s_skip) return;
+    }
     for (int i = tid; i < 64 * STR; i += FUSED_NT) h[i] = 0;
     if (tid < 64) s_bad[tid] = 0;
     __syncthreads();
@@ -388,12 +401,20 @@ __global__ __launch_bounds__(FUSED_NT) void k_fused_hist_all(FusedParams P) {
         const u32 cnt = h[l * STR + c];
         if (cnt && gene0 + l < P.ncols) atomicAdd(&P.hist_all[(size_t)(gene0 + l) * RT + c], cnt);
     }
-    if (tid < 64 && act && s_bad[tid]) P.gene_flags[gene] = 1u;
+    if (tid < 64 && act && s_bad[tid]) { if (WIDE) P.wide_bad[gene] = 1u; else P.gene_flags[gene] = 1u; }
 }
-// per gene: histogram -> cumulative table, column tie sum, column total
-template <int RT> __global__ void k_fused_tables_all(FusedParams P) {
+// per gene: histogram -> cumulative table, column tie sum, column total.  WIDE (OVR second stage): only for the genes the first
+// pass flagged and whose every row fits the wider table; they become candidates (gene_flags = 2) and their tile joins the list
+// the wide main pass works through (wide_tiles; tile_mark keeps a tile from being listed twice).
+template <int RT, bool WIDE = false> __global__ void k_fused_tables_all(FusedParams P) {
     const int gene = blockIdx.x * blockDim.x + threadIdx.x;
     if (gene >= P.ncols) return;
+    if (WIDE) {
+        if (P.gene_flags[gene] != 1u || P.wide_bad[gene] != 0u) return;
+        P.gene_flags[gene] = 2u;
+        u32 *tile_mark = P.wide_bad + P.ncols; // [tiles]
+        if (atomicExch(&tile_mark[gene >> 6], 1u) == 0u) P.wide_tiles[1 + atomicAdd(&P.wide_tiles[0], 1u)] = (u32)(gene >> 6);
+    }
     const u32 *h = P.hist_all + (size_t)gene * RT;
     u32 *cum = P.ref_cum + (size_t)(gene >> 6) * (64 * (RT + 1)) + (gene & 63); // [tile][value][lane]
     u32 run = 0;
@@ -426,7 +447,7 @@ template <int RT, bool OVR, int CB> static inline size_t fused_main_lds_bytes() 
     return (size_t)(RT + 1) * 64 * 4 + (size_t)(FUSED_NT / 64) * (OVR ? 1 : RT * CB / 32) * 64 * 4;
 }
 template <typename InT, int RT, bool OVR, int CB, int U = FUSED_U, bool WIDE = false>
-__global__ __launch_bounds__(FUSED_NT, WIDE ? 1 : ((OVR || CB == 8) ? 4 : 3)) void k_ovo_fused(FusedParams P) {
+__global__ __launch_bounds__(FUSED_NT, WIDE ? (OVR ? 2 : 1) : ((OVR || CB == 8) ? 4 : 3)) void k_ovo_fused(FusedParams P) {
     constexpr int NT = FUSED_NT, NW = NT / 64, CSTR = RT + 1, BW = OVR ? 1 : RT * CB / 32;
     // Both tables are laid out [value][lane]: the LDS bank of a lookup is set by the lane alone, whatever the values
     // (32-bit cells: conflict-free; 8- / 16-bit cells: four / two neighbouring lanes share a bank).  With [lane][value]

@@ -338,7 +338,8 @@ def test_backed_memmap_input_streams_chunks(tmp_path, test, monkeypatch):
     np.testing.assert_array_equal(np.load(tmp_path / "x.npy"), X)
 
 
-def test_fused_route_second_pass_takes_counts_up_to_255(engine):
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_fused_route_second_pass_takes_counts_up_to_255(engine, test):
     """Counts of 64 .. 255 (highly expressed genes of a real count matrix) stay on the single-pass fused route: its second,
     256-value pass takes the genes the 64-value pass flags, on the device, without a host round trip.  Poisson(60) genes next
     to Poisson(3) genes; one gene with a count of 300 (beyond the wider table too) and one fractional gene still go to the
@@ -352,7 +353,8 @@ def test_fused_route_second_pass_takes_counts_up_to_255(engine):
     X[:, 34] = np.where(rng.rand(n) < 0.1, 0.5, X[:, 34])
     X[:, 36] = 255.0 * (rng.rand(n) < 0.5)     # the last value of the wider table
     labels = make_labels(rng, n, 40, n_ref=800)
-    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    rr = g.encoded_ref_group if test == "ovo" else None
     want = oracle.run(X, g)
     Xd = torch.from_numpy(X).cuda()
     engine.set_groups(g)
@@ -373,9 +375,9 @@ def test_fused_route_second_pass_takes_counts_up_to_255(engine):
     assert prof["k_transpose_permute"]["launches"] < prof2["k_transpose_permute"]["launches"], (prof, prof2)
     for a, b in zip(got, narrow_only):
         assert a.tobytes() == b.tobytes()
-    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what="counts up to 255")
+    assert_planes_match(got, want, ref_row=rr, what=f"counts up to 255 {test}")
     # the same through CSR byte windows (k_csr_densify writes bytes: values up to 254 fit)
     from scipy import sparse
     M = sparse.csr_matrix(X[:, :120])
     got = engine.run_sparse("csr", M.data, M.indices, M.indptr, M.shape, 0, 120)
-    assert_planes_match(got, tuple(a[:, :120] for a in want), ref_row=g.encoded_ref_group, what="csr byte window, counts up to 254")
+    assert_planes_match(got, tuple(a[:, :120] for a in want), ref_row=rr, what=f"csr byte window, counts up to 254 {test}")
