@@ -83,6 +83,7 @@ def parse(argv=None):
     ap.add_argument("--no-scopes", action="store_true", help="skip timing scopes (ii) and (iii)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-events", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-defer", action="store_true", help="dense passes wait for their route flags inside the call (no ILLICO_FLAG_DEFER)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU baseline run")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)       # test hook: gloo
@@ -257,7 +258,7 @@ def main():
         if sparse_fmt:
             eng.run_sparse(sparse_fmt, csx[0], csx[1], csx[2], (N, M), lb, ub, out=out)
         else:
-            eng.run_dense(X, lb, ub, out=out, defer=not in_step)
+            eng.run_dense(X, lb, ub, out=out, defer=not in_step and not args.no_defer)
 
     def step():
         nonlocal stages
