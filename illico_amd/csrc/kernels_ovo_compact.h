@@ -1,0 +1,533 @@
+// Dense one-versus-reference (OVO) on continuous values: group-wise compaction + look-ups in a bucketed reference.
+//
+// The two-pass route of kernels_ovo.h transposes the whole window (zeros included) and lets one wavefront prove every
+// group's keys distinct, compact them and look them up.  Expression matrices are mostly zeros, and a group's zeros need
+// no look-up at all: they are one run whose rank follows from three counts.  So here
+//
+//   k_group_compact     one workgroup per (group, 64-gene block): reads the group's rows of X once (256-byte row segments,
+//                       64 rows at a time through LDS), converts to keys and writes, per gene, the group's NON-ZERO keys
+//                       packed at the start of the group's slot of the gene-major key buffer; beside them the number of
+//                       non-zeros (16 bit) and the group's value sum (float64, fixed order: deterministic).  HBM-bound:
+//                       X once in, the non-zeros once out.
+//   k_ovo_rank_compact  one workgroup per gene: the reference's non-zero keys are dealt into value buckets in LDS
+//                       (one 32-bit table word per bucket: keys << 16 | first key), then one wavefront per group looks every
+//                       non-zero key up: S2 += 2 #A<q + #A==q.  Ties inside a group are found, not assumed away: a
+//                       one-word-per-key Bloom table flags keys that MAY repeat an earlier key of the group; each flagged
+//                       key is then compared with all keys of the group (ballots), which yields its exact multiplicity.
+//                       No sort, no compaction, no second Bloom table; integer arithmetic only => bit-exact statistics.
+//
+// Replaces the same reference code as kernels_ovo.h: dense_ovo_mwu_kernel_over_contiguous_col_chunk (illico/ovo/dense_ovo.py:
+// 65-137), i.e. the per-column sorts (utils/ranking.py:161-172) and rank_sum_and_ties_from_sorted (utils/ranking.py:52-158),
+// and the group sums of utils/math.py:27-39.  Formulas as in kernels_ovo.h: with t = #A==q + (earlier equal keys of the group),
+//   S2 = sum_b [2 #A<b + #A==b],   tie_sum = T_A(non-zeros) + 3 sum_b t (t + 1) + (z_A + z_B)^3 - (z_A + z_B).
+#pragma once
+#include "common.h"
+#include "kernels_ovo.h" // count_ok
+
+#define GCMP_NT 256
+#define OCR_NT 1024
+#define OCR_KMAX 4          // 64-key rounds per group: groups of up to 256 non-zero keys
+#define OCR_BLOOM_WORDS 256 // per wavefront: 8192 bits
+
+// Workgroup -> group, so that the workgroups one XCD receives (every 8th) cover runs of 32 consecutive groups: the
+// per-(gene, group) words written at the end (2-byte counts, 8-byte sums; consecutive groups are adjacent) then fill
+// whole 64-byte / 256-byte pieces inside ONE L2 instead of an eighth of them in each.
+__device__ __forceinline__ int gcmp_slot_group(int bx) {
+    const int xcd = bx & 7, i = bx >> 3;
+    return (((i >> 5) * 8 + xcd) << 5) + (i & 31);
+}
+static inline int gcmp_slots(int G) { return (G + 255) / 256 * 256; }
+#define GCMP_SEG_ROWS 512 // the reference group is packed in independent segments of this many rows (one workgroup each)
+static inline int gcmp_ref_segments(long long n_ref) { return (int)((n_ref + GCMP_SEG_ROWS - 1) / GCMP_SEG_ROWS); }
+
+struct GroupCompactParams {
+    const void *X;          // row-major [N, ld]
+    long long ld, col0;
+    int ncols;
+    const int *perm;        // cells in group-contiguous order (GroupContainer.indices)
+    const int *pos_ptr;     // [G+1] first position of each group in that order
+    int G, ref, nseg;       // ref: reference group (-1: none); nseg = gcmp_ref_segments(its size); grid.x = pad8(nseg) + gcmp_slots(G)
+    void *Xt;               // keys, gene-major, xt_stride keys per gene; group g's non-zeros at pos_ptr[g] ...
+    long long xt_stride;
+    u16 *nnz;               // [ncols][G] non-zero keys per (gene, group); the reference's entry is not written
+    double *out_sum;        // [ncols][G] value sums (expm1'd if is_log1p); the reference's entry is not written
+    u16 *seg_nnz;           // [ncols][nseg] non-zero keys per segment of the reference (segment s at pos_ptr[ref] + s * GCMP_SEG_ROWS)
+    double *seg_sum;        // [ncols][nseg]
+    int is_log1p;
+    u32 *gene_flags;        // optional: set to 1 for genes holding a value that is not a small count (k_ovo_counts's input)
+    int count_limit;
+};
+
+template <typename InT> __device__ __forceinline__ double gcmp_value(InT v, int is_log1p);
+template <> __device__ __forceinline__ double gcmp_value<float>(float v, int is_log1p) { return is_log1p ? (double)expm1f(v) : (double)v; }
+template <> __device__ __forceinline__ double gcmp_value<double>(double v, int is_log1p) { return is_log1p ? expm1(v) : v; }
+template <> __device__ __forceinline__ double gcmp_value<int32_t>(int32_t v, int is_log1p) { return is_log1p ? expm1((double)v) : (double)v; }
+template <> __device__ __forceinline__ double gcmp_value<int64_t>(int64_t v, int is_log1p) { return is_log1p ? expm1((double)v) : (double)v; }
+
+// One workgroup: the rows [row0, row0 + n) of the group-contiguous order (one group, or one segment of the reference) x 64 genes.
+// Per 64-row chunk: thread (q, r0) loads VEC genes of rows r0, r0 + RPI, ...; keys go through a gene-major LDS tile; wavefront w
+// then packs genes 16 w ... 16 w + 15: lanes = rows, ballot -> consecutive output slots.  The next chunk's rows (and the row
+// indices of the chunk after it) are in flight meanwhile.  Value sums: per-thread partials over the thread's own loads,
+// combined through LDS in a fixed order at the end.
+template <typename InT, typename KeyT, bool VECLOAD>
+__global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P) {
+    constexpr int VEC = 16 / (int)sizeof(InT);
+    constexpr int LPR = 64 / VEC;      // lanes per 64-gene row segment
+    constexpr int RPI = GCMP_NT / LPR; // rows per load iteration
+    constexpr int NLD = 64 / RPI;      // loads per thread per 64-row chunk
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
+    typedef InT __attribute__((ext_vector_type(VEC))) InV;
+    __shared__ KeyT tile[64][65];
+    static_assert(sizeof(tile) >= sizeof(double) * RPI * 64, "the tile doubles as the sum scratch");
+
+    const int nseg_pad = (P.nseg + 7) & ~7;
+    int g, row0, n, seg = -1;
+    if ((int)blockIdx.x < nseg_pad) {
+        seg = blockIdx.x;
+        if (seg >= P.nseg) return;
+        g = P.ref;
+        row0 = P.pos_ptr[g] + seg * GCMP_SEG_ROWS;
+        n = min(GCMP_SEG_ROWS, P.pos_ptr[g + 1] - row0);
+    } else {
+        g = gcmp_slot_group((int)blockIdx.x - nseg_pad);
+        if (g >= P.G || g == P.ref) return;
+        row0 = P.pos_ptr[g];
+        n = P.pos_ptr[g + 1] - row0;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.y * 64;
+    const int q = tid % LPR, r0 = tid / LPR;
+    const InT *X = (const InT *)P.X;
+    KeyT *Xt = (KeyT *)P.Xt;
+    const int cq = c0 + q * VEC;
+    const bool colv = cq + VEC <= P.ncols;
+    const int nchunks = (n + 63) >> 6;
+
+    int rows[NLD]; // row indices of the chunk after the one whose loads are in flight
+    InV nxt[NLD];
+    auto load_rows = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = c * 64 + r0 + i * RPI;
+            rows[i] = p < n ? P.perm[row0 + p] : -1;
+        }
+    };
+    auto load_chunk = [&]() { // from rows[]
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            InV v;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = (InT)0;
+            if (rows[i] >= 0) {
+                const InT *src = X + (long long)rows[i] * P.ld + P.col0 + cq;
+                if (VECLOAD && colv) v = *reinterpret_cast<const InV *>(src);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        if (cq + e < P.ncols) v[e] = src[e];
+                }
+            }
+            nxt[i] = v;
+        }
+    };
+
+    int cntv = 0;     // lane i < 16: non-zero keys written so far for gene 16 * wave + i
+    double sum[VEC];  // per-thread partial value sums of its VEC genes
+    bool viol[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sum[e] = 0.0; viol[e] = false; }
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (nchunks) { load_rows(0); load_chunk(); }
+    if (nchunks > 1) load_rows(1);
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int r = r0 + i * RPI;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const InT v = nxt[i][e];
+                tile[q * VEC + e][r] = key_of(v);
+                sum[e] += gcmp_value<InT>(v, P.is_log1p); // rows past the end were loaded as zeros
+                if (P.gene_flags) viol[e] |= !count_ok(v, P.count_limit);
+            }
+        }
+        if (c + 1 < nchunks) load_chunk();   // in flight while this chunk is packed
+        if (c + 2 < nchunks) load_rows(c + 2);
+        __syncthreads();
+        const int rem = n - c * 64; // rows of this chunk
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int gi = wave * 16 + i;
+            const KeyT k = tile[gi][lane];
+            const bool nz = lane < rem && k != ZEROK;
+            const u64 m = __ballot(nz);
+            const int ci = __builtin_amdgcn_readlane(cntv, i);
+            if (nz && c0 + gi < P.ncols) Xt[(long long)(c0 + gi) * P.xt_stride + row0 + ci + (int)__popcll(m & lt_mask)] = k;
+            cntv += lane == i ? (int)__popcll(m) : 0;
+        }
+        __syncthreads();
+    }
+    if (P.gene_flags) { // at most one (checked) store per gene per thread; a stale-L1 miss only repeats the store
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (viol[e] && cq + e < P.ncols && P.gene_flags[cq + e] == 0) P.gene_flags[cq + e] = 1u;
+    }
+    // value sums: [RPI row slots][64 genes] partials -> 64 threads add them in row-slot order
+    double *part = (double *)&tile[0][0];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) part[r0 * 64 + q * VEC + e] = sum[e];
+    const int my_cnt = cntv;
+    __syncthreads();
+    if (tid < 64 && c0 + tid < P.ncols) {
+        double tot = 0.0;
+#pragma unroll 4
+        for (int r = 0; r < RPI; ++r) tot += part[r * 64 + tid];
+        if (seg >= 0) P.seg_sum[(size_t)(c0 + tid) * P.nseg + seg] = tot;
+        else P.out_sum[(size_t)(c0 + tid) * P.G + g] = tot;
+    }
+    const int gene = c0 + wave * 16 + lane;
+    if (lane < 16 && gene < P.ncols) {
+        if (seg >= 0) P.seg_nnz[(size_t)gene * P.nseg + seg] = (u16)my_cnt;
+        else P.nnz[(size_t)gene * P.G + g] = (u16)my_cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-gene ranking over the packed layout
+// ---------------------------------------------------------------------------------------------
+struct OvoCompactParams {
+    const void *Xs;          // packed keys (k_group_compact)
+    long long gene_stride;
+    const int *pos_ptr;      // [G+1]
+    const int *counts;       // [G]
+    const u16 *nnz;          // [n_genes][G]
+    const u16 *seg_nnz;      // [n_genes][nseg] the reference's segments (k_group_compact)
+    const double *seg_sum;   // [n_genes][nseg]
+    double *out_sum;         // [n_genes][G]: the reference's entry is written here (sum of its segments, in order)
+    int G, ref, n_genes, nseg;
+    int ref_cap;             // LDS key slots for the reference's non-zeros (>= the reference group's size)
+    int nbk_lg;              // log2(value buckets)
+    long long *out_2u;       // [n_genes][G]
+    u64 *out_tie;            // [n_genes][G]
+    const u32 *gene_flags;   // optional: genes with flag 0 are skipped (count-valued: k_ovo_counts has them)
+};
+
+__host__ __device__ static inline size_t ocr_lds_bytes(int ref_cap, int nbk_lg, size_t key_size) {
+    size_t b = (((size_t)ref_cap + 4) * key_size + 15) & ~(size_t)15;
+    b += (size_t)4 << nbk_lg;
+    b += (size_t)(OCR_NT / 64) * OCR_BLOOM_WORDS * 4;
+    b += 256; // reduction words
+    return b;
+}
+
+__device__ __forceinline__ u32 ocr_hash(u32 k) { return k ^ (k >> 10); }
+__device__ __forceinline__ u32 ocr_hash(u64 k) { const u32 f = (u32)(k ^ (k >> 32)); return f ^ (f >> 10); }
+
+template <typename KeyT> struct OcrRef {
+    const KeyT *A;
+    const u32 *tab;
+    KeyT kmin;
+    int shift;
+    u32 last; // buckets - 1
+};
+template <typename KeyT> __device__ __forceinline__ u32 ocr_bucket(const OcrRef<KeyT> &R, KeyT q) {
+    const KeyT d = q > R.kmin ? (KeyT)(q - R.kmin) : (KeyT)0;
+    const KeyT b = d >> R.shift;
+    return b < (KeyT)R.last ? (u32)b : R.last;
+}
+// table word of a bucket: keys in it << 16 | index of its first key
+__device__ __forceinline__ u32 ocr_lo(u32 e) { return e & 0xFFFFu; }
+__device__ __forceinline__ u32 ocr_hi(u32 e) { return (e & 0xFFFFu) + (e >> 16); }
+template <typename KeyT> __device__ __forceinline__ u32 ocr_count_eq(const OcrRef<KeyT> &R, KeyT q, u32 lo, u32 hi) {
+    u32 a = 0;
+    for (u32 j = lo; j < hi; ++j) a += R.A[j] == q ? 1u : 0u;
+    return a;
+}
+
+// One group of nB non-zero keys, NR = ceil(nB / 64) rounds of 64 (cur[r] = key r * 64 + lane; lanes past the last key hold
+// ZEROK).  Straight-line per round: Bloom insert (one returning LDS atomic), table word, 4 keys of the bucket, 8 compares.
+// Per-lane partial results: less = sum of #A<q (non-zero reference keys), eqs = sum of #A==q, TT = sum t (t + 1); negs
+// (uniform) = keys below zero.  bloom[] is all-zero on entry and on exit.
+template <typename KeyT, int NR>
+__device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, const OcrRef<KeyT> &R, u32 *bloom, int lane, u64 lt_mask,
+                                          u32 &less_out, u32 &eq_out, u64 &TT_out, u32 &negs_out) {
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
+    const int rem = nB - 64 * (NR - 1);               // keys of the last round, 1..64
+    const u64 vlast = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+    const bool vl = (vlast >> lane) & 1ull;
+    u32 wofs[NR], ent[NR], less = 0;
+    u64 fm[NR], em = 0, mm = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { // Bloom inserts of every round first: a key's flag says "may repeat an EARLIER key"
+        const KeyT q = cur[r];
+        const u32 h = ocr_hash(q);
+        wofs[r] = (h >> 5) & (OCR_BLOOM_WORDS - 1);
+        bool flag = false;
+        if (r < NR - 1 || vl) {
+            const u32 old = atomicOr(&bloom[wofs[r]], 1u << (h & 31));
+            flag = (old >> (h & 31)) & 1u;
+        }
+        fm[r] = __ballot(flag);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const KeyT q = cur[r];
+        const u32 e = R.tab[ocr_bucket(R, q)];
+        ent[r] = e;
+        const u32 lo = ocr_lo(e);
+        const KeyT a0 = R.A[lo], a1 = R.A[lo + 1], a2 = R.A[lo + 2], a3 = R.A[lo + 3]; // past the bucket: later buckets / the pad: > q or == MAXK
+        if (r < NR - 1 || vl) bloom[wofs[r]] = 0u; // wipe (LDS operations of one wavefront execute in order)
+        u32 l = lo + (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u) + (a3 < q ? 1u : 0u);
+        u64 e4 = __ballot(a0 == q) | __ballot(a1 == q) | __ballot(a2 == q) | __ballot(a3 == q);
+        u64 m4 = __ballot(e >= (5u << 16));
+        u64 n4 = __ballot(q < ZEROK);
+        if (r == NR - 1) { l = vl ? l : 0u; e4 &= vlast; m4 &= vlast; n4 &= vlast; }
+        less += l;
+        em |= e4; mm |= m4;
+        negs_out += (u32)__popcll(n4);
+    }
+    u32 a[NR], eqs = 0;
+    u64 TT = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) a[r] = 0u;
+    if (mm | em) { // rare: a bucket of more than 4 keys, or a key that ties with the reference: exact counts for those lanes
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const KeyT q = cur[r];
+            const bool valid = r < NR - 1 || vl;
+            const u32 lo = ocr_lo(ent[r]), hi = ocr_hi(ent[r]);
+            if (valid && hi > lo + 4u) {
+                u32 extra = 0;
+                for (u32 t = lo + 4u; t < hi; ++t) extra += R.A[t] < q ? 1u : 0u;
+                less += extra;
+            }
+            if (valid) {
+                const u32 c = ocr_count_eq(R, q, lo, hi); // bounded by the bucket: the pad's MAXK never counts
+                a[r] = c;
+                eqs += c;
+                TT += (u64)c * ((u64)c + 1ull);
+            }
+        }
+    }
+    u64 anyf = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) anyf |= fm[r];
+    if (anyf) { // keys that may repeat an earlier key of the group: exact multiplicities by comparison
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            while (fm[r]) {
+                const int sl = __ffsll((long long)fm[r]) - 1;
+                KeyT q;
+                if constexpr (sizeof(KeyT) == 8) {
+                    q = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(cur[r] >> 32), sl) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)cur[r], sl);
+                } else q = (KeyT)__builtin_amdgcn_readlane((int)cur[r], sl);
+                u64 m[NR];
+                int c = 0;
+#pragma unroll
+                for (int s = 0; s < NR; ++s) {
+                    m[s] = __ballot(cur[s] == q); // q is a non-zero key: the ZEROK lanes past the end never match
+                    c += (int)__popcll(m[s]);
+                }
+                if (c > 1) {
+                    int before = 0;
+#pragma unroll
+                    for (int s = 0; s < NR; ++s) {
+                        if (cur[s] == q) {
+                            const u64 o = (u64)(before + (int)__popcll(m[s] & lt_mask));
+                            TT += o * (2ull * a[s] + o + 1ull); // (a + o)(a + o + 1) - a (a + 1)
+                        }
+                        before += (int)__popcll(m[s]);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NR; ++s) fm[s] &= ~m[s];
+            }
+        }
+    }
+    less_out = less;
+    eq_out = eqs;
+    TT_out = TT;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NT = OCR_NT, NW = NT / 64, KMAX = OCR_KMAX;
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK, MAXK = KeyInfo<KeyT>::MAXK;
+    const int NBK = 1 << P.nbk_lg;
+    KeyT *A = (KeyT *)smem;
+    size_t off = (((size_t)P.ref_cap + 4) * sizeof(KeyT) + 15) & ~(size_t)15;
+    u32 *tab = (u32 *)(smem + off);
+    off += (size_t)4 << P.nbk_lg;
+    u32 *bloom_all = (u32 *)(smem + off);
+    off += (size_t)NW * OCR_BLOOM_WORDS * 4;
+    u64 *s_red = (u64 *)(smem + off); // [NW]
+    KeyT *s_kr = (KeyT *)(s_red + NW); // [2] min, max
+    u32 *s_cnt = (u32 *)(s_kr + 2);    // [0] negatives  [1] non-zero keys
+    u32 *s_scan = s_cnt + 4;           // [NW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gene = blockIdx.x;
+    if (P.gene_flags && P.gene_flags[gene] == 0) return;
+    const int G = P.G, ref = P.ref;
+    const int n_ref = P.counts[ref];
+    const u16 *nnz = P.nnz + (size_t)gene * G;
+    const KeyT *Xg = (const KeyT *)P.Xs + (long long)gene * P.gene_stride;
+    const KeyT *src = Xg + P.pos_ptr[ref];
+    const u16 *seg_nnz = P.seg_nnz + (size_t)gene * P.nseg;
+    // the reference's non-zero keys lie in nseg packed segments: wavefront w walks segments w, w + NW, ...
+    auto for_ref = [&](auto f) {
+        for (int sg = wave; sg < P.nseg; sg += NW) {
+            const int c = (int)seg_nnz[sg];
+            const KeyT *sp = src + (size_t)sg * GCMP_SEG_ROWS;
+            for (int i = lane; i < c; i += 64) f(sp[i]);
+        }
+    };
+
+    // ---- the reference's non-zero keys -> value buckets ----
+    for (int i = tid; i < NW * OCR_BLOOM_WORDS; i += NT) bloom_all[i] = 0u;
+    for (int b = tid; b < NBK; b += NT) tab[b] = 0u;
+    if (tid == 0) { s_kr[0] = MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; }
+    __syncthreads();
+    {
+        KeyT tmin = MAXK, tmax = (KeyT)0;
+        u32 ng = 0;
+        for_ref([&](KeyT k) {
+            tmin = k < tmin ? k : tmin;
+            tmax = k > tmax ? k : tmax;
+            ng += k < ZEROK ? 1u : 0u;
+        });
+        ng = (u32)wave_sum((int)ng);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const KeyT o1 = __shfl_xor(tmin, d), o2 = __shfl_xor(tmax, d);
+            tmin = o1 < tmin ? o1 : tmin;
+            tmax = o2 > tmax ? o2 : tmax;
+        }
+        if (lane == 0) {
+            atomicMin(&s_kr[0], tmin);
+            atomicMax(&s_kr[1], tmax);
+            if (ng) atomicAdd(&s_cnt[0], ng);
+        }
+        if (tid < P.nseg) atomicAdd(&s_cnt[1], (u32)seg_nnz[tid]); // nseg <= 128 (reference of at most 65535 cells)
+        if (tid == NT - 1) { // the reference's value sum: its segments' sums in order
+            double t = 0.0;
+            for (int sg = 0; sg < P.nseg; ++sg) t += P.seg_sum[(size_t)gene * P.nseg + sg];
+            P.out_sum[(size_t)gene * G + ref] = t;
+        }
+    }
+    __syncthreads();
+    const u32 nA = s_cnt[1];
+    const u32 aZ = (u32)n_ref - nA;
+    OcrRef<KeyT> R;
+    R.A = A; R.tab = tab; R.last = (u32)NBK - 1u;
+    R.kmin = nA ? s_kr[0] : (KeyT)0;
+    {
+        const KeyT range = nA ? (KeyT)(s_kr[1] - s_kr[0]) : (KeyT)0;
+        const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
+        R.shift = bits > P.nbk_lg ? bits - P.nbk_lg : 0;
+    }
+    const u32 nneg = s_cnt[0];
+    for_ref([&](KeyT k) { atomicAdd(&tab[ocr_bucket(R, k)], 1u); });
+    __syncthreads();
+    { // exclusive scan of the bucket counts; word = keys << 16 | end of the bucket.
+      // Each wavefront owns a contiguous slice of the table and walks it 64 consecutive words at a time (no bank conflicts).
+        const int per_wave = NBK / NW, iters = per_wave / 64; // NBK >= NW * 64
+        u32 *slice = tab + wave * per_wave;
+        u32 tot = 0;
+        for (int it = 0; it < iters; ++it) tot += slice[it * 64 + lane];
+        tot = (u32)wave_sum((int)tot);
+        if (lane == 0) s_scan[wave] = tot;
+        __syncthreads();
+        u32 base = 0;
+        for (int w = 0; w < wave; ++w) base += s_scan[w];
+        for (int it = 0; it < iters; ++it) {
+            const u32 cb = slice[it * 64 + lane];
+            const u32 inc = (u32)wave_incl_scan_add((int)cb);
+            slice[it * 64 + lane] = (cb << 16) | (base + inc); // keys << 16 | END: the scatter below counts the low half down to the start
+            base += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+    }
+    __syncthreads();
+    for_ref([&](KeyT k) {
+        const u32 pos = (atomicSub(&tab[ocr_bucket(R, k)], 1u) & 0xFFFFu) - 1u;
+        A[pos] = k;
+    });
+    if (tid < 4) A[nA + tid] = MAXK;
+    __syncthreads();
+    u64 T_A = 0; // ties among the reference's non-zero keys: sum over keys of (run length^2 - 1)
+    {
+        u64 ta = 0;
+        for (u32 i = tid; i < nA; i += NT) {
+            const KeyT q = A[i];
+            const u32 e = tab[ocr_bucket(R, q)];
+            const u64 a = ocr_count_eq(R, q, ocr_lo(e), ocr_hi(e));
+            ta += a * a - 1ull;
+        }
+        ta = wave_sum(ta);
+        if (lane == 0) s_red[wave] = ta;
+        __syncthreads();
+        for (int w = 0; w < NW; ++w) T_A += s_red[w];
+    }
+
+    // ---- every other group: one wavefront each, 64 groups per output block ----
+    u32 *bloom = bloom_all + wave * OCR_BLOOM_WORDS;
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int g0 = wave * 64; g0 < G; g0 += NW * 64) {
+        const int gl = g0 + lane;
+        const bool has = gl < G && gl != ref;
+        const u32 my_n = has ? (u32)nnz[gl] : 0u;
+        const int my_pos = gl < G ? P.pos_ptr[gl] : 0;
+        TrReduce<u32> rS2;
+        u64 tt_out = 0;   // lane j: sum t (t + 1) over group g0 + j's keys (non-zero only where keys tie)
+        u32 neg_out = 0;  // lane j: group g0 + j's keys below zero
+        KeyT nxt[KMAX];
+        int nB_n = 0;
+        auto fetch = [&](int j) {
+            nB_n = j < 64 ? (int)__builtin_amdgcn_readlane((int)my_n, j) : 0;
+            const KeyT *seg = Xg + __builtin_amdgcn_readlane(my_pos, j & 63);
+#pragma unroll
+            for (int r = 0; r < KMAX; ++r)
+                if (r * 64 < nB_n) nxt[r] = (r * 64 + lane < nB_n) ? seg[r * 64 + lane] : ZEROK;
+        };
+        fetch(0);
+        for (int j = 0; j < 64; ++j) { // always 64 pushes so that the transpose-reduce completes
+            KeyT cur[KMAX];
+#pragma unroll
+            for (int r = 0; r < KMAX; ++r) cur[r] = nxt[r];
+            const int nB = nB_n;
+            fetch(j + 1);
+            u32 S2 = 0;
+            if (nB) { // uniform
+                u32 less = 0, eqs = 0, negs = 0;
+                u64 TT = 0;
+                if (nB <= 64) ocr_group<KeyT, 1>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else if (nB <= 128) ocr_group<KeyT, 2>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else if (nB <= 192) ocr_group<KeyT, 3>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else ocr_group<KeyT, 4>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                S2 = 2u * less + eqs;
+                const u64 tm = __ballot(TT != 0ull);
+                if (tm) {
+                    const u64 tot = wave_sum(TT);
+                    if (lane == j) tt_out = tot;
+                }
+                if (negs && lane == j) neg_out = negs;
+            }
+            rS2.push(S2, j, lane);
+        }
+        if (gl < G) { // lane j now holds the totals of group g0 + j
+            const size_t o = (size_t)gene * G + gl;
+            if (gl == ref) {
+                P.out_2u[o] = -2;
+                P.out_tie[o] = 0;
+            } else {
+                const long long n_g = P.counts[gl];
+                const u64 zc = (u64)(n_g - (long long)my_n);       // the group's zeros: one run against aZ reference zeros
+                const u64 S2 = (u64)rS2.result + 2ull * aZ * (u64)(my_n - neg_out) + zc * (2ull * nneg + aZ);
+                const u64 t0 = (u64)aZ + zc;
+                P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
+                P.out_tie[o] = T_A + 3ull * tt_out + (t0 * t0 * t0 - t0);
+            }
+        }
+    }
+}
