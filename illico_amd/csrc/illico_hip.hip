@@ -16,6 +16,7 @@
 #include "common.h"
 #include "kernels_finalize.h"
 #include "kernels_ovo.h"
+#include "kernels_ovo_compact.h"
 #include "kernels_ovo_counts.h"
 #include "kernels_ovo_fused.h"
 #include "kernels_ovr.h"
@@ -44,10 +45,12 @@ enum {
     KID_OVR_RANK_PARTS,
     KID_VALUE_SUMS,
     KID_OVO_FUSED_WIDE,
+    KID_GROUP_COMPACT,
+    KID_OVO_RANK_COMPACT,
     KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
-                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums", "k_ovo_fused_wide"};
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums", "k_ovo_fused_wide", "k_group_compact", "k_ovo_rank_compact"};
 
 // A dense call made with ILLICO_FLAG_DEFER whose fused pass is in flight: which genes it could not take is known only once
 // its route flags have reached the host; they are then recomputed by the two-pass routes (resolve_pending).
@@ -90,6 +93,7 @@ struct illico_ctx {
     int64_t scratch_bytes = 24ll << 30;
     bool no_counts_path = false;
     bool no_fused_path = false;
+    bool no_packed_dense = false;      // 1: dense OVO on continuous values takes the transpose + k_ovo_rank route (no group-wise packing)
     bool no_fused_wide = false;        // 1: no second, 256-value pass of the fused OVO route (genes beyond 63 go to the two-pass routes)
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
@@ -304,6 +308,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_fused_wide")) c->no_fused_wide = value != 0;
+    else if (!strcmp(key, "no_packed_dense")) c->no_packed_dense = value != 0;
     else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
     else if (!strcmp(key, "no_csc_counts_mixed")) c->no_csc_counts_mixed = value != 0;
     else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
@@ -555,6 +560,70 @@ static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t m
     }
     if (big) return runend ? launch_ovo_t<KeyT, 16, true, false>(c, P, lds, flags) : launch_ovo_t<KeyT, 16, false, false>(c, P, lds, flags);
     return runend ? launch_ovo_t<KeyT, 4, true, false>(c, P, lds, flags) : launch_ovo_t<KeyT, 4, false, false>(c, P, lds, flags);
+}
+
+// ---- packed dense OVO route (kernels_ovo_compact.h) ----
+// value buckets of the packed rank kernel: the most (up to 2^14) that fit LDS beside the reference's keys; 0: no fit
+template <typename KeyT> static int packed_nbk_lg(int64_t n_ref) {
+    for (int lg = 14; lg >= 10; --lg)
+        if (ocr_lds_bytes((int)n_ref, lg, sizeof(KeyT)) <= kMaxLds) return lg;
+    return 0;
+}
+// Sizes the route holds: reference of at most 65535 cells whose keys fit LDS in both kernels (k_ovo_rank takes the tie-heavy
+// genes), other groups of at most 1024 cells (k_ovo_rank's register form).
+template <typename KeyT> static bool packed_route_fits(const illico_ctx *c) {
+    if (c->ref < 0 || c->no_packed_dense) return false;
+    const int64_t n_ref = c->h_counts[c->ref];
+    return n_ref >= 1 && n_ref <= 65535 && c->max_nonref <= 1024 && packed_nbk_lg<KeyT>(n_ref) > 0 && ovo_sort_route_fits<KeyT>(n_ref, c->max_nonref);
+}
+
+template <typename InT, typename KeyT>
+static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0, int nb, int N, KeyT *Xt, int64_t stride, int dtype, int flags,
+                          long long *s2u, u64 *stie, double *ssum) {
+    const int G = (int)c->n_groups, ref = (int)c->ref;
+    const int64_t n_ref = c->h_counts[ref];
+    const int nseg = gcmp_ref_segments(n_ref);
+    int rc;
+    void *v;
+    if ((rc = get_scratch(c, "packed_nnz", (size_t)nb * G * 2 + (size_t)nb * nseg * 2 + 64, &v))) return rc;
+    u16 *nnz = (u16 *)v;
+    u16 *seg_nnz = nnz + (((size_t)nb * G + 7) & ~(size_t)7);
+    if ((rc = get_scratch(c, "packed_seg_sum", (size_t)nb * nseg * 8 + (size_t)nb * 4, &v))) return rc;
+    double *seg_sum = (double *)v;
+    u32 *route = (u32 *)(seg_sum + (size_t)nb * nseg);
+    HIPCHK(c, hipMemsetAsync(route, 0, (size_t)nb * 4, c->stream));
+    const int is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
+    {
+        GroupCompactParams Q;
+        Q.X = X; Q.ld = ld; Q.col0 = col0; Q.ncols = nb; Q.perm = c->d_perm; Q.pos_ptr = c->d_posptr; Q.G = G; Q.ref = ref; Q.nseg = nseg;
+        Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.out_sum = ssum; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum; Q.is_log1p = is_log1p;
+        constexpr int VEC = 16 / (int)sizeof(InT);
+        const bool aligned = ((uintptr_t)X % 16 == 0) && (ld % VEC == 0) && (col0 % VEC == 0);
+        const dim3 grid(((nseg + 7) & ~7) + gcmp_slots(G), (nb + 63) / 64);
+        ProfScope ps(c, KID_GROUP_COMPACT);
+        if (aligned) hipLaunchKernelGGL((k_group_compact<InT, KeyT, true>), grid, dim3(GCMP_NT), 0, c->stream, Q);
+        else hipLaunchKernelGGL((k_group_compact<InT, KeyT, false>), grid, dim3(GCMP_NT), 0, c->stream, Q);
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        OvoCompactParams C;
+        C.Xs = Xt; C.gene_stride = stride; C.pos_ptr = c->d_posptr; C.counts = c->d_counts; C.nnz = nnz; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum;
+        C.out_sum = ssum; C.G = G; C.ref = ref; C.n_genes = nb; C.nseg = nseg; C.ref_cap = (int)n_ref; C.nbk_lg = packed_nbk_lg<KeyT>(n_ref);
+        C.out_2u = s2u; C.out_tie = stie; C.route = route;
+        const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
+        auto kern = k_ovo_rank_compact<KeyT>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ProfScope ps(c, KID_OVO_RANK_COMPACT);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(OCR_NT), lds, c->stream, C);
+        HIPCHK(c, hipGetLastError());
+    }
+    // the genes the packed kernel left (tie-heavy reference column, a group of more than 256 non-zeros): k_ovo_rank over the
+    // packed layout; its workgroups return at once for every other gene
+    OvoParams P;
+    P.Xs = Xt; P.gene_stride = stride; P.pos_ptr = c->d_posptr; P.seg_ptr = nullptr; P.counts = c->d_counts;
+    P.G = G; P.ref = ref; P.n_genes = nb; P.dt = dtype; P.is_log1p = is_log1p;
+    P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = nullptr; P.nnz = nnz; P.only = route;
+    return launch_ovo<KeyT>(c, P, n_ref, c->max_nonref, nullptr, nullptr, false);
 }
 
 template <typename InT, typename KeyT>
@@ -976,8 +1045,11 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
     u64 *stie = (u64 *)(s2u + (size_t)nb_max * G);
     double *ssum = (double *)(stie + (size_t)nb_max * G);
     double *gtot = ssum + (size_t)nb_max * G;
+    // dense OVO: group-wise packing + look-ups (kernels_ovo_compact.h) whenever the sizes allow; it has no histogram side path
+    // (count-valued genes reach this function only when the fused route is off) and holds ties exactly
+    const bool packed = !ovr && packed_route_fits<KeyT>(c);
     u32 *gflags = nullptr;
-    if (counts_path_allowed(c, flags)) {
+    if (counts_path_allowed(c, flags) && !packed) {
         if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
         gflags = (u32 *)v;
     }
@@ -1004,6 +1076,19 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             HIPCHK(c, hipMemcpy2DAsync(xin, (size_t)nb * sizeof(InT), (const InT *)X + b0, (size_t)ld * sizeof(InT),
                                        (size_t)nb * sizeof(InT), (size_t)N, hipMemcpyHostToDevice, c->stream));
             src = xin; src_ld = nb; src_col0 = 0;
+        }
+        if (packed) {
+            if ((rc = run_ovo_packed<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, dtype, flags, s2u, stie, ssum))) return rc;
+            if (c->tap) {
+                const size_t off = (size_t)(b0 - col_lb) * G, cnt = (size_t)nb * G;
+                HIPCHK(c, hipMemcpyAsync(c->tap->two_u + off, s2u, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->tap->tie + off, stie, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->tap->sum + off, ssum, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                continue;
+            }
+            if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
+            continue;
         }
         if (gflags) HIPCHK(c, hipMemsetAsync(gflags, 0, (size_t)nb * 4, c->stream));
         if ((rc = launch_transpose<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, gflags))) return rc;

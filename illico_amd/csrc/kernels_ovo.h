@@ -131,6 +131,10 @@ struct OvoParams {
     long long *out_2u;       // [n_genes][G]  2*U (U of the reference sample, as scipy's mannwhitneyu(ref, grp))
     u64 *out_tie;            // [n_genes][G]  sum_v (t^3 - t)
     double *out_sum;         // [n_genes][G]  sum of values (expm1'd if is_log1p)
+    // packed dense layout (kernels_ovo_compact.h): group g's NON-ZERO keys at gene * gene_stride + pos_ptr[g], nnz[gene][g] of them
+    // (the reference's entry included); zeros are implicit, as in the sparse layout.  only: genes to process (flag 1), or null.
+    const u16 *nnz = nullptr;
+    const u32 *only = nullptr;
 };
 
 // The reference column in LDS, looked up by every value of the other groups.  Two forms, chosen per gene:
@@ -576,6 +580,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
 
     for (int gene = blockIdx.x; gene < P.n_genes; gene += gridDim.x) {
         if (gene_flags && gene_flags[gene] == 0) continue; // count-valued gene: handled by k_ovo_counts
+        if (P.only && P.only[gene] != 1u) continue;
         // ---- reference column -> LDS, sorted ----
         long long rstart;
         u32 nA;
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
             nA = sp[ref + 1] - sp[ref];
         } else {
             rstart = (long long)gene * P.gene_stride + P.pos_ptr[ref];
-            nA = (u32)n_ref;
+            nA = P.nnz ? (u32)P.nnz[(size_t)gene * G + ref] : (u32)n_ref;
         }
         const u32 zA_impl = (u32)n_ref - nA; // implicit zeros of the reference (sparse layout)
         RefBk<KeyT> bk;
@@ -648,7 +653,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
         __syncthreads();
         T_A = *s_TA;
         refsum = *s_refsum;
-        nnegA = P.seg_ptr ? lower_bound_pow2(A, nA, topA, ZEROK) : 0u;
+        nnegA = (P.seg_ptr || P.nnz) ? lower_bound_pow2(A, nA, topA, ZEROK) : 0u;
         // reference cells below zero / equal to zero (explicit zeros of the dense layout), for a group's zero run
         lbZ = lower_bound_pow2(A, nA, topA, ZEROK);
         aZ = upper_bound_pow2(A, nA, topA, ZEROK) - lbZ;
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                     const int n_g = P.counts[g];
                     long long bstart;
                     if (sp) { bstart = sp[g]; nB_n = (int)(sp[g + 1] - sp[g]); }
-                    else { bstart = (long long)gene * P.gene_stride + P.pos_ptr[g]; nB_n = n_g; }
+                    else { bstart = (long long)gene * P.gene_stride + P.pos_ptr[g]; nB_n = P.nnz ? (int)P.nnz[(size_t)gene * G + g] : n_g; }
                     zB_n = n_g - nB_n;
                     const KeyT *seg = Xs + bstart;
 #pragma unroll

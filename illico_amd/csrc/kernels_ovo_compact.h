@@ -22,7 +22,6 @@
 //   S2 = sum_b [2 #A<b + #A==b],   tie_sum = T_A(non-zeros) + 3 sum_b t (t + 1) + (z_A + z_B)^3 - (z_A + z_B).
 #pragma once
 #include "common.h"
-#include "kernels_ovo.h" // count_ok
 
 #define GCMP_NT 256
 #define OCR_NT 1024
@@ -54,8 +53,6 @@ struct GroupCompactParams {
     u16 *seg_nnz;           // [ncols][nseg] non-zero keys per segment of the reference (segment s at pos_ptr[ref] + s * GCMP_SEG_ROWS)
     double *seg_sum;        // [ncols][nseg]
     int is_log1p;
-    u32 *gene_flags;        // optional: set to 1 for genes holding a value that is not a small count (k_ovo_counts's input)
-    int count_limit;
 };
 
 template <typename InT> __device__ __forceinline__ double gcmp_value(InT v, int is_log1p);
@@ -133,9 +130,8 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
 
     int cntv = 0;     // lane i < 16: non-zero keys written so far for gene 16 * wave + i
     double sum[VEC];  // per-thread partial value sums of its VEC genes
-    bool viol[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { sum[e] = 0.0; viol[e] = false; }
+    for (int e = 0; e < VEC; ++e) sum[e] = 0.0;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     if (nchunks) { load_rows(0); load_chunk(); }
     if (nchunks > 1) load_rows(1);
@@ -148,7 +144,6 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
                 const InT v = nxt[i][e];
                 tile[q * VEC + e][r] = key_of(v);
                 sum[e] += gcmp_value<InT>(v, P.is_log1p); // rows past the end were loaded as zeros
-                if (P.gene_flags) viol[e] |= !count_ok(v, P.count_limit);
             }
         }
         if (c + 1 < nchunks) load_chunk();   // in flight while this chunk is packed
@@ -166,11 +161,6 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
             cntv += lane == i ? (int)__popcll(m) : 0;
         }
         __syncthreads();
-    }
-    if (P.gene_flags) { // at most one (checked) store per gene per thread; a stale-L1 miss only repeats the store
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-            if (viol[e] && cq + e < P.ncols && P.gene_flags[cq + e] == 0) P.gene_flags[cq + e] = 1u;
     }
     // value sums: [RPI row slots][64 genes] partials -> 64 threads add them in row-slot order
     double *part = (double *)&tile[0][0];
@@ -196,11 +186,11 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
 // per-gene ranking over the packed layout
 // ---------------------------------------------------------------------------------------------
 struct OvoCompactParams {
-    const void *Xs;          // packed keys (k_group_compact)
+    void *Xs;                // packed keys (k_group_compact)
     long long gene_stride;
     const int *pos_ptr;      // [G+1]
     const int *counts;       // [G]
-    const u16 *nnz;          // [n_genes][G]
+    u16 *nnz;                // [n_genes][G]
     const u16 *seg_nnz;      // [n_genes][nseg] the reference's segments (k_group_compact)
     const double *seg_sum;   // [n_genes][nseg]
     double *out_sum;         // [n_genes][G]: the reference's entry is written here (sum of its segments, in order)
@@ -209,8 +199,12 @@ struct OvoCompactParams {
     int nbk_lg;              // log2(value buckets)
     long long *out_2u;       // [n_genes][G]
     u64 *out_tie;            // [n_genes][G]
-    const u32 *gene_flags;   // optional: genes with flag 0 are skipped (count-valued: k_ovo_counts has them)
+    u32 *route;              // [n_genes], zeroed by the host: set to 1 for the genes this kernel leaves to k_ovo_rank (packed
+                             // mode): a value bucket of more than OCR_MAX_BUCKET reference keys (a tie-heavy column: it wants the
+                             // sorted reference and the sort form of the group loop) or a group of more than 256 non-zeros.
+                             // For those the reference's segments are moved together and nnz[gene][ref] is set.
 };
+#define OCR_MAX_BUCKET 24
 
 __host__ __device__ static inline size_t ocr_lds_bytes(int ref_cap, int nbk_lg, size_t key_size) {
     size_t b = (((size_t)ref_cap + 4) * key_size + 15) & ~(size_t)15;
@@ -363,17 +357,16 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     off += (size_t)NW * OCR_BLOOM_WORDS * 4;
     u64 *s_red = (u64 *)(smem + off); // [NW]
     KeyT *s_kr = (KeyT *)(s_red + NW); // [2] min, max
-    u32 *s_cnt = (u32 *)(s_kr + 2);    // [0] negatives  [1] non-zero keys
+    u32 *s_cnt = (u32 *)(s_kr + 2);    // [0] negatives  [1] non-zero keys  [2] largest bucket  [3] largest group (non-zeros)
     u32 *s_scan = s_cnt + 4;           // [NW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene = blockIdx.x;
-    if (P.gene_flags && P.gene_flags[gene] == 0) return;
     const int G = P.G, ref = P.ref;
     const int n_ref = P.counts[ref];
-    const u16 *nnz = P.nnz + (size_t)gene * G;
-    const KeyT *Xg = (const KeyT *)P.Xs + (long long)gene * P.gene_stride;
-    const KeyT *src = Xg + P.pos_ptr[ref];
+    u16 *nnz = P.nnz + (size_t)gene * G;
+    KeyT *Xg = (KeyT *)P.Xs + (long long)gene * P.gene_stride;
+    KeyT *src = Xg + P.pos_ptr[ref];
     const u16 *seg_nnz = P.seg_nnz + (size_t)gene * P.nseg;
     // the reference's non-zero keys lie in nseg packed segments: wavefront w walks segments w, w + NW, ...
     auto for_ref = [&](auto f) {
@@ -387,7 +380,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     // ---- the reference's non-zero keys -> value buckets ----
     for (int i = tid; i < NW * OCR_BLOOM_WORDS; i += NT) bloom_all[i] = 0u;
     for (int b = tid; b < NBK; b += NT) tab[b] = 0u;
-    if (tid == 0) { s_kr[0] = MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; }
+    if (tid == 0) { s_kr[0] = MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; s_cnt[3] = 0u; }
     __syncthreads();
     {
         KeyT tmin = MAXK, tmax = (KeyT)0;
@@ -410,6 +403,10 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
             if (ng) atomicAdd(&s_cnt[0], ng);
         }
         if (tid < P.nseg) atomicAdd(&s_cnt[1], (u32)seg_nnz[tid]); // nseg <= 128 (reference of at most 65535 cells)
+        u32 gmax = 0;
+        for (int gq = tid; gq < G; gq += NT) gmax = max(gmax, gq == ref ? 0u : (u32)nnz[gq]);
+        gmax = (u32)wave_incl_scan_max((int)gmax);
+        if (lane == 63 && gmax) atomicMax(&s_cnt[3], gmax);
         if (tid == NT - 1) { // the reference's value sum: its segments' sums in order
             double t = 0.0;
             for (int sg = 0; sg < P.nseg; ++sg) t += P.seg_sum[(size_t)gene * P.nseg + sg];
@@ -434,11 +431,26 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
       // Each wavefront owns a contiguous slice of the table and walks it 64 consecutive words at a time (no bank conflicts).
         const int per_wave = NBK / NW, iters = per_wave / 64; // NBK >= NW * 64
         u32 *slice = tab + wave * per_wave;
-        u32 tot = 0;
-        for (int it = 0; it < iters; ++it) tot += slice[it * 64 + lane];
+        u32 tot = 0, bmax = 0;
+        for (int it = 0; it < iters; ++it) { const u32 cb = slice[it * 64 + lane]; tot += cb; bmax = max(bmax, cb); }
         tot = (u32)wave_sum((int)tot);
+        bmax = (u32)wave_incl_scan_max((int)bmax);
         if (lane == 0) s_scan[wave] = tot;
+        if (lane == 63 && bmax > OCR_MAX_BUCKET) atomicMax(&s_cnt[2], bmax);
         __syncthreads();
+        if (s_cnt[2] > OCR_MAX_BUCKET || s_cnt[3] > 64u * OCR_KMAX) { // uniform: this gene goes to k_ovo_rank
+            u32 dst = P.nseg ? (u32)seg_nnz[0] : 0u;
+            for (int sg = 1; sg < P.nseg; ++sg) { // move the reference's segments together (a segment holds at most NT / 2 keys)
+                const u32 c = (u32)seg_nnz[sg];
+                KeyT k = (KeyT)0;
+                if ((u32)tid < c) k = src[(size_t)sg * GCMP_SEG_ROWS + tid];
+                __syncthreads();
+                if ((u32)tid < c) src[dst + tid] = k;
+                dst += c;
+            }
+            if (tid == 0) { nnz[ref] = (u16)nA; P.route[gene] = 1u; }
+            return;
+        }
         u32 base = 0;
         for (int w = 0; w < wave; ++w) base += s_scan[w];
         for (int it = 0; it < iters; ++it) {

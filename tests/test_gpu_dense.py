@@ -34,14 +34,16 @@ def _run(engine, X, grpc, **kw):
     return engine.run_dense(X, kw.pop("col_lb", 0), kw.pop("col_ub", X.shape[1]), **kw)
 
 
-@pytest.fixture(params=["fused+counts+sort", "fused-host+counts+sort", "counts+sort", "sort-only"])
+@pytest.fixture(params=["fused+counts+sort", "fused-host+counts+sort", "packed", "counts+sort", "sort-only"])
 def route(request, engine):
-    """Dense OVO has three device routes per gene: the fused single-pass histogram kernel (integer values < 64; X
-    device-resident, or a host matrix copied up in column windows), the two-pass histogram kernel (integer values
-    < 2048) and the general sort route.  The params switch routes off so that each one is exercised on the same data."""
+    """Dense OVO has four device routes per gene: the fused single-pass histogram kernel (integer values < 64; X
+    device-resident, or a host matrix copied up in column windows), the packed route (group-wise packing + look-ups), and
+    behind it the transpose route with the two-pass histogram kernel (integer values < 2048) and the general sort kernel.
+    The params switch routes off so that each one is exercised on the same data."""
     global _DEVICE_INPUT
     _DEVICE_INPUT = request.param == "fused+counts+sort"
     engine.set_option("no_fused_path", 0 if request.param.startswith("fused") else 1)
+    engine.set_option("no_packed_dense", 1 if request.param in ("counts+sort", "sort-only") else 0)
     engine.set_option("no_counts_path", 1 if request.param == "sort-only" else 0)
     # fused OVR has a one-pass form (per-group histograms) and a two-pass form: the host-input param runs the latter
     engine.set_option("no_ovr_one_pass", 1 if request.param.startswith("fused-host") else 0)
@@ -56,6 +58,7 @@ def route(request, engine):
     engine.set_option("no_counts_path", 0)
     engine.set_option("no_fused_path", 0)
     engine.set_option("no_ovr_one_pass", 0)
+    engine.set_option("no_packed_dense", 0)
     _DEVICE_INPUT = False
 
 
@@ -372,7 +375,8 @@ def test_fused_route_second_pass_takes_counts_up_to_255(engine, test):
         engine.set_option("profile", 0)
     assert "k_ovo_fused_wide" in prof and "k_ovo_fused_wide" not in prof2, (prof, prof2)
     # with the second pass only genes 33 and 34 are left for the two-pass routes (one short run), without it a third of the matrix
-    assert prof["k_transpose_permute"]["launches"] < prof2["k_transpose_permute"]["launches"], (prof, prof2)
+    first = "k_group_compact" if test == "ovo" else "k_transpose_permute"  # first kernel of the two-pass routes
+    assert prof[first]["launches"] < prof2[first]["launches"], (prof, prof2)
     for a, b in zip(got, narrow_only):
         assert a.tobytes() == b.tobytes()
     assert_planes_match(got, want, ref_row=rr, what=f"counts up to 255 {test}")

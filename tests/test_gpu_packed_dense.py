@@ -1,0 +1,161 @@
+"""GPU parity tests of the packed dense OVO route (illico_amd/csrc/kernels_ovo_compact.h): group-wise packing of the non-zero
+keys (k_group_compact) + look-ups in the bucketed reference (k_ovo_rank_compact), tie-heavy genes handed to k_ovo_rank.
+
+Replaces the reference's dense OVO kernel (illico/ovo/dense_ovo.py:65-137).  Bar: statistics (2U, tie sums) identical to
+the transpose + sort route and to the oracle's planes; p-values / fold changes at rtol 1e-12.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import assert_planes_match, make_labels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from illico_amd._lib import get_engine
+    eng = get_engine()
+    eng.set_option("no_fused_path", 1)  # every gene through the two-pass routes
+    yield eng
+    eng.set_option("no_fused_path", 0)
+    eng.set_option("no_packed_dense", 0)
+    eng.set_option("profile", 0)
+
+
+def _both_routes(engine, X, g, lb=0, ub=None, **kw):
+    """(planes, statistics, kernel profile) of the packed route and of the route it replaces, same engine, same input."""
+    ub = X.shape[1] if ub is None else ub
+    engine.set_groups(g)
+    out = []
+    for off in (0, 1):
+        engine.set_option("no_packed_dense", off)
+        engine.set_option("profile", 1)
+        engine.profile_reset()
+        try:
+            planes = engine.run_dense(X, lb, ub, **kw)
+            prof = engine.profile_get()
+        finally:
+            engine.set_option("profile", 0)
+        stats = engine.rank_statistics(X, lb, ub, is_log1p=kw.get("is_log1p", False))
+        out.append((planes, stats, prof))
+    engine.set_option("no_packed_dense", 0)
+    return out
+
+
+def _check(engine, X, labels, *, what, fc_rtol=1e-12, **kw):
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    (p_new, s_new, prof_new), (p_old, s_old, prof_old) = _both_routes(engine, X, g, **kw)
+    assert "k_group_compact" in prof_new and "k_ovo_rank_compact" in prof_new and "k_transpose_permute" not in prof_new, prof_new
+    assert "k_group_compact" not in prof_old and "k_transpose_permute" in prof_old, prof_old
+    np.testing.assert_array_equal(s_new[0], s_old[0], err_msg=f"2U {what}")
+    np.testing.assert_array_equal(s_new[1], s_old[1], err_msg=f"tie sums {what}")
+    np.testing.assert_allclose(s_new[2], s_old[2], rtol=1e-13, atol=0, err_msg=f"value sums {what}")
+    lb, ub = kw.get("lb", 0), kw.get("ub", X.shape[1])
+    Xh = X.cpu().numpy() if hasattr(X, "cpu") else X
+    want = oracle.run(np.ascontiguousarray(Xh, dtype=np.float64), g, col_lb=lb, col_ub=ub, **{k: v for k, v in kw.items() if k not in ("lb", "ub")})
+    assert_planes_match(p_new, want, ref_row=g.encoded_ref_group, fc_rtol=fc_rtol, what=what)
+    return prof_new
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
+def test_packed_route_matches_sort_route_and_oracle(engine, dtype):
+    """Continuous columns, a tie-heavy column, a column of few distinct values, mixed signs, a constant and an all-zero
+    column, ragged groups (1 .. ~90 cells), a reference of three packing segments."""
+    rng = np.random.RandomState(5)
+    n, m = 6000, 70
+    labels = make_labels(rng, n, 90, n_ref=1300)
+    X = np.log1p(rng.poisson(4.0, size=(n, m)) * rng.uniform(0.5, 1.5, size=(n, m))) * (rng.rand(n, m) < 0.5)
+    X[:, 3] = rng.poisson(300.0, size=n)                      # large counts: ties everywhere -> k_ovo_rank
+    X[:, 4] = rng.choice([0.0, 0.25, 0.5, 7.75], size=n)      # four distinct values
+    X[:, 5] = rng.randn(n)                                    # mixed sign, no zeros
+    X[:, 6] = 2.5                                             # constant
+    X[:, 7] = 0.0
+    X[:, 8] = -np.abs(X[:, 8])                                # negative with zeros
+    X[:, 9] = np.where(rng.rand(n) < 0.02, 3.25, 0.0)         # almost empty
+    if np.issubdtype(dtype, np.integer):
+        X = np.round(X * 1000.0)
+    X = X.astype(dtype)
+    prof = _check(engine, X, labels, what=f"packed {np.dtype(dtype).name}")
+    assert "k_ovo_rank" in prof  # the tie-heavy genes (and only those workgroups do work)
+
+
+def test_packed_route_duplicates_across_rounds_and_with_the_reference(engine):
+    """A group of 150 cells (three rounds of 64 keys) whose keys repeat across rounds, repeat a reference key, and repeat a
+    reference key that itself repeats: the Bloom flags + ballot comparison must give the exact multiplicities."""
+    rng = np.random.RandomState(11)
+    n, m = 3000, 8
+    labels = np.array(["non-targeting"] * 700 + ["pert_a"] * 150 + ["pert_b"] * 40 + [f"pert_{i % 30:03d}" for i in range(n - 890)])
+    X = rng.uniform(0.1, 5.0, size=(n, m)).astype(np.float32) * (rng.rand(n, m) < 0.9)
+    a0 = 700
+    X[a0 + 140, 0] = X[a0 + 3, 0]                # same group, rounds 2 and 0
+    X[a0 + 70, 0] = X[a0 + 3, 0]                 # ... and round 1: a triple
+    X[a0 + 10, 1] = X[5, 1]                      # ties with one reference key
+    X[a0 + 100, 1] = X[5, 1]                     # ... twice
+    X[6, 2] = X[7, 2] = X[8, 2]                  # a repeated reference key
+    X[a0 + 20, 2] = X[6, 2]; X[a0 + 149, 2] = X[6, 2]
+    X[a0:a0 + 150, 3] = np.float32(1.5)          # a group of one value
+    perm = rng.permutation(n)
+    prof = _check(engine, X[perm], labels[perm], what="duplicates")
+    assert "k_ovo_rank" in prof
+
+
+def test_packed_route_groups_beyond_256_nonzeros_go_to_k_ovo_rank(engine):
+    rng = np.random.RandomState(12)
+    n, m = 4000, 6
+    labels = np.array(["non-targeting"] * 600 + ["pert_big"] * 700 + [f"pert_{i % 50:03d}" for i in range(n - 1300)])
+    X = rng.uniform(0.1, 5.0, size=(n, m)).astype(np.float32)
+    X[:, :3] *= rng.rand(n, 3) < 0.2             # genes 0-2: the big group keeps <= 256 non-zeros (about 140)
+    perm = rng.permutation(n)
+    _check(engine, X[perm], labels[perm], what="big group")
+
+
+@pytest.mark.parametrize("lb,ub", [(0, 37), (1, 36), (3, 4), (5, 70)])
+def test_packed_route_column_windows_and_unaligned_rows(engine, lb, ub):
+    """Windows that start off a 16-byte boundary and a row pitch that is not a multiple of 4 elements (scalar loads)."""
+    import torch
+    rng = np.random.RandomState(13)
+    n, m = 2500, 70
+    labels = make_labels(rng, n, 25, n_ref=300)
+    X = (rng.gamma(2.0, 1.0, size=(n, m)) * (rng.rand(n, m) < 0.4)).astype(np.float32)
+    _check(engine, X, labels, what=f"window {lb}:{ub}", lb=lb, ub=ub)
+    Xd = torch.zeros((n, m + 3), dtype=torch.float32, device="cuda")[:, :m]  # pitch 73
+    Xd.copy_(torch.from_numpy(X))
+    _check(engine, Xd, labels, what=f"device window {lb}:{ub}", lb=lb, ub=ub)
+
+
+def test_packed_route_log1p_fold_change_and_options(engine):
+    rng = np.random.RandomState(14)
+    n, m = 2000, 20
+    labels = make_labels(rng, n, 12, n_ref=250)
+    X = np.log1p(rng.poisson(3.0, size=(n, m)) * rng.uniform(0.5, 1.5, size=(n, m))).astype(np.float32)
+    # expm1 is evaluated in float32 (utils/math.py:212): device and libm expm1f may differ by an f32 ulp
+    _check(engine, X, labels, what="log1p", fc_rtol=1e-6, is_log1p=True)
+    _check(engine, X, labels, what="less", alternative="less", use_continuity=False, tie_correct=False)
+
+
+def test_packed_route_tiny_cases(engine):
+    rng = np.random.RandomState(15)
+    for n_ref, others in [(1, [1, 1, 2]), (2, [1]), (65, [64, 65, 63]), (513, [3])]:
+        labels = np.array(["non-targeting"] * n_ref + sum(([f"pert_{i}"] * k for i, k in enumerate(others)), []))
+        X = rng.uniform(-1, 1, size=(labels.size, 5)).astype(np.float32) * (rng.rand(labels.size, 5) < 0.7)
+        _check(engine, X, labels, what=f"tiny {n_ref} {others}")
+
+
+def test_reference_beyond_16_bit_positions_takes_the_other_route(engine):
+    rng = np.random.RandomState(16)
+    n = 70000
+    labels = np.array(["non-targeting"] * 66000 + [f"pert_{i % 20}" for i in range(n - 66000)])
+    X = (rng.uniform(0.1, 3.0, size=(n, 3)) * (rng.rand(n, 3) < 0.3)).astype(np.float32)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    engine.set_groups(g)
+    engine.set_option("profile", 1)
+    engine.profile_reset()
+    try:
+        got = engine.run_dense(X, 0, 3)
+        prof = engine.profile_get()
+    finally:
+        engine.set_option("profile", 0)
+    assert "k_group_compact" not in prof, prof
+    assert_planes_match(got, oracle.run(X.astype(np.float64), g), ref_row=g.encoded_ref_group, what="large reference")

@@ -102,12 +102,13 @@ int main(int argc, char **argv) {
     // ---- packed route ----
     const int nseg = gcmp_ref_segments(n_ref);
     u16 *seg_nnz; double *seg_sum; CK(hipMalloc(&seg_nnz, (size_t)M * nseg * 2)); CK(hipMalloc(&seg_sum, (size_t)M * nseg * 8));
+    u32 *route; CK(hipMalloc(&route, M * 4)); CK(hipMemset(route, 0, M * 4));
     GroupCompactParams Q;
     Q.X = X; Q.ld = M; Q.col0 = 0; Q.ncols = M; Q.perm = d_perm; Q.pos_ptr = d_pos; Q.G = G; Q.ref = 0; Q.nseg = nseg; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum; Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.out_sum = ssum[1];
-    Q.is_log1p = 0; Q.gene_flags = nullptr; Q.count_limit = 0;
+    Q.is_log1p = 0;
     OvoCompactParams C;
     C.Xs = Xt; C.gene_stride = stride; C.pos_ptr = d_pos; C.counts = d_counts; C.nnz = nnz; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum; C.out_sum = ssum[1]; C.nseg = nseg; C.G = G; C.ref = 0; C.n_genes = M; C.ref_cap = n_ref; C.nbk_lg = nbk_lg;
-    C.out_2u = s2u[1]; C.out_tie = stie[1]; C.gene_flags = nullptr;
+    C.out_2u = s2u[1]; C.out_tie = stie[1]; C.route = route;
     const size_t lds_new = ocr_lds_bytes(n_ref, nbk_lg, 4);
     auto knew = k_ovo_rank_compact<u32>;
     CK(hipFuncSetAttribute((const void *)knew, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
@@ -116,7 +117,13 @@ int main(int argc, char **argv) {
         hipEventRecord(e0);
         hipLaunchKernelGGL((k_group_compact<float, u32, true>), dim3(((nseg + 7) & ~7) + gcmp_slots(G), (M + 63) / 64), dim3(GCMP_NT), 0, 0, Q);
         hipEventRecord(e1);
+        hipMemsetAsync(route, 0, M * 4, 0);
         hipLaunchKernelGGL(knew, dim3(M), dim3(OCR_NT), lds_new, 0, C);
+        {
+            OvoParams P2 = P;
+            P2.out_2u = s2u[1]; P2.out_tie = stie[1]; P2.out_sum = nullptr; P2.nnz = nnz; P2.only = route;
+            hipLaunchKernelGGL(kold, dim3(M), dim3(512), lds_old, 0, P2, (const u32 *)nullptr);
+        }
         hipEventRecord(e2);
         CK(hipEventSynchronize(e2));
         CK(hipGetLastError());
