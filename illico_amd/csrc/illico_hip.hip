@@ -563,9 +563,9 @@ static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t m
 }
 
 // ---- packed dense OVO route (kernels_ovo_compact.h) ----
-// value buckets of the packed rank kernel: the most (up to 2^14) that fit LDS beside the reference's keys; 0: no fit
+// value buckets of the packed rank kernel: the most (up to 2^17, half a byte each) that fit LDS beside the reference's keys; 0: no fit
 template <typename KeyT> static int packed_nbk_lg(int64_t n_ref) {
-    for (int lg = 14; lg >= 10; --lg)
+    for (int lg = 17; lg >= 14; --lg)
         if (ocr_lds_bytes((int)n_ref, lg, sizeof(KeyT)) <= kMaxLds) return lg;
     return 0;
 }

@@ -196,19 +196,28 @@ struct OvoCompactParams {
     double *out_sum;         // [n_genes][G]: the reference's entry is written here (sum of its segments, in order)
     int G, ref, n_genes, nseg;
     int ref_cap;             // LDS key slots for the reference's non-zeros (>= the reference group's size)
-    int nbk_lg;              // log2(value buckets)
+    int nbk_lg;              // log2(value buckets), 14 .. 17
     long long *out_2u;       // [n_genes][G]
     u64 *out_tie;            // [n_genes][G]
     u32 *route;              // [n_genes], zeroed by the host: set to 1 for the genes this kernel leaves to k_ovo_rank (packed
-                             // mode): a value bucket of more than OCR_MAX_BUCKET reference keys (a tie-heavy column: it wants the
-                             // sorted reference and the sort form of the group loop) or a group of more than 256 non-zeros.
-                             // For those the reference's segments are moved together and nnz[gene][ref] is set.
+                             // mode): crowded value buckets (a tie-heavy column: it wants the sorted reference and the sort form
+                             // of the group loop) or a group of more than 256 non-zeros.  For those the reference's segments are
+                             // moved together and nnz[gene][ref] is set.
 };
-#define OCR_MAX_BUCKET 24
+// a gene leaves this kernel when one table word (16 buckets) holds more than OCR_MAX_WORD reference keys, or when more than an
+// eighth of the reference's keys sit in words with an overfull bucket
+#define OCR_MAX_WORD 32
 
+// The reference's non-zero keys in LDS.  Value buckets (key - kmin) >> shift, 2^nbk_lg of them; keys are stored in bucket order
+// (any order inside a bucket).  The table costs HALF A BYTE per bucket: one 64-bit word per 16 buckets,
+//     low half  : 16 two-bit counters = keys in each of the 16 buckets (0 .. 3)
+//     high half : keys in all earlier words (16 bit); bit 31 = some bucket of this word holds more than 3 keys ("overfull word")
+// so a bucket's first key is at  prefix + (sum of the counters below it)  = two popcounts, and with ~30 buckets per key nearly
+// every bucket holds 0 or 1 keys: a look-up reads one table word and two keys.  Overfull words (and a bucket of exactly 3, and
+// keys that tie with the reference) take an exact per-lane walk over the word's / bucket's keys.
 __host__ __device__ static inline size_t ocr_lds_bytes(int ref_cap, int nbk_lg, size_t key_size) {
     size_t b = (((size_t)ref_cap + 4) * key_size + 15) & ~(size_t)15;
-    b += (size_t)4 << nbk_lg;
+    b += (((size_t)1 << nbk_lg) / 16 + 2) * 8;
     b += (size_t)(OCR_NT / 64) * OCR_BLOOM_WORDS * 4;
     b += 256; // reduction words
     return b;
@@ -219,27 +228,38 @@ __device__ __forceinline__ u32 ocr_hash(u64 k) { const u32 f = (u32)(k ^ (k >> 3
 
 template <typename KeyT> struct OcrRef {
     const KeyT *A;
-    const u32 *tab;
+    const u32 *tab; // word W: tab[2 W] counters, tab[2 W + 1] prefix | overfull flag; one sentinel word (prefix = all keys)
     KeyT kmin;
     int shift;
     u32 last; // buckets - 1
+    u32 nA;   // keys
 };
 template <typename KeyT> __device__ __forceinline__ u32 ocr_bucket(const OcrRef<KeyT> &R, KeyT q) {
     const KeyT d = q > R.kmin ? (KeyT)(q - R.kmin) : (KeyT)0;
     const KeyT b = d >> R.shift;
     return b < (KeyT)R.last ? (u32)b : R.last;
 }
-// table word of a bucket: keys in it << 16 | index of its first key
-__device__ __forceinline__ u32 ocr_lo(u32 e) { return e & 0xFFFFu; }
-__device__ __forceinline__ u32 ocr_hi(u32 e) { return (e & 0xFFFFu) + (e >> 16); }
-template <typename KeyT> __device__ __forceinline__ u32 ocr_count_eq(const OcrRef<KeyT> &R, KeyT q, u32 lo, u32 hi) {
-    u32 a = 0;
-    for (u32 j = lo; j < hi; ++j) a += R.A[j] == q ? 1u : 0u;
-    return a;
+// keys in the buckets below position sh (= 2 * bucket-in-word) of a counter word: each 2-bit value = b0 + 2 b1 = (b0 + b1) + b1
+__device__ __forceinline__ u32 ocr_below(u32 w, u32 sh) {
+    const u32 x = w & ((1u << sh) - 1u);
+    return (u32)__popc(x) + (u32)__popc(x & 0xAAAAAAAAu);
+}
+// exact look-up: the keys that can be < q without being counted by the word's prefix lie in [lo, hi): the bucket, or the
+// whole word when it is overfull (the order of its keys is arbitrary then)
+template <typename KeyT> __device__ __forceinline__ void ocr_find_exact(const OcrRef<KeyT> &R, KeyT q, u32 &less, u32 &eq) {
+    const u32 b = ocr_bucket(R, q), W = b >> 4, sh = (b & 15u) << 1;
+    const u32 w = R.tab[2 * W], h = R.tab[2 * W + 1];
+    u32 lo, hi;
+    if (h >> 31) { lo = h & 0xFFFFu; hi = R.tab[2 * W + 3] & 0xFFFFu; }
+    else { lo = h + ocr_below(w, sh); hi = lo + ((w >> sh) & 3u); }
+    u32 l = lo, a = 0;
+    for (u32 t = lo; t < hi; ++t) { const KeyT k = R.A[t]; l += k < q ? 1u : 0u; a += k == q ? 1u : 0u; }
+    less = l;
+    eq = a;
 }
 
 // One group of nB non-zero keys, NR = ceil(nB / 64) rounds of 64 (cur[r] = key r * 64 + lane; lanes past the last key hold
-// ZEROK).  Straight-line per round: Bloom insert (one returning LDS atomic), table word, 4 keys of the bucket, 8 compares.
+// ZEROK).  Straight-line per round: Bloom insert (one returning LDS atomic), one table word, 2 keys, 4 compares.
 // Per-lane partial results: less = sum of #A<q (non-zero reference keys), eqs = sum of #A==q, TT = sum t (t + 1); negs
 // (uniform) = keys below zero.  bloom[] is all-zero on entry and on exit.
 template <typename KeyT, int NR>
@@ -249,58 +269,88 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
     const int rem = nB - 64 * (NR - 1);               // keys of the last round, 1..64
     const u64 vlast = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
     const bool vl = (vlast >> lane) & 1ull;
-    u32 wofs[NR], ent[NR], less = 0;
-    u64 fm[NR], em = 0, mm = 0;
+    u32 wofs[NR], lessr[NR], cnt_[NR];
+    KeyT k0[NR], k1[NR], k2[NR];
+    u64 fm[NR], eqm = 0, ovm = 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) { // Bloom inserts of every round first: a key's flag says "may repeat an EARLIER key"
         const KeyT q = cur[r];
         const u32 h = ocr_hash(q);
         wofs[r] = (h >> 5) & (OCR_BLOOM_WORDS - 1);
         bool flag = false;
+#ifndef OCR_X_NOBLOOM
         if (r < NR - 1 || vl) {
             const u32 old = atomicOr(&bloom[wofs[r]], 1u << (h & 31));
             flag = (old >> (h & 31)) & 1u;
         }
+#endif
         fm[r] = __ballot(flag);
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const KeyT q = cur[r];
-        const u32 e = R.tab[ocr_bucket(R, q)];
-        ent[r] = e;
-        const u32 lo = ocr_lo(e);
-        const KeyT a0 = R.A[lo], a1 = R.A[lo + 1], a2 = R.A[lo + 2], a3 = R.A[lo + 3]; // past the bucket: later buckets / the pad: > q or == MAXK
-        if (r < NR - 1 || vl) bloom[wofs[r]] = 0u; // wipe (LDS operations of one wavefront execute in order)
-        u32 l = lo + (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u) + (a3 < q ? 1u : 0u);
-        u64 e4 = __ballot(a0 == q) | __ballot(a1 == q) | __ballot(a2 == q) | __ballot(a3 == q);
-        u64 m4 = __ballot(e >= (5u << 16));
-        u64 n4 = __ballot(q < ZEROK);
-        if (r == NR - 1) { l = vl ? l : 0u; e4 &= vlast; m4 &= vlast; n4 &= vlast; }
-        less += l;
-        em |= e4; mm |= m4;
+        const u32 b = ocr_bucket(R, q), sh = (b & 15u) << 1;
+        const u32 *pw = R.tab + 2 * (b >> 4);
+        const u32 w = pw[0], h = pw[1];
+        const u32 lo = min((h + ocr_below(w, sh)) & 0xFFFFu, R.nA); // meaningless in an overfull word (bit 31 of h): redone below
+        const KeyT a0 = R.A[lo], a1 = R.A[lo + 1], a2 = R.A[lo + 2]; // a bucket holds at most 3; past it: later buckets / the pad: > q or == MAXK
+#ifndef OCR_X_NOBLOOM
+        if (r < NR - 1 || vl) bloom[wofs[r]] = 0u;       // wipe (LDS operations of one wavefront execute in order)
+#endif
+        u32 l = lo + (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u);
+        u64 e4 = __ballot(a0 == q) | __ballot(a1 == q) | __ballot(a2 == q), o4 = __ballot((int)h < 0), n4 = __ballot(q < ZEROK);
+        if (r == NR - 1) { l = vl ? l : 0u; e4 &= vlast; o4 &= vlast; n4 &= vlast; }
+        lessr[r] = l; cnt_[r] = (w >> sh) & 3u; k0[r] = a0; k1[r] = a1; k2[r] = a2;
+        eqm |= e4; ovm |= o4;
         negs_out += (u32)__popcll(n4);
     }
-    u32 a[NR], eqs = 0;
+    u32 a[NR], eqs = 0, less = 0;
     u64 TT = 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) a[r] = 0u;
-    if (mm | em) { // rare: a bucket of more than 4 keys, or a key that ties with the reference: exact counts for those lanes
+#ifdef OCR_X_NORARE
+    eqm = ovm = 0;
+#endif
+#ifdef OCR_X_NOOV
+    ovm = 0;
+#endif
+#ifdef OCR_X_NOEQ
+    eqm = 0;
+#endif
+    if (eqm) { // a key that ties with the reference somewhere in the group: count, bounded by the bucket (the pad's MAXK never counts)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const KeyT q = cur[r];
-            const bool valid = r < NR - 1 || vl;
-            const u32 lo = ocr_lo(ent[r]), hi = ocr_hi(ent[r]);
-            if (valid && hi > lo + 4u) {
-                u32 extra = 0;
-                for (u32 t = lo + 4u; t < hi; ++t) extra += R.A[t] < q ? 1u : 0u;
-                less += extra;
+            const u32 e = ((cnt_[r] > 0u && k0[r] == q) ? 1u : 0u) + ((cnt_[r] > 1u && k1[r] == q) ? 1u : 0u) + ((cnt_[r] > 2u && k2[r] == q) ? 1u : 0u);
+            a[r] = (r < NR - 1 || vl) ? e : 0u;
+        }
+    }
+    if (ovm) { // a key in an overfull word (its keys lie in [wlo, whi) in any order): the first 8 in line, the rest lane by lane
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const KeyT q = cur[r];
+            const u32 W = ocr_bucket(R, q) >> 4;
+            const u32 h = R.tab[2 * W + 1];
+            const bool ov = (r < NR - 1 || vl) && (int)h < 0;
+            const u32 wlo = min(h & 0xFFFFu, R.nA), whi = ov ? (R.tab[2 * W + 3] & 0xFFFFu) : wlo;
+            u32 l = wlo, e = 0;
+#pragma unroll
+            for (u32 t = 0; t < 8; ++t) {
+                const KeyT k = R.A[wlo + t]; // (the pad is 4 keys: reads past it stay inside the table's LDS and are masked out)
+                l += (wlo + t < whi && k < q) ? 1u : 0u;
+                e += (wlo + t < whi && k == q) ? 1u : 0u;
             }
-            if (valid) {
-                const u32 c = ocr_count_eq(R, q, lo, hi); // bounded by the bucket: the pad's MAXK never counts
-                a[r] = c;
-                eqs += c;
-                TT += (u64)c * ((u64)c + 1ull);
-            }
+            for (u32 t = wlo + 8u; t < whi; ++t) { const KeyT k = R.A[t]; l += k < q ? 1u : 0u; e += k == q ? 1u : 0u; }
+            if (ov) { lessr[r] = l; a[r] = e; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) less += lessr[r];
+    if (eqm | ovm) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            eqs += a[r];
+            TT += (u64)a[r] * ((u64)a[r] + 1ull);
         }
     }
     u64 anyf = 0;
@@ -348,17 +398,17 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NT = OCR_NT, NW = NT / 64, KMAX = OCR_KMAX;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK, MAXK = KeyInfo<KeyT>::MAXK;
-    const int NBK = 1 << P.nbk_lg;
+    const int NWD = (1 << P.nbk_lg) >> 4; // table words
     KeyT *A = (KeyT *)smem;
     size_t off = (((size_t)P.ref_cap + 4) * sizeof(KeyT) + 15) & ~(size_t)15;
     u32 *tab = (u32 *)(smem + off);
-    off += (size_t)4 << P.nbk_lg;
+    off += ((size_t)NWD + 2) * 8;
     u32 *bloom_all = (u32 *)(smem + off);
     off += (size_t)NW * OCR_BLOOM_WORDS * 4;
     u64 *s_red = (u64 *)(smem + off); // [NW]
     KeyT *s_kr = (KeyT *)(s_red + NW); // [2] min, max
-    u32 *s_cnt = (u32 *)(s_kr + 2);    // [0] negatives  [1] non-zero keys  [2] largest bucket  [3] largest group (non-zeros)
-    u32 *s_scan = s_cnt + 4;           // [NW]
+    u32 *s_cnt = (u32 *)(s_kr + 2);    // [0] negatives  [1] non-zero keys  [2] fullest overfull word  [3] largest group  [4] keys in overfull words
+    u32 *s_scan = s_cnt + 8;           // [NW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene = blockIdx.x;
@@ -379,8 +429,9 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
 
     // ---- the reference's non-zero keys -> value buckets ----
     for (int i = tid; i < NW * OCR_BLOOM_WORDS; i += NT) bloom_all[i] = 0u;
-    for (int b = tid; b < NBK; b += NT) tab[b] = 0u;
-    if (tid == 0) { s_kr[0] = MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; s_cnt[3] = 0u; }
+    for (int i = tid; i < 2 * (NWD + 2); i += NT) tab[i] = 0u;
+    for (int i = tid; i < P.ref_cap + 4; i += NT) A[i] = MAXK; // empty slots (the scatter claims them by compare-and-swap) and the pad
+    if (tid == 0) { s_kr[0] = MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; s_cnt[3] = 0u; s_cnt[4] = 0u; }
     __syncthreads();
     {
         KeyT tmin = MAXK, tmax = (KeyT)0;
@@ -417,28 +468,45 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     const u32 nA = s_cnt[1];
     const u32 aZ = (u32)n_ref - nA;
     OcrRef<KeyT> R;
-    R.A = A; R.tab = tab; R.last = (u32)NBK - 1u;
+    R.A = A; R.tab = tab; R.last = (1u << P.nbk_lg) - 1u;
     R.kmin = nA ? s_kr[0] : (KeyT)0;
     {
         const KeyT range = nA ? (KeyT)(s_kr[1] - s_kr[0]) : (KeyT)0;
         const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
         R.shift = bits > P.nbk_lg ? bits - P.nbk_lg : 0;
     }
+    R.nA = nA;
     const u32 nneg = s_cnt[0];
-    for_ref([&](KeyT k) { atomicAdd(&tab[ocr_bucket(R, k)], 1u); });
+    // counters: +1 on the bucket's two bits; a bucket already at 3 takes the increment back and marks its word overfull (the
+    // carry it sent into the next field in between is removed by the subtraction; whatever the fields of such a word end up
+    // holding is never used).  The word's key count is kept in the high half meanwhile.
+    for_ref([&](KeyT k) {
+        const u32 b = ocr_bucket(R, k), sh = (b & 15u) << 1;
+        u32 *pw = tab + 2 * (b >> 4);
+        atomicAdd(&pw[1], 1u);
+        const u32 old = atomicAdd(&pw[0], 1u << sh);
+        if (((old >> sh) & 3u) == 3u) {
+            atomicSub(&pw[0], 1u << sh);
+            atomicOr(&pw[1], 0x80000000u);
+        }
+    });
     __syncthreads();
-    { // exclusive scan of the bucket counts; word = keys << 16 | end of the bucket.
-      // Each wavefront owns a contiguous slice of the table and walks it 64 consecutive words at a time (no bank conflicts).
-        const int per_wave = NBK / NW, iters = per_wave / 64; // NBK >= NW * 64
-        u32 *slice = tab + wave * per_wave;
-        u32 tot = 0, bmax = 0;
-        for (int it = 0; it < iters; ++it) { const u32 cb = slice[it * 64 + lane]; tot += cb; bmax = max(bmax, cb); }
+    { // exclusive scan of the words' key counts.  Each wavefront owns a contiguous slice and walks it 64 words at a time.
+        const int per_wave = NWD / NW, iters = per_wave / 64; // NWD >= NW * 64
+        u32 *slice = tab + 2 * (wave * per_wave);
+        u32 tot = 0, fmax = 0, ftot = 0;
+        for (int it = 0; it < iters; ++it) {
+            const u32 h = slice[2 * (it * 64 + lane) + 1], c = h & 0xFFFFu;
+            tot += c;
+            if (h >> 31) { fmax = max(fmax, c); ftot += c; }
+        }
         tot = (u32)wave_sum((int)tot);
-        bmax = (u32)wave_incl_scan_max((int)bmax);
-        if (lane == 0) s_scan[wave] = tot;
-        if (lane == 63 && bmax > OCR_MAX_BUCKET) atomicMax(&s_cnt[2], bmax);
+        ftot = (u32)wave_sum((int)ftot);
+        fmax = (u32)wave_incl_scan_max((int)fmax);
+        if (lane == 0) { s_scan[wave] = tot; if (ftot) atomicAdd(&s_cnt[4], ftot); }
+        if (lane == 63 && fmax) atomicMax(&s_cnt[2], fmax);
         __syncthreads();
-        if (s_cnt[2] > OCR_MAX_BUCKET || s_cnt[3] > 64u * OCR_KMAX) { // uniform: this gene goes to k_ovo_rank
+        if (s_cnt[2] > OCR_MAX_WORD || s_cnt[4] * 8u > nA || s_cnt[3] > 64u * OCR_KMAX) { // uniform: this gene goes to k_ovo_rank
             u32 dst = P.nseg ? (u32)seg_nnz[0] : 0u;
             for (int sg = 1; sg < P.nseg; ++sg) { // move the reference's segments together (a segment holds at most NT / 2 keys)
                 const u32 c = (u32)seg_nnz[sg];
@@ -454,27 +522,33 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         u32 base = 0;
         for (int w = 0; w < wave; ++w) base += s_scan[w];
         for (int it = 0; it < iters; ++it) {
-            const u32 cb = slice[it * 64 + lane];
-            const u32 inc = (u32)wave_incl_scan_add((int)cb);
-            slice[it * 64 + lane] = (cb << 16) | (base + inc); // keys << 16 | END: the scatter below counts the low half down to the start
+            const u32 h = slice[2 * (it * 64 + lane) + 1], c = h & 0xFFFFu;
+            const u32 inc = (u32)wave_incl_scan_add((int)c);
+            slice[2 * (it * 64 + lane) + 1] = (base + inc - c) | (h & 0x80000000u);
             base += (u32)__builtin_amdgcn_readlane((int)inc, 63);
         }
+        if (tid == 0) { tab[2 * NWD + 1] = nA; tab[2 * NWD + 3] = nA; } // sentinel words: where the last word's keys end
     }
     __syncthreads();
+    // scatter: a key's bucket owns the slots [lo, hi) (an overfull word: the word's slots); the first empty one is claimed
     for_ref([&](KeyT k) {
-        const u32 pos = (atomicSub(&tab[ocr_bucket(R, k)], 1u) & 0xFFFFu) - 1u;
-        A[pos] = k;
+        const u32 b = ocr_bucket(R, k), W = b >> 4, sh = (b & 15u) << 1;
+        const u32 w = tab[2 * W], h = tab[2 * W + 1];
+        u32 lo, hi;
+        if (h >> 31) { lo = h & 0xFFFFu; hi = tab[2 * W + 3] & 0xFFFFu; }
+        else { lo = h + ocr_below(w, sh); hi = lo + ((w >> sh) & 3u); }
+        if (k != MAXK) // (a key equal to the empty marker is in place already)
+            for (u32 t = lo; t < hi; ++t)
+                if (atomicCAS(&A[t], MAXK, k) == MAXK) break;
     });
-    if (tid < 4) A[nA + tid] = MAXK;
     __syncthreads();
     u64 T_A = 0; // ties among the reference's non-zero keys: sum over keys of (run length^2 - 1)
     {
         u64 ta = 0;
         for (u32 i = tid; i < nA; i += NT) {
-            const KeyT q = A[i];
-            const u32 e = tab[ocr_bucket(R, q)];
-            const u64 a = ocr_count_eq(R, q, ocr_lo(e), ocr_hi(e));
-            ta += a * a - 1ull;
+            u32 l, a;
+            ocr_find_exact(R, A[i], l, a);
+            ta += (u64)a * a - 1ull;
         }
         ta = wave_sum(ta);
         if (lane == 0) s_red[wave] = ta;
@@ -485,6 +559,9 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     // ---- every other group: one wavefront each, 64 groups per output block ----
     u32 *bloom = bloom_all + wave * OCR_BLOOM_WORDS;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#ifdef OCR_X_BUILDONLY
+    if (T_A != 12345ull) return;
+#endif
     for (int g0 = wave * 64; g0 < G; g0 += NW * 64) {
         const int gl = g0 + lane;
         const bool has = gl < G && gl != ref;

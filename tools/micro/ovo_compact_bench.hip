@@ -28,8 +28,15 @@ __global__ void k_fill(float *X, int N, int M, int mode) {
     const int r = (int)(i / M), c = (int)(i % M);
     const u32 h1 = mix(r, c), h2 = mix(c * 7919u + 1u, r), h3 = mix(r * 31u + 7u, c + 12345u);
     const float mean = 0.1f + 14.9f * (float)(mix(c, 0xABCDu) >> 8) / 16777216.0f;
-    const float u1 = ((float)(h1 >> 8) + 0.5f) / 16777216.0f;
-    const float cnt = floorf(-mean * logf(u1));
+    // Poisson(mean) by multiplication of uniforms (Knuth), as bench.py's torch.poisson
+    const float L = expf(-mean);
+    float pr = 1.0f, cnt = -1.0f;
+    u32 hs = h1;
+    do {
+        hs = mix(hs, 0x51ED27u + (u32)cnt);
+        pr *= ((float)(hs >> 8) + 0.5f) / 16777216.0f;
+        cnt += 1.0f;
+    } while (pr > L);
     const bool keep = (h2 & 1u) != 0;
     const float u = 0.5f + (float)(h3 >> 8) / 16777216.0f;
     float v = mode == 0 ? log1pf(cnt * u) : cnt;
@@ -50,7 +57,7 @@ int main(int argc, char **argv) {
     const int N = 300000, G = 2000, n_ref = 10000;
     const int M = argc > 1 ? atoi(argv[1]) : 2048;
     const int mode = argc > 2 ? atoi(argv[2]) : 0;
-    const int nbk_lg = argc > 3 ? atoi(argv[3]) : 14;
+    const int nbk_lg = argc > 3 ? atoi(argv[3]) : 17;
     float *X; CK(hipMalloc(&X, (size_t)N * M * 4));
     k_fill<<<(unsigned)(((long long)N * M + 255) / 256), 256>>>(X, N, M, mode);
     // groups
