@@ -83,6 +83,9 @@ struct illico_ctx {
     int *d_codes = nullptr;       // [N] group code of each cell
     int *d_perm = nullptr;        // [N] cell index at group-contiguous position p
     int *d_posptr = nullptr;      // [G+1]
+    int *d_pk_blk = nullptr;      // packed dense layout (kernels_ovo_compact.h): [pk_nblk+1] first group of each block, then [pk_nblk] first key slot
+    int pk_nblk = 0, pk_ref_out = 0;
+    int64_t pk_stride = 0;        // keys per gene in the packed layout
     int *d_counts = nullptr;      // [G]
     int *d_code_by_pos = nullptr; // [N] group code at position p
     u32 *d_hist_off = nullptr;    // [G+1] OVR one-pass histograms: words per lane before group g (16 per group of <= 255 cells, else 32)
@@ -254,7 +257,7 @@ int illico_ctx_create(int device_id, illico_ctx **out_ctx) {
 }
 
 static void free_groups(illico_ctx *c) {
-    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos}) {
+    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos, &c->d_pk_blk}) {
         if (*p) hipFree(*p);
         *p = nullptr;
     }
@@ -424,6 +427,30 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
         HIPCHK(c, hipMemcpy(c->d_hist_off, ho.data(), ho.size() * sizeof(u32), hipMemcpyHostToDevice));
         c->hist_words = ho[n_groups];
     }
+    c->pk_nblk = 0;
+    if (ref >= 0) { // blocks of the packed dense layout: consecutive groups (never the reference) of >= GCMP_BLOCK_ROWS rows together
+        std::vector<int> g0, g1, out;
+        int64_t pos = 0, rows = 0;
+        bool open = false;
+        auto close = [&](int64_t end) { g1.push_back((int)end); pos += (rows + 63) & ~63ll; open = false; };
+        for (int64_t g = 0; g < n_groups; ++g) {
+            if (g == ref) { if (open) close(g); continue; }
+            if (!open) { g0.push_back((int)g); out.push_back((int)pos); rows = 0; open = true; }
+            rows += counts[g];
+            if (rows >= GCMP_BLOCK_ROWS) close(g + 1);
+        }
+        if (open) close(n_groups);
+        std::vector<int> packed;
+        packed.insert(packed.end(), g0.begin(), g0.end());
+        packed.insert(packed.end(), g1.begin(), g1.end());
+        packed.insert(packed.end(), out.begin(), out.end());
+        if (packed.empty()) packed.push_back(0);
+        c->pk_nblk = (int)g0.size();
+        c->pk_ref_out = (int)pos;
+        c->pk_stride = pos + ((counts[ref] + 63) & ~63ll) + 64;
+        HIPCHK(c, hipMalloc((void **)&c->d_pk_blk, packed.size() * sizeof(int)));
+        HIPCHK(c, hipMemcpy(c->d_pk_blk, packed.data(), packed.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     if (n_groups <= 65535) {
         std::vector<u16> c16(codes.begin(), codes.end());
         HIPCHK(c, hipMalloc((void **)&c->d_codes16, c16.size() * sizeof(u16)));
@@ -588,26 +615,30 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
     if ((rc = get_scratch(c, "packed_nnz", (size_t)nb * G * 2 + (size_t)nb * nseg * 2 + 64, &v))) return rc;
     u16 *nnz = (u16 *)v;
     u16 *seg_nnz = nnz + (((size_t)nb * G + 7) & ~(size_t)7);
-    if ((rc = get_scratch(c, "packed_seg_sum", (size_t)nb * nseg * 8 + (size_t)nb * 4, &v))) return rc;
+    if ((rc = get_scratch(c, "packed_seg_sum", (size_t)nb * nseg * 8 + (size_t)nb * 4 + (size_t)nb * G * 4, &v))) return rc;
     double *seg_sum = (double *)v;
     u32 *route = (u32 *)(seg_sum + (size_t)nb * nseg);
+    u32 *gofs = route + nb;
     HIPCHK(c, hipMemsetAsync(route, 0, (size_t)nb * 4, c->stream));
     const int is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
     {
         GroupCompactParams Q;
         Q.X = X; Q.ld = ld; Q.col0 = col0; Q.ncols = nb; Q.perm = c->d_perm; Q.pos_ptr = c->d_posptr; Q.G = G; Q.ref = ref; Q.nseg = nseg;
-        Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.out_sum = ssum; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum; Q.is_log1p = is_log1p;
+        Q.blk_g0 = c->d_pk_blk; Q.blk_g1 = c->d_pk_blk + c->pk_nblk; Q.blk_out = c->d_pk_blk + 2 * c->pk_nblk; Q.nblk = c->pk_nblk; Q.ref_out = c->pk_ref_out;
+        Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.gofs = gofs; Q.out_sum = ssum; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum;
         constexpr int VEC = 16 / (int)sizeof(InT);
         const bool aligned = ((uintptr_t)X % 16 == 0) && (ld % VEC == 0) && (col0 % VEC == 0);
-        const dim3 grid(((nseg + 7) & ~7) + gcmp_slots(G), (nb + 63) / 64);
+        const dim3 grid(((nseg + 7) & ~7) + c->pk_nblk, (nb + 63) / 64);
         ProfScope ps(c, KID_GROUP_COMPACT);
-        if (aligned) hipLaunchKernelGGL((k_group_compact<InT, KeyT, true>), grid, dim3(GCMP_NT), 0, c->stream, Q);
-        else hipLaunchKernelGGL((k_group_compact<InT, KeyT, false>), grid, dim3(GCMP_NT), 0, c->stream, Q);
+        if (aligned && !is_log1p) hipLaunchKernelGGL((k_group_compact<InT, KeyT, true, false>), grid, dim3(GCMP_NT), 0, c->stream, Q);
+        else if (aligned) hipLaunchKernelGGL((k_group_compact<InT, KeyT, true, true>), grid, dim3(GCMP_NT), 0, c->stream, Q);
+        else if (!is_log1p) hipLaunchKernelGGL((k_group_compact<InT, KeyT, false, false>), grid, dim3(GCMP_NT), 0, c->stream, Q);
+        else hipLaunchKernelGGL((k_group_compact<InT, KeyT, false, true>), grid, dim3(GCMP_NT), 0, c->stream, Q);
         HIPCHK(c, hipGetLastError());
     }
     {
         OvoCompactParams C;
-        C.Xs = Xt; C.gene_stride = stride; C.pos_ptr = c->d_posptr; C.counts = c->d_counts; C.nnz = nnz; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum;
+        C.Xs = Xt; C.gene_stride = stride; C.counts = c->d_counts; C.nnz = nnz; C.gofs = gofs; C.ref_out = c->pk_ref_out; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum;
         C.out_sum = ssum; C.G = G; C.ref = ref; C.n_genes = nb; C.nseg = nseg; C.ref_cap = (int)n_ref; C.nbk_lg = packed_nbk_lg<KeyT>(n_ref);
         C.out_2u = s2u; C.out_tie = stie; C.route = route;
         const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
@@ -622,7 +653,7 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
     OvoParams P;
     P.Xs = Xt; P.gene_stride = stride; P.pos_ptr = c->d_posptr; P.seg_ptr = nullptr; P.counts = c->d_counts;
     P.G = G; P.ref = ref; P.n_genes = nb; P.dt = dtype; P.is_log1p = is_log1p;
-    P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = nullptr; P.nnz = nnz; P.only = route;
+    P.ref_cap = 0; P.out_2u = s2u; P.out_tie = stie; P.out_sum = nullptr; P.nnz = nnz; P.gofs = gofs; P.only = route;
     return launch_ovo<KeyT>(c, P, n_ref, c->max_nonref, nullptr, nullptr, false);
 }
 
@@ -1012,7 +1043,10 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
     const int G = (int)c->n_groups;
     const bool ovr = c->ref < 0;
     const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
-    const int64_t stride = (N + 63) & ~63ll;
+    // dense OVO: group-wise packing + look-ups (kernels_ovo_compact.h) whenever the sizes allow; it has no histogram side path
+    // (count-valued genes reach this function only when the fused route is off) and holds ties exactly
+    const bool packed = !ovr && packed_route_fits<KeyT>(c);
+    const int64_t stride = packed ? c->pk_stride : ((N + 63) & ~63ll);
     int rc;
     void *v;
     // Flagged genes scattered through the window would make one tiny launch sequence each: runs closer than 32 genes
@@ -1045,9 +1079,6 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
     u64 *stie = (u64 *)(s2u + (size_t)nb_max * G);
     double *ssum = (double *)(stie + (size_t)nb_max * G);
     double *gtot = ssum + (size_t)nb_max * G;
-    // dense OVO: group-wise packing + look-ups (kernels_ovo_compact.h) whenever the sizes allow; it has no histogram side path
-    // (count-valued genes reach this function only when the fused route is off) and holds ties exactly
-    const bool packed = !ovr && packed_route_fits<KeyT>(c);
     u32 *gflags = nullptr;
     if (counts_path_allowed(c, flags) && !packed) {
         if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;

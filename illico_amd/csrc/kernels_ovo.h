@@ -131,9 +131,10 @@ struct OvoParams {
     long long *out_2u;       // [n_genes][G]  2*U (U of the reference sample, as scipy's mannwhitneyu(ref, grp))
     u64 *out_tie;            // [n_genes][G]  sum_v (t^3 - t)
     double *out_sum;         // [n_genes][G]  sum of values (expm1'd if is_log1p)
-    // packed dense layout (kernels_ovo_compact.h): group g's NON-ZERO keys at gene * gene_stride + pos_ptr[g], nnz[gene][g] of them
-    // (the reference's entry included); zeros are implicit, as in the sparse layout.  only: genes to process (flag 1), or null.
+    // packed dense layout (kernels_ovo_compact.h): group g's NON-ZERO keys at gene * gene_stride + gofs[gene][g], nnz[gene][g] of
+    // them (the reference's entries included); zeros are implicit, as in the sparse layout.  only: genes to process (flag 1), or null.
     const u16 *nnz = nullptr;
+    const u32 *gofs = nullptr;
     const u32 *only = nullptr;
 };
 
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
             rstart = sp[ref];
             nA = sp[ref + 1] - sp[ref];
         } else {
-            rstart = (long long)gene * P.gene_stride + P.pos_ptr[ref];
+            rstart = (long long)gene * P.gene_stride + (P.nnz ? (long long)P.gofs[(size_t)gene * G + ref] : (long long)P.pos_ptr[ref]);
             nA = P.nnz ? (u32)P.nnz[(size_t)gene * G + ref] : (u32)n_ref;
         }
         const u32 zA_impl = (u32)n_ref - nA; // implicit zeros of the reference (sparse layout)
@@ -711,7 +712,8 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
                     const int n_g = P.counts[g];
                     long long bstart;
                     if (sp) { bstart = sp[g]; nB_n = (int)(sp[g + 1] - sp[g]); }
-                    else { bstart = (long long)gene * P.gene_stride + P.pos_ptr[g]; nB_n = P.nnz ? (int)P.nnz[(size_t)gene * G + g] : n_g; }
+                    else if (P.nnz) { bstart = (long long)gene * P.gene_stride + P.gofs[(size_t)gene * G + g]; nB_n = (int)P.nnz[(size_t)gene * G + g]; }
+                    else { bstart = (long long)gene * P.gene_stride + P.pos_ptr[g]; nB_n = n_g; }
                     zB_n = n_g - nB_n;
                     const KeyT *seg = Xs + bstart;
 #pragma unroll

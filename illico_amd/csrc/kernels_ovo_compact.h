@@ -23,36 +23,37 @@
 #pragma once
 #include "common.h"
 
-#define GCMP_NT 256
+#define GCMP_NT 512
 #define OCR_NT 1024
 #define OCR_KMAX 4          // 64-key rounds per group: groups of up to 256 non-zero keys
 #define OCR_BLOOM_WORDS 256 // per wavefront: 8192 bits
 
-// Workgroup -> group, so that the workgroups one XCD receives (every 8th) cover runs of 32 consecutive groups: the
-// per-(gene, group) words written at the end (2-byte counts, 8-byte sums; consecutive groups are adjacent) then fill
-// whole 64-byte / 256-byte pieces inside ONE L2 instead of an eighth of them in each.
-__device__ __forceinline__ int gcmp_slot_group(int bx) {
-    const int xcd = bx & 7, i = bx >> 3;
-    return (((i >> 5) * 8 + xcd) << 5) + (i & 31);
-}
-static inline int gcmp_slots(int G) { return (G + 255) / 256 * 256; }
-#define GCMP_SEG_ROWS 512 // the reference group is packed in independent segments of this many rows (one workgroup each)
+#define GCMP_SEG_ROWS 512    // the reference group is packed in independent segments of this many rows (one workgroup each)
+#define GCMP_BLOCK_ROWS 1024 // other groups: consecutive groups of at least this many rows together share one workgroup
 static inline int gcmp_ref_segments(long long n_ref) { return (int)((n_ref + GCMP_SEG_ROWS - 1) / GCMP_SEG_ROWS); }
 
+// Packed key layout of one gene (pk_stride keys): [block 0 | block 1 | ... | reference segments].  A block = consecutive groups
+// (never the reference); its region starts at a multiple of 64 keys and holds the groups' non-zero keys back to back, group
+// after group: one workgroup writes them front to back, so its stores of successive 64-row chunks land next to each other
+// and meet in L2 as whole lines.  gofs[gene][g] = where group g's keys start, nnz[gene][g] = how many.
 struct GroupCompactParams {
     const void *X;          // row-major [N, ld]
     long long ld, col0;
     int ncols;
     const int *perm;        // cells in group-contiguous order (GroupContainer.indices)
     const int *pos_ptr;     // [G+1] first position of each group in that order
-    int G, ref, nseg;       // ref: reference group (-1: none); nseg = gcmp_ref_segments(its size); grid.x = pad8(nseg) + gcmp_slots(G)
-    void *Xt;               // keys, gene-major, xt_stride keys per gene; group g's non-zeros at pos_ptr[g] ...
+    const int *blk_g0;      // [nblk] first group of each block (blocks never contain the reference)
+    const int *blk_g1;      // [nblk] one past its last group
+    const int *blk_out;     // [nblk] first key slot of each block
+    int G, ref, nseg, nblk; // nseg = gcmp_ref_segments(reference size); grid.x = pad8(nseg) + nblk
+    int ref_out;            // first key slot of the reference's segments (segment s at ref_out + s * GCMP_SEG_ROWS)
+    void *Xt;               // keys, gene-major, xt_stride keys per gene
     long long xt_stride;
     u16 *nnz;               // [ncols][G] non-zero keys per (gene, group); the reference's entry is not written
-    double *out_sum;        // [ncols][G] value sums (expm1'd if is_log1p); the reference's entry is not written
-    u16 *seg_nnz;           // [ncols][nseg] non-zero keys per segment of the reference (segment s at pos_ptr[ref] + s * GCMP_SEG_ROWS)
+    u32 *gofs;              // [ncols][G] first key slot of (gene, group); the reference's entry is not written
+    double *out_sum;        // [ncols][G] value sums (expm1'd if LOG1P); the reference's entry is not written
+    u16 *seg_nnz;           // [ncols][nseg] non-zero keys per segment of the reference
     double *seg_sum;        // [ncols][nseg]
-    int is_log1p;
 };
 
 template <typename InT> __device__ __forceinline__ double gcmp_value(InT v, int is_log1p);
@@ -61,12 +62,13 @@ template <> __device__ __forceinline__ double gcmp_value<double>(double v, int i
 template <> __device__ __forceinline__ double gcmp_value<int32_t>(int32_t v, int is_log1p) { return is_log1p ? expm1((double)v) : (double)v; }
 template <> __device__ __forceinline__ double gcmp_value<int64_t>(int64_t v, int is_log1p) { return is_log1p ? expm1((double)v) : (double)v; }
 
-// One workgroup: the rows [row0, row0 + n) of the group-contiguous order (one group, or one segment of the reference) x 64 genes.
-// Per 64-row chunk: thread (q, r0) loads VEC genes of rows r0, r0 + RPI, ...; keys go through a gene-major LDS tile; wavefront w
-// then packs genes 16 w ... 16 w + 15: lanes = rows, ballot -> consecutive output slots.  The next chunk's rows (and the row
-// indices of the chunk after it) are in flight meanwhile.  Value sums: per-thread partials over the thread's own loads,
-// combined through LDS in a fixed order at the end.
-template <typename InT, typename KeyT, bool VECLOAD>
+// One workgroup: one block of groups (or one segment of the reference) x 64 genes.  The block's rows go by in 64-row chunks,
+// group after group (a group's last chunk is padded with zero rows): thread (q, r0) loads VEC genes of rows r0, r0 + RPI, ...;
+// keys go through a gene-major LDS tile; wavefront w then packs genes 16 w ... 16 w + 15: lanes = rows, ballot -> consecutive
+// output slots after the keys already written.  The next chunk's rows (and the row indices of the chunk after it) are in
+// flight meanwhile, across group boundaries.  Value sums: per-thread partials over the thread's own loads, combined through LDS
+// in a fixed order at each group's end.
+template <typename InT, typename KeyT, bool VECLOAD, bool LOG1P>
 __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P) {
     constexpr int VEC = 16 / (int)sizeof(InT);
     constexpr int LPR = 64 / VEC;      // lanes per 64-gene row segment
@@ -78,38 +80,63 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
     static_assert(sizeof(tile) >= sizeof(double) * RPI * 64, "the tile doubles as the sum scratch");
 
     const int nseg_pad = (P.nseg + 7) & ~7;
-    int g, row0, n, seg = -1;
+    int gA, gB, out0, seg = -1, seg_row0 = 0, seg_n = 0;
     if ((int)blockIdx.x < nseg_pad) {
         seg = blockIdx.x;
         if (seg >= P.nseg) return;
-        g = P.ref;
-        row0 = P.pos_ptr[g] + seg * GCMP_SEG_ROWS;
-        n = min(GCMP_SEG_ROWS, P.pos_ptr[g + 1] - row0);
+        gA = P.ref; gB = P.ref + 1;
+        seg_row0 = P.pos_ptr[P.ref] + seg * GCMP_SEG_ROWS;
+        seg_n = min(GCMP_SEG_ROWS, P.pos_ptr[P.ref + 1] - seg_row0);
+        out0 = P.ref_out + seg * GCMP_SEG_ROWS;
     } else {
-        g = gcmp_slot_group((int)blockIdx.x - nseg_pad);
-        if (g >= P.G || g == P.ref) return;
-        row0 = P.pos_ptr[g];
-        n = P.pos_ptr[g + 1] - row0;
+        const int b = (int)blockIdx.x - nseg_pad;
+        gA = P.blk_g0[b]; gB = P.blk_g1[b];
+        out0 = P.blk_out[b];
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c0 = blockIdx.y * 64;
     const int q = tid % LPR, r0 = tid / LPR;
     const InT *X = (const InT *)P.X;
     KeyT *Xt = (KeyT *)P.Xt;
     const int cq = c0 + q * VEC;
     const bool colv = cq + VEC <= P.ncols;
-    const int nchunks = (n + 63) >> 6;
+    const int geneW = c0 + wave * (64 / (GCMP_NT / 64)) + lane; // lanes 0..GPW-1: the gene whose counts this lane keeps
 
-    int rows[NLD]; // row indices of the chunk after the one whose loads are in flight
-    InV nxt[NLD];
-    auto load_rows = [&](int c) {
+    // chunk cursors (uniform scalars): group, chunk inside it, the group's rows and first position -- one for the loads being
+    // issued (i*), one for the chunk being packed (c*)
+    auto grp_rows = [&](int g, int &n, int &row0) {
+        if (g >= gB) { n = 0; row0 = 0; }
+        else if (seg >= 0) { row0 = seg_row0; n = seg_n; }
+        else { row0 = P.pos_ptr[g]; n = P.pos_ptr[g + 1] - row0; }
+    };
+#define GCMP_CUR_SKIP(g, c, n, row0) while (g < gB && n == 0) { ++g; c = 0; grp_rows(g, n, row0); }
+#define GCMP_CUR_NEXT(g, c, n, row0) { ++c; if (c * 64 >= n) { ++g; c = 0; grp_rows(g, n, row0); GCMP_CUR_SKIP(g, c, n, row0) } }
+    if (seg < 0) { // groups without cells have no chunk: their outputs here
+        for (int g = gA; g < gB; ++g)
+            if (P.pos_ptr[g + 1] == P.pos_ptr[g] && tid < 64 && c0 + tid < P.ncols) {
+                P.nnz[(size_t)(c0 + tid) * P.G + g] = 0;
+                P.gofs[(size_t)(c0 + tid) * P.G + g] = (u32)out0;
+                P.out_sum[(size_t)(c0 + tid) * P.G + g] = 0.0;
+            }
+    }
+
+    // staging of packed keys (4-byte keys): per gene a 128-key ring piece in LDS; whenever 64 keys are there, one 256-byte
+    // aligned store of full lines goes out.  (Pieces of a line written one store at a time make the L2 fetch the line first.)
+    constexpr bool STAGE = sizeof(KeyT) == 4;
+    constexpr int NWV = GCMP_NT / 64, GPW = 64 / NWV; // wavefronts, genes packed by each
+    __shared__ KeyT stage[STAGE ? NWV * GPW * 128 : 1];
+    KeyT *st = stage + (STAGE ? wave * GPW * 128 : 0);
+
+    int rows[NLD]; // row indices of the next chunk to load
+    InV bufA[NLD], bufB[NLD];
+    auto load_rows = [&](int c, int n, int row0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int p = c * 64 + r0 + i * RPI;
             rows[i] = p < n ? P.perm[row0 + p] : -1;
         }
     };
-    auto load_chunk = [&]() { // from rows[]
+    auto load_chunk = [&](InV (&buf)[NLD]) { // from rows[]
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             InV v;
@@ -124,62 +151,103 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
                         if (cq + e < P.ncols) v[e] = src[e];
                 }
             }
-            nxt[i] = v;
+            buf[i] = v;
         }
     };
 
-    int cntv = 0;     // lane i < 16: non-zero keys written so far for gene 16 * wave + i
-    double sum[VEC];  // per-thread partial value sums of its VEC genes
+    int cntv = 0, gstartv = 0; // lane i < GPW: keys written so far for gene GPW * wave + i; ... when the current group began
+    double sum[VEC];           // per-thread partial value sums of its VEC genes, current group
 #pragma unroll
     for (int e = 0; e < VEC; ++e) sum[e] = 0.0;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (nchunks) { load_rows(0); load_chunk(); }
-    if (nchunks > 1) load_rows(1);
-    for (int c = 0; c < nchunks; ++c) {
+    int ig = gA, ic = 0, in_, irow0;
+    grp_rows(ig, in_, irow0);
+    GCMP_CUR_SKIP(ig, ic, in_, irow0)
+    int cg = ig, cc = 0, cn = in_, crow0 = irow0;
+    bool rows_ready = false;
+    // two chunks of rows in flight (bufA: the chunk packed next, bufB: the one after), row indices of a third
+    if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) load_chunk(bufA); }
+    if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) load_chunk(bufB); }
+    if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) rows_ready = true; }
+    auto step = [&](InV (&buf)[NLD]) { // pack the chunk in buf, then refill buf with the chunk rows[] describes
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int r = r0 + i * RPI;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const InT v = nxt[i][e];
+                const InT v = buf[i][e];
                 tile[q * VEC + e][r] = key_of(v);
-                sum[e] += gcmp_value<InT>(v, P.is_log1p); // rows past the end were loaded as zeros
+                sum[e] += gcmp_value<InT>(v, LOG1P ? 1 : 0); // rows past the group's end were loaded as zeros
             }
         }
-        if (c + 1 < nchunks) load_chunk();   // in flight while this chunk is packed
-        if (c + 2 < nchunks) load_rows(c + 2);
+        if (rows_ready) { load_chunk(buf); rows_ready = false; }
+        if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) rows_ready = true; }
         __syncthreads();
-        const int rem = n - c * 64; // rows of this chunk
 #pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int gi = wave * 16 + i;
+        for (int i = 0; i < GPW; ++i) {
+            const int gi = wave * GPW + i;
             const KeyT k = tile[gi][lane];
-            const bool nz = lane < rem && k != ZEROK;
+            const bool nz = k != ZEROK; // (rows past the group's end were loaded as zeros)
             const u64 m = __ballot(nz);
             const int ci = __builtin_amdgcn_readlane(cntv, i);
-            if (nz && c0 + gi < P.ncols) Xt[(long long)(c0 + gi) * P.xt_stride + row0 + ci + (int)__popcll(m & lt_mask)] = k;
-            cntv += lane == i ? (int)__popcll(m) : 0;
+            KeyT *dst = Xt + (long long)(c0 + gi) * P.xt_stride + out0; // uniform
+            const int pos = (int)__popcll(m & lt_mask), nk = (int)__popcll(m);
+            if constexpr (STAGE) {
+                const int fill = ci & 63; // out0 is a multiple of 64: the staged keys start a 256-byte piece
+                KeyT *sg = st + i * 128;
+                if (nz) sg[fill + pos] = k;
+                if (fill + nk >= 64) { // uniform
+                    wave_lds_fence();
+                    const KeyT full = sg[lane], over = sg[64 + lane];
+                    if (c0 + gi < P.ncols) dst[(ci - fill) + lane] = full;
+                    wave_lds_fence();
+                    if (lane < fill + nk - 64) sg[lane] = over;
+                }
+            } else {
+                if (nz && c0 + gi < P.ncols) dst[ci + pos] = k;
+            }
+            cntv += lane == i ? nk : 0;
         }
         __syncthreads();
-    }
-    // value sums: [RPI row slots][64 genes] partials -> 64 threads add them in row-slot order
-    double *part = (double *)&tile[0][0];
+        if ((cc + 1) * 64 >= cn) { // the group's last chunk: its sums ([RPI row slots][64 genes] partials, added in row-slot order), counts, start
+            double *part = (double *)&tile[0][0];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) part[r0 * 64 + q * VEC + e] = sum[e];
-    const int my_cnt = cntv;
-    __syncthreads();
-    if (tid < 64 && c0 + tid < P.ncols) {
-        double tot = 0.0;
+            for (int e = 0; e < VEC; ++e) { part[r0 * 64 + q * VEC + e] = sum[e]; sum[e] = 0.0; }
+            __syncthreads();
+            if (tid < 64 && c0 + tid < P.ncols) {
+                double tot = 0.0;
 #pragma unroll 4
-        for (int r = 0; r < RPI; ++r) tot += part[r * 64 + tid];
-        if (seg >= 0) P.seg_sum[(size_t)(c0 + tid) * P.nseg + seg] = tot;
-        else P.out_sum[(size_t)(c0 + tid) * P.G + g] = tot;
+                for (int r = 0; r < RPI; ++r) tot += part[r * 64 + tid];
+                if (seg >= 0) P.seg_sum[(size_t)(c0 + tid) * P.nseg + seg] = tot;
+                else P.out_sum[(size_t)(c0 + tid) * P.G + cg] = tot;
+            }
+            if (lane < GPW && geneW < P.ncols) {
+                if (seg >= 0) P.seg_nnz[(size_t)geneW * P.nseg + seg] = (u16)cntv;
+                else {
+                    P.nnz[(size_t)geneW * P.G + cg] = (u16)(cntv - gstartv);
+                    P.gofs[(size_t)geneW * P.G + cg] = (u32)(out0 + gstartv);
+                }
+            }
+            gstartv = cntv;
+            __syncthreads();
+        }
+        GCMP_CUR_NEXT(cg, cc, cn, crow0)
+    };
+    while (cg < gB) {
+        step(bufA);
+        if (cg < gB) step(bufB);
     }
-    const int gene = c0 + wave * 16 + lane;
-    if (lane < 16 && gene < P.ncols) {
-        if (seg >= 0) P.seg_nnz[(size_t)gene * P.nseg + seg] = (u16)my_cnt;
-        else P.nnz[(size_t)gene * P.G + g] = (u16)my_cnt;
+    if constexpr (STAGE) { // what is left in the staging pieces: one partial store per gene
+        wave_lds_fence();
+#pragma unroll 4
+        for (int i = 0; i < GPW; ++i) {
+            const int gi = wave * GPW + i;
+            const int ci = __builtin_amdgcn_readlane(cntv, i), fill = ci & 63;
+            if (lane < fill && c0 + gi < P.ncols) Xt[(long long)(c0 + gi) * P.xt_stride + out0 + (ci - fill) + lane] = st[i * 128 + lane];
+        }
     }
+#undef GCMP_CUR_SKIP
+#undef GCMP_CUR_NEXT
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -188,9 +256,10 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
 struct OvoCompactParams {
     void *Xs;                // packed keys (k_group_compact)
     long long gene_stride;
-    const int *pos_ptr;      // [G+1]
     const int *counts;       // [G]
     u16 *nnz;                // [n_genes][G]
+    u32 *gofs;               // [n_genes][G] first key slot of each group
+    int ref_out;             // first key slot of the reference's segments
     const u16 *seg_nnz;      // [n_genes][nseg] the reference's segments (k_group_compact)
     const double *seg_sum;   // [n_genes][nseg]
     double *out_sum;         // [n_genes][G]: the reference's entry is written here (sum of its segments, in order)
@@ -202,7 +271,7 @@ struct OvoCompactParams {
     u32 *route;              // [n_genes], zeroed by the host: set to 1 for the genes this kernel leaves to k_ovo_rank (packed
                              // mode): crowded value buckets (a tie-heavy column: it wants the sorted reference and the sort form
                              // of the group loop) or a group of more than 256 non-zeros.  For those the reference's segments are
-                             // moved together and nnz[gene][ref] is set.
+                             // moved together and nnz / gofs[gene][ref] are set.
 };
 // a gene leaves this kernel when one table word (16 buckets) holds more than OCR_MAX_WORD reference keys, or when more than an
 // eighth of the reference's keys sit in words with an overfull bucket
@@ -416,7 +485,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     const int n_ref = P.counts[ref];
     u16 *nnz = P.nnz + (size_t)gene * G;
     KeyT *Xg = (KeyT *)P.Xs + (long long)gene * P.gene_stride;
-    KeyT *src = Xg + P.pos_ptr[ref];
+    KeyT *src = Xg + P.ref_out;
     const u16 *seg_nnz = P.seg_nnz + (size_t)gene * P.nseg;
     // the reference's non-zero keys lie in nseg packed segments: wavefront w walks segments w, w + NW, ...
     auto for_ref = [&](auto f) {
@@ -516,7 +585,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
                 if ((u32)tid < c) src[dst + tid] = k;
                 dst += c;
             }
-            if (tid == 0) { nnz[ref] = (u16)nA; P.route[gene] = 1u; }
+            if (tid == 0) { nnz[ref] = (u16)nA; P.gofs[(size_t)gene * G + ref] = (u32)P.ref_out; P.route[gene] = 1u; }
             return;
         }
         u32 base = 0;
@@ -566,7 +635,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         const int gl = g0 + lane;
         const bool has = gl < G && gl != ref;
         const u32 my_n = has ? (u32)nnz[gl] : 0u;
-        const int my_pos = gl < G ? P.pos_ptr[gl] : 0;
+        const int my_pos = has ? (int)P.gofs[(size_t)gene * G + gl] : 0;
         TrReduce<u32> rS2;
         u64 tt_out = 0;   // lane j: sum t (t + 1) over group g0 + j's keys (non-zero only where keys tie)
         u32 neg_out = 0;  // lane j: group g0 + j's keys below zero

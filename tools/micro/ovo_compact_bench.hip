@@ -75,7 +75,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(d_perm, perm.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_pos, pos.data(), (G + 1) * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_counts, counts.data(), G * 4, hipMemcpyHostToDevice));
-    const long long stride = (N + 63) & ~63ll;
+    const long long stride = ((N + 63) & ~63ll) + 64 * 400;
     u32 *Xt; CK(hipMalloc(&Xt, (size_t)M * stride * 4));
     long long *s2u[2]; u64 *stie[2]; double *ssum[2];
     for (int v = 0; v < 2; ++v) {
@@ -110,11 +110,28 @@ int main(int argc, char **argv) {
     const int nseg = gcmp_ref_segments(n_ref);
     u16 *seg_nnz; double *seg_sum; CK(hipMalloc(&seg_nnz, (size_t)M * nseg * 2)); CK(hipMalloc(&seg_sum, (size_t)M * nseg * 8));
     u32 *route; CK(hipMalloc(&route, M * 4)); CK(hipMemset(route, 0, M * 4));
+    // blocks of the packed layout (as illico_set_groups builds them)
+    std::vector<int> bg0, bg1, bout;
+    long long ppos = 0, prow = 0; bool open = false;
+    auto close = [&](int end) { bg1.push_back(end); ppos += (prow + 63) & ~63ll; open = false; };
+    for (int g = 0; g < G; ++g) {
+        if (g == 0) { if (open) close(g); continue; }
+        if (!open) { bg0.push_back(g); bout.push_back((int)ppos); prow = 0; open = true; }
+        prow += counts[g];
+        if (prow >= GCMP_BLOCK_ROWS) close(g + 1);
+    }
+    if (open) close(G);
+    const int nblk = (int)bg0.size(), ref_out = (int)ppos;
+    const long long pk_stride = ppos + ((n_ref + 63) & ~63) + 64;
+    if (pk_stride > stride) { printf("packed stride %lld > %lld\n", pk_stride, stride); return 1; }
+    std::vector<int> pk; pk.insert(pk.end(), bg0.begin(), bg0.end()); pk.insert(pk.end(), bg1.begin(), bg1.end()); pk.insert(pk.end(), bout.begin(), bout.end());
+    int *d_pk; CK(hipMalloc(&d_pk, pk.size() * 4)); CK(hipMemcpy(d_pk, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    u32 *gofs; CK(hipMalloc(&gofs, (size_t)M * G * 4));
+    printf("packed layout: %d blocks, stride %lld (dense %lld)\n", nblk, pk_stride, stride);
     GroupCompactParams Q;
-    Q.X = X; Q.ld = M; Q.col0 = 0; Q.ncols = M; Q.perm = d_perm; Q.pos_ptr = d_pos; Q.G = G; Q.ref = 0; Q.nseg = nseg; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum; Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.out_sum = ssum[1];
-    Q.is_log1p = 0;
+    Q.X = X; Q.ld = M; Q.col0 = 0; Q.ncols = M; Q.perm = d_perm; Q.pos_ptr = d_pos; Q.G = G; Q.ref = 0; Q.nseg = nseg; Q.blk_g0 = d_pk; Q.blk_g1 = d_pk + nblk; Q.blk_out = d_pk + 2 * nblk; Q.nblk = nblk; Q.ref_out = ref_out; Q.gofs = gofs; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum; Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.out_sum = ssum[1];
     OvoCompactParams C;
-    C.Xs = Xt; C.gene_stride = stride; C.pos_ptr = d_pos; C.counts = d_counts; C.nnz = nnz; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum; C.out_sum = ssum[1]; C.nseg = nseg; C.G = G; C.ref = 0; C.n_genes = M; C.ref_cap = n_ref; C.nbk_lg = nbk_lg;
+    C.Xs = Xt; C.gene_stride = stride; C.counts = d_counts; C.nnz = nnz; C.gofs = gofs; C.ref_out = ref_out; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum; C.out_sum = ssum[1]; C.nseg = nseg; C.G = G; C.ref = 0; C.n_genes = M; C.ref_cap = n_ref; C.nbk_lg = nbk_lg;
     C.out_2u = s2u[1]; C.out_tie = stie[1]; C.route = route;
     const size_t lds_new = ocr_lds_bytes(n_ref, nbk_lg, 4);
     auto knew = k_ovo_rank_compact<u32>;
@@ -122,13 +139,13 @@ int main(int argc, char **argv) {
     printf("LDS: old %zu B, packed %zu B\n", lds_old, lds_new);
     auto run_new = [&]() {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_group_compact<float, u32, true>), dim3(((nseg + 7) & ~7) + gcmp_slots(G), (M + 63) / 64), dim3(GCMP_NT), 0, 0, Q);
+        hipLaunchKernelGGL((k_group_compact<float, u32, true, false>), dim3(((nseg + 7) & ~7) + nblk, (M + 63) / 64), dim3(GCMP_NT), 0, 0, Q);
         hipEventRecord(e1);
         hipMemsetAsync(route, 0, M * 4, 0);
         hipLaunchKernelGGL(knew, dim3(M), dim3(OCR_NT), lds_new, 0, C);
         {
             OvoParams P2 = P;
-            P2.out_2u = s2u[1]; P2.out_tie = stie[1]; P2.out_sum = nullptr; P2.nnz = nnz; P2.only = route;
+            P2.out_2u = s2u[1]; P2.out_tie = stie[1]; P2.out_sum = nullptr; P2.nnz = nnz; P2.gofs = gofs; P2.only = route;
             hipLaunchKernelGGL(kold, dim3(M), dim3(512), lds_old, 0, P2, (const u32 *)nullptr);
         }
         hipEventRecord(e2);
