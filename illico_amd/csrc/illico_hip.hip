@@ -85,7 +85,9 @@ struct illico_ctx {
     int *d_posptr = nullptr;      // [G+1]
     int *d_pk_blk = nullptr;      // packed dense layout (kernels_ovo_compact.h): [pk_nblk+1] first group of each block, then [pk_nblk] first key slot
     int pk_nblk = 0, pk_ref_out = 0;
+    int *d_pk_code = nullptr;     // padded dense layout (dense OVR): group code of every key slot (holes: 0, they hold zero keys)
     int64_t pk_stride = 0;        // keys per gene in the packed layout
+    int64_t pk_len = 0;           // ... of which the blocks take the first pk_len (the padded dense layout's row length)
     int *d_counts = nullptr;      // [G]
     int *d_code_by_pos = nullptr; // [N] group code at position p
     u32 *d_hist_off = nullptr;    // [G+1] OVR one-pass histograms: words per lane before group g (16 per group of <= 255 cells, else 32)
@@ -257,7 +259,7 @@ int illico_ctx_create(int device_id, illico_ctx **out_ctx) {
 }
 
 static void free_groups(illico_ctx *c) {
-    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos, &c->d_pk_blk}) {
+    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos, &c->d_pk_blk, &c->d_pk_code}) {
         if (*p) hipFree(*p);
         *p = nullptr;
     }
@@ -428,7 +430,7 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
         c->hist_words = ho[n_groups];
     }
     c->pk_nblk = 0;
-    if (ref >= 0) { // blocks of the packed dense layout: consecutive groups (never the reference) of >= GCMP_BLOCK_ROWS rows together
+    { // blocks of the packed / padded dense layouts: consecutive groups (never the reference) of >= GCMP_BLOCK_ROWS rows together
         std::vector<int> g0, g1, out;
         int64_t pos = 0, rows = 0;
         bool open = false;
@@ -447,9 +449,20 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
         if (packed.empty()) packed.push_back(0);
         c->pk_nblk = (int)g0.size();
         c->pk_ref_out = (int)pos;
-        c->pk_stride = pos + ((counts[ref] + 63) & ~63ll) + 64;
+        c->pk_len = pos;
+        c->pk_stride = pos + (ref >= 0 ? ((counts[ref] + 63) & ~63ll) : 0) + 64;
         HIPCHK(c, hipMalloc((void **)&c->d_pk_blk, packed.size() * sizeof(int)));
         HIPCHK(c, hipMemcpy(c->d_pk_blk, packed.data(), packed.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (ref < 0) { // dense OVR walks the padded rows: group code per key slot
+            std::vector<int> pc((size_t)c->pk_stride, 0);
+            for (size_t b = 0; b < g0.size(); ++b) {
+                int64_t o = out[b];
+                for (int g = g0[b]; g < g1[b]; ++g)
+                    for (int64_t k = 0; k < counts[g]; ++k) pc[(size_t)o++] = g;
+            }
+            HIPCHK(c, hipMalloc((void **)&c->d_pk_code, pc.size() * sizeof(int)));
+            HIPCHK(c, hipMemcpy(c->d_pk_code, pc.data(), pc.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
     }
     if (n_groups <= 65535) {
         std::vector<u16> c16(codes.begin(), codes.end());
@@ -604,6 +617,27 @@ template <typename KeyT> static bool packed_route_fits(const illico_ctx *c) {
     return n_ref >= 1 && n_ref <= 65535 && c->max_nonref <= 1024 && packed_nbk_lg<KeyT>(n_ref) > 0 && ovo_sort_route_fits<KeyT>(n_ref, c->max_nonref);
 }
 
+// k_group_compact over one gene batch; pack = false: the padded dense layout (every key kept, sums only)
+template <typename InT, typename KeyT>
+static int launch_group_compact(illico_ctx *c, GroupCompactParams Q, int nb, int flags, bool pack) {
+    constexpr int VEC = 16 / (int)sizeof(InT);
+    const bool aligned = ((uintptr_t)Q.X % 16 == 0) && (Q.ld % VEC == 0) && (Q.col0 % VEC == 0);
+    const bool lg = flags & ILLICO_FLAG_LOG1P;
+    const dim3 grid(((Q.nseg + 7) & ~7) + Q.nblk, (nb + 63) / 64);
+    ProfScope ps(c, KID_GROUP_COMPACT);
+#define GC_LAUNCH(V, L, K) hipLaunchKernelGGL((k_group_compact<InT, KeyT, V, L, K>), grid, dim3(GCMP_NT), 0, c->stream, Q)
+    if (pack) {
+        if (aligned && !lg) GC_LAUNCH(true, false, true); else if (aligned) GC_LAUNCH(true, true, true);
+        else if (!lg) GC_LAUNCH(false, false, true); else GC_LAUNCH(false, true, true);
+    } else {
+        if (aligned && !lg) GC_LAUNCH(true, false, false); else if (aligned) GC_LAUNCH(true, true, false);
+        else if (!lg) GC_LAUNCH(false, false, false); else GC_LAUNCH(false, true, false);
+    }
+#undef GC_LAUNCH
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+
 template <typename InT, typename KeyT>
 static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0, int nb, int N, KeyT *Xt, int64_t stride, int dtype, int flags,
                           long long *s2u, u64 *stie, double *ssum) {
@@ -626,15 +660,7 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         Q.X = X; Q.ld = ld; Q.col0 = col0; Q.ncols = nb; Q.perm = c->d_perm; Q.pos_ptr = c->d_posptr; Q.G = G; Q.ref = ref; Q.nseg = nseg;
         Q.blk_g0 = c->d_pk_blk; Q.blk_g1 = c->d_pk_blk + c->pk_nblk; Q.blk_out = c->d_pk_blk + 2 * c->pk_nblk; Q.nblk = c->pk_nblk; Q.ref_out = c->pk_ref_out;
         Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.gofs = gofs; Q.out_sum = ssum; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum;
-        constexpr int VEC = 16 / (int)sizeof(InT);
-        const bool aligned = ((uintptr_t)X % 16 == 0) && (ld % VEC == 0) && (col0 % VEC == 0);
-        const dim3 grid(((nseg + 7) & ~7) + c->pk_nblk, (nb + 63) / 64);
-        ProfScope ps(c, KID_GROUP_COMPACT);
-        if (aligned && !is_log1p) hipLaunchKernelGGL((k_group_compact<InT, KeyT, true, false>), grid, dim3(GCMP_NT), 0, c->stream, Q);
-        else if (aligned) hipLaunchKernelGGL((k_group_compact<InT, KeyT, true, true>), grid, dim3(GCMP_NT), 0, c->stream, Q);
-        else if (!is_log1p) hipLaunchKernelGGL((k_group_compact<InT, KeyT, false, false>), grid, dim3(GCMP_NT), 0, c->stream, Q);
-        else hipLaunchKernelGGL((k_group_compact<InT, KeyT, false, true>), grid, dim3(GCMP_NT), 0, c->stream, Q);
-        HIPCHK(c, hipGetLastError());
+        if ((rc = launch_group_compact<InT, KeyT>(c, Q, nb, flags, true))) return rc;
     }
     {
         OvoCompactParams C;
@@ -956,9 +982,9 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
 static void flagged_runs(const u32 *hf, int64_t wn, int64_t w0, std::vector<std::pair<int64_t, int64_t>> &runs) {
     // (1 = the gene left the fused route; 2 = taken by its second, wider pass: done)
     for (int64_t j = 0; j < wn;) {
-        if (hf[j] != 1u) { ++j; continue; }
+        if (hf[j] != 1u && hf[j] != 3u) { ++j; continue; } // (3: flagged by the probe as no count at all)
         int64_t e = j;
-        while (e < wn && hf[e] == 1u) ++e;
+        while (e < wn && (hf[e] == 1u || hf[e] == 3u)) ++e;
         if (!runs.empty() && runs.back().second == w0 + j) runs.back().second = w0 + e;
         else runs.push_back({w0 + j, w0 + e});
         j = e;
@@ -1046,7 +1072,9 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
     // dense OVO: group-wise packing + look-ups (kernels_ovo_compact.h) whenever the sizes allow; it has no histogram side path
     // (count-valued genes reach this function only when the fused route is off) and holds ties exactly
     const bool packed = !ovr && packed_route_fits<KeyT>(c);
-    const int64_t stride = packed ? c->pk_stride : ((N + 63) & ~63ll);
+    // dense OVR: the transposition with the group sums folded in (k_group_compact keeping every key: padded dense layout)
+    const bool padded = ovr && !c->no_packed_dense && c->pk_nblk > 0 && c->max_nonref <= 65535 && c->pk_stride < (1ll << 31);
+    const int64_t stride = (packed || padded) ? c->pk_stride : ((N + 63) & ~63ll);
     int rc;
     void *v;
     // Flagged genes scattered through the window would make one tiny launch sequence each: runs closer than 32 genes
@@ -1121,8 +1149,17 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
             continue;
         }
+        if (padded) {
+            GroupCompactParams Q;
+            memset(&Q, 0, sizeof Q);
+            Q.X = src; Q.ld = src_ld; Q.col0 = src_col0; Q.ncols = nb; Q.perm = c->d_perm; Q.pos_ptr = c->d_posptr; Q.G = G; Q.ref = -1; Q.nseg = 0;
+            Q.blk_g0 = c->d_pk_blk; Q.blk_g1 = c->d_pk_blk + c->pk_nblk; Q.blk_out = c->d_pk_blk + 2 * c->pk_nblk; Q.nblk = c->pk_nblk;
+            Q.Xt = Xt; Q.xt_stride = stride; Q.out_sum = ssum;
+            if ((rc = launch_group_compact<InT, KeyT>(c, Q, nb, flags, false))) return rc;
+        } else {
         if (gflags) HIPCHK(c, hipMemsetAsync(gflags, 0, (size_t)nb * 4, c->stream));
         if ((rc = launch_transpose<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, gflags))) return rc;
+        }
         if (!ovr) {
             OvoParams P;
             P.Xs = Xt; P.gene_stride = stride; P.pos_ptr = c->d_posptr; P.seg_ptr = nullptr; P.counts = c->d_counts;
@@ -1140,8 +1177,8 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
         } else {
             bool done = false;
-            if ((rc = run_ovr_dense_parts<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot, &done))) return rc;
-            if (!done && (rc = run_ovr_dense_batch<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot))) return rc;
+            if ((rc = run_ovr_dense_parts<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot, &done, padded))) return rc;
+            if (!done && (rc = run_ovr_dense_batch<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot, padded))) return rc;
             if (c->tap) {
                 const size_t off = (size_t)(b0 - col_lb) * G, cnt = (size_t)nb * G;
                 HIPCHK(c, hipMemcpyAsync(c->tap->two_u + off, s2u, cnt * 8, hipMemcpyDeviceToHost, c->stream));

@@ -68,7 +68,10 @@ template <> __device__ __forceinline__ double gcmp_value<int64_t>(int64_t v, int
 // output slots after the keys already written.  The next chunk's rows (and the row indices of the chunk after it) are in
 // flight meanwhile, across group boundaries.  Value sums: per-thread partials over the thread's own loads, combined through LDS
 // in a fixed order at each group's end.
-template <typename InT, typename KeyT, bool VECLOAD, bool LOG1P>
+// PACK = false (dense OVR): every key of the block's rows is kept, zeros included -- the "padded dense" layout: the key rows of
+// kernels_ovo.h with each block starting at a multiple of 64 keys (holes hold the zero key) -- and only the sums are written
+// beside the keys: the transposition with the group sums folded in.
+template <typename InT, typename KeyT, bool VECLOAD, bool LOG1P, bool PACK = true>
 __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P) {
     constexpr int VEC = 16 / (int)sizeof(InT);
     constexpr int LPR = 64 / VEC;      // lanes per 64-gene row segment
@@ -114,8 +117,10 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
     if (seg < 0) { // groups without cells have no chunk: their outputs here
         for (int g = gA; g < gB; ++g)
             if (P.pos_ptr[g + 1] == P.pos_ptr[g] && tid < 64 && c0 + tid < P.ncols) {
-                P.nnz[(size_t)(c0 + tid) * P.G + g] = 0;
-                P.gofs[(size_t)(c0 + tid) * P.G + g] = (u32)out0;
+                if (PACK) {
+                    P.nnz[(size_t)(c0 + tid) * P.G + g] = 0;
+                    P.gofs[(size_t)(c0 + tid) * P.G + g] = (u32)out0;
+                }
                 P.out_sum[(size_t)(c0 + tid) * P.G + g] = 0.0;
             }
     }
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
         for (int i = 0; i < GPW; ++i) {
             const int gi = wave * GPW + i;
             const KeyT k = tile[gi][lane];
-            const bool nz = k != ZEROK; // (rows past the group's end were loaded as zeros)
+            const bool nz = PACK ? k != ZEROK : lane < cn - cc * 64; // (rows past the group's end were loaded as zeros)
             const u64 m = __ballot(nz);
             const int ci = __builtin_amdgcn_readlane(cntv, i);
             KeyT *dst = Xt + (long long)(c0 + gi) * P.xt_stride + out0; // uniform
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
                 if (seg >= 0) P.seg_sum[(size_t)(c0 + tid) * P.nseg + seg] = tot;
                 else P.out_sum[(size_t)(c0 + tid) * P.G + cg] = tot;
             }
-            if (lane < GPW && geneW < P.ncols) {
+            if (PACK && lane < GPW && geneW < P.ncols) {
                 if (seg >= 0) P.seg_nnz[(size_t)geneW * P.nseg + seg] = (u16)cntv;
                 else {
                     P.nnz[(size_t)geneW * P.G + cg] = (u16)(cntv - gstartv);
@@ -243,7 +248,16 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
         for (int i = 0; i < GPW; ++i) {
             const int gi = wave * GPW + i;
             const int ci = __builtin_amdgcn_readlane(cntv, i), fill = ci & 63;
-            if (lane < fill && c0 + gi < P.ncols) Xt[(long long)(c0 + gi) * P.xt_stride + out0 + (ci - fill) + lane] = st[i * 128 + lane];
+            if ((PACK ? lane < fill : fill > 0) && c0 + gi < P.ncols) // (padded dense: the hole up to the next block holds zeros)
+                Xt[(long long)(c0 + gi) * P.xt_stride + out0 + (ci - fill) + lane] = lane < fill ? st[i * 128 + lane] : ZEROK;
+        }
+    }
+    if constexpr (!STAGE && !PACK) { // padded dense, keys stored directly: the hole up to the next block holds zeros
+#pragma unroll 4
+        for (int i = 0; i < GPW; ++i) {
+            const int gi = wave * GPW + i;
+            const int ci = __builtin_amdgcn_readlane(cntv, i), hole = (64 - (ci & 63)) & 63;
+            if (lane < hole && c0 + gi < P.ncols) Xt[(long long)(c0 + gi) * P.xt_stride + out0 + ci + lane] = ZEROK;
         }
     }
 #undef GCMP_CUR_SKIP
@@ -340,7 +354,7 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
     const bool vl = (vlast >> lane) & 1ull;
     u32 wofs[NR], lessr[NR], cnt_[NR];
     KeyT k0[NR], k1[NR], k2[NR];
-    u64 fm[NR], eqm = 0, ovm = 0;
+    u64 fm[NR], eqr[NR], ovr_[NR], eqm = 0, ovm = 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) { // Bloom inserts of every round first: a key's flag says "may repeat an EARLIER key"
         const KeyT q = cur[r];
@@ -370,6 +384,7 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
         u64 e4 = __ballot(a0 == q) | __ballot(a1 == q) | __ballot(a2 == q), o4 = __ballot((int)h < 0), n4 = __ballot(q < ZEROK);
         if (r == NR - 1) { l = vl ? l : 0u; e4 &= vlast; o4 &= vlast; n4 &= vlast; }
         lessr[r] = l; cnt_[r] = (w >> sh) & 3u; k0[r] = a0; k1[r] = a1; k2[r] = a2;
+        eqr[r] = e4; ovr_[r] = o4;
         eqm |= e4; ovm |= o4;
         negs_out += (u32)__popcll(n4);
     }
@@ -389,14 +404,17 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
     if (eqm) { // a key that ties with the reference somewhere in the group: count, bounded by the bucket (the pad's MAXK never counts)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const KeyT q = cur[r];
-            const u32 e = ((cnt_[r] > 0u && k0[r] == q) ? 1u : 0u) + ((cnt_[r] > 1u && k1[r] == q) ? 1u : 0u) + ((cnt_[r] > 2u && k2[r] == q) ? 1u : 0u);
-            a[r] = (r < NR - 1 || vl) ? e : 0u;
+            if (eqr[r]) { // uniform
+                const KeyT q = cur[r];
+                const u32 e = ((cnt_[r] > 0u && k0[r] == q) ? 1u : 0u) + ((cnt_[r] > 1u && k1[r] == q) ? 1u : 0u) + ((cnt_[r] > 2u && k2[r] == q) ? 1u : 0u);
+                a[r] = (r < NR - 1 || vl) ? e : 0u;
+            }
         }
     }
     if (ovm) { // a key in an overfull word (its keys lie in [wlo, whi) in any order): the first 8 in line, the rest lane by lane
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
+            if (!ovr_[r]) continue; // uniform
             const KeyT q = cur[r];
             const u32 W = ocr_bucket(R, q) >> 4;
             const u32 h = R.tab[2 * W + 1];
@@ -419,7 +437,7 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             eqs += a[r];
-            TT += (u64)a[r] * ((u64)a[r] + 1ull);
+            TT += (u64)a[r] * ((u64)a[r] + 1ull); // (a <= 65535)
         }
     }
     u64 anyf = 0;
@@ -665,8 +683,16 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
                 else ocr_group<KeyT, 4>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
                 S2 = 2u * less + eqs;
                 const u64 tm = __ballot(TT != 0ull);
-                if (tm) {
-                    const u64 tot = wave_sum(TT);
+                if (tm) { // ties are few: mostly one lane holds the whole term
+                    u64 tot;
+                    if ((tm & (tm - 1ull)) == 0ull) {
+                        const int sl = __ffsll((long long)tm) - 1;
+                        tot = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(TT >> 32), sl) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)TT, sl);
+                    } else {
+                        tot = TT;
+                        tot += xor_lanes<1>(tot, lane); tot += xor_lanes<2>(tot, lane); tot += xor_lanes<4>(tot, lane);
+                        tot += xor_lanes<8>(tot, lane); tot += xor_lanes<16>(tot, lane); tot += xor_lanes<32>(tot, lane);
+                    }
                     if (lane == j) tt_out = tot;
                 }
                 if (negs && lane == j) neg_out = negs;

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_fused_probe(FusedParams P) {
     const int gene = blockIdx.x * 64 + lane;
     if (gene >= P.ncols) return;
     const InT *Xg = (const InT *)P.X + P.col0 + gene;
-    bool bad = false;
+    bool bad = false, hopeless = false; // hopeless: not a count below 256 either: the wider second stage need not look at this gene
     constexpr int PER = FUSED_PROBE_ROWS / 4;
     InT v[8];
     for (int i0 = 0; i0 < PER; i0 += 8) {
@@ -214,12 +214,14 @@ __global__ __launch_bounds__(256) void k_fused_probe(FusedParams P) {
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            bool exact;
+            bool exact, exact_wide;
             clamp_count<InT, RT>(v[u], exact);
+            clamp_count<InT, 256>(v[u], exact_wide);
             bad |= !exact;
+            hopeless |= !exact_wide;
         }
     }
-    if (bad) P.gene_flags[gene] = 1u;
+    if (bad) P.gene_flags[gene] = hopeless ? 3u : 1u; // 3: as 1 (the host's two-pass routes), and skipped by the 256-value stage
 }
 
 // ---- reference tables: one 1024-thread workgroup per 64-gene tile; lane = gene.  All 16 wavefronts add into one
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
         P.ref_TA[gene] = ta;
         P.ref_sum[gene] = sum;
         if (WIDE) { if (!s_bad[lane]) { P.gene_flags[gene] = 2u; s_skip = 2; } } // candidate for the wide main pass (else it stays flagged); s_skip = 2: this tile has one
-        else if (s_bad[lane]) P.gene_flags[gene] = 1u;
+        else if (s_bad[lane] && P.gene_flags[gene] != 3u) P.gene_flags[gene] = 1u;
         const size_t o = (size_t)P.ref * P.out_ld + gene;
         P.out_p[o] = 1.0;                                                            // sparse_ovo.py:140-143
         P.out_u[o] = -1.0;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(FUSED_NT) void k_fused_ref_hist(FusedParams P) {
         const u32 cnt = h[l * STR + c];
         if (cnt && gene0 + l < P.ncols) atomicAdd(&P.hist_all[(size_t)(gene0 + l) * RT + c], cnt);
     }
-    if (tid < 64 && act && s_bad[tid]) P.gene_flags[gene] = 1u;
+    if (tid < 64 && act && s_bad[tid] && P.gene_flags[gene] != 3u) P.gene_flags[gene] = 1u;
 }
 
 // ---- OVR tables.  For one-versus-rest every cell is ranked against the whole column, so the table is the
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(FUSED_NT) void k_fused_hist_all(FusedParams P) {
         const u32 cnt = h[l * STR + c];
         if (cnt && gene0 + l < P.ncols) atomicAdd(&P.hist_all[(size_t)(gene0 + l) * RT + c], cnt);
     }
-    if (tid < 64 && act && s_bad[tid]) { if (WIDE) P.wide_bad[gene] = 1u; else P.gene_flags[gene] = 1u; }
+    if (tid < 64 && act && s_bad[tid]) { if (WIDE) P.wide_bad[gene] = 1u; else if (P.gene_flags[gene] != 3u) P.gene_flags[gene] = 1u; }
 }
 // per gene: histogram -> cumulative table, column tie sum, column total.  WIDE (OVR second stage): only for the genes the first
 // pass flagged and whose every row fits the wider table; they become candidates (gene_flags = 2) and their tile joins the list
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(FUSED_NT, WIDE ? (OVR ? 2 : 1) : ((OVR || CB == 8) 
         if (!OVR)
             for (int i = 0; i < BW; ++i) cbw[i * 64 + lane] = 0; // the wavefront's own block, in-order LDS: no barrier needed
     }
-    if (act && bad) P.gene_flags[gene] = 1u;
+    if (act && bad && P.gene_flags[gene] != 3u) P.gene_flags[gene] = 1u;
     } // items
 }
 
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_ovr_group_hists(FusedParams P) 
             if (wv >> 16) atomicAdd(&P.hist_all[(size_t)(gene0 + l) * RT + c0 + 2], wv >> 16);
         }
     }
-    if (act && bad) P.gene_flags[gene] = 1u;
+    if (act && bad && P.gene_flags[gene] != 3u) P.gene_flags[gene] = 1u;
 }
 
 // histograms -> rank sums, U, p, fold change.  grid (tiles, group chunks); lane = gene; s[c] = cum[c] + cum[c+1] sits

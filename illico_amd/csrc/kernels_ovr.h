@@ -26,6 +26,7 @@ struct OvrParams {
     const int *counts;        // [G]
     int G, n_genes, dt, is_log1p;
     long long n_cells;
+    long long scan_len = 0;   // dense layout: keys per gene row to walk (0: n_cells); larger in the padded layout (holes hold zero keys)
     int ref;                  // OVO-through-global-sort mode: reference group code
     const u32 *gene_flags;    // OVO mode: process only genes whose flag is non-zero (nullptr = all)
     u64 *acc_global;          // ACCG: per-gene accumulators [n_genes][3*G] in HBM (group counts beyond what LDS holds)
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
         int n;
         const u32 *sp = nullptr;
         if (SPARSE) { sp = P.seg_ptr + (size_t)gene * (G + 1); start = sp[0]; n = (int)(sp[G] - sp[0]); }
-        else { start = (long long)gene * P.stride; n = (int)P.n_cells; }
+        else { start = (long long)gene * P.stride; n = (int)(P.scan_len ? P.scan_len : P.n_cells); }
         KeyT *ka = (KeyT *)P.keys_a + start, *kb = (KeyT *)P.keys_b + start;
         u32 *va = P.vals_a + start, *vb = P.vals_b + start;
 

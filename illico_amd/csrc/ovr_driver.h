@@ -44,9 +44,11 @@ static int launch_gene_totals(illico_ctx *c, const double *ssum, int G, int nb, 
     return ILLICO_OK;
 }
 
+// padded = true: Xt is the padded dense layout of k_group_compact (slot codes c->d_pk_code, c->pk_stride slots per gene; the value
+// sums are in ssum already)
 template <typename KeyT>
 static int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags,
-                               long long *s2u, u64 *stie, double *ssum, double *gtot) {
+                               long long *s2u, u64 *stie, double *ssum, double *gtot, bool padded = false) {
     void *v;
     int rc;
     if ((rc = get_scratch(c, "ovr_kb", (size_t)nb * stride * sizeof(KeyT), &v))) return rc;
@@ -57,10 +59,10 @@ static int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     u32 *vb = (u32 *)v;
     OvrParams P;
     P.keys_a = Xt; P.keys_b = kb; P.vals_a = va; P.vals_b = vb;
-    P.code_by_pos = c->d_code_by_pos; P.seg_ptr = nullptr; P.stride = stride; P.pos_ptr = c->d_posptr;
+    P.code_by_pos = padded ? c->d_pk_code : c->d_code_by_pos; P.seg_ptr = nullptr; P.stride = stride; P.pos_ptr = c->d_posptr;
     P.counts = c->d_counts; P.G = (int)c->n_groups; P.n_genes = nb; P.dt = dtype;
-    P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = N; P.ref = -1; P.gene_flags = nullptr;
-    P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum;
+    P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = N; P.scan_len = padded ? c->pk_len : 0; P.ref = -1; P.gene_flags = nullptr;
+    P.out_2u = s2u; P.out_tie = stie; P.out_sum = padded ? nullptr : ssum;
     if ((rc = launch_ovr_gene<KeyT, false>(c, P))) return rc;
     return launch_gene_totals(c, ssum, (int)c->n_groups, nb, gtot);
 }
@@ -71,7 +73,7 @@ static int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
 // them (run by run).  *done = false: the route does not apply (nothing was launched).
 template <typename KeyT>
 static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags,
-                               long long *s2u, u64 *stie, double *ssum, double *gtot, bool *done) {
+                               long long *s2u, u64 *stie, double *ssum, double *gtot, bool *done, bool padded = false) {
     *done = false;
     const int G = (int)c->n_groups;
     if (c->no_ovr_parts_path || G > 65535 || c->max_nonref >= (1ll << 23) ||
@@ -104,10 +106,10 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     HIPCHK(c, hipMemsetAsync(s2u, 0, (size_t)nb * G * 8, c->stream));
     // per-group value sums from the group-contiguous key rows, in a fixed order (the parts see a group's values in an order
     // that depends on timing)
-    if ((rc = launch_group_sums_rows<KeyT>(c, Xt, stride, nb, dtype, flags, ssum))) return rc;
+    if (!padded && (rc = launch_group_sums_rows<KeyT>(c, Xt, stride, nb, dtype, flags, ssum))) return rc;
     {
         OvrPartParams Q;
-        Q.Xt = Xt; Q.stride = stride; Q.n_genes = nb; Q.n_cells = N; Q.code_by_pos = c->d_code_by_pos; Q.cap = cap;
+        Q.Xt = Xt; Q.stride = stride; Q.n_genes = nb; Q.n_cells = padded ? (int)c->pk_len : N; Q.code_by_pos = padded ? c->d_pk_code : c->d_code_by_pos; Q.cap = cap;
         Q.out_keys = pkeys; Q.out_codes = pcodes; Q.part_start = part_start; Q.gene_info = gene_info; Q.unit_list = unit_list; Q.n_units = unit_ctr;
         ProfScope ps(c, KID_OVR_PART);
         auto kern = k_ovr_partition<KeyT>;
@@ -155,7 +157,7 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
             if (h[(size_t)e * 4 + 3] || h[(size_t)nb * 4 + e]) last = e;
         const int sub = last - first + 1;
         if ((rc = run_ovr_dense_batch<KeyT>(c, Xt + (size_t)first * stride, stride, sub, N, dtype, flags, s2u + (size_t)first * G,
-                                            stie + (size_t)first * G, ssum + (size_t)first * G, gtot + first)))
+                                            stie + (size_t)first * G, ssum + (size_t)first * G, gtot + first, padded)))
             return rc;
         j = last + 1;
     }

@@ -375,7 +375,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             if (bytes) { if ((rc = run_fused_ovo<uint8_t>(c, v, ldD, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc; }
             else if ((rc = run_fused_ovo<float>(c, v, ldD, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc;
             for (int64_t j = 0; j < wn; ++j)
-                if (hf[j] == 1u) { // (2 = taken by the fused route's second, wider pass)
+                if (hf[j] == 1u || hf[j] == 3u) { // (2 = taken by the fused route's second, wider pass)
                     if (bad_lo < 0) bad_lo = w0 + j;
                     bad_hi = w0 + j;
                 }

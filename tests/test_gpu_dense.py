@@ -375,7 +375,7 @@ def test_fused_route_second_pass_takes_counts_up_to_255(engine, test):
         engine.set_option("profile", 0)
     assert "k_ovo_fused_wide" in prof and "k_ovo_fused_wide" not in prof2, (prof, prof2)
     # with the second pass only genes 33 and 34 are left for the two-pass routes (one short run), without it a third of the matrix
-    first = "k_group_compact" if test == "ovo" else "k_transpose_permute"  # first kernel of the two-pass routes
+    first = "k_group_compact"  # first kernel of the two-pass routes (group-wise packing / padded transposition)
     assert prof[first]["launches"] < prof2[first]["launches"], (prof, prof2)
     for a, b in zip(got, narrow_only):
         assert a.tobytes() == b.tobytes()
