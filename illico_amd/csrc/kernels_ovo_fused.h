@@ -257,7 +257,7 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
     const InT *Xg = (const InT *)P.X + P.col0 + gene0;
     const int lane_c = act ? lane : 0;
     u32 *hl = h + lane * STR;
-    bool bad = false;
+    bool bad = false, hopeless = false; // hopeless (64-value pass only): a reference value that is no count below 256 either
     for (int p = p0 + wave * UR; p < p1; p += NW * UR) {
         InT v[UR];
         // rows past p1 are other groups' (or the padding's): valid memory, masked below
@@ -268,10 +268,11 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
             bool exact;
             const u32 c = clamp_count<InT, RT>(v[u], exact);
             bad |= valid && !exact;
+            if (!WIDE && RT < FUSED_WIDE_RT) { bool ew; clamp_count<InT, FUSED_WIDE_RT>(v[u], ew); hopeless |= valid && !ew; }
             atomicAdd(&hl[c], valid ? 1u : 0u);
         }
     }
-    if (bad) s_bad[lane] = 1;
+    if (bad) atomicMax(&s_bad[lane], hopeless ? 2 : 1);
     __syncthreads();
     if (wave == 0) { // counts -> cumulative counts, in place: h[lane][c] = # reference cells < c, c = 0 .. RT
         u32 run = 0;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
         P.ref_TA[gene] = ta;
         P.ref_sum[gene] = sum;
         if (WIDE) { if (!s_bad[lane]) { P.gene_flags[gene] = 2u; s_skip = 2; } } // candidate for the wide main pass (else it stays flagged); s_skip = 2: this tile has one
-        else if (s_bad[lane] && P.gene_flags[gene] != 3u) P.gene_flags[gene] = 1u;
+        else if (s_bad[lane] && P.gene_flags[gene] != 3u) P.gene_flags[gene] = s_bad[lane] == 2 ? 3u : 1u; // 3: the 256-value stage need not look
         const size_t o = (size_t)P.ref * P.out_ld + gene;
         P.out_p[o] = 1.0;                                                            // sparse_ovo.py:140-143
         P.out_u[o] = -1.0;

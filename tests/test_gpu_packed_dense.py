@@ -159,3 +159,50 @@ def test_reference_beyond_16_bit_positions_takes_the_other_route(engine):
         engine.set_option("profile", 0)
     assert "k_group_compact" not in prof, prof
     assert_planes_match(got, oracle.run(X.astype(np.float64), g), ref_row=g.encoded_ref_group, what="large reference")
+
+
+# ---- dense OVR: the padded transposition (k_group_compact keeping every key, group sums folded in) -------------------------
+def _check_ovr(engine, X, labels, *, what, fc_rtol=1e-12, **kw):
+    _, g = oracle.encode_and_count_groups(labels, None)
+    (p_new, s_new, prof_new), (p_old, s_old, prof_old) = _both_routes(engine, X, g, **kw)
+    assert "k_group_compact" in prof_new and "k_transpose_permute" not in prof_new, prof_new
+    assert "k_group_compact" not in prof_old and "k_transpose_permute" in prof_old, prof_old
+    np.testing.assert_array_equal(s_new[0], s_old[0], err_msg=f"2U {what}")
+    np.testing.assert_array_equal(s_new[1], s_old[1], err_msg=f"tie sums {what}")
+    np.testing.assert_allclose(s_new[2], s_old[2], rtol=1e-13, atol=0, err_msg=f"value sums {what}")
+    lb, ub = kw.get("lb", 0), kw.get("ub", X.shape[1])
+    Xh = X.cpu().numpy() if hasattr(X, "cpu") else X
+    want = oracle.run(np.ascontiguousarray(Xh, dtype=np.float64), g, col_lb=lb, col_ub=ub, **{k: v for k, v in kw.items() if k not in ("lb", "ub")})
+    assert_planes_match(p_new, want, fc_rtol=fc_rtol, what=what)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
+def test_padded_ovr_route_matches_transpose_route_and_oracle(engine, dtype):
+    rng = np.random.RandomState(21)
+    n, m = 5000, 70
+    labels = make_labels(rng, n, 60)
+    X = np.log1p(rng.poisson(4.0, size=(n, m)) * rng.uniform(0.5, 1.5, size=(n, m))) * (rng.rand(n, m) < 0.5)
+    X[:, 3] = rng.poisson(300.0, size=n)       # ties everywhere
+    X[:, 5] = rng.randn(n)                     # mixed sign, no zeros
+    X[:, 6] = 2.5
+    X[:, 7] = 0.0
+    if np.issubdtype(dtype, np.integer):
+        X = np.round(X * 1000.0)
+    _check_ovr(engine, X.astype(dtype), labels, what=f"padded ovr {np.dtype(dtype).name}")
+
+
+@pytest.mark.parametrize("lb,ub", [(0, 37), (1, 36), (5, 70)])
+def test_padded_ovr_route_windows_unaligned_rows_and_log1p(engine, lb, ub):
+    import torch
+    rng = np.random.RandomState(22)
+    n, m = 3000, 70
+    labels = np.array([f"pert_{i % 7}" for i in range(1500)] + ["pert_big"] * 1200 + [f"pert_small_{i % 150}" for i in range(300)])
+    X = (rng.gamma(2.0, 1.0, size=(n, m)) * (rng.rand(n, m) < 0.4)).astype(np.float32)
+    perm = rng.permutation(n)
+    X, labels = X[perm], labels[perm]
+    _check_ovr(engine, X, labels, what=f"ovr window {lb}:{ub}", lb=lb, ub=ub)
+    Xd = torch.zeros((n, m + 3), dtype=torch.float32, device="cuda")[:, :m]  # pitch 73
+    Xd.copy_(torch.from_numpy(X))
+    _check_ovr(engine, Xd, labels, what=f"ovr device window {lb}:{ub}", lb=lb, ub=ub)
+    # expm1 is evaluated in float32 (utils/math.py:212): device and libm expm1f may differ by an f32 ulp
+    _check_ovr(engine, np.log1p(X), labels, what="ovr log1p", fc_rtol=1e-6, lb=lb, ub=ub, is_log1p=True)
