@@ -98,6 +98,7 @@ struct illico_ctx {
     int64_t scratch_bytes = 24ll << 30;
     bool no_counts_path = false;
     bool no_fused_path = false;
+    bool no_ovr_packed_partition = false; // 1: dense OVR partitions the padded rows (every key) instead of the packed ones
     bool no_packed_dense = false;      // 1: dense OVO on continuous values takes the transpose + k_ovo_rank route (no group-wise packing)
     bool no_fused_wide = false;        // 1: no second, 256-value pass of the fused OVO route (genes beyond 63 go to the two-pass routes)
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
@@ -314,6 +315,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_fused_wide")) c->no_fused_wide = value != 0;
     else if (!strcmp(key, "no_packed_dense")) c->no_packed_dense = value != 0;
+    else if (!strcmp(key, "no_ovr_packed_partition")) c->no_ovr_packed_partition = value != 0;
     else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
     else if (!strcmp(key, "no_csc_counts_mixed")) c->no_csc_counts_mixed = value != 0;
     else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
@@ -659,7 +661,7 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         GroupCompactParams Q;
         Q.X = X; Q.ld = ld; Q.col0 = col0; Q.ncols = nb; Q.perm = c->d_perm; Q.pos_ptr = c->d_posptr; Q.G = G; Q.ref = ref; Q.nseg = nseg;
         Q.blk_g0 = c->d_pk_blk; Q.blk_g1 = c->d_pk_blk + c->pk_nblk; Q.blk_out = c->d_pk_blk + 2 * c->pk_nblk; Q.nblk = c->pk_nblk; Q.ref_out = c->pk_ref_out;
-        Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.gofs = gofs; Q.out_sum = ssum; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum;
+        Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.gofs = gofs; Q.blk_cnt = nullptr; Q.out_sum = ssum; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum;
         if ((rc = launch_group_compact<InT, KeyT>(c, Q, nb, flags, true))) return rc;
     }
     {
@@ -1149,13 +1151,30 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
             continue;
         }
+        OvrPackedInput pki;
+        const bool ovr_packed = padded && !c->no_ovr_packed_partition && !c->no_ovr_parts_path && G <= 65535;
         if (padded) {
             GroupCompactParams Q;
             memset(&Q, 0, sizeof Q);
             Q.X = src; Q.ld = src_ld; Q.col0 = src_col0; Q.ncols = nb; Q.perm = c->d_perm; Q.pos_ptr = c->d_posptr; Q.G = G; Q.ref = -1; Q.nseg = 0;
             Q.blk_g0 = c->d_pk_blk; Q.blk_g1 = c->d_pk_blk + c->pk_nblk; Q.blk_out = c->d_pk_blk + 2 * c->pk_nblk; Q.nblk = c->pk_nblk;
             Q.Xt = Xt; Q.xt_stride = stride; Q.out_sum = ssum;
-            if ((rc = launch_group_compact<InT, KeyT>(c, Q, nb, flags, false))) return rc;
+            if (ovr_packed) { // packed rows (non-zero keys only) for the partition; flagged genes are written again, padded, below
+                if ((rc = get_scratch(c, "packed_nnz", (size_t)nb * G * 2 + 64, &v))) return rc;
+                Q.nnz = (u16 *)v;
+                if ((rc = get_scratch(c, "packed_seg_sum", (size_t)nb * G * 4 + (size_t)nb * c->pk_nblk * 4 + 64, &v))) return rc;
+                Q.gofs = (u32 *)v;
+                Q.blk_cnt = Q.gofs + (size_t)nb * G;
+                pki.nnz = Q.nnz; pki.blk_cnt = Q.blk_cnt;
+                const GroupCompactParams Q0 = Q;
+                pki.repad = [c, Q0, Xt, stride, flags, G](int first, int sub) -> int {
+                    GroupCompactParams R = Q0;
+                    R.col0 = Q0.col0 + first; R.ncols = sub; R.Xt = (KeyT *)Xt + (size_t)first * stride;
+                    R.out_sum = Q0.out_sum + (size_t)first * G; R.nnz = nullptr; R.gofs = nullptr; R.blk_cnt = nullptr;
+                    return launch_group_compact<InT, KeyT>(c, R, sub, flags, false);
+                };
+            }
+            if ((rc = launch_group_compact<InT, KeyT>(c, Q, nb, flags, ovr_packed))) return rc;
         } else {
         if (gflags) HIPCHK(c, hipMemsetAsync(gflags, 0, (size_t)nb * 4, c->stream));
         if ((rc = launch_transpose<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, gflags))) return rc;
@@ -1177,8 +1196,11 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
         } else {
             bool done = false;
-            if ((rc = run_ovr_dense_parts<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot, &done, padded))) return rc;
-            if (!done && (rc = run_ovr_dense_batch<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot, padded))) return rc;
+            if ((rc = run_ovr_dense_parts<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot, &done, padded, ovr_packed ? &pki : nullptr))) return rc;
+            if (!done) { // the parts route does not take these sizes: the general route, over padded rows
+                if (ovr_packed && (rc = pki.repad(0, nb))) return rc;
+                if ((rc = run_ovr_dense_batch<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot, padded))) return rc;
+            }
             if (c->tap) {
                 const size_t off = (size_t)(b0 - col_lb) * G, cnt = (size_t)nb * G;
                 HIPCHK(c, hipMemcpyAsync(c->tap->two_u + off, s2u, cnt * 8, hipMemcpyDeviceToHost, c->stream));

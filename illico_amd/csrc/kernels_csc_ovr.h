@@ -563,6 +563,176 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition(OvrPartParams P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same split over the PACKED key rows of k_group_compact (kernels_ovo_compact.h): only the non-zero keys are there -- block
+// after block of groups, blk_cnt[gene][block] keys from slot blk_out[block] on, a group's keys back to back with the next
+// group's -- so the three walks read 45 % of a half-empty matrix instead of all of it.  One wavefront takes a block at a time;
+// a key's group code is the block's first group plus the group ends (running sums of nnz[gene][group]) at or below the key's
+// offset: a few compares against scalars.
+// ---------------------------------------------------------------------------------------------------------------------
+struct OvrPartPackedParams {
+    const void *Xt;            // [n_genes][stride] packed keys
+    long long stride;
+    int n_genes, G, nblk;
+    const u16 *nnz;            // [n_genes][G]
+    const u32 *blk_cnt;        // [n_genes][nblk]
+    const int *blk_g0, *blk_g1, *blk_out; // [nblk] first group, one past the last, first key slot
+    int cap;
+    void *out_keys;
+    u16 *out_codes;
+    u32 *part_start, *gene_info, *unit_list, *n_units; // as OvrPartParams
+};
+
+template <typename KeyT>
+__global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedParams P) {
+    constexpr int NT = OVRP_NT, NW = NT / 64, NB = 1 << OVRP_LG;
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
+    constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
+    extern __shared__ __align__(16) unsigned char smem[];
+    u32 *hist = (u32 *)smem;                         // [NB] counts, then exclusive offsets in value order
+    u32 *tmp = hist + NB;                            // [NT]
+    u32 *pstart = tmp + NT;                          // [OVRP_PMAX + 1]
+    u32 *pfill = pstart + OVRP_PMAX + 1;             // [OVRP_PMAX]
+    u32 *s_mx = pfill + OVRP_PMAX;                   // [0] largest bucket  [1] negatives
+    KeyT *s_k = (KeyT *)(s_mx + 2 + ((2 * OVRP_PMAX + 1) & 1)); // [2] smallest / largest non-zero key (8-byte aligned)
+    unsigned char *part_of = (unsigned char *)(s_k + 2); // [NB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    constexpr int UL = 4; // 64-key pieces of a block in flight per wavefront
+    const int gene = blockIdx.x;
+    const KeyT *row = (const KeyT *)P.Xt + (size_t)gene * P.stride;
+    const u32 *bcnt = P.blk_cnt + (size_t)gene * P.nblk;
+    const u16 *nnz = P.nnz + (size_t)gene * P.G;
+    for (int b = tid; b < NB; b += NT) hist[b] = 0u;
+    if (tid < OVRP_PMAX) pfill[tid] = 0u;
+    if (tid == 0) { s_mx[0] = 0u; s_mx[1] = 0u; s_k[0] = MAXK; s_k[1] = (KeyT)0; }
+    __syncthreads();
+    { // key range for the bucket function, from every 8th block
+        KeyT tmin = MAXK, tmax = (KeyT)0;
+        for (int b = wave * 8; b < P.nblk; b += NW * 8) {
+            const int n_b = (int)bcnt[b];
+            const KeyT *src = row + P.blk_out[b];
+            for (int i = lane; i < n_b; i += 64) { const KeyT k = src[i]; tmin = k < tmin ? k : tmin; tmax = k > tmax ? k : tmax; }
+        }
+        tmin = wave_min_key(tmin);
+        tmax = wave_max_key(tmax);
+        if (lane == 0) { atomicMin(&s_k[0], tmin); atomicMax(&s_k[1], tmax); }
+    }
+    __syncthreads();
+    const bool have_range = s_k[1] >= s_k[0];
+    const KeyT kmin = have_range ? s_k[0] : (KeyT)0, kmax = have_range ? s_k[1] : (KeyT)0;
+    const int shift = max(0, key_bits((KeyT)(kmax - kmin)) - OVRP_LG);
+    auto bucket_of = [&](KeyT key) -> u32 {
+        const KeyT d = key > kmin ? (KeyT)((KeyT)(key - kmin) >> shift) : (KeyT)0;
+        return (u32)(d < (KeyT)(NB - 1) ? d : (KeyT)(NB - 1));
+    };
+    {
+        u32 neg = 0;
+        for (int b = wave; b < P.nblk; b += NW) {
+            const int n_b = (int)bcnt[b];
+            const KeyT *src = row + P.blk_out[b];
+            for (int o = 0; o < n_b; o += 64 * UL) {
+                KeyT k[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) { const int i = o + u * 64 + lane; k[u] = i < n_b ? src[i] : ZEROK; }
+#pragma unroll
+                for (int u = 0; u < UL; ++u)
+                    if (k[u] != ZEROK) { // (packed keys are never the zero key: this is the "past the end" mark)
+                        atomicAdd(&hist[bucket_of(k[u])], 1u);
+                        neg += k[u] < ZEROK ? 1u : 0u;
+                    }
+            }
+        }
+        neg = (u32)wave_sum((int)neg);
+        if (lane == 0 && neg) atomicAdd(&s_mx[1], neg);
+    }
+    __syncthreads();
+    u32 mx = 0;
+    for (int b = tid; b < NB; b += NT) mx = max(mx, hist[b]);
+    mx = (u32)wave_incl_scan_max((int)mx);
+    if (lane == 63) atomicMax(&s_mx[0], mx);
+    __syncthreads();
+    mx = s_mx[0];
+    const u32 n = block_excl_scan_inplace<NT>(hist, NB, tmp, tid);
+    const u32 nneg = s_mx[1];
+    const bool skew = (unsigned long long)mx * 4ull > (unsigned long long)P.cap;
+    const u32 quota = skew ? 1u : (u32)P.cap - mx;
+    const u32 n_parts = n ? (n - 1) / quota + 1 : 0u;
+    const bool bad = skew || n_parts > (u32)OVRP_PMAX;
+    u32 *gi = P.gene_info + (size_t)gene * 4;
+    u32 *ps_out = P.part_start + (size_t)gene * (OVRP_PMAX + 1);
+    if (bad) { // uniform: this gene goes to the general route
+        if (tid == 0) { gi[0] = n; gi[1] = nneg; gi[2] = 0u; gi[3] = 1u; }
+        return;
+    }
+    for (int b = tid; b < NB; b += NT) {
+        const u32 p = hist[b] / quota;
+        part_of[b] = (unsigned char)min(p, (u32)OVRP_PMAX - 1);
+        if (p < n_parts && (b == 0 || hist[b - 1] / quota != p)) pstart[p] = hist[b];
+    }
+    if (tid == 0) pstart[n_parts] = n;
+    const int p_bits = 32 - __clz(n_parts);
+    __syncthreads();
+    for (int b = wave; b < P.nblk; b += NW) {
+        const int n_b = (int)bcnt[b];
+        const KeyT *src = row + P.blk_out[b];
+        int gcur = P.blk_g0[b];
+        const int glast = P.blk_g1[b];
+        int gend = gcur < glast ? (int)nnz[gcur] : 0; // offset (inside the block) where group gcur's keys end
+        for (int o = 0; o < n_b; o += 64 * UL) {
+            KeyT k[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) { const int i = o + u * 64 + lane; k[u] = i < n_b ? src[i] : ZEROK; }
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int off = o + u * 64 + lane;
+                if (o + u * 64 >= n_b) break; // uniform
+                // group code: gcur + the group ends at or below this key's offset (empty groups repeat an end: skipped over)
+                int cd = gcur;
+                {
+                    int g = gcur, e = gend;
+                    while (e < o + u * 64 + 64 && g + 1 < glast) { // uniform
+                        cd += off >= e ? 1 : 0;
+                        ++g;
+                        e += (int)nnz[g];
+                    }
+                    // the next piece starts at o + u * 64 + 64: advance past the groups that end at or before it
+                    while (gend <= o + u * 64 + 64 && gcur + 1 < glast) { ++gcur; gend += (int)nnz[gcur]; }
+                }
+                const bool nz = k[u] != ZEROK;
+                const int p = nz ? (int)part_of[bucket_of(k[u])] : (int)n_parts; // n_parts = not a record
+                u64 m = ~0ull;
+                for (int bit = 0; bit < p_bits; ++bit) {
+                    const bool on = (p >> bit) & 1;
+                    const u64 bl = __ballot(on);
+                    m &= on ? bl : ~bl;
+                }
+                u32 slot = 0;
+                if (nz) { // one LDS atomic per (wavefront, part present in it): the lowest lane of each match set
+                    const int leader = __ffsll((long long)m) - 1;
+                    u32 b0 = 0;
+                    if (lane == leader) b0 = atomicAdd(&pfill[p], (u32)__popcll(m));
+                    b0 = (u32)__shfl((int)b0, leader);
+                    slot = pstart[p] + b0 + (u32)__popcll(m & lt_mask);
+                }
+                if (nz) {
+                    const size_t oo = (size_t)gene * P.stride + slot;
+                    ((KeyT *)P.out_keys)[oo] = k[u];
+                    P.out_codes[oo] = (u16)cd;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid <= (int)n_parts) ps_out[tid] = pstart[tid];
+    if (tid == 0) {
+        gi[0] = n; gi[1] = nneg; gi[2] = n_parts; gi[3] = 0u;
+        s_mx[0] = n_parts ? atomicAdd(P.n_units, n_parts) : 0u;
+    }
+    __syncthreads();
+    if (tid < (int)n_parts) P.unit_list[s_mx[0] + tid] = (u32)gene * OVRP_PMAX + tid;
+}
+
 // per (gene, group): the accumulated parts -> 2 U and the tie term (the CSC epilogue of k_csc_ovr_gene)
 struct OvrPartsFinishParams {
     u64 *gacc;               // in: packed rank sums / counts   (aliases out_2u: same element, read before written)

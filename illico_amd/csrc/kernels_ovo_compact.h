@@ -51,6 +51,7 @@ struct GroupCompactParams {
     long long xt_stride;
     u16 *nnz;               // [ncols][G] non-zero keys per (gene, group); the reference's entry is not written
     u32 *gofs;              // [ncols][G] first key slot of (gene, group); the reference's entry is not written
+    u32 *blk_cnt;           // optional [ncols][nblk]: keys written per (gene, block) (dense OVR walks the packed rows block by block)
     double *out_sum;        // [ncols][G] value sums (expm1'd if LOG1P); the reference's entry is not written
     u16 *seg_nnz;           // [ncols][nseg] non-zero keys per segment of the reference
     double *seg_sum;        // [ncols][nseg]
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
     static_assert(sizeof(tile) >= sizeof(double) * RPI * 64, "the tile doubles as the sum scratch");
 
     const int nseg_pad = (P.nseg + 7) & ~7;
-    int gA, gB, out0, seg = -1, seg_row0 = 0, seg_n = 0;
+    int gA, gB, out0, seg = -1, seg_row0 = 0, seg_n = 0, blk = 0;
     if ((int)blockIdx.x < nseg_pad) {
         seg = blockIdx.x;
         if (seg >= P.nseg) return;
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
         const int b = (int)blockIdx.x - nseg_pad;
         gA = P.blk_g0[b]; gB = P.blk_g1[b];
         out0 = P.blk_out[b];
+        blk = b;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c0 = blockIdx.y * 64;
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
         step(bufA);
         if (cg < gB) step(bufB);
     }
+    if (PACK && seg < 0 && P.blk_cnt && lane < GPW && geneW < P.ncols) P.blk_cnt[(size_t)geneW * P.nblk + blk] = (u32)cntv;
     if constexpr (STAGE) { // what is left in the staging pieces: one partial store per gene
         wave_lds_fence();
 #pragma unroll 4

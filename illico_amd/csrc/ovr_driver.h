@@ -1,5 +1,6 @@
 // Host-side launch of the OVR per-gene kernel (included by illico_hip.hip after the context helpers).
 #pragma once
+#include <functional>
 
 constexpr int kOvrThreads = 256; // several small workgroups per CU overlap each other's barriers (1024 measured the same)
 
@@ -71,9 +72,17 @@ static int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
 // fit the LDS key buffer, rank every part with the bucket / sorted forms of k_csc_ovr_gene, sum the parts up.  Genes whose
 // values crowd into one coarse bucket (heavy ties) are recomputed by the general route over the gene range that covers
 // them (run by run).  *done = false: the route does not apply (nothing was launched).
+// packed = non-null: Xt holds the PACKED rows of k_group_compact (non-zero keys only; nnz / blk_cnt beside them): the partition walks
+// those; genes that leave the route are first written again in the padded layout (repad(first gene, count)) for the general route.
+struct OvrPackedInput {
+    const u16 *nnz;
+    const u32 *blk_cnt;
+    std::function<int(int, int)> repad;
+};
 template <typename KeyT>
 static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags,
-                               long long *s2u, u64 *stie, double *ssum, double *gtot, bool *done, bool padded = false) {
+                               long long *s2u, u64 *stie, double *ssum, double *gtot, bool *done, bool padded = false,
+                               const OvrPackedInput *packed = nullptr) {
     *done = false;
     const int G = (int)c->n_groups;
     if (c->no_ovr_parts_path || G > 65535 || c->max_nonref >= (1ll << 23) ||
@@ -107,7 +116,17 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     // per-group value sums from the group-contiguous key rows, in a fixed order (the parts see a group's values in an order
     // that depends on timing)
     if (!padded && (rc = launch_group_sums_rows<KeyT>(c, Xt, stride, nb, dtype, flags, ssum))) return rc;
-    {
+    if (packed) {
+        OvrPartPackedParams Q;
+        Q.Xt = Xt; Q.stride = stride; Q.n_genes = nb; Q.G = G; Q.nblk = c->pk_nblk; Q.nnz = packed->nnz; Q.blk_cnt = packed->blk_cnt;
+        Q.blk_g0 = c->d_pk_blk; Q.blk_g1 = c->d_pk_blk + c->pk_nblk; Q.blk_out = c->d_pk_blk + 2 * c->pk_nblk; Q.cap = cap;
+        Q.out_keys = pkeys; Q.out_codes = pcodes; Q.part_start = part_start; Q.gene_info = gene_info; Q.unit_list = unit_list; Q.n_units = unit_ctr;
+        ProfScope ps(c, KID_OVR_PART);
+        auto kern = k_ovr_partition_packed<KeyT>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovrp_lds_bytes()));
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(OVRP_NT), ovrp_lds_bytes(), c->stream, Q);
+        HIPCHK(c, hipGetLastError());
+    } else {
         OvrPartParams Q;
         Q.Xt = Xt; Q.stride = stride; Q.n_genes = nb; Q.n_cells = padded ? (int)c->pk_len : N; Q.code_by_pos = padded ? c->d_pk_code : c->d_code_by_pos; Q.cap = cap;
         Q.out_keys = pkeys; Q.out_codes = pcodes; Q.part_start = part_start; Q.gene_info = gene_info; Q.unit_list = unit_list; Q.n_units = unit_ctr;
@@ -156,6 +175,7 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
         for (int e = j + 1; e < nb && e - last <= 16; ++e)
             if (h[(size_t)e * 4 + 3] || h[(size_t)nb * 4 + e]) last = e;
         const int sub = last - first + 1;
+        if (packed && (rc = packed->repad(first, sub))) return rc;
         if ((rc = run_ovr_dense_batch<KeyT>(c, Xt + (size_t)first * stride, stride, sub, N, dtype, flags, s2u + (size_t)first * G,
                                             stie + (size_t)first * G, ssum + (size_t)first * G, gtot + first, padded)))
             return rc;

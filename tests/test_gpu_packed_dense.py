@@ -161,8 +161,18 @@ def test_reference_beyond_16_bit_positions_takes_the_other_route(engine):
     assert_planes_match(got, oracle.run(X.astype(np.float64), g), ref_row=g.encoded_ref_group, what="large reference")
 
 
-# ---- dense OVR: the padded transposition (k_group_compact keeping every key, group sums folded in) -------------------------
+# ---- dense OVR: k_group_compact in place of the transposition, group sums folded in; the partition walks the packed rows (non-zero
+# keys only) or, with "no_ovr_packed_partition", the padded rows (every key) -------------------------------------------------
 def _check_ovr(engine, X, labels, *, what, fc_rtol=1e-12, **kw):
+    for padded_rows in (0, 1):
+        engine.set_option("no_ovr_packed_partition", padded_rows)
+        try:
+            _check_ovr_once(engine, X, labels, what=f"{what} padded_rows={padded_rows}", fc_rtol=fc_rtol, **kw)
+        finally:
+            engine.set_option("no_ovr_packed_partition", 0)
+
+
+def _check_ovr_once(engine, X, labels, *, what, fc_rtol=1e-12, **kw):
     _, g = oracle.encode_and_count_groups(labels, None)
     (p_new, s_new, prof_new), (p_old, s_old, prof_old) = _both_routes(engine, X, g, **kw)
     assert "k_group_compact" in prof_new and "k_transpose_permute" not in prof_new, prof_new

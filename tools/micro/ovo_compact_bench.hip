@@ -129,7 +129,7 @@ int main(int argc, char **argv) {
     u32 *gofs; CK(hipMalloc(&gofs, (size_t)M * G * 4));
     printf("packed layout: %d blocks, stride %lld (dense %lld)\n", nblk, pk_stride, stride);
     GroupCompactParams Q;
-    Q.X = X; Q.ld = M; Q.col0 = 0; Q.ncols = M; Q.perm = d_perm; Q.pos_ptr = d_pos; Q.G = G; Q.ref = 0; Q.nseg = nseg; Q.blk_g0 = d_pk; Q.blk_g1 = d_pk + nblk; Q.blk_out = d_pk + 2 * nblk; Q.nblk = nblk; Q.ref_out = ref_out; Q.gofs = gofs; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum; Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.out_sum = ssum[1];
+    Q.X = X; Q.ld = M; Q.col0 = 0; Q.ncols = M; Q.perm = d_perm; Q.pos_ptr = d_pos; Q.G = G; Q.ref = 0; Q.nseg = nseg; Q.blk_g0 = d_pk; Q.blk_g1 = d_pk + nblk; Q.blk_out = d_pk + 2 * nblk; Q.nblk = nblk; Q.ref_out = ref_out; Q.gofs = gofs; Q.blk_cnt = nullptr; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum; Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.out_sum = ssum[1];
     OvoCompactParams C;
     C.Xs = Xt; C.gene_stride = stride; C.counts = d_counts; C.nnz = nnz; C.gofs = gofs; C.ref_out = ref_out; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum; C.out_sum = ssum[1]; C.nseg = nseg; C.G = G; C.ref = 0; C.n_genes = M; C.ref_cap = n_ref; C.nbk_lg = nbk_lg;
     C.out_2u = s2u[1]; C.out_tie = stie[1]; C.route = route;
