@@ -364,12 +364,10 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
         const u32 h = ocr_hash(q);
         wofs[r] = (h >> 5) & (OCR_BLOOM_WORDS - 1);
         bool flag = false;
-#ifndef OCR_X_NOBLOOM
         if (r < NR - 1 || vl) {
             const u32 old = atomicOr(&bloom[wofs[r]], 1u << (h & 31));
             flag = (old >> (h & 31)) & 1u;
         }
-#endif
         fm[r] = __ballot(flag);
     }
 #pragma unroll
@@ -380,9 +378,7 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
         const u32 w = pw[0], h = pw[1];
         const u32 lo = min((h + ocr_below(w, sh)) & 0xFFFFu, R.nA); // meaningless in an overfull word (bit 31 of h): redone below
         const KeyT a0 = R.A[lo], a1 = R.A[lo + 1], a2 = R.A[lo + 2]; // a bucket holds at most 3; past it: later buckets / the pad: > q or == MAXK
-#ifndef OCR_X_NOBLOOM
         if (r < NR - 1 || vl) bloom[wofs[r]] = 0u;       // wipe (LDS operations of one wavefront execute in order)
-#endif
         u32 l = lo + (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u);
         u64 e4 = __ballot(a0 == q) | __ballot(a1 == q) | __ballot(a2 == q), o4 = __ballot((int)h < 0), n4 = __ballot(q < ZEROK);
         if (r == NR - 1) { l = vl ? l : 0u; e4 &= vlast; o4 &= vlast; n4 &= vlast; }
@@ -395,15 +391,6 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
     u64 TT = 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) a[r] = 0u;
-#ifdef OCR_X_NORARE
-    eqm = ovm = 0;
-#endif
-#ifdef OCR_X_NOOV
-    ovm = 0;
-#endif
-#ifdef OCR_X_NOEQ
-    eqm = 0;
-#endif
     if (eqm) { // a key that ties with the reference somewhere in the group: count, bounded by the bucket (the pad's MAXK never counts)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -649,9 +636,6 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     // ---- every other group: one wavefront each, 64 groups per output block ----
     u32 *bloom = bloom_all + wave * OCR_BLOOM_WORDS;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#ifdef OCR_X_BUILDONLY
-    if (T_A != 12345ull) return;
-#endif
     for (int g0 = wave * 64; g0 < G; g0 += NW * 64) {
         const int gl = g0 + lane;
         const bool has = gl < G && gl != ref;
