@@ -355,8 +355,7 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
     const int rem = nB - 64 * (NR - 1);               // keys of the last round, 1..64
     const u64 vlast = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
     const bool vl = (vlast >> lane) & 1ull;
-    u32 wofs[NR], lessr[NR], cnt_[NR];
-    KeyT k0[NR], k1[NR], k2[NR];
+    u32 wofs[NR], lessr[NR];
     u64 fm[NR], eqr[NR], ovr_[NR], eqm = 0, ovm = 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) { // Bloom inserts of every round first: a key's flag says "may repeat an EARLIER key"
@@ -382,7 +381,7 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
         u32 l = lo + (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u);
         u64 e4 = __ballot(a0 == q) | __ballot(a1 == q) | __ballot(a2 == q), o4 = __ballot((int)h < 0), n4 = __ballot(q < ZEROK);
         if (r == NR - 1) { l = vl ? l : 0u; e4 &= vlast; o4 &= vlast; n4 &= vlast; }
-        lessr[r] = l; cnt_[r] = (w >> sh) & 3u; k0[r] = a0; k1[r] = a1; k2[r] = a2;
+        lessr[r] = l;
         eqr[r] = e4; ovr_[r] = o4;
         eqm |= e4; ovm |= o4;
         negs_out += (u32)__popcll(n4);
@@ -394,9 +393,12 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
     if (eqm) { // a key that ties with the reference somewhere in the group: count, bounded by the bucket (the pad's MAXK never counts)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            if (eqr[r]) { // uniform
+            if (eqr[r]) { // uniform; the round's table word and keys are read again here rather than kept in registers all along
                 const KeyT q = cur[r];
-                const u32 e = ((cnt_[r] > 0u && k0[r] == q) ? 1u : 0u) + ((cnt_[r] > 1u && k1[r] == q) ? 1u : 0u) + ((cnt_[r] > 2u && k2[r] == q) ? 1u : 0u);
+                const u32 b = ocr_bucket(R, q), sh = (b & 15u) << 1;
+                const u32 w = R.tab[2 * (b >> 4)], h = R.tab[2 * (b >> 4) + 1], c = (w >> sh) & 3u;
+                const u32 lo = min((h + ocr_below(w, sh)) & 0xFFFFu, R.nA);
+                const u32 e = ((c > 0u && R.A[lo] == q) ? 1u : 0u) + ((c > 1u && R.A[lo + 1] == q) ? 1u : 0u) + ((c > 2u && R.A[lo + 2] == q) ? 1u : 0u);
                 a[r] = (r < NR - 1 || vl) ? e : 0u;
             }
         }

@@ -128,21 +128,33 @@ def _continuous_slice(c2, lb, ub):
     return torch.log1p(blk * torch.empty_like(blk).uniform_(0.5, 1.5, generator=gen)).contiguous()
 
 
-def test_c2_continuous_ovo_bucketed_reference_equals_sorted_reference(c2):
-    """Full-size groups (300k cells, 2000 groups, 10 000 reference cells), continuous values: the sort route with the
-    reference column in value buckets gives the same planes, bit for bit, as with the sorted reference column; sampled
-    genes against the CPU oracle."""
+def test_c2_continuous_ovo_packed_route_equals_transpose_route(c2):
+    """Full-size groups (300k cells, 2000 groups, 10 000 reference cells), continuous values: the packed route (group-wise
+    packing + look-ups in the counted bitmap of the reference, kernels_ovo_compact.h) gives the same U and p, bit for bit, as the
+    transposition + k_ovo_rank route -- with that route's reference column in value buckets and sorted --; fold changes at
+    1e-13 (the group sums are formed by different kernels); sampled genes against the CPU oracle."""
     Xc = _continuous_slice(c2, 2048, 2048 + 192)
     grpc = c2["gc"](c2["codes"], G, False)
     eng = c2["eng"]
-    got = [a.cpu().numpy() for a in _planes(c2, grpc, X=Xc)]
-    eng.set_option("no_ovo_ref_buckets", 1)
+    eng.set_option("profile", 1)
+    eng.profile_reset()
     try:
-        want = [a.cpu().numpy() for a in _planes(c2, grpc, X=Xc)]
+        got = [a.cpu().numpy() for a in _planes(c2, grpc, X=Xc)]
+        prof = eng.profile_get()
     finally:
-        eng.set_option("no_ovo_ref_buckets", 0)
-    for a, b in zip(got, want):
-        np.testing.assert_array_equal(a, b)
+        eng.set_option("profile", 0)
+    assert "k_group_compact" in prof and "k_ovo_rank_compact" in prof and "k_transpose_permute" not in prof, prof
+    for sorted_ref in (0, 1):
+        eng.set_option("no_packed_dense", 1)
+        eng.set_option("no_ovo_ref_buckets", sorted_ref)
+        try:
+            want = [a.cpu().numpy() for a in _planes(c2, grpc, X=Xc)]
+        finally:
+            eng.set_option("no_ovo_ref_buckets", 0)
+            eng.set_option("no_packed_dense", 0)
+        np.testing.assert_array_equal(got[0], want[0])
+        np.testing.assert_array_equal(got[1], want[1])
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-13, atol=0, equal_nan=True)
     cols = [0, 77, 191]
     ora = oracle.run(Xc[:, cols].contiguous().cpu().numpy(), grpc, batch_size=1, n_threads=len(cols))
     assert_planes_match(tuple(a[:, cols] for a in got), ora, ref_row=0, what="continuous OVO spot check")
