@@ -26,10 +26,14 @@
 #define GCMP_NT 512
 #define OCR_NT 1024
 #define OCR_KMAX 4          // 64-key rounds per group: groups of up to 256 non-zero keys
-#define OCR_BLOOM_WORDS 256 // per wavefront: 8192 bits
+#ifndef OCR_BLOOM_WORDS
+#define OCR_BLOOM_WORDS 256
+#endif // per wavefront: 8192 bits
 
 #define GCMP_SEG_ROWS 512    // the reference group is packed in independent segments of this many rows (one workgroup each)
-#define GCMP_BLOCK_ROWS 1024 // other groups: consecutive groups of at least this many rows together share one workgroup
+#ifndef GCMP_BLOCK_ROWS
+#define GCMP_BLOCK_ROWS 1024
+#endif // other groups: consecutive groups of at least this many rows together share one workgroup
 static inline int gcmp_ref_segments(long long n_ref) { return (int)((n_ref + GCMP_SEG_ROWS - 1) / GCMP_SEG_ROWS); }
 
 // Packed key layout of one gene (pk_stride keys): [block 0 | block 1 | ... | reference segments].  A block = consecutive groups
