@@ -1,20 +1,24 @@
-// Dense one-versus-reference (OVO) on continuous values: group-wise compaction + look-ups in a bucketed reference.
+// Dense input, any values: group-wise packing of the key rows (OVO and OVR) + look-ups in a counted bitmap of the reference (OVO).
 //
 // The two-pass route of kernels_ovo.h transposes the whole window (zeros included) and lets one wavefront prove every
 // group's keys distinct, compact them and look them up.  Expression matrices are mostly zeros, and a group's zeros need
 // no look-up at all: they are one run whose rank follows from three counts.  So here
 //
-//   k_group_compact     one workgroup per (group, 64-gene block): reads the group's rows of X once (256-byte row segments,
-//                       64 rows at a time through LDS), converts to keys and writes, per gene, the group's NON-ZERO keys
-//                       packed at the start of the group's slot of the gene-major key buffer; beside them the number of
-//                       non-zeros (16 bit) and the group's value sum (float64, fixed order: deterministic).  HBM-bound:
-//                       X once in, the non-zeros once out.
-//   k_ovo_rank_compact  one workgroup per gene: the reference's non-zero keys are dealt into value buckets in LDS
-//                       (one 32-bit table word per bucket: keys << 16 | first key), then one wavefront per group looks every
-//                       non-zero key up: S2 += 2 #A<q + #A==q.  Ties inside a group are found, not assumed away: a
-//                       one-word-per-key Bloom table flags keys that MAY repeat an earlier key of the group; each flagged
-//                       key is then compared with all keys of the group (ballots), which yields its exact multiplicity.
-//                       No sort, no compaction, no second Bloom table; integer arithmetic only => bit-exact statistics.
+//   k_group_compact     one workgroup per (block of consecutive groups, 64 genes): reads the block's rows of X once (256-byte
+//                       row segments, 64 rows at a time through LDS, two chunks in flight), converts to keys and writes, per
+//                       gene, the groups' NON-ZERO keys back to back into the block's region of the gene's key row, as whole
+//                       256-byte stores out of an LDS staging piece; beside them, per (gene, group): the number of non-zeros
+//                       (16 bit), where they start, and the group's value sum (float64, fixed order: deterministic).  HBM:
+//                       X once in, the non-zeros once out.  PACK = false keeps every key (dense OVR's transposition with the
+//                       group sums folded in); dense OVR's partition (kernels_csc_ovr.h) walks either form.
+//   k_ovo_rank_compact  one workgroup per gene: the reference's non-zero keys are dealt into value buckets in LDS -- 2^17
+//                       buckets at half a byte each: per 16 buckets one 64-bit word of 2-bit counters + 16-bit prefix --, then
+//                       one wavefront per group looks every non-zero key up (one table word, three keys, six compares):
+//                       S2 += 2 #A<q + #A==q.  Ties inside a group are found, not assumed away: a one-word-per-key Bloom
+//                       table flags keys that MAY repeat an earlier key of the group; each flagged key is then compared with
+//                       all keys of the group (ballots), which yields its exact multiplicity.  No sort, no compaction, no
+//                       second Bloom table; integer arithmetic only => bit-exact statistics.  Genes whose reference keys crowd
+//                       (heavy ties) are left, flagged, to k_ovo_rank over the same packed layout.
 //
 // Replaces the same reference code as kernels_ovo.h: dense_ovo_mwu_kernel_over_contiguous_col_chunk (illico/ovo/dense_ovo.py:
 // 65-137), i.e. the per-column sorts (utils/ranking.py:161-172) and rank_sum_and_ties_from_sorted (utils/ranking.py:52-158),
@@ -27,8 +31,8 @@
 #define OCR_NT 1024
 #define OCR_KMAX 4          // 64-key rounds per group: groups of up to 256 non-zero keys
 #ifndef OCR_BLOOM_WORDS
-#define OCR_BLOOM_WORDS 256
-#endif // per wavefront: 8192 bits
+#define OCR_BLOOM_WORDS 256 // per wavefront: 8192 bits
+#endif
 
 #define GCMP_SEG_ROWS 512    // the reference group is packed in independent segments of this many rows (one workgroup each)
 #ifndef GCMP_BLOCK_ROWS
