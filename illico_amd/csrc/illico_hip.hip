@@ -605,18 +605,26 @@ static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t m
 }
 
 // ---- packed dense OVO route (kernels_ovo_compact.h) ----
-// value buckets of the packed rank kernel: the most (up to 2^17, half a byte each) that fit LDS beside the reference's keys; 0: no fit
-template <typename KeyT> static int packed_nbk_lg(int64_t n_ref) {
-    for (int lg = 17; lg >= 14; --lg)
-        if (ocr_lds_bytes((int)n_ref, lg, sizeof(KeyT)) <= kMaxLds) return lg;
-    return 0;
+// LDS sizing of the packed rank kernel: key slots for the reference's NON-ZERO keys and the bucket count (2^lg, half a byte each).
+// A reference whose every cell fits beside 2^17 buckets gets one slot per cell; a larger one gets the slots that fit beside 2^16
+// buckets -- an expression matrix is mostly zeros, so the non-zeros of a 33 000-cell reference still fit -- and a gene whose
+// non-zeros exceed the slots is left to k_ovo_rank by the kernel (as the tie-heavy ones are).
+template <typename KeyT> static void packed_ref_sizing(int64_t n_ref, int *cap, int *lg) {
+    if (ocr_lds_bytes((int)n_ref, 17, sizeof(KeyT)) <= kMaxLds) { *cap = (int)n_ref; *lg = 17; return; }
+    // 2^17 buckets while 60 % of the reference's cells would still fit the slots left beside them, else 2^16 and more slots
+    const size_t fixed17 = ocr_lds_bytes(0, 17, sizeof(KeyT));
+    const int64_t cap17 = fixed17 < kMaxLds ? (int64_t)((kMaxLds - fixed17) / sizeof(KeyT)) - 8 : 0;
+    if (cap17 > 0 && n_ref * 6 <= cap17 * 10) { *lg = 17; *cap = (int)std::min<int64_t>(n_ref, cap17); return; }
+    *lg = 16;
+    const size_t fixed = ocr_lds_bytes(0, 16, sizeof(KeyT));
+    *cap = (int)std::min<int64_t>(n_ref, (int64_t)((kMaxLds - fixed) / sizeof(KeyT)) - 8);
 }
-// Sizes the route holds: reference of at most 65535 cells whose keys fit LDS in both kernels (k_ovo_rank takes the tie-heavy
-// genes), other groups of at most 1024 cells (k_ovo_rank's register form).
+// Sizes the route holds: reference of at most 65535 cells whose keys fit k_ovo_rank's LDS (it takes the tie-heavy genes and those
+// whose non-zeros exceed the packed kernel's key slots), other groups of at most 1024 cells (k_ovo_rank's register form).
 template <typename KeyT> static bool packed_route_fits(const illico_ctx *c) {
     if (c->ref < 0 || c->no_packed_dense) return false;
     const int64_t n_ref = c->h_counts[c->ref];
-    return n_ref >= 1 && n_ref <= 65535 && c->max_nonref <= 1024 && packed_nbk_lg<KeyT>(n_ref) > 0 && ovo_sort_route_fits<KeyT>(n_ref, c->max_nonref);
+    return n_ref >= 1 && n_ref <= 65535 && c->max_nonref <= 1024 && ovo_sort_route_fits<KeyT>(n_ref, c->max_nonref);
 }
 
 // k_group_compact over one gene batch; pack = false: the padded dense layout (every key kept, sums only)
@@ -667,7 +675,8 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
     {
         OvoCompactParams C;
         C.Xs = Xt; C.gene_stride = stride; C.counts = c->d_counts; C.nnz = nnz; C.gofs = gofs; C.ref_out = c->pk_ref_out; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum;
-        C.out_sum = ssum; C.G = G; C.ref = ref; C.n_genes = nb; C.nseg = nseg; C.ref_cap = (int)n_ref; C.nbk_lg = packed_nbk_lg<KeyT>(n_ref);
+        C.out_sum = ssum; C.G = G; C.ref = ref; C.n_genes = nb; C.nseg = nseg;
+        packed_ref_sizing<KeyT>(n_ref, &C.ref_cap, &C.nbk_lg);
         C.out_2u = s2u; C.out_tie = stie; C.route = route;
         const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
         auto kern = k_ovo_rank_compact<KeyT>;

@@ -289,7 +289,7 @@ struct OvoCompactParams {
     const double *seg_sum;   // [n_genes][nseg]
     double *out_sum;         // [n_genes][G]: the reference's entry is written here (sum of its segments, in order)
     int G, ref, n_genes, nseg;
-    int ref_cap;             // LDS key slots for the reference's non-zeros (>= the reference group's size)
+    int ref_cap;             // LDS key slots for the reference's non-zeros (a gene with more of them is left to k_ovo_rank)
     int nbk_lg;              // log2(value buckets), 14 .. 17
     long long *out_2u;       // [n_genes][G]
     u64 *out_tie;            // [n_genes][G]
@@ -298,9 +298,9 @@ struct OvoCompactParams {
                              // of the group loop) or a group of more than 256 non-zeros.  For those the reference's segments are
                              // moved together and nnz / gofs[gene][ref] are set.
 };
-// a gene leaves this kernel when one table word (16 buckets) holds more than OCR_MAX_WORD reference keys, or when more than an
-// eighth of the reference's keys sit in words with an overfull bucket
-#define OCR_MAX_WORD 32
+// a gene leaves this kernel when one table word (16 buckets) holds more than OCR_MAX_WORD reference keys, or when more than half
+// of the reference's keys sit in words with an overfull bucket (such words are walked key by key: exact, but slow)
+#define OCR_MAX_WORD 64
 
 // The reference's non-zero keys in LDS.  Value buckets (key - kmin) >> shift, 2^nbk_lg of them; keys are stored in bucket order
 // (any order inside a bucket).  The table costs HALF A BYTE per bucket: one 64-bit word per 16 buckets,
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         if (lane == 0) { s_scan[wave] = tot; if (ftot) atomicAdd(&s_cnt[4], ftot); }
         if (lane == 63 && fmax) atomicMax(&s_cnt[2], fmax);
         __syncthreads();
-        if (s_cnt[2] > OCR_MAX_WORD || s_cnt[4] * 8u > nA || s_cnt[3] > 64u * OCR_KMAX) { // uniform: this gene goes to k_ovo_rank
+        if (nA > (u32)P.ref_cap || s_cnt[2] > OCR_MAX_WORD || s_cnt[4] * 2u > nA || s_cnt[3] > 64u * OCR_KMAX) { // uniform: this gene goes to k_ovo_rank
             u32 dst = P.nseg ? (u32)seg_nnz[0] : 0u;
             for (int sg = 1; sg < P.nseg; ++sg) { // move the reference's segments together (a segment holds at most NT / 2 keys)
                 const u32 c = (u32)seg_nnz[sg];

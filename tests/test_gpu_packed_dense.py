@@ -143,6 +143,22 @@ def test_packed_route_tiny_cases(engine):
         _check(engine, X, labels, what=f"tiny {n_ref} {others}")
 
 
+def test_packed_route_reference_larger_than_its_key_slots(engine):
+    """A reference of 30 000 cells does not fit the packed kernel's LDS key slots cell for cell: the slots are sized for non-zero
+    keys (20 400 beside 2^17 buckets), a gene with more non-zeros than that is left to k_ovo_rank on the device, a sparser one is
+    ranked by the packed kernel."""
+    rng = np.random.RandomState(17)
+    n_ref, others = 30000, 24
+    labels = np.array(["non-targeting"] * n_ref + [f"pert_{i % others:02d}" for i in range(others * 90)])
+    n = labels.size
+    X = rng.gamma(2.0, 1.0, size=(n, 4)).astype(np.float32)
+    X[:, 0] *= rng.rand(n) < 0.2          # 6 000 reference non-zeros: fits
+    X[:, 2] *= rng.rand(n) < 0.72         # ~21 600: more than the slots
+    X[:, 3] = np.round(X[:, 3], 1) * (rng.rand(n) < 0.5)  # ties, 15 000 non-zeros
+    perm = rng.permutation(n)
+    _check(engine, X[perm], labels[perm], what="large reference")
+
+
 def test_reference_beyond_16_bit_positions_takes_the_other_route(engine):
     rng = np.random.RandomState(16)
     n = 70000
