@@ -598,7 +598,7 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
     unsigned char *part_of = (unsigned char *)(s_k + 2); // [NB]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    constexpr int UL = 4; // 64-key pieces of a block in flight per wavefront
+    constexpr int UL = 8; // 64-key pieces of a block in flight per wavefront (a block of ~1024 rows holds ~500 keys)
     const int gene = blockIdx.x;
     const KeyT *row = (const KeyT *)P.Xt + (size_t)gene * P.stride;
     const u32 *bcnt = P.blk_cnt + (size_t)gene * P.nblk;
