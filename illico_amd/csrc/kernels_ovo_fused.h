@@ -271,6 +271,9 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
             if (!WIDE && RT < FUSED_WIDE_RT) { bool ew; clamp_count<InT, FUSED_WIDE_RT>(v[u], ew); hopeless |= valid && !ew; }
             atomicAdd(&hl[c], valid ? 1u : 0u);
         }
+        // every gene of the tile already known to be no count at all (continuous data: after the first rows): nothing this
+        // wavefront would still add is used -- the genes are flagged 3 and recomputed, reference row included, by the two-pass routes
+        if (!WIDE && RT < FUSED_WIDE_RT && __all(hopeless || !act)) break;
     }
     if (bad) atomicMax(&s_bad[lane], hopeless ? 2 : 1);
     __syncthreads();
