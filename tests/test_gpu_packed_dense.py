@@ -143,6 +143,24 @@ def test_packed_route_tiny_cases(engine):
         _check(engine, X, labels, what=f"tiny {n_ref} {others}")
 
 
+def test_packed_routes_many_tiny_groups_and_exact_round_sizes(engine):
+    """Blocks of hundreds of 1 - 3 cell groups (a 64-key piece of a block then spans dozens of groups: the group codes of the OVR
+    partition, the per-group offsets of the OVO rank kernel), and groups of exactly 64 / 65 / 128 / 192 / 256 / 257 non-zero keys
+    (the rank kernel's round boundaries; 257 leaves for k_ovo_rank)."""
+    rng = np.random.RandomState(18)
+    tiny = np.concatenate([np.full(rng.randint(1, 4), i) for i in range(1500)])
+    labels = np.array(["non-targeting"] * 300 + [f"tiny_{c:04d}" for c in tiny] +
+                      sum(([f"exact_{k:03d}"] * k for k in (64, 65, 128, 192, 256, 257)), []))
+    n = labels.size
+    X = rng.uniform(0.1, 9.0, size=(n, 6)).astype(np.float32)   # no zeros: a group's non-zeros = its cells
+    X[:, 1] *= rng.rand(n) < 0.5
+    X[:, 2] = np.round(X[:, 2], 1)
+    perm = rng.permutation(n)
+    X, labels = X[perm], labels[perm]
+    _check(engine, X, labels, what="tiny groups ovo")
+    _check_ovr(engine, X, labels, what="tiny groups ovr")
+
+
 def test_packed_route_reference_larger_than_its_key_slots(engine):
     """A reference of 30 000 cells does not fit the packed kernel's LDS key slots cell for cell: the slots are sized for non-zero
     keys (20 400 beside 2^17 buckets), a gene with more non-zeros than that is left to k_ovo_rank on the device, a sparser one is
