@@ -516,8 +516,10 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
 
     // ---- the reference's non-zero keys -> value buckets ----
     for (int i = tid; i < NW * OCR_BLOOM_WORDS; i += NT) bloom_all[i] = 0u;
-    for (int i = tid; i < 2 * (NWD + 2); i += NT) tab[i] = 0u;
-    for (int i = tid; i < P.ref_cap + 4; i += NT) A[i] = MAXK; // empty slots (the scatter claims them by compare-and-swap) and the pad
+    {
+        uint4 *t4 = (uint4 *)tab; // (the table starts on a 16-byte boundary and holds an even number of 64-bit words)
+        for (int i = tid; i < (NWD + 2) / 2; i += NT) t4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (tid == 0) { s_kr[0] = MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; s_cnt[3] = 0u; s_cnt[4] = 0u; }
     __syncthreads();
     {
@@ -554,6 +556,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     __syncthreads();
     const u32 nA = s_cnt[1];
     const u32 aZ = (u32)n_ref - nA;
+    for (u32 i = tid; i < min(nA, (u32)P.ref_cap) + 4u; i += NT) A[i] = MAXK; // empty slots (the scatter claims them by compare-and-swap) and the pad
     OcrRef<KeyT> R;
     R.A = A; R.tab = tab; R.last = (1u << P.nbk_lg) - 1u;
     R.kmin = nA ? s_kr[0] : (KeyT)0;

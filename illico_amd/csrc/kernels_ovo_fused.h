@@ -600,16 +600,20 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_ovr_group_hists(FusedParams P) 
     const u32 row_bytes = (u32)P.ld * (u32)sizeof(InT), col_bytes = (u32)lane_c * (u32)sizeof(InT);
     const const_int_p permc = (const_int_p)P.perm;
     u32 *cbw = cntB[wave];
-    __shared__ int s_skip;
-    if (wave == 0) { // every gene of this tile already sent to the slower routes (k_fused_probe)? then there is nothing to do here
-        const bool flagged = !act || P.gene_flags[gene] != 0;
-        const bool all = __all(flagged);
-        if (lane == 0) s_skip = all ? 1 : 0;
+    // every gene of this tile already sent to the slower routes (k_fused_probe)? then there is nothing to do here.  One wavefront
+    // decides for all (other workgroups may flag genes meanwhile); the answer travels through hpack[0] before that is zeroed: a
+    // word of its own would cost a resident workgroup (4 x 40 KB fill the CU's 160 KB of LDS)
+    if (wave == 0) {
+        const bool all = __all(!act || P.gene_flags[gene] != 0);
+        if (lane == 0) hpack[0] = all ? 1u : 0u;
     }
+    __syncthreads();
+    const u32 skip = hpack[0];
+    __syncthreads();
+    if (skip) return;
     for (int i = tid; i < (RT / 2) * 64; i += NT) hpack[i] = 0;
     for (int i = 0; i < BWMAX; ++i) cbw[i * 64 + lane] = 0;
     __syncthreads();
-    if (s_skip) return;
     bool bad = false;
     const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
     const size_t tiles = gridDim.x;

@@ -243,6 +243,26 @@ __global__ void k_sample_noncount(const InT *__restrict__ data, long long nnz, i
     }
 }
 
+// The same over the stored entries of the CSC columns [lb, ub), with the window's bounds read from indptr ON THE DEVICE: the
+// driver enqueues it together with its own copy of indptr and waits once for both (n_bad[2] = the samples taken).
+template <typename InT, typename IdxT>
+__global__ void k_sample_noncount_cols(const InT *__restrict__ data, const IdxT *__restrict__ indptr, long long lb, long long ub, int max_samples,
+                                       int limit, u32 *__restrict__ n_bad) {
+    const long long k0 = (long long)indptr[lb], nnz = (long long)indptr[ub] - k0;
+    const int n_samples = (int)(nnz < (long long)max_samples ? nnz : (long long)max_samples);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) n_bad[2] = (u32)n_samples;
+    if (i >= n_samples) return;
+    const long long k = (long long)((double)i * (double)nnz / (double)n_samples);
+    const InT v = data[k0 + (k < nnz ? k : nnz - 1)];
+    const bool integer = v >= (InT)0 && v < (InT)(1 << 24) && (InT)(int)v == v;
+    const u64 b0 = __ballot(!integer), b1 = __ballot(integer && v >= (InT)limit);
+    if ((threadIdx.x & 63) == 0) {
+        if (b0) atomicAdd(n_bad, (u32)__popcll(b0));
+        if (b1) atomicAdd(n_bad + 1, (u32)__popcll(b1));
+    }
+}
+
 // ---- CSR -> CSC on the device, for a window of W columns [c0, c0 + W): a two-pass blocked transposition.  Row blocks
 // of TR_RB rows are contiguous runs of the CSR arrays, so both passes read them coalesced; per block an LDS table over
 // the window's columns counts (pass 1) or hands out positions (pass 2), and an entry's destination lies in a run of its

@@ -297,16 +297,51 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     int rc;
     void *v;
 
-    // host copy of indptr (batch planning for CSC; total nnz for CSR)
-    std::vector<IdxT> h_indptr(n_ptr);
+    // CSC, count-valued, groups of at most 255 cells: per-group histograms in LDS (OVO and OVR) -- when a sample of the window's
+    // stored values says they are counts at all
+    int n_big_groups = 0;
+    for (int g = 0; g < G; ++g) n_big_groups += (g != c->ref && c->h_counts[g] > 255) ? 1 : 0;
+    const bool counts_route = !is_csr && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && n_big_groups <= CSCC_MAX_BIG &&
+                              cscc_lds_bytes(G, 32) + 8192 <= kMaxLds && n_rows < (1ll << 30) &&
+                              (ovr || c->h_counts[c->ref] < 30000); // 32-bit inner terms of the sweep
+    // CSR, count-valued, not too sparse: dense windows + the fused single-pass kernels (below); the same question about the values
+    const bool window_route = is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) &&
+                              (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes;
+    u32 h_sample[4] = {0, 0, 0, 0}; // non-integers, integers beyond the table, samples taken
+    bool sampled = false;
+
+    // what the host needs of indptr: all of it for CSC (batch planning), its two ends for CSR (total stored entries)
+    std::vector<IdxT> h_indptr;
+    IdxT ends[2] = {0, 0};
     if (in_dev) { // on the context's stream: ordered after whatever produced indptr on it (a blocking hipMemcpy runs on the
         // null stream, which non-blocking streams -- torch's side streams -- do not synchronise with)
-        HIPCHK(c, hipMemcpyAsync(h_indptr.data(), indptr, n_ptr * sizeof(IdxT), hipMemcpyDeviceToHost, c->stream));
+        if ((counts_route && W > 0) || window_route) { // the sample of the stored values rides along: one wait for both
+            if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
+            u32 *d_cnt = (u32 *)v;
+            HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
+            hipLaunchKernelGGL((k_sample_noncount_cols<InT, IdxT>), dim3((1 << 16) / 256), dim3(256), 0, c->stream, (const InT *)data,
+                               (const IdxT *)indptr, (long long)(is_csr ? 0 : col_lb), (long long)(is_csr ? n_rows : col_ub), 1 << 16,
+                               is_csr ? FUSED_RT : CSCC_RT, d_cnt);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(h_sample, d_cnt, 16, hipMemcpyDeviceToHost, c->stream));
+            sampled = true;
+        }
+        if (is_csr) {
+            HIPCHK(c, hipMemcpyAsync(&ends[0], indptr, sizeof(IdxT), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&ends[1], (const IdxT *)indptr + (n_ptr - 1), sizeof(IdxT), hipMemcpyDeviceToHost, c->stream));
+        } else {
+            h_indptr.resize(n_ptr);
+            HIPCHK(c, hipMemcpyAsync(h_indptr.data(), indptr, n_ptr * sizeof(IdxT), hipMemcpyDeviceToHost, c->stream));
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!is_csr) { ends[0] = h_indptr[0]; ends[1] = h_indptr[n_ptr - 1]; }
+    } else {
+        if (!is_csr) h_indptr.assign((const IdxT *)indptr, (const IdxT *)indptr + n_ptr);
+        ends[0] = ((const IdxT *)indptr)[0];
+        ends[1] = ((const IdxT *)indptr)[n_ptr - 1];
     }
-    else memcpy(h_indptr.data(), indptr, n_ptr * sizeof(IdxT));
-    const int64_t total_nnz = (int64_t)h_indptr[n_ptr - 1];
-    if (h_indptr[0] != 0) return fail(c, ILLICO_ERR_ARG, "indptr[0] must be 0");
+    const int64_t total_nnz = (int64_t)ends[1];
+    if (ends[0] != 0) return fail(c, ILLICO_ERR_ARG, "indptr[0] must be 0");
 
     // device views of the matrix: stored entry k of the caller's arrays is d_data[k - kshift] / d_indices[k - kshift]
     const InT *d_data = (const InT *)data;
@@ -331,22 +366,23 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
 
     // ---- CSR, count-valued, not too sparse: dense float32 windows + the fused single-pass kernels (k_csr_densify) ----
     const double density = (double)total_nnz / ((double)std::max<int64_t>(n_rows, 1) * (double)std::max<int64_t>(n_cols, 1));
-    bool dense_window = is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) && density >= 0.015 &&
-                        (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes && total_nnz > 0;
+    bool dense_window = window_route && density >= 0.015 && total_nnz > 0;
     if (dense_window) { // worth it only for count-valued data: look at 64k evenly spaced stored values first
-        const int n_samples = (int)std::min<int64_t>(total_nnz, 1 << 16);
-        if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
-        u32 *d_cnt = (u32 *)v;
-        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
-        hipLaunchKernelGGL((k_sample_noncount<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, d_data, (long long)total_nnz,
-                           n_samples, FUSED_RT, d_cnt);
-        HIPCHK(c, hipGetLastError());
-        u32 n_bad[2] = {0, 0};
-        HIPCHK(c, hipMemcpyAsync(n_bad, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!sampled) { // (device-resident arrays: taken with the indptr copy above)
+            const int n_samples = (int)std::min<int64_t>(total_nnz, 1 << 16);
+            if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
+            u32 *d_cnt = (u32 *)v;
+            HIPCHK(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
+            hipLaunchKernelGGL((k_sample_noncount<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, d_data, (long long)total_nnz,
+                               n_samples, FUSED_RT, d_cnt);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(h_sample, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            h_sample[2] = (u32)n_samples;
+        }
         // the genes this route cannot take are redone over the column window that covers them, so it needs nearly all of
         // them to fit: no non-integers, few values beyond the table
-        dense_window = (double)n_bad[0] <= 0.02 * (double)n_samples && (double)n_bad[1] <= 0.005 * (double)n_samples;
+        dense_window = (double)h_sample[0] <= 0.02 * (double)h_sample[2] && (double)h_sample[1] <= 0.005 * (double)h_sample[2];
     }
     if (dense_window) {
         // byte cells (the fused kernels only take integers below 64): a quarter of the window's traffic both ways;
@@ -501,14 +537,11 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     // stragglers of the single-kernel route are batched together); CSR batches are contiguous windows.
     std::vector<int64_t> cols(W);
     for (int64_t j = 0; j < W; ++j) cols[j] = col_lb + j;
-    // CSC, count-valued, groups of at most 255 cells: per-group histograms in LDS (OVO and OVR)
-    int n_big_groups = 0;
-    for (int g = 0; g < G; ++g) n_big_groups += (g != c->ref && c->h_counts[g] > 255) ? 1 : 0;
-    if (!is_csr && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && n_big_groups <= CSCC_MAX_BIG && cscc_lds_bytes(G, 32) + 8192 <= kMaxLds &&
-        n_rows < (1ll << 30) && (ovr || c->h_counts[c->ref] < 30000)) { // 32-bit inner terms of the sweep
+    if (counts_route) {
         const int64_t k0 = (int64_t)h_indptr[col_lb], k1 = (int64_t)h_indptr[col_ub];
         bool counts = k1 > k0;
-        if (counts) { // count-valued at all?  64k evenly spaced stored values of the window decide
+        if (counts && sampled) counts = (double)h_sample[0] <= 0.02 * (double)h_sample[2]; // (taken with the indptr copy above)
+        else if (counts) { // count-valued at all?  64k evenly spaced stored values of the window decide
             const int n_samples = (int)std::min<int64_t>(k1 - k0, 1 << 16);
             if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
             u32 *d_cnt = (u32 *)v;
