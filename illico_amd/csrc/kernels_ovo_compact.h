@@ -28,7 +28,9 @@
 #include "common.h"
 
 #define GCMP_NT 512
+#ifndef OCR_NT
 #define OCR_NT 1024
+#endif
 #define OCR_KMAX 4          // 64-key rounds per group: groups of up to 256 non-zero keys
 #ifndef OCR_BLOOM_WORDS
 #define OCR_BLOOM_WORDS 256 // per wavefront: 8192 bits
