@@ -450,3 +450,28 @@ def test_explicitly_stored_zeros_are_ranked_as_zeros(engine, test, fmt):
                         what=f"stored zeros {fmt} {test}")
     rows = np.arange(dense.shape[0]) != (g.encoded_ref_group if test == "ovo" else -1)
     assert (got[1][rows] != sparse_ref[rows][:, :, 1]).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_sparse_type_extremes(engine, fmt, test, dtype, route):
+    """The largest / smallest value of the type (the largest integer's sortable key is the all-ones pattern the kernels use for
+    empty slots and padding), +-infinity: a few cells of a column, a third of a column.  Negative stored values are ranked with
+    dense semantics, so the dense oracle is the judge."""
+    rng = np.random.RandomState(3)
+    n, m = 3000, 8
+    labels = make_labels(rng, n, 25, n_ref=600)
+    integer = np.issubdtype(dtype, np.integer)
+    big = np.iinfo(dtype).max if integer else np.inf
+    small = np.iinfo(dtype).min if integer else -np.inf
+    X = (rng.poisson(3.0, size=(n, m)) * rng.randint(1, 1000, size=(n, m))).astype(dtype)
+    X[rng.rand(n, m) < 0.7] = 0
+    X[rng.rand(n) < 0.01, 0] = big
+    X[rng.rand(n) < 0.3, 1] = big
+    X[rng.rand(n) < 0.05, 2] = small
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    want = oracle.run(np.ascontiguousarray(X, dtype=np.float64), g)
+    M = (sparse.csc_matrix if fmt == "csc" else sparse.csr_matrix)(X)
+    got = _run(engine, M, g)
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group if test == "ovo" else None, what=f"{fmt} {test} {np.dtype(dtype).name} {route}")
