@@ -95,7 +95,7 @@ struct illico_ctx {
     u16 *d_codes16 = nullptr;     // [N] d_codes as 16-bit values when G <= 65535 (half the cache lines per codes[row] gather), else null
     // options
     int64_t gene_batch = 0;
-    int64_t scratch_bytes = 24ll << 30;
+    int64_t scratch_bytes = 24ll << 30; // (illico_ctx_create: min(64 GiB, a quarter of the device's memory))
     bool no_counts_path = false;
     bool no_fused_path = false;
     bool no_ovr_packed_partition = false; // 1: dense OVR partitions the padded rows (every key) instead of the packed ones
@@ -255,6 +255,11 @@ int illico_ctx_create(int device_id, illico_ctx **out_ctx) {
         return ILLICO_ERR_HIP;
     }
     c->own_stream = true;
+    { // scratch cap: 64 GiB of the 288 GB an MI355X carries (a C2-shaped continuous OVR pass then runs as one gene batch), a quarter
+      // of the device's memory on anything smaller; "scratch_bytes" overrides
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) c->scratch_bytes = (int64_t)std::min<size_t>((size_t)64 << 30, total_b / 4);
+    }
     *out_ctx = c;
     return ILLICO_OK;
 }

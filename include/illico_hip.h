@@ -71,7 +71,8 @@ int illico_ctx_create(int device_id, illico_ctx **out_ctx);
 int illico_ctx_destroy(illico_ctx *ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int illico_ctx_set_stream(illico_ctx *ctx, void *hip_stream);
-/* Tunables: "gene_batch" (genes per device pass, 0 = auto), "scratch_bytes" (cap of device scratch),
+/* Tunables: "gene_batch" (genes per device pass, 0 = auto), "scratch_bytes" (cap of device scratch; default: 64 GiB or a
+ * quarter of the device's memory, whichever is less),
  * "profile" (1 = bracket kernel launches with HIP events on the context's stream), "profile_only" (kernel id: time
  * that kernel only, -1 = all), "fused_groups_per_wg" / "ovr_hist_groups_per_wg" (launch geometry, 0 = auto).
  * Route switches, all 0 by default; every route produces the same integers, the switches exist so that tests and
