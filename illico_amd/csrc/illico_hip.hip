@@ -100,6 +100,7 @@ struct illico_ctx {
     bool no_fused_path = false;
     bool no_ovr_packed_partition = false; // 1: dense OVR partitions the padded rows (every key) instead of the packed ones
     bool no_packed_dense = false;      // 1: dense OVO on continuous values takes the transpose + k_ovo_rank route (no group-wise packing)
+    int packed_eq_buckets = -1;        // packed rank kernel: distribution-following bucket function; -1 = for references above 16384 cells
     bool no_fused_wide = false;        // 1: no second, 256-value pass of the fused OVO route (genes beyond 63 go to the two-pass routes)
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
@@ -320,6 +321,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_fused_wide")) c->no_fused_wide = value != 0;
     else if (!strcmp(key, "no_packed_dense")) c->no_packed_dense = value != 0;
+    else if (!strcmp(key, "packed_eq_buckets")) c->packed_eq_buckets = (int)value;
     else if (!strcmp(key, "no_ovr_packed_partition")) c->no_ovr_packed_partition = value != 0;
     else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
     else if (!strcmp(key, "no_csc_counts_mixed")) c->no_csc_counts_mixed = value != 0;
@@ -616,10 +618,10 @@ static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t m
 // non-zeros exceed the slots is left to k_ovo_rank by the kernel (as the tie-heavy ones are).
 template <typename KeyT> static void packed_ref_sizing(int64_t n_ref, int *cap, int *lg) {
     if (ocr_lds_bytes((int)n_ref, 17, sizeof(KeyT)) <= kMaxLds) { *cap = (int)n_ref; *lg = 17; return; }
-    // 2^17 buckets while 60 % of the reference's cells would still fit the slots left beside them, else 2^16 and more slots
+    // 2^17 buckets while 55 % of the reference's cells would still fit the slots left beside them, else 2^16 and more slots
     const size_t fixed17 = ocr_lds_bytes(0, 17, sizeof(KeyT));
     const int64_t cap17 = fixed17 < kMaxLds ? (int64_t)((kMaxLds - fixed17) / sizeof(KeyT)) - 8 : 0;
-    if (cap17 > 0 && n_ref * 6 <= cap17 * 10) { *lg = 17; *cap = (int)std::min<int64_t>(n_ref, cap17); return; }
+    if (cap17 > 0 && n_ref * 55 <= cap17 * 100) { *lg = 17; *cap = (int)std::min<int64_t>(n_ref, cap17); return; }
     *lg = 16;
     const size_t fixed = ocr_lds_bytes(0, 16, sizeof(KeyT));
     *cap = (int)std::min<int64_t>(n_ref, (int64_t)((kMaxLds - fixed) / sizeof(KeyT)) - 8);
@@ -684,7 +686,10 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         packed_ref_sizing<KeyT>(n_ref, &C.ref_cap, &C.nbk_lg);
         C.out_2u = s2u; C.out_tie = stie; C.route = route;
         const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
-        auto kern = k_ovo_rank_compact<KeyT>;
+        // large references: the bucket function follows the reference's distribution (a crowded stretch of values would otherwise
+        // fill buckets beyond three keys and send whole table words to key-by-key walks); "packed_eq_buckets" = 0 / 1 forces
+        const bool eq = c->packed_eq_buckets >= 0 ? c->packed_eq_buckets != 0 : n_ref > 16384;
+        auto kern = eq ? k_ovo_rank_compact<KeyT, true> : k_ovo_rank_compact<KeyT, false>;
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ProfScope ps(c, KID_OVO_RANK_COMPACT);
         hipLaunchKernelGGL(kern, dim3(nb), dim3(OCR_NT), lds, c->stream, C);

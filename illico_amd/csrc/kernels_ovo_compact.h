@@ -18,7 +18,9 @@
 //                       table flags keys that MAY repeat an earlier key of the group; each flagged key is then compared with
 //                       all keys of the group (ballots), which yields its exact multiplicity.  No sort, no compaction, no
 //                       second Bloom table; integer arithmetic only => bit-exact statistics.  Genes whose reference keys crowd
-//                       (heavy ties) are left, flagged, to k_ovo_rank over the same packed layout.
+//                       (heavy ties) are left, flagged, to k_ovo_rank over the same packed layout.  For large references
+//                       (EQ = true) the bucket of a key is not a plain shift of key - kmin but follows the reference's
+//                       distribution: 256 coarse cells, each with a power-of-two share of the buckets in proportion to its keys.
 //
 // Replaces the same reference code as kernels_ovo.h: dense_ovo_mwu_kernel_over_contiguous_col_chunk (illico/ovo/dense_ovo.py:
 // 65-137), i.e. the per-column sorts (utils/ranking.py:161-172) and rank_sum_and_ties_from_sorted (utils/ranking.py:52-158),
@@ -315,6 +317,7 @@ __host__ __device__ static inline size_t ocr_lds_bytes(int ref_cap, int nbk_lg, 
     size_t b = (((size_t)ref_cap + 4) * key_size + 15) & ~(size_t)15;
     b += (((size_t)1 << nbk_lg) / 16 + 2) * 8;
     b += (size_t)(OCR_NT / 64) * OCR_BLOOM_WORDS * 4;
+    b += 2048; // coarse cells of the distribution-following bucket function: table + counters
     b += 256; // reduction words
     return b;
 }
@@ -322,18 +325,34 @@ __host__ __device__ static inline size_t ocr_lds_bytes(int ref_cap, int nbk_lg, 
 __device__ __forceinline__ u32 ocr_hash(u32 k) { return k ^ (k >> 10); }
 __device__ __forceinline__ u32 ocr_hash(u64 k) { const u32 f = (u32)(k ^ (k >> 32)); return f ^ (f >> 10); }
 
-template <typename KeyT> struct OcrRef {
+// EQ: the bucket function follows the reference's distribution.  256 coarse cells from the high bits of key - kmin; cell c owns
+// 2^e[c] consecutive fine buckets, e[c] chosen from the cell's key count so that a crowded stretch of values is spread over as many
+// buckets per key as a sparse one (ctab[c] = first fine bucket | (cshift - e[c]) << 24).  Monotone, like the plain shift: nothing
+// downstream changes.  Costs one more 4-byte LDS read per look-up; used for large references, where the plain function would leave
+// the crowded stretch with buckets of four and more keys (whole table words then fall back to key-by-key walks).
+template <typename KeyT, bool EQ> struct OcrRef {
     const KeyT *A;
     const u32 *tab; // word W: tab[2 W] counters, tab[2 W + 1] prefix | overfull flag; one sentinel word (prefix = all keys)
     KeyT kmin;
     int shift;
     u32 last; // buckets - 1
     u32 nA;   // keys
+    const u32 *ctab; // EQ: [256]
+    int cshift;      // EQ
+    KeyT cmask;      // EQ: (1 << cshift) - 1
 };
-template <typename KeyT> __device__ __forceinline__ u32 ocr_bucket(const OcrRef<KeyT> &R, KeyT q) {
+template <typename KeyT, bool EQ> __device__ __forceinline__ u32 ocr_bucket(const OcrRef<KeyT, EQ> &R, KeyT q) {
     const KeyT d = q > R.kmin ? (KeyT)(q - R.kmin) : (KeyT)0;
-    const KeyT b = d >> R.shift;
-    return b < (KeyT)R.last ? (u32)b : R.last;
+    if constexpr (EQ) {
+        const KeyT c = d >> R.cshift;
+        if (c > (KeyT)255) return R.last; // above every reference key
+        const u32 t = R.ctab[(u32)c];
+        const u32 f = (t & 0xFFFFFFu) + (u32)((KeyT)(d & R.cmask) >> (t >> 24));
+        return f < R.last ? f : R.last;
+    } else {
+        const KeyT b = d >> R.shift;
+        return b < (KeyT)R.last ? (u32)b : R.last;
+    }
 }
 // keys in the buckets below position sh (= 2 * bucket-in-word) of a counter word: each 2-bit value = b0 + 2 b1 = (b0 + b1) + b1
 __device__ __forceinline__ u32 ocr_below(u32 w, u32 sh) {
@@ -342,7 +361,7 @@ __device__ __forceinline__ u32 ocr_below(u32 w, u32 sh) {
 }
 // exact look-up: the keys that can be < q without being counted by the word's prefix lie in [lo, hi): the bucket, or the
 // whole word when it is overfull (the order of its keys is arbitrary then)
-template <typename KeyT> __device__ __forceinline__ void ocr_find_exact(const OcrRef<KeyT> &R, KeyT q, u32 &less, u32 &eq) {
+template <typename KeyT, bool EQ> __device__ __forceinline__ void ocr_find_exact(const OcrRef<KeyT, EQ> &R, KeyT q, u32 &less, u32 &eq) {
     const u32 b = ocr_bucket(R, q), W = b >> 4, sh = (b & 15u) << 1;
     const u32 w = R.tab[2 * W], h = R.tab[2 * W + 1];
     u32 lo, hi;
@@ -358,8 +377,8 @@ template <typename KeyT> __device__ __forceinline__ void ocr_find_exact(const Oc
 // ZEROK).  Straight-line per round: Bloom insert (one returning LDS atomic), one table word, 2 keys, 4 compares.
 // Per-lane partial results: less = sum of #A<q (non-zero reference keys), eqs = sum of #A==q, TT = sum t (t + 1); negs
 // (uniform) = keys below zero.  bloom[] is all-zero on entry and on exit.
-template <typename KeyT, int NR>
-__device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, const OcrRef<KeyT> &R, u32 *bloom, int lane, u64 lt_mask,
+template <typename KeyT, int NR, bool EQ>
+__device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, const OcrRef<KeyT, EQ> &R, u32 *bloom, int lane, u64 lt_mask,
                                           u32 &less_out, u32 &eq_out, u64 &TT_out, u32 &negs_out) {
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     const int rem = nB - 64 * (NR - 1);               // keys of the last round, 1..64
@@ -482,7 +501,7 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
     TT_out = TT;
 }
 
-template <typename KeyT>
+template <typename KeyT, bool EQ>
 __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NT = OCR_NT, NW = NT / 64, KMAX = OCR_KMAX;
@@ -494,6 +513,9 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     off += ((size_t)NWD + 2) * 8;
     u32 *bloom_all = (u32 *)(smem + off);
     off += (size_t)NW * OCR_BLOOM_WORDS * 4;
+    u32 *ctab = (u32 *)(smem + off); // [256] coarse cells (EQ)
+    u32 *ccnt = ctab + 256;          // [256] their key counts
+    off += 2048;
     u64 *s_red = (u64 *)(smem + off); // [NW]
     KeyT *s_kr = (KeyT *)(s_red + NW); // [2] min, max
     u32 *s_cnt = (u32 *)(s_kr + 2);    // [0] negatives  [1] non-zero keys  [2] fullest overfull word  [3] largest group  [4] keys in overfull words
@@ -522,6 +544,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         uint4 *t4 = (uint4 *)tab; // (the table starts on a 16-byte boundary and holds an even number of 64-bit words)
         for (int i = tid; i < (NWD + 2) / 2; i += NT) t4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
+    if (EQ && tid < 256) ccnt[tid] = 0u;
     if (tid == 0) { s_kr[0] = MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; s_cnt[3] = 0u; s_cnt[4] = 0u; }
     __syncthreads();
     {
@@ -559,15 +582,42 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     const u32 nA = s_cnt[1];
     const u32 aZ = (u32)n_ref - nA;
     for (u32 i = tid; i < min(nA, (u32)P.ref_cap) + 4u; i += NT) A[i] = MAXK; // empty slots (the scatter claims them by compare-and-swap) and the pad
-    OcrRef<KeyT> R;
+    OcrRef<KeyT, EQ> R;
     R.A = A; R.tab = tab; R.last = (1u << P.nbk_lg) - 1u;
     R.kmin = nA ? s_kr[0] : (KeyT)0;
+    R.ctab = ctab;
     {
         const KeyT range = nA ? (KeyT)(s_kr[1] - s_kr[0]) : (KeyT)0;
         const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
         R.shift = bits > P.nbk_lg ? bits - P.nbk_lg : 0;
+        R.cshift = bits > 8 ? bits - 8 : 0;
+        R.cmask = (KeyT)(((KeyT)1 << R.cshift) - (KeyT)1);
     }
     R.nA = nA;
+    if constexpr (EQ) { // key counts of the 256 coarse cells -> each cell's share of the fine buckets
+        for_ref([&](KeyT k) { atomicAdd(&ccnt[(u32)((KeyT)(k - R.kmin) >> R.cshift)], 1u); });
+        __syncthreads();
+        if (wave == 0) { // four cells per lane.  A cell of cnt keys asks for cnt (NB - 256) / (2 n) buckets, rounded up to a power of
+            // two (less than twice that) and at least one: the shares add up to at most NB
+            const u64 nb_free = (u64)(1u << P.nbk_lg) - 256ull, den = 2ull * (u64)max(nA, 1u);
+            u32 e4[4], sz = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 want = (u64)ccnt[lane * 4 + j] * nb_free / den;
+                u32 e = want <= 1ull ? 0u : (u32)(64 - __clzll((long long)(want - 1ull)));
+                e = min(e, (u32)R.cshift);
+                e4[j] = e;
+                sz += 1u << e;
+            }
+            u32 base = (u32)wave_incl_scan_add((int)sz) - sz;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ctab[lane * 4 + j] = base | (((u32)R.cshift - e4[j]) << 24);
+                base += 1u << e4[j];
+            }
+        }
+        __syncthreads();
+    }
     const u32 nneg = s_cnt[0];
     // counters: +1 on the bucket's two bits; a bucket already at 3 takes the increment back and marks its word overfull (the
     // carry it sent into the next field in between is removed by the subtraction; whatever the fields of such a word end up

@@ -81,7 +81,9 @@ int illico_ctx_set_stream(illico_ctx *ctx, void *hip_stream);
  * "no_csc_counts_mixed" = 1: its 8-bit cell form only),
  * "no_packed_dense" (dense two-pass routes: group-wise packing of the non-zero keys + look-ups in a counted bitmap of the reference
  * for OVO, the transposition with the group sums folded in for OVR; 1 = the plain transposition and the kernels behind it;
- * "no_ovr_packed_partition" = 1: dense OVR splits the padded key rows -- every key -- instead of the packed ones),
+ * "no_ovr_packed_partition" = 1: dense OVR splits the padded key rows -- every key -- instead of the packed ones;
+ * "packed_eq_buckets": the packed OVO kernel's value buckets follow the reference's distribution, 1 = always, 0 = never,
+ * -1 = for references of more than 16384 cells, the default),
  * "no_ovo_ref_buckets" (OVO sort route: reference column in value buckets instead of sorted), "no_ovr_parts_path" (dense OVR, any values: value-range parts ranked in LDS; "ovr_parts_cap" > 0 caps the keys per part), "no_csc_gene_path" (CSC OVO single-kernel route), "no_csc_ovr_gene_path" (CSC OVR single-kernel route; "csc_ovr_sorted_form" = 1 makes it sort every
  * gene in LDS, the form tie-heavy columns take, instead of bucketing the keys), "no_csc_regroup_lds" (two-kernel CSC route: regroup with scattered
  * stores only),

@@ -13,14 +13,18 @@ from conftest import assert_planes_match, make_labels
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def engine():
+@pytest.fixture(scope="module", params=["auto", "eq-buckets"])
+def engine(request):
+    """"eq-buckets": the packed rank kernel's distribution-following bucket function (on its own only for references above
+    16384 cells) forced on every case."""
     from illico_amd._lib import get_engine
     eng = get_engine()
     eng.set_option("no_fused_path", 1)  # every gene through the two-pass routes
+    eng.set_option("packed_eq_buckets", 1 if request.param == "eq-buckets" else -1)
     yield eng
     eng.set_option("no_fused_path", 0)
     eng.set_option("no_packed_dense", 0)
+    eng.set_option("packed_eq_buckets", -1)
     eng.set_option("profile", 0)
 
 
@@ -163,7 +167,7 @@ def test_packed_routes_many_tiny_groups_and_exact_round_sizes(engine):
 
 def test_packed_route_reference_larger_than_its_key_slots(engine):
     """A reference of 30 000 cells does not fit the packed kernel's LDS key slots cell for cell: the slots are sized for non-zero
-    keys (20 400 beside 2^17 buckets), a gene with more non-zeros than that is left to k_ovo_rank on the device, a sparser one is
+    keys (about 19 900 beside 2^17 buckets), a gene with more non-zeros than that is left to k_ovo_rank on the device, a sparser one is
     ranked by the packed kernel."""
     rng = np.random.RandomState(17)
     n_ref, others = 30000, 24

@@ -2,7 +2,7 @@
 // (kernels_ovo.h) on a C2-shaped synthetic matrix built on the device: 300k cells x M genes, 2000 groups (reference = 10 000
 // cells), continuous values log1p(count * U(0.5, 1.5)) with half the entries zeroed (mode 0) or plain counts (mode 1: ties).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I illico_amd/csrc -o tools/micro/ovo_compact_bench tools/micro/ovo_compact_bench.hip
-// Run:   tools/micro/ovo_compact_bench [genes] [mode] [nbk_lg] [key slots]
+// Run:   tools/micro/ovo_compact_bench [genes] [mode] [nbk_lg] [key slots] [eq buckets]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +59,7 @@ int main(int argc, char **argv) {
     const int mode = argc > 2 ? atoi(argv[2]) : 0;
     const int nbk_lg = argc > 3 ? atoi(argv[3]) : 17;
     const int ref_cap_arg = argc > 4 ? atoi(argv[4]) : 0; // key slots of the packed rank kernel (0: one per reference cell)
+    const int eq_arg = argc > 5 ? atoi(argv[5]) : 0;      // 1: distribution-following bucket function
     float *X; CK(hipMalloc(&X, (size_t)N * M * 4));
     k_fill<<<(unsigned)(((long long)N * M + 255) / 256), 256>>>(X, N, M, mode);
     // groups
@@ -135,7 +136,7 @@ int main(int argc, char **argv) {
     C.Xs = Xt; C.gene_stride = stride; C.counts = d_counts; C.nnz = nnz; C.gofs = gofs; C.ref_out = ref_out; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum; C.out_sum = ssum[1]; C.nseg = nseg; C.G = G; C.ref = 0; C.n_genes = M; C.ref_cap = ref_cap_arg > 0 ? ref_cap_arg : n_ref; C.nbk_lg = nbk_lg;
     C.out_2u = s2u[1]; C.out_tie = stie[1]; C.route = route;
     const size_t lds_new = ocr_lds_bytes(C.ref_cap, nbk_lg, 4);
-    auto knew = k_ovo_rank_compact<u32>;
+    auto knew = eq_arg ? k_ovo_rank_compact<u32, true> : k_ovo_rank_compact<u32, false>;
     CK(hipFuncSetAttribute((const void *)knew, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
     printf("LDS: old %zu B, packed %zu B\n", lds_old, lds_new);
     auto run_new = [&]() {
