@@ -1,4 +1,6 @@
 """Randomised shapes / formats / dtypes / options through every input path of the engine vs the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 from scipy import sparse
@@ -9,10 +11,26 @@ from conftest import assert_planes_match
 pytestmark = pytest.mark.gpu
 
 
+def _env_seeds():
+    """ILLICO_FUZZ_SEEDS="40-99,106-130": more seeds for a one-off sweep (below 100: small cases, from 100: large ones)."""
+    out = []
+    for part in filter(None, os.environ.get("ILLICO_FUZZ_SEEDS", "").split(",")):
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
 @pytest.fixture(scope="module")
 def engine():
+    """ILLICO_FUZZ_OPTIONS="no_fused_path=1,packed_eq_buckets=1": engine options for the whole sweep (forces routes)."""
     from illico_amd._lib import get_engine
-    return get_engine()
+    eng = get_engine()
+    opts = [kv.split("=") for kv in filter(None, os.environ.get("ILLICO_FUZZ_OPTIONS", "").split(","))]
+    for k, v in opts:
+        eng.set_option(k, int(v))
+    yield eng
+    for k, _ in opts:
+        eng.set_option(k, -1 if k == "packed_eq_buckets" else 0)
 
 
 def _case(seed):
@@ -50,7 +68,7 @@ def _case(seed):
     return X, dtype, labels, ref, lb, ub, opts, kind
 
 
-@pytest.mark.parametrize("seed", list(range(40)) + [100, 101, 102, 103, 104, 105])
+@pytest.mark.parametrize("seed", list(range(40)) + [100, 101, 102, 103, 104, 105] + _env_seeds())
 def test_random_case_all_input_paths(engine, seed):
     import torch
     X, dtype, labels, ref, lb, ub, opts, kind = _case(seed)
