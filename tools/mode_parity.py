@@ -27,13 +27,10 @@ def one(st, defer=False):
 for _ in range(8): one(sets[0])
 def show(tag, seq, defer=False):
     print(f"{tag:<44}", " ".join(f"{one(sets[i], defer):.3f}" for i in seq))
-for off in (1, 0, 1, 0):  # tile = workgroup x, against XCD-contiguous tile runs (the default)
-    eng.set_option("no_xcd_tiles", off)
-    print("tile = workgroup x" if off else "XCD-contiguous tile runs")
-    show("set 0 x 8", [0] * 8)
-    show("set 1 x 8", [1] * 8)
-    show("set 2 x 8", [2] * 8)
-    show("set 3 x 8", [3] * 8)
+show("set 0 x 8", [0] * 8)
+show("set 1 x 8", [1] * 8)
+show("set 2 x 8", [2] * 8)
+show("set 3 x 8", [3] * 8)
 show("alternating 0 1", [0, 1] * 5)
 show("alternating 0 1, deferred", [0, 1] * 5, True)
 show("alternating 2 3", [2, 3] * 5)
