@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: (group x gene) tests/sec of the asymptotic Wilcoxon rank-sum hot path.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5shard]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5shard|c5]
 
 Workloads (BASELINE.json configs, synthetic data generated on the device, SURVEY.md 8d recipe: Poisson(gene mean
 ~U(0.1, 15)) counts as float32 with a fraction of the entries zeroed, one reference group of N/30 cells, the other
@@ -9,27 +9,32 @@ cells uniform over the remaining groups):
   c2       dense 300k cells x 8k genes x 2k groups, one-versus-reference (OVO), 50 % zeros   [default; configs[1]]
   c3       the same shape as CSC (float32 data, int32 indices), 90 % zeros, OVO                [configs[2]]
   c4       c2 with reference=None: one-versus-rest (OVR)                                      [configs[3]]
-  c5shard  one GPU's gene shard of configs[4]: 1M cells x 3750 genes x 5k groups, dense OVO (8 ranks = the 30k genes)
-A "step" is one pass of the hot path over the whole matrix, input resident in HBM, outputs (three float64 [G, M]
-planes) left in HBM.
+  c5       dense 1M cells x 30k genes x 5k groups, OVO: configs[4] whole (120 GB: fits one 288 GB MI355X)
+  c5shard  one GPU's gene shard of configs[4] as a workload of its own: 1M cells x 3750 genes x 5k groups
+A "step" is one pass of the hot path over the workload's whole matrix, input resident in HBM.  At N = 1 the three
+float64 [G, M] result planes stay in HBM.
 
-`--gpus N` with N > 1: when the process is not already a rank of a torch.distributed launch (the driver's
-`python -m torch.distributed.run ... bench.py --gpus N`), it starts N ranks itself -- fresh child processes, one per
-GPU, before this process has touched a GPU -- over RCCL (backend "nccl").  Genes shard across ranks; no input is ever
-exchanged.  Default scaling is weak (every rank owns a full workload-sized gene shard); `--scaling strong` shards ONE
-workload's genes by rank_gene_range.  A timed step ends, exactly as at N = 1, with the result planes resident in the HBM
-of the GPU that computed them; the path's only collective -- the gather of the planes to rank 0 -- runs once after the
-timed steps, is timed on its own and reported under "final_gather" (`--gather-in-step` issues it inside every step, per
-gene block, overlapped with the next block's compute).
+`--gpus N` with N > 1 (started by the driver's `python -m torch.distributed.run ... bench.py --gpus N`, or, with no
+launcher, by this script itself: fresh child processes, one per GPU, over RCCL = backend "nccl"): STRONG scaling by
+default -- the SAME workload, its genes split into one contiguous range per rank (illico_amd.distributed); the matrix
+is generated per 256-gene block from (seed, block), so every N computes the identical problem and no input is ever
+exchanged.  The path's one collective -- the gather of every rank's planes to rank 0 -- is INSIDE the timed steps:
+step k's gather runs on RCCL's stream under step k + 1's pass, and all K gathers have completed when the clock
+stops, so `value` = tests / (pass + gather).  `pass_only` (the same steps without the gather) is reported beside it.
+`--scaling weak` gives every rank a full workload-sized gene shard instead.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline       achieved algorithmic GB/s of the dominant kernel (HIP events on the engine's stream, live, inside the
                  timed region) against the 8 TB/s HBM peak; `traffic` = PMC bytes per launch from profiles/traffic.json
   cpu_baseline   the CPU oracle (C restatement of illico's algorithm, oracle/, built -O3 -march=native on this box,
                  threads pinned one per physical core) on a bounded sample of the same workload: all physical cores, and
-                 `at_8_threads` (the reference's headline setting, README.md:4)
-  parity         genes of the LAST timed step's planes compared with the oracle: measured errors, not asserted ones
+                 `at_8_threads` (the reference's headline setting, README.md:4)            [N = 1 only]
+  parity         16 genes of the LAST timed step's planes compared with the oracle: measured errors, not asserted ones
   timing_scopes  SURVEY.md 8d: (i) engine = ms_per_step, (ii) engine + H2D / D2H transfers, (iii) the drop-in call
+  c5_strong      BASELINE configs[4] (1M x 30k x 5k dense OVO) measured in the same launch, genes split over the N
+                 ranks: ms per pass, ms per gather, ms per pass + gather (overlapped as above), bytes into rank 0,
+                 roofline fraction -- so a driver that only ever runs `bench.py --gpus N` records configs[4] at every N
+                 (`--no-c5` skips it; `--c5-cells/--c5-genes/--c5-groups` shrink it for tests)
 """
 from __future__ import annotations
 
@@ -55,6 +60,8 @@ WORKLOADS = {
                label="CSC {N}x{M}x{G} OVO, 90% zeros (K562-shaped, BASELINE configs[2])"),
     "c4": dict(cells=300_000, genes=8_000, groups=2_000, sparsity=0.5, test="ovr", fmt="dense",
                label="dense {N}x{M}x{G} OVR (BASELINE configs[3])"),
+    "c5": dict(cells=1_000_000, genes=30_000, groups=5_000, sparsity=0.5, test="ovo", fmt="dense",
+               label="dense {N}x{M}x{G} OVO (BASELINE configs[4], genes sharded over the ranks)"),
     "c5shard": dict(cells=1_000_000, genes=3_750, groups=5_000, sparsity=0.5, test="ovo", fmt="dense",
                     label="dense {N}x{M}x{G} OVO: one GPU's gene shard of BASELINE configs[4] (1M x 30k x 5k over 8 GPUs)"),
 }
@@ -67,21 +74,28 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--cells", type=int, default=None)
-    ap.add_argument("--genes", type=int, default=None, help="genes per GPU (weak scaling) / in total (--scaling strong)")
+    ap.add_argument("--genes", type=int, default=None, help="genes in total (--scaling strong) / per GPU (--scaling weak)")
     ap.add_argument("--groups", type=int, default=None)
     ap.add_argument("--sparsity", type=float, default=None)
     ap.add_argument("--test", choices=["ovo", "ovr"], default=None)
     ap.add_argument("--format", choices=["dense", "csc", "csr"], default=None, dest="fmt")
-    ap.add_argument("--values", choices=["counts", "continuous"], default="counts",
-                    help="counts: the headline Poisson counts; continuous: log1p(counts * U(0.5,1.5)), the secondary stress of SURVEY.md 8d")
+    ap.add_argument("--values", choices=["counts", "continuous", "nb"], default="counts",
+                    help="counts: the headline Poisson counts; continuous: log1p(counts * U(0.5,1.5)), the secondary stress of SURVEY.md 8d; "
+                         "nb: heavy-tailed counts (log-normal gene means: ~20 %% of the genes beyond 63, ~4 %% beyond 255 -- what a real count "
+                         "matrix's highly expressed genes look like)")
     ap.add_argument("--mean-max", type=float, default=15.0, help="gene means ~ U(0.1, mean-max); 15 = the reference's fixture (SURVEY.md 8d)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--gene-batch", type=int, default=0, help="genes per engine pass (0 = auto)")
-    ap.add_argument("--gather-batches", type=int, default=8, help="gene blocks per gather (N>1)")
-    ap.add_argument("--gather-in-step", action="store_true", help="N>1: gather every step's planes to rank 0 inside the timed region")
+    ap.add_argument("--gather-batches", type=int, default=1, help="gene blocks per step, each gathered on its own (N>1)")
+    ap.add_argument("--no-gather-in-step", action="store_true", help="N>1: time the passes alone; the gather runs once afterwards and is reported apart")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scopes", action="store_true", help="skip timing scopes (ii) and (iii)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the c5_strong object (BASELINE configs[4] in the same launch)")
+    ap.add_argument("--c5-cells", type=int, default=1_000_000)
+    ap.add_argument("--c5-genes", type=int, default=30_000)
+    ap.add_argument("--c5-groups", type=int, default=5_000)
+    ap.add_argument("--c5-steps", type=int, default=3)
     ap.add_argument("--no-events", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-defer", action="store_true", help="dense passes wait for their route flags inside the call (no ILLICO_FLAG_DEFER)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU baseline run")
@@ -115,25 +129,39 @@ def group_container(codes, n_groups, ovr):
     return GroupContainer(codes.astype(np.int64), counts, indices, indptr, -1 if ovr else 0)
 
 
-def make_matrix(torch, n_cells, n_genes, sparsity, seed, device, continuous=False, mean_max=15.0):
-    """Poisson(gene mean ~ U(0.1, 15)) float32 with `sparsity` of the entries zeroed, generated on device."""
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
+GEN_BLOCK = 256  # genes per generator block: block j of a workload is a function of (seed, j) alone
+
+
+def make_matrix(torch, n_cells, n_genes, sparsity, seed, device, continuous=False, mean_max=15.0, values=None, gene_lb=0):
+    """Columns [gene_lb, gene_lb + n_genes) of the workload's matrix: Poisson(gene mean) float32 with `sparsity` of the
+    entries zeroed, generated on the device block by block.  A block's generator is seeded by (seed, block number), so a rank
+    that owns a gene range computes exactly the columns a single GPU would have."""
+    values = values or ("continuous" if continuous else "counts")
     # the row pitch is padded to a multiple of 128 bytes (the C-ABI takes any leading dimension): the fused kernels read
     # 256-byte row segments, which then cover two 128-byte lines instead of straddling three (C5 shard, 3750 genes: a pitch
     # of 15 000 bytes would misalign every row; C2's 32 000 bytes are aligned as they are)
     ld = (n_genes + 31) // 32 * 32
     X = torch.empty((n_cells, ld), dtype=torch.float32, device=device)[:, :n_genes]
-    means = torch.empty(n_genes, device=device).uniform_(0.1, mean_max, generator=gen)
-    step = 256
-    for j in range(0, n_genes, step):
-        m = means[j:j + step]
-        rates = m.unsqueeze(0).expand(n_cells, m.numel()).contiguous()
+    gen = torch.Generator(device=device)
+    j = gene_lb
+    while j < gene_lb + n_genes:
+        blk_no = j // GEN_BLOCK
+        b0, b1 = blk_no * GEN_BLOCK, (blk_no + 1) * GEN_BLOCK
+        gen.manual_seed(int(seed) * 1_000_003 + blk_no)
+        if values == "nb":   # log-normal gene means, median 7.7: P(a gene's largest count > 63) ~ 0.2, P(> 255) ~ 0.04
+            m = torch.exp(torch.empty(GEN_BLOCK, device=device).normal_(2.04, 1.8, generator=gen)).clamp_(0.05, 2000.0)
+        else:
+            m = torch.empty(GEN_BLOCK, device=device).uniform_(0.1, mean_max, generator=gen)
+        rates = m.unsqueeze(0).expand(n_cells, GEN_BLOCK).contiguous()
         blk = torch.poisson(rates, generator=gen)
         keep = torch.rand(blk.shape, device=device, generator=gen) >= sparsity
-        if continuous:  # normalised-like data: (almost) no ties among the non-zeros
+        if values == "continuous":  # normalised-like data: (almost) no ties among the non-zeros
             blk = torch.log1p(blk * torch.empty_like(blk).uniform_(0.5, 1.5, generator=gen))
-        X[:, j:j + step] = blk * keep
+        blk = blk * keep
+        lo, hi = max(j, b0), min(gene_lb + n_genes, b1)
+        X[:, lo - gene_lb: hi - gene_lb] = blk[:, lo - b0: hi - b0]
+        j = hi
+        del rates, blk, keep
     return X
 
 
@@ -181,6 +209,230 @@ def spawn_ranks(args) -> int:
     return rc
 
 
+class Job:
+    """One workload on this rank's GPU: data, engine calls, the gather; `measure` times it."""
+
+    def __init__(self, torch, dist, eng, args, *, cells, genes_total, groups, sparsity, test, fmt, values, mean_max, seed,
+                 rank, world, device, scaling):
+        from illico_amd.distributed import rank_gene_range
+        self.torch, self.dist, self.eng, self.args = torch, dist, eng, args
+        self.rank, self.world, self.device = rank, world, device
+        self.N, self.G, self.test, self.fmt = cells, groups, test, fmt
+        self.ovr = test == "ovr"
+        if scaling == "strong":  # one workload's genes, one contiguous range per rank (equal expected stored entries per gene
+            # in this synthetic matrix: ranges by gene count; illico_amd.distributed balances real sparse input by stored entries)
+            self.g_lb, self.g_ub = rank_gene_range(genes_total, rank, world)
+            self.M_total = genes_total
+        else:
+            self.g_lb, self.g_ub = rank * genes_total, (rank + 1) * genes_total
+            self.M_total = genes_total * world
+        self.M = self.g_ub - self.g_lb
+        self.codes = make_labels(cells, groups, seed)
+        self.grpc = group_container(self.codes, groups, self.ovr)
+        self.X = make_matrix(torch, cells, max(self.M, 1), sparsity, seed, device, values=values, mean_max=mean_max, gene_lb=self.g_lb)[:, :self.M]
+        self.sparse_fmt = fmt if fmt != "dense" else None
+        self.csx, self.nnz, self.X_sample = None, None, None
+        if self.sparse_fmt:
+            self.X_sample = self.X[:, :min(self.M, 1024)].clone()  # dense copy of the first genes: oracle spot checks / CPU baseline sample
+            self.csx = compress(torch, self.X, self.sparse_fmt)
+            self.nnz = int(self.csx[0].numel())
+            self.X = None
+            torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        eng.set_groups(self.grpc)
+
+    def alg_bytes(self):
+        """input once + 4 B per cell of codes + three f64 planes (this rank's share)."""
+        if self.sparse_fmt:
+            return self.nnz * 8 + ((self.M if self.sparse_fmt == "csc" else self.N) + 1) * 4 + 4 * self.N + 24 * self.G * self.M
+        return self.N * self.M * 4 + 4 * self.N + 24 * self.G * self.M
+
+    def setup(self, n_blocks, gather):
+        from illico_amd.distributed import rank_gene_range, shard_bounds
+        torch = self.torch
+        self.gather = gather and self.world > 1
+        self.blocks = [b for b in shard_bounds(self.M, max(1, n_blocks)) if b[1] > b[0]] if not self.gather else shard_bounds(self.M, max(1, n_blocks))
+        # one contiguous (3, G, w) staging tensor per gene block: the engine writes its planes straight into it.  Two sets, used
+        # by alternate steps: a consumer (the gather, or whoever reads the planes) works on step k's set while step k + 1
+        # computes into the other -- and with ILLICO_FLAG_DEFER a dense pass is enqueued before the previous one's route flags
+        # have been looked at, so there is no host round trip between passes.
+        if self.gather:  # every rank's block b must have ONE width (torch.distributed.gather): the widest rank's
+            ranges = [rank_gene_range(self.M_total, r, self.world) for r in range(self.world)]
+            self.widths = [max(shard_bounds(ub - lb, len(self.blocks))[b][1] - shard_bounds(ub - lb, len(self.blocks))[b][0]
+                               for lb, ub in ranges) for b in range(len(self.blocks))]
+        else:
+            self.widths = [ub - lb for lb, ub in self.blocks]
+        self.stage_sets = [[torch.zeros((3, self.G, max(w, 1)), dtype=torch.float64, device=self.device) for w in self.widths] for _ in range(2)]
+        self.recv_sets = None
+        if self.gather and self.rank == 0:
+            self.recv_sets = [[[torch.empty_like(st) for _ in range(self.world)] for st in ss] for ss in self.stage_sets]
+        self.step_no = 0
+        self.pending = []
+        self.stages = self.stage_sets[0]
+
+    def run_block(self, lb, ub, out, defer):
+        if self.sparse_fmt:
+            self.eng.run_sparse(self.sparse_fmt, self.csx[0], self.csx[1], self.csx[2], (self.N, self.M), lb, ub, out=out, defer=defer)
+        else:
+            self.eng.run_dense(self.X, lb, ub, out=out, defer=defer)
+
+    def step(self):
+        from illico_amd.distributed import gather_block_async
+        k = self.step_no & 1
+        self.stages = self.stage_sets[k]
+        self.step_no += 1
+        handles = []
+        for b, (lb, ub) in enumerate(self.blocks):
+            st = self.stages[b]
+            if ub > lb:
+                w = ub - lb
+                self.run_block(lb, ub, (st[0][:, :w], st[1][:, :w], st[2][:, :w]), defer=not self.gather and not self.args.no_defer)
+            if self.gather:  # complete planes (the call above waited for its route flags): hand them to RCCL, do not wait
+                handles.append(gather_block_async(st, self.recv_sets[k][b] if self.rank == 0 else None, self.rank, self.world))
+        # the gather of step k - 1 ran under this step's pass; its buffers are the next step's
+        for h in self.pending:
+            h.wait()
+        self.pending = handles
+
+    def drain(self):
+        for h in self.pending:
+            h.wait()
+        self.pending = []
+
+    def sync(self):
+        self.drain()
+        self.eng.synchronize()  # completes a deferred pass (genes the fused route could not take), then waits for the stream
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def timed(self, steps):
+        """`steps` steps between two barriers; the MAX over ranks, in seconds."""
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            red_dev = self.device if self.args.backend == "nccl" else self.torch.device("cpu")
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=red_dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def host_columns(self, cols):
+        """Dense float32 host copy of a few of this rank's genes (whatever the input format)."""
+        torch = self.torch
+        if not self.sparse_fmt:
+            return self.X[:, cols].contiguous().cpu().numpy()
+        out = np.zeros((self.N, len(cols)), dtype=np.float32)
+        data, indices, indptr = self.csx
+        if self.sparse_fmt == "csc":
+            ip = indptr.cpu().numpy()
+            for i, c in enumerate(cols):
+                s, e = int(ip[c]), int(ip[c + 1])
+                out[indices[s:e].cpu().numpy(), i] = data[s:e].cpu().numpy()
+            return out
+        for i, c in enumerate(cols):  # CSR: one pass over the column indices per gene, on the device
+            pos = (indices == int(c)).nonzero().flatten()
+            rows = torch.searchsorted(indptr[1:].to(torch.int64), pos, right=True)
+            out[rows.cpu().numpy(), i] = data[pos].cpu().numpy()
+        return out
+
+    def plane_columns(self, cols):
+        got = [np.empty((self.G, len(cols))) for _ in range(3)]
+        for i, c in enumerate(cols):
+            for b, (lb, ub) in enumerate(self.blocks):
+                if lb <= c < ub:
+                    for k in range(3):
+                        got[k][:, i] = self.stages[b][k][:, c - lb].cpu().numpy()
+        return got
+
+    def parity(self, n_genes=16):
+        import oracle
+        cols = sorted(set(np.linspace(0, self.M - 1, min(n_genes, self.M)).astype(int).tolist()))
+        want = oracle.run(self.host_columns(cols), self.grpc, batch_size=1, n_threads=min(len(cols), 8))
+        got = self.plane_columns(cols)
+        mask = np.ones(self.G, dtype=bool)
+        if not self.ovr:
+            mask[0] = False  # the reference leaves the reference group's row unspecified (SURVEY.md 8b)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            perr = np.abs(got[0][mask] - want[0][mask]) / np.abs(want[0][mask])
+            ferr = np.abs(got[2] - want[2]) / np.abs(want[2])
+        perr = np.where(got[0][mask] == want[0][mask], 0.0, perr)
+        ferr = np.where((got[2] == want[2]) | (np.isnan(got[2]) & np.isnan(want[2])), 0.0, ferr)
+        return {"genes_checked": cols, "tests_checked": int(mask.sum() * len(cols)),
+                "statistic_mismatches": int((got[1][mask] != want[1][mask]).sum()),
+                "p_value_max_rel_err": float(np.max(perr)), "fold_change_max_rel_err": float(np.max(ferr)),
+                "bar": "statistic exact; p_value and fold_change rtol 1e-12", "against": "oracle/ (CPU restatement pinned to the reference's outputs)"}
+
+
+def measure(job, steps, warmup, settle=5, events=True):
+    """First call, settle + warm-up, one profiled step, the timed steps (gather inside when job.gather); returns a dict."""
+    eng = job.eng
+    job.sync()
+    t0 = time.perf_counter()
+    job.step()
+    job.drain()
+    eng.synchronize()
+    first_call_ms = (time.perf_counter() - t0) * 1e3
+    # The first ~8 passes of a fresh process run up to 6 % slower than the steady state (tools/ramp.py): a few settling
+    # passes before the W warm-up steps, so that a small W still measures the steady state.  Untimed, like the warm-up.
+    for _ in range(settle + warmup):
+        job.step()
+    job.sync()
+    # One untimed step with HIP events around every kernel: the per-kernel breakdown, and which kernel dominates.
+    # Inside the timed region only that kernel carries events (each event pair drains the stream around a launch).
+    eng.profile(True)
+    eng.profile_reset()
+    job.step()
+    job.sync()
+    breakdown = eng.profile_get()
+    dom = max(breakdown.items(), key=lambda kv: kv[1]["ms"])[0] if breakdown else None
+    eng.profile_only(dom)
+    eng.profile_reset()
+    if not events:  # diagnostic only: the contract wants the dominant kernel timed inside the timed region
+        eng.profile(False)
+    dt = job.timed(steps)
+    prof = eng.profile_get()
+    eng.profile(False)
+    eng.profile_only(None)
+    return {"dt": dt, "ms_per_step": dt / steps * 1e3, "first_call_ms": first_call_ms, "breakdown": breakdown, "dom": dom, "prof": prof,
+            "settle": settle}
+
+
+def roofline_of(job, m, steps, wl_key):
+    dom, prof = m["dom"], m["prof"]
+    if not dom or dom not in prof:
+        return None
+    alg = job.alg_bytes()
+    launches = prof[dom]["launches"]
+    avg_ms = prof[dom]["ms"] / launches
+    bytes_per_launch = alg * steps / launches
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tf = ROOT / "profiles" / "traffic.json"
+    if tf.exists() and wl_key is not None:
+        try:  # PMC traffic is only valid for the workload it was collected on
+            for ent in json.loads(tf.read_text()).get("entries", []):
+                if ent.get("kernel_id") == dom and all(ent.get("workload", {}).get(k) == v for k, v in wl_key.items()) \
+                        and launches == steps * ent.get("launches_per_step", 1):
+                    traffic = ent.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    pipe = alg / (m["pass_ms"] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / steps,
+            "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "all_kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in m["breakdown"].items()},
+            "all_kernels_note": "one untimed step with events around every kernel, taken before the timed region",
+            "pipeline_achieved": round(pipe, 2), "pipeline_frac": round(pipe / HBM_PEAK_GBS, 5),
+            "pipeline_note": "this rank's algorithmic bytes over its pass time (the gather excluded)"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -211,27 +463,6 @@ def main():
             dist.init_process_group(backend=args.backend)
 
     from illico_amd._lib import Engine
-    from illico_amd.distributed import gather_block_async, rank_gene_range, shard_bounds
-
-    N, G = args.cells, args.groups
-    if args.scaling == "strong":  # one workload's genes, sharded
-        g_lb, g_ub = rank_gene_range(args.genes, rank, world)
-        M, M_total = g_ub - g_lb, args.genes
-    else:
-        M, M_total = args.genes, args.genes * world
-    ovr = args.test == "ovr"
-    sparse_fmt = args.fmt if args.fmt != "dense" else None
-    codes = make_labels(N, G, args.seed)
-    grpc = group_container(codes, G, ovr)
-    X = make_matrix(torch, N, M, args.sparsity, args.seed + 1000 * rank, device, args.values == "continuous", args.mean_max)  # this rank's gene shard
-    csx, nnz = None, None
-    if sparse_fmt:
-        csx = compress(torch, X, sparse_fmt)
-        nnz = int(csx[0].numel())
-        del X
-        X = None
-        torch.cuda.empty_cache()
-    torch.cuda.synchronize()
 
     eng = Engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -240,110 +471,46 @@ def main():
     for kv in args.engine_option:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    eng.set_groups(grpc)
-    in_step = world > 1 and args.gather_in_step
-    n_blocks = max(1, args.gather_batches) if in_step else 1
-    blocks = [b for b in shard_bounds(M, n_blocks) if b[1] > b[0]]
-    # one contiguous (3, G, w) staging tensor per gene block: the engine writes its planes straight into it.  Two sets, used
-    # by alternate steps (a consumer reads step k's planes while step k + 1 computes): with ILLICO_FLAG_DEFER a dense pass is
-    # then enqueued before the previous one's route flags have been looked at -- no host round trip between passes.
-    stage_sets = [[torch.empty((3, G, ub - lb), dtype=torch.float64, device=device) for (lb, ub) in blocks] for _ in range(2)]
-    stages = stage_sets[0]
-    step_no = [0]
-    recvs = None
-    if world > 1 and rank == 0:
-        recvs = [[torch.empty_like(st) for _ in range(world)] for st in stages]
 
-    def run_block(lb, ub, out):
-        if sparse_fmt:
-            eng.run_sparse(sparse_fmt, csx[0], csx[1], csx[2], (N, M), lb, ub, out=out)
-        else:
-            eng.run_dense(X, lb, ub, out=out, defer=not in_step and not args.no_defer)
+    N, G = args.cells, args.groups
+    job = Job(torch, dist, eng, args, cells=N, genes_total=args.genes, groups=G, sparsity=args.sparsity, test=args.test, fmt=args.fmt,
+              values=args.values, mean_max=args.mean_max, seed=args.seed, rank=rank, world=world, device=device, scaling=args.scaling)
+    M, M_total, ovr, sparse_fmt, nnz = job.M, job.M_total, job.ovr, job.sparse_fmt, job.nnz
+    in_step = world > 1 and not args.no_gather_in_step
+    job.setup(args.gather_batches, gather=in_step)
 
-    def step():
-        nonlocal stages
-        stages = stage_sets[step_no[0] & 1]
-        step_no[0] += 1
-        handles = []
-        for b, (lb, ub) in enumerate(blocks):
-            st = stages[b]
-            run_block(lb, ub, (st[0], st[1], st[2]))
-            if in_step:
-                handles.append(gather_block_async(st, recvs[b] if rank == 0 else None, rank, world))
-        for h in handles:
-            h.wait()
-
-    def final_gather():
-        """The path's one collective: every rank's planes to rank 0 (torch.distributed.gather over RCCL)."""
-        hs = [gather_block_async(stages[b], recvs[b] if rank == 0 else None, rank, world) for b in range(len(blocks))]
-        for h in hs:
-            h.wait()
-
-    def sync():
-        eng.synchronize()  # completes a deferred pass (genes the fused route could not take), then waits for the stream
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # first call of a fresh context: scratch allocation, route decision -- what a single drop-in call pays
-    sync()
-    t0 = time.perf_counter()
-    step()
-    eng.synchronize()
-    first_call_ms = (time.perf_counter() - t0) * 1e3
-    # The first ~8 passes of a fresh process run up to 6 % slower than the steady state (tools/ramp.py): a few settling
-    # passes before the W warm-up steps, so that a small W still measures the steady state.  Untimed, like the warm-up.
-    settle = 5
-    for _ in range(settle + args.warmup):
-        step()
-    sync()
-    # One untimed step with HIP events around every kernel: the per-kernel breakdown, and which kernel dominates.
-    # Inside the timed region only that kernel carries events (each event pair drains the stream around a launch).
-    eng.profile(True)
-    eng.profile_reset()
-    step()
-    sync()
-    breakdown = eng.profile_get()
-    dom = max(breakdown.items(), key=lambda kv: kv[1]["ms"])[0] if breakdown else None
-    eng.profile_only(dom)
-    eng.profile_reset()
-    if args.no_events:  # diagnostic only: the contract wants the dominant kernel timed inside the timed region
-        eng.profile(False)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    prof = eng.profile_get()
-    eng.profile(False)
-    eng.profile_only(None)
-    gather_ms = None
-    if world > 1:
-        red_dev = device if args.backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        if not in_step:  # the final gather, once, timed on its own (second call: RCCL connections already set up)
-            final_gather()
-            sync()
-            tg = time.perf_counter()
-            final_gather()
-            sync()
-            t = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gather_ms = float(t.item()) * 1e3
-
-    ms_per_step = dt / args.steps * 1e3
+    m = measure(job, args.steps, args.warmup, events=not args.no_events)
+    ms_per_step = m["ms_per_step"]
     tests_per_step = G * M_total
-    value = tests_per_step / (dt / args.steps)
+    value = tests_per_step / (m["dt"] / args.steps)
+
+    # N > 1: the same steps without the gather (pass only), and -- when the gather is not in the step -- the gather alone
+    pass_only_ms, gather_ms = ms_per_step, None
+    if world > 1:
+        if in_step:
+            job.sync()
+            job.setup(args.gather_batches, gather=False)
+            for _ in range(2):
+                job.step()
+            pass_only_ms = job.timed(args.steps) / args.steps * 1e3
+            job.setup(args.gather_batches, gather=True)  # (the planes of the last gathered step are recomputed for the parity leg)
+            job.step()
+            job.sync()
+        else:
+            job.setup(args.gather_batches, gather=True)
+            job.step(); job.sync()           # RCCL connections set up
+            t0 = time.perf_counter()
+            job.step(); job.sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if args.backend == "nccl" else torch.device("cpu"))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gather_ms = max(0.0, float(t.item()) * 1e3 - ms_per_step)
+    m["pass_ms"] = pass_only_ms
 
     # what this box's HBM delivers to a plain streaming read (boxes of the pool differ by up to 15 %: 1.65 vs 1.90 ms for the
     # same C2 kernel, DESIGN.md section 5): torch's sum over the resident input
     calib = None
-    if rank == 0:
-        src = X if X is not None else csx[0]
+    if rank == 0 and M > 0:
+        src = job.X if job.X is not None else job.csx[0]
         src.sum(); torch.cuda.synchronize()
         tc = time.perf_counter()
         for _ in range(5):
@@ -352,116 +519,54 @@ def main():
         calib = {"stream_read_GBs": round(src.numel() * src.element_size() * 5 / (time.perf_counter() - tc) / 1e9, 1),
                  "what": "torch .sum() over the resident input, 5 passes: the box's own streaming-read rate, for comparing runs on different boxes"}
 
+    result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (HIP events recorded on the engine's stream) ----
-        # input once + 4 B per cell of codes + three f64 planes
-        if sparse_fmt:
-            alg_bytes_step = nnz * 8 + ((M if sparse_fmt == "csc" else N) + 1) * 4 + 4 * N + 24 * G * M
-        else:
-            alg_bytes_step = N * M * 4 + 4 * N + 24 * G * M
         wl_key = {"workload": args.workload, "cells": N, "genes_per_gpu": M, "groups": G, "test": args.test, "format": args.fmt,
                   "values": args.values, "sparsity": args.sparsity}
         if args.mean_max != 15.0:
             wl_key["mean_max"] = args.mean_max
-        roofline = None
-        if dom and dom in prof:
-            launches = prof[dom]["launches"]
-            avg_ms = prof[dom]["ms"] / launches
-            bytes_per_launch = alg_bytes_step * args.steps / launches
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            tf = ROOT / "profiles" / "traffic.json"
-            if tf.exists():
-                try:  # PMC traffic is only valid for the workload it was collected on
-                    for ent in json.loads(tf.read_text()).get("entries", []):
-                        if ent.get("kernel_id") == dom and all(ent.get("workload", {}).get(k) == v for k, v in wl_key.items()) \
-                                and launches == args.steps * ent.get("launches_per_step", 1):
-                            traffic = ent.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches / args.steps,
-                        "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                        "all_kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in breakdown.items()},
-                        "all_kernels_note": "one untimed step with events around every kernel, taken before the timed region",
-                        "pipeline_achieved": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9, 2),
-                        "pipeline_frac": round(alg_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        roofline = roofline_of(job, m, args.steps, wl_key)
 
-        def host_columns(cols):
-            """Dense float32 host copy of a few of this rank's genes (whatever the input format)."""
-            if not sparse_fmt:
-                return X[:, cols].contiguous().cpu().numpy()
-            if sparse_fmt == "csc":
-                out = np.zeros((N, len(cols)), dtype=np.float32)
-                ip = csx[2].cpu().numpy()
-                for i, c in enumerate(cols):
-                    s, e = int(ip[c]), int(ip[c + 1])
-                    out[csx[1][s:e].cpu().numpy(), i] = csx[0][s:e].cpu().numpy()
-                return out
-            raise SystemExit("parity / CPU baseline sampling for device CSR input is not implemented in bench.py")
-
-        # ---- parity of what was just timed: a few genes of the final step's planes against the oracle ----
-        parity = None
-        if not args.no_parity and sparse_fmt != "csr":
-            import oracle
-            cols = sorted({0, M // 3, M // 2, M - 1})
-            want = oracle.run(host_columns(cols), grpc, batch_size=1, n_threads=min(len(cols), 8))
-            got = [np.empty((G, len(cols))) for _ in range(3)]
-            for i, c in enumerate(cols):
-                for b, (lb, ub) in enumerate(blocks):
-                    if lb <= c < ub:
-                        for k in range(3):
-                            got[k][:, i] = stages[b][k][:, c - lb].cpu().numpy()
-            mask = np.ones(G, dtype=bool)
-            if not ovr:
-                mask[0] = False  # the reference leaves the reference group's row unspecified (SURVEY.md 8b)
-            with np.errstate(divide="ignore", invalid="ignore"):
-                perr = np.abs(got[0][mask] - want[0][mask]) / np.abs(want[0][mask])
-                ferr = np.abs(got[2] - want[2]) / np.abs(want[2])
-            perr = np.where(got[0][mask] == want[0][mask], 0.0, perr)
-            ferr = np.where((got[2] == want[2]) | (np.isnan(got[2]) & np.isnan(want[2])), 0.0, ferr)
-            parity = {"genes_checked": cols, "tests_checked": int(mask.sum() * len(cols)),
-                      "statistic_mismatches": int((got[1][mask] != want[1][mask]).sum()),
-                      "p_value_max_rel_err": float(np.max(perr)), "fold_change_max_rel_err": float(np.max(ferr)),
-                      "bar": "statistic exact; p_value and fold_change rtol 1e-12", "against": "oracle/ (CPU restatement pinned to the reference's outputs)"}
+        # ---- parity of what was just timed: 16 genes of the final step's planes against the oracle ----
+        parity = None if args.no_parity or M == 0 else job.parity(16)
 
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample, threads pinned ----
         cpu = None
-        if not args.no_cpu_baseline and world == 1 and sparse_fmt != "csr":  # contract: rank 0 at N = 1 only
+        if not args.no_cpu_baseline and world == 1:  # contract: rank 0 at N = 1 only
             import oracle
             oracle.use_native(True)
             n_phys = oracle.pin_threads(True)
             from scipy import sparse as sp
+            M_s = M if not sparse_fmt else int(job.X_sample.shape[1])
 
             def sample(ns):
-                if sparse_fmt == "csc":
-                    ip = csx[2][: ns + 1].cpu().numpy().astype(np.int64)
-                    return sp.csc_matrix((csx[0][: ip[-1]].cpu().numpy(), csx[1][: ip[-1]].cpu().numpy(), ip), shape=(N, ns))
-                return X[:, :ns].contiguous().cpu().numpy()
+                if sparse_fmt:  # the same stored entries in the same format, from the dense copy of the first genes
+                    Xs = job.X_sample[:, :ns].contiguous().cpu().numpy()
+                    return sp.csc_matrix(Xs) if sparse_fmt == "csc" else sp.csr_matrix(Xs)
+                return job.X[:, :ns].contiguous().cpu().numpy()
 
             def timed(n_threads, batch, seconds):
                 """Probe with one batch per thread, then a run sized to ~`seconds`; returns (tests/s, genes, wall)."""
-                ns = min(M, n_threads * batch)
+                ns = min(M_s, n_threads * batch)
                 Xs = sample(ns)
                 t1 = time.perf_counter()
-                oracle.run(Xs, grpc, batch_size=batch, n_threads=n_threads)
+                oracle.run(Xs, job.grpc, batch_size=batch, n_threads=n_threads)
                 el = time.perf_counter() - t1
-                ns2 = int(min(M, (G * ns / el) * seconds / G))
+                ns2 = int(min(M_s, (G * ns / el) * seconds / G))
                 ns2 = max(n_threads * batch, (ns2 // (n_threads * batch)) * (n_threads * batch))
                 if ns2 > ns:
-                    ns = min(ns2, M)
+                    ns = min(ns2, M_s)
                     Xs = sample(ns)
                     t1 = time.perf_counter()
-                    oracle.run(Xs, grpc, batch_size=batch, n_threads=n_threads)
+                    oracle.run(Xs, job.grpc, batch_size=batch, n_threads=n_threads)
                     el = time.perf_counter() - t1
                 return G * ns / el, ns, el
 
             # all physical cores: chunks wide enough that the row gathers use whole cache lines, narrow enough to keep every
             # core busy within the sample; 8 threads: the reference's 256-gene chunks (README.md:124 benchmarks)
-            b_all = int(max(8, min(256, M // max(n_phys, 1))))
+            b_all = int(max(8, min(256, M_s // max(n_phys, 1))))
             v_all, ns_all, el_all = timed(n_phys, b_all, args.cpu_seconds)
-            v_8, ns_8, el_8 = timed(min(8, n_phys), int(min(256, max(8, M // 8))), args.cpu_seconds)
+            v_8, ns_8, el_8 = timed(min(8, n_phys), int(min(256, max(8, M_s // 8))), args.cpu_seconds)
             oracle.pin_threads(False)
             oracle.use_native(False)
             what = f"same {N}x{M}x{G} {args.test.upper()} {args.fmt} workload; oracle/ (C restatement of illico's algorithm), -O3 -march=native, OpenMP over gene chunks, threads pinned one per physical core"
@@ -472,23 +577,26 @@ def main():
                    "logical_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
 
         # ---- timing scopes (ii) engine + transfers and (iii) the drop-in call, SURVEY.md 8d ----
-        scopes = {"engine_ms": round(ms_per_step, 4), "first_call_ms": round(first_call_ms, 3)}
+        scopes = {"engine_ms": round(ms_per_step, 4), "first_call_ms": round(m["first_call_ms"], 3),
+                  "claim": "the >= 100x-over-CPU target of BASELINE.json is an engine-scope (input resident in HBM) figure; (ii) and (iii) are PCIe-bound"}
         if not args.no_scopes and world == 1:
             try:
                 import pandas as pd
                 from illico_amd import AnnDataLite, asymptotic_wilcoxon
+                csx = job.csx
                 if sparse_fmt:
                     from scipy import sparse as sp
                     ctor = sp.csc_matrix if sparse_fmt == "csc" else sp.csr_matrix
                     Xh = ctor((csx[0].cpu().numpy(), csx[1].cpu().numpy(), csx[2].cpu().numpy()), shape=(N, M))
                     run_host = lambda: eng.run_sparse(sparse_fmt, Xh.data, Xh.indices, Xh.indptr, (N, M), 0, M)
                 else:
-                    Xh = X.contiguous().cpu().numpy()
+                    Xh = job.X.contiguous().cpu().numpy()
                     run_host = lambda: eng.run_dense(Xh, 0, M)
                 run_host()  # scratch for the staged route
                 t1 = time.perf_counter()
                 run_host()
                 scopes["engine_plus_transfers_ms"] = round((time.perf_counter() - t1) * 1e3, 2)
+                codes = job.codes
                 labels = np.where(codes == 0, "non-targeting", np.char.add("pert_", np.char.zfill(codes.astype(str), 5)))
                 adata = AnnDataLite(Xh, obs=pd.DataFrame({"pert": labels}))
                 kw = dict(is_log1p=False, group_keys="pert", reference=None if ovr else "non-targeting")
@@ -496,7 +604,7 @@ def main():
                 df = asymptotic_wilcoxon(adata, **kw)
                 scopes["drop_in_call_ms"] = round((time.perf_counter() - t1) * 1e3, 2)
                 scopes["drop_in_rows"] = int(len(df))
-                scopes["note"] = ("(ii) host-resident input -> host planes: pageable H2D of the matrix and D2H of 24 B per test included; "
+                scopes["note"] = ("(ii) host-resident input -> host planes: H2D of the matrix and D2H of 24 B per test included; "
                                   "(iii) illico_amd.asymptotic_wilcoxon(adata, ...) on the same host matrix: group encoding, (ii), DataFrame assembly")
                 del df, adata, Xh
             except MemoryError as e:  # a host too small for a second copy of the workload
@@ -506,22 +614,76 @@ def main():
             "metric": "(group x gene) tests/sec", "value": round(value, 1), "unit": "tests/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload]["label"].format(N=N, M=M, G=G) + ("" if args.values == "counts" else " [continuous values]"),
+            "config": {"workload": WORKLOADS[args.workload]["label"].format(N=N, M=M_total, G=G) + ("" if args.values == "counts" else f" [{args.values} values]"),
                        "workload_id": args.workload, "cells": N, "genes_per_gpu": M, "genes_total": M_total, "groups": G, "format": args.fmt,
-                       "test": args.test, "sparsity": args.sparsity, "gene_mean_max": args.mean_max, "nnz_per_gpu": nnz, "settle_steps": settle,
-                       "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU"},
+                       "test": args.test, "sparsity": args.sparsity, "values": args.values, "gene_mean_max": args.mean_max, "nnz_per_gpu": nnz,
+                       "settle_steps": m["settle"],
+                       "parallelism": f"gene-shard x{world}, planes gathered to rank 0" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "timing_scopes": scopes, "box_calibration": calib,
         }
         if world > 1:
             plane_bytes = 24 * G * M
-            result["final_gather"] = ({"in_timed_step": True, "blocks_per_step": len(blocks), "bytes_per_rank_per_step": plane_bytes}
-                                      if in_step else
-                                      {"in_timed_step": False, "ms": round(gather_ms, 3), "bytes_per_rank": plane_bytes,
-                                       "bytes_into_rank0": plane_bytes * (world - 1),
-                                       "one_pass_plus_gather_ms": round(ms_per_step + gather_ms, 3),
-                                       "tests_per_s_pass_plus_gather": round(tests_per_step / ((ms_per_step + gather_ms) * 1e-3), 1),
-                                       "note": "timed steps end with each rank's planes in its own HBM (as at N=1); the one "
-                                               "collective of the path runs once per job, after them"})
+            result["pass_only"] = {"ms_per_step": round(pass_only_ms, 4), "tests_per_s": round(tests_per_step / (pass_only_ms * 1e-3), 1),
+                                   "note": "the same steps without the gather: every rank's planes stay in its own HBM"}
+            if in_step:
+                result["final_gather"] = {"in_timed_step": True, "blocks_per_step": len(job.blocks), "bytes_per_rank_per_step": plane_bytes,
+                                          "bytes_into_rank0_per_step": 24 * G * (M_total - M),
+                                          "note": "value = tests / (pass + gather): step k's gather (torch.distributed.gather over RCCL) runs under step "
+                                                  "k + 1's pass, every gather has completed when the clock stops"}
+            else:
+                result["final_gather"] = {"in_timed_step": False, "ms": round(gather_ms, 3), "bytes_per_rank": plane_bytes,
+                                          "bytes_into_rank0": 24 * G * (M_total - M),
+                                          "one_pass_plus_gather_ms": round(ms_per_step + gather_ms, 3),
+                                          "tests_per_s_pass_plus_gather": round(tests_per_step / ((ms_per_step + gather_ms) * 1e-3), 1)}
+
+    # ---- BASELINE configs[4] in the same launch: 1M x 30k x 5k dense OVO, genes split over the ranks ----
+    if not args.no_c5:
+        del job
+        torch.cuda.empty_cache()
+        c5 = None
+        try:
+            t_gen = time.perf_counter()
+            j5 = Job(torch, dist, eng, args, cells=args.c5_cells, genes_total=args.c5_genes, groups=args.c5_groups, sparsity=0.5, test="ovo",
+                     fmt="dense", values="counts", mean_max=15.0, seed=args.seed + 5, rank=rank, world=world, device=device, scaling="strong")
+            t_gen = time.perf_counter() - t_gen
+            j5.setup(1, gather=False)
+            m5 = measure(j5, args.c5_steps, 1, settle=2)
+            m5["pass_ms"] = m5["ms_per_step"]
+            both_ms, gather_alone_ms = m5["ms_per_step"], 0.0
+            if world > 1:
+                j5.sync()
+                j5.setup(1, gather=True)
+                for _ in range(2):
+                    j5.step()
+                both_ms = j5.timed(args.c5_steps) / args.c5_steps * 1e3
+                j5.sync()
+                t0 = time.perf_counter()     # one gather by itself (no pass under it)
+                from illico_amd.distributed import gather_block_async
+                hs = [gather_block_async(st, j5.recv_sets[0][b] if rank == 0 else None, rank, world) for b, st in enumerate(j5.stage_sets[0])]
+                for h in hs:
+                    h.wait()
+                torch.cuda.synchronize(); dist.barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if args.backend == "nccl" else torch.device("cpu"))
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                gather_alone_ms = float(t.item()) * 1e3
+            if rank == 0:
+                tests5 = args.c5_groups * args.c5_genes
+                r5 = roofline_of(j5, m5, args.c5_steps, None)
+                c5 = {"workload": WORKLOADS["c5"]["label"].format(N=args.c5_cells, M=args.c5_genes, G=args.c5_groups), "scaling": "strong",
+                      "cells": args.c5_cells, "genes_total": args.c5_genes, "genes_per_gpu": j5.M, "groups": args.c5_groups, "steps": args.c5_steps,
+                      "ms_pass": round(m5["ms_per_step"], 4), "ms_gather_alone": round(gather_alone_ms, 4), "ms_pass_plus_gather": round(both_ms, 4),
+                      "tests_per_s": round(tests5 / (both_ms * 1e-3), 1), "tests_per_s_pass_only": round(tests5 / (m5["ms_per_step"] * 1e-3), 1),
+                      "bytes_into_rank0": 24 * args.c5_groups * (args.c5_genes - j5.M), "input_bytes_per_gpu": int(args.c5_cells) * j5.M * 4,
+                      "roofline": None if r5 is None else {k: r5[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "pipeline_frac", "all_kernels_ms_per_step")},
+                      "parity": None if args.no_parity else j5.parity(8), "generate_s": round(t_gen, 1),
+                      "note": "tests_per_s = tests / (pass + gather), the gather of step k under the pass of step k + 1; at N = 1 there is no gather"}
+        except (MemoryError, RuntimeError) as e:
+            if rank == 0:
+                c5 = {"skipped": f"{type(e).__name__}: {str(e)[:300]}"}
+        if rank == 0:
+            result["c5_strong"] = c5
+
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

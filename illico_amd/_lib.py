@@ -283,7 +283,9 @@ class Engine:
         return planes
 
     def run_sparse(self, fmt, data, indices, indptr, shape, col_lb, col_ub, *, is_log1p=False, use_continuity=True,
-                   tie_correct=True, alternative="two-sided", out=None, device_out=False):
+                   tie_correct=True, alternative="two-sided", out=None, device_out=False, defer=False):
+        """``defer=True`` (device-resident CSC arrays and device planes only; ignored elsewhere): return once the count-valued
+        pass is enqueued; the planes are complete after ``synchronize()`` or the next call on this engine."""
         alt = self._alt(alternative)
         n_rows, n_cols = int(shape[0]), int(shape[1])
         if _is_torch_tensor(data):
@@ -302,7 +304,8 @@ class Engine:
         planes, ptrs, oflag, out_ld = self._outputs(out, G, W, device_out)
         if ptrs is None:
             return planes
-        flags = self._flags(is_log1p, use_continuity, tie_correct) | (FLAG_INPUT_DEVICE if d.on_device else 0) | oflag
+        flags = self._flags(is_log1p, use_continuity, tie_correct) | (FLAG_INPUT_DEVICE if d.on_device else 0) | oflag | \
+            (FLAG_DEFER if defer else 0)
         fn = self.lib.illico_run_csc if fmt == "csc" else self.lib.illico_run_csr
         self._bind_torch_stream(d.keep, i.keep, p.keep, *planes)
         self._check(fn(self.h, d.ptr, dtype_code(d.np_dtype), i.ptr, p.ptr, IDX_I32 if i.np_dtype == np.int32 else IDX_I64,

@@ -56,6 +56,10 @@ static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank
 // its route flags have reached the host; they are then recomputed by the two-pass routes (resolve_pending).
 struct PendingDense {
     bool on = false;
+    int kind = 0;                 // 0: dense (X, ld), 1: CSC (sp_*: the count-valued CSC pass, sparse_driver.h)
+    const void *sp_data = nullptr, *sp_indices = nullptr, *sp_indptr = nullptr;
+    int idx_dtype = 0;
+    int64_t n_cols = 0;
     const void *X = nullptr;
     int dtype = 0, flags = 0, alternative = 0, slot = 0;
     int64_t N = 0, ld = 0, col_lb = 0, col_ub = 0, out_ld = 0;
@@ -1055,7 +1059,7 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
             if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf, slot, ovr))) return rc;
             c->pend_next ^= 1;
             PendingDense &q = c->pend;
-            q.on = true; q.X = X; q.dtype = dtype; q.flags = flags & ~ILLICO_FLAG_DEFER; q.alternative = alternative; q.slot = slot;
+            q.on = true; q.kind = 0; q.X = X; q.dtype = dtype; q.flags = flags & ~ILLICO_FLAG_DEFER; q.alternative = alternative; q.slot = slot;
             q.N = N; q.ld = ld; q.col_lb = col_lb; q.col_ub = col_ub; q.out_ld = o.ld; q.p = o.p; q.u = o.u; q.fc = o.fc;
             return ILLICO_OK;
         }
@@ -1237,10 +1241,12 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
 // Completes a deferred dense call: waits for its route flags and sends the genes the fused pass could not take through the
 // two-pass routes.  Every entry point that takes the context runs this first (illico_run_dense may enqueue its own fused pass
 // before it, see there), so results are complete after illico_ctx_synchronize or any later call.
+static int resolve_pending_csc(illico_ctx *c, const PendingDense &q); // sparse_driver.h
 static int resolve_pending(illico_ctx *c, PendingDense q) {
     if (!q.on) return ILLICO_OK;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventSynchronize(c->pend_event[q.slot]));
+    if (q.kind == 1) return resolve_pending_csc(c, q);
     std::vector<std::pair<int64_t, int64_t>> runs;
     flagged_runs((const u32 *)c->pend_pinned[q.slot], q.col_ub - q.col_lb, q.col_lb, runs);
     if (runs.empty()) return ILLICO_OK;

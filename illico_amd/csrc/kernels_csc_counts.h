@@ -26,10 +26,15 @@
 // 1.51 ms -> sweep rolled, no spills 1.05 -> 16 entries per thread in flight 1.01 -> mixed cells, 2 x 512 threads per CU 0.79
 // -> 16-bit codes 0.65 ms.  Phases of the 1.01 ms form: zeroing + launch 0.15, entry loop 0.64, sweep + stores 0.2.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 #define CSCC_NT 512
 #define CSCC_UL 16 // entries per thread and round
+// the forms the library launches (tools/micro/cscc_bench.hip times the others against them)
+#define CSCC_WT true
+#define CSCC_LEAN true
+#define CSCC_PUTB(OVRF) false // (a branch-free entry: 0.58 -> 0.60 ms at C3, the branches skip more than they cost)
 #define CSCC_RT 64 // widest table (values 1 .. 63); the 32-value form is used when 64 bytes per group do not fit LDS
 
 struct CscCountsParams {
@@ -48,6 +53,8 @@ struct CscCountsParams {
     u64 *out_tie;
     double *out_sum;
     double *gene_total;                  // OVR: [nb] the column's value sum (what k_gene_totals would add up from out_sum), or nullptr
+    const u32 *verdict;                  // deferred calls: {non-integers, -, samples} of k_sample_noncount_cols, looked at on the device
+                                         // (more than 2 % non-integers: not a count matrix, every gene is left to the general routes); or nullptr
 };
 
 #define CSCM_WPG 9 // words per group of the mixed layout
@@ -55,17 +62,21 @@ struct CscCountsParams {
 static inline size_t cscc_lds_bytes(int G, int rt) { return (size_t)G * (rt ? rt : CSCM_WPG * 4) + (((size_t)G + 15) & ~(size_t)15); }
 
 #define CSCC_MAX_BIG 8
+
 // C16: group codes come from codes16[row] (the host's case whenever a code table exists: sparse input is limited to fewer than
 // 65 536 groups); else `indices` already holds the codes (the device CSR -> CSC transposition writes them).
-template <typename InT, typename IdxT, bool OVR, int RT, bool HAS_BIG, bool MIXED, bool C16>
-__global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCountsParams P) { // (waves per SIMD: two workgroups per CU for the mixed form)
+// WT: the sweep reads one precomputed {A, B, C} word triple per value instead of forming the terms per (group, value) cell.
+// ABL: ablation bits for tools/micro/cscc_bench.hip only (timing builds with wrong results; the library instantiates 0).
+template <typename InT, typename IdxT, bool OVR, int RT, bool HAS_BIG, bool MIXED, bool C16, bool WT = false, int ABL = 0, int NTT = CSCC_NT, bool LEAN = false, bool PUTB = true>
+__global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_counts(CscCountsParams P) { // (waves per SIMD: two workgroups per CU for the mixed form)
     static_assert(!MIXED || RT == 64, "the mixed layout holds the values 1 .. 63");
-    constexpr int NT = CSCC_NT, UL = (HAS_BIG && MIXED) ? CSCC_UL / 2 : CSCC_UL, WPG = MIXED ? CSCM_WPG : RT / 4; // words per group (UL halved where 16 entries in flight would spill)
+    constexpr int NT = NTT, UL = ((HAS_BIG && MIXED) || NTT == 1024) ? CSCC_UL / 2 : CSCC_UL, WPG = MIXED ? CSCM_WPG : RT / 4; // words per group (UL halved where 16 entries in flight would spill)
     extern __shared__ __align__(16) u32 cscc_h[];             // [WPG][G] words
     __shared__ u32 hsel[RT];   // OVO: histogram of the reference group's stored values; OVR: of the whole column
     __shared__ u32 hbig[HAS_BIG ? CSCC_MAX_BIG * RT : 1]; // 32-bit cells of the few groups with more than 255 cells
     signed char *slot = (signed char *)(cscc_h + (size_t)WPG * P.G); // [G] copy of big_slot (HAS_BIG)
     __shared__ u32 cum[RT + 1]; // cum[c] = # selected stored values < c (c >= 1)
+    __shared__ uint4 wtab[WT ? RT : 1]; // per value c: {A, B, C, -}: 2 rank(c) term, 3 tS^2 - 1, 3 tS (B, C: OVO tie term)
     __shared__ u64 s_T, s_sum;
     __shared__ u32 s_nnz, s_entries, s_cells;
     __shared__ int s_bad;
@@ -74,9 +85,163 @@ __global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCounts
     const InT *data = (const InT *)P.data;
     const IdxT *indices = (const IdxT *)P.indices, *indptr = (const IdxT *)P.indptr;
 
+    if (P.verdict && (double)P.verdict[0] > 0.02 * (double)P.verdict[2]) { // uniform: decided from a value sample, without the host
+        for (int gene = blockIdx.x; gene < P.nb; gene += gridDim.x)
+            if (tid == 0) P.fallback[gene] = 1u;
+        return;
+    }
     for (int gene = blockIdx.x; gene < P.nb; gene += gridDim.x) {
         const long long col = P.gene_cols ? (long long)P.gene_cols[gene] : P.col0 + gene;
         const long long k0 = (long long)indptr[col] - P.kshift, k1 = (long long)indptr[col + 1] - P.kshift;
+        bool bad = false;
+        u32 n_ent = 0; // MIXED: entries this thread put into the packed group tables
+        // one stored entry (value v, group code cd) into the tables: ONE non-returning LDS atomic (two for the selected group)
+        auto put = [&](InT v, int cd) {
+            if (v != (InT)0) {
+                const int c = (v > (InT)0 && v < (InT)RT) ? (int)v : 0;
+                if (c == 0 || (InT)c != v) bad = true; // negative, fractional, NaN or beyond the table
+                else {
+                    if (ABL & 2) { n_ent += (u32)(c + cd); return; }
+                    const int bs = HAS_BIG ? (int)slot[cd] : -1;
+                    if (bs >= 0) atomicAdd(&hbig[bs * RT + c], 1u);
+                    else if (OVR || cd != ref) {
+                        if (MIXED) {
+                            const int wi = c < 8 ? (c >> 2) : 2 + ((c - 8) >> 3);
+                            const int sh = c < 8 ? (c & 3) * 8 : ((c - 8) & 7) * 4;
+                            atomicAdd(&cscc_h[wi * G + cd], 1u << sh);
+                            ++n_ent;
+                        } else atomicAdd(&cscc_h[(c >> 2) * G + cd], 1u << ((c & 3) * 8));
+                    }
+                    if (OVR || cd == ref) atomicAdd(&hsel[c], 1u);
+                }
+            }
+        };
+        auto code_of = [&](IdxT row) -> int {
+            if (ABL & 1) return 1 + ((int)row & 1023);
+            return C16 ? (int)P.codes16[(long long)row] : (int)row; // (entries past k1: row 0, value 0 -> ignored)
+        };
+        auto zero_tables = [&]() {
+            if (!(ABL & 32)) {
+                uint4 *h4 = (uint4 *)cscc_h;
+                const int n4 = (G * WPG) >> 2;
+                for (int i = tid; i < n4; i += NT) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+                for (int i = (n4 << 2) + tid; i < G * WPG; i += NT) cscc_h[i] = 0;
+            }
+            if (tid < RT) hsel[tid] = 0;
+            if (HAS_BIG) {
+                for (int i = tid; i < CSCC_MAX_BIG * RT; i += NT) hbig[i] = 0;
+                for (int i = tid; i < G; i += NT) slot[i] = P.big_slot[i];
+            }
+            if (tid == 0) { s_bad = 0; s_entries = 0; s_cells = 0; }
+        };
+        if constexpr (LEAN) {
+            // The same two-stage pipeline with a straight-line body.  (i) A wavefront owns UL * 64 consecutive entries of a
+            // round: every round but a column's last is FULL, and its 2 UL requests are one 32-bit lane offset + immediate
+            // offsets off a scalar base -- no per-lane bound, no branch, no 64-bit address per request.  The last round clamps
+            // its entry numbers to the column's last entry (requests stay unconditional) and drops the surplus lanes when it
+            // counts.  (ii) An entry goes into the tables without a branch: a value that is no count in [1, RT) adds 0, a
+            // reference-group entry redirects the SAME atomic to the selected histogram (OVO).
+            typedef const __attribute__((address_space(1))) char *gchar_p;
+            typedef const __attribute__((address_space(1))) InT *gval_p;
+            typedef const __attribute__((address_space(1))) IdxT *gidx_p;
+            typedef const __attribute__((address_space(1))) u16 *gu16_p;
+            typedef __attribute__((address_space(3))) u32 *lds_u32_p;
+            constexpr u32 span = (u32)NT * UL;
+            const u32 n = (u32)(k1 - k0); // (a column holds fewer than 2^31 stored entries: at most one per row)
+            const u32 R = (ABL & 16) ? 0u : (n + span - 1) / span;
+            const gchar_p dbase = (gchar_p)(data + k0), ibase = (gchar_p)(indices + k0), cbase = (gchar_p)P.codes16;
+            const u32 e_w = (u32)(tid >> 6) * (UL * 64) + (u32)lane;
+            const u32 last = n - 1u;
+            const u32 h_lds = (u32)(uintptr_t)(lds_u32_p)cscc_h, sel_lds = (u32)(uintptr_t)(lds_u32_p)hsel;
+            const u32 G4 = (u32)G * 4u;
+            InT vn[UL];
+            IdxT in[UL];
+            auto load_full = [&](u32 r) { // one lane offset, immediate offsets
+                const u32 e0 = r * span + e_w;
+                const gchar_p pv = dbase + (size_t)(e0 * (u32)sizeof(InT)), pi = ibase + (size_t)(e0 * (u32)sizeof(IdxT));
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    vn[u] = *(gval_p)(pv + u * 64 * (int)sizeof(InT));
+                    in[u] = *(gidx_p)(pi + u * 64 * (int)sizeof(IdxT));
+                }
+            };
+            auto load_clamped = [&](u32 r) { // the column's last, partial round
+                const u32 e0 = r * span + e_w;
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const u32 e = min(e0 + u * 64u, last);
+                    vn[u] = *(gval_p)(dbase + (size_t)(e * (u32)sizeof(InT)));
+                    in[u] = *(gidx_p)(ibase + (size_t)(e * (u32)sizeof(IdxT)));
+                }
+            };
+            auto put_lean = [&](InT v, u32 cd, bool live) {
+                // c = the value as a table index, 0 when it is none (zero, negative, fractional, NaN, beyond the table)
+                int c = (v > (InT)0 && v < (InT)RT) ? (int)v : 0;
+                const bool exact = (InT)c == v; // (v == 0: c == 0, exact)
+                if (!live) c = 0;
+                bad |= live && !exact;
+                if (ABL & 2) { n_ent += (u32)c + cd; return; }
+                u32 addr, inc;
+                if (MIXED) { // nibble number of the cell inside the group's words: bytes for 1 .. 7, nibbles from 8 on
+                    const u32 q = (u32)c < 8u ? 2u * (u32)c : (u32)c + 8u;
+                    addr = h_lds + (q >> 3) * G4 + cd * 4u;
+                    inc = 1u << ((q & 7u) * 4u);
+                } else {
+                    addr = h_lds + ((u32)c >> 2) * G4 + cd * 4u;
+                    inc = 1u << (((u32)c & 3u) * 8u);
+                }
+                if (c == 0) inc = 0u;
+                bool packed = c != 0;
+                if (HAS_BIG) { // the few groups of more than 255 cells: 32-bit cells of their own
+                    const int bs = (int)slot[cd];
+                    if (bs >= 0) { addr = (u32)(uintptr_t)(lds_u32_p)hbig + (u32)(bs * RT + c) * 4u; inc = c != 0 ? 1u : 0u; packed = false; }
+                }
+                if (!OVR) { // the reference group's entries go to the selected histogram instead
+                    const bool is_ref = (int)cd == ref;
+                    if (is_ref) { addr = sel_lds + (u32)c * 4u; inc = c != 0 ? 1u : 0u; packed = false; }
+                }
+                __hip_atomic_fetch_add((lds_u32_p)(uintptr_t)addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (OVR) __hip_atomic_fetch_add((lds_u32_p)(uintptr_t)(sel_lds + (u32)c * 4u), c != 0 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (MIXED) n_ent += packed ? 1u : 0u;
+            };
+            // round r: its group codes are requested, then (PF) the next round's values / row indices, then it is counted.
+            // Three copies of the body -- next round full / partial / none -- so that neither kind of request sits under a
+            // condition inside the loop (the compiler merges two conditional request groups into one with 2 UL computed 64-bit
+            // addresses).
+            auto round = [&](u32 r, auto pf, auto partial) {
+                InT v[UL];
+                u32 cd[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    v[u] = vn[u];
+                    if (ABL & 1) cd[u] = 1u + ((u32)in[u] & 1023u);
+                    else cd[u] = C16 ? (u32)*(gu16_p)(cbase + (size_t)((u32)in[u] * 2u)) : (u32)in[u]; // (n_cells < 2^30: host-checked)
+                }
+                if constexpr (decltype(pf)::value == 1) load_full(r + 1);
+                if constexpr (decltype(pf)::value == 2) load_clamped(r + 1);
+                const u32 e0 = r * span + e_w;
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const bool live = !decltype(partial)::value || e0 + u * 64u <= last;
+                    if constexpr (PUTB) put_lean(v[u], cd[u], live);
+                    else put(live ? v[u] : (InT)0, (int)cd[u]);
+                }
+            };
+            typedef std::integral_constant<int, 0> I0;
+            typedef std::integral_constant<int, 1> I1;
+            typedef std::integral_constant<int, 2> I2;
+            const u32 Rf = (ABL & 16) ? 0u : n / span; // full rounds; R - Rf = 0 or 1 partial round behind them
+            if (Rf > 0) load_full(0);
+            else if (R > 0) load_clamped(0);
+            zero_tables();
+            __syncthreads();
+            for (u32 r = 0; r + 1 < Rf; ++r) round(r, I1(), I0());
+            if (Rf > 0) {
+                if (R > Rf) round(Rf - 1, I2(), I0());
+                else round(Rf - 1, I0(), I0());
+            }
+            if (R > Rf) round(Rf, I0(), I1());
+        } else {
         // (the first round's loads are in flight while the tables are zeroed)
         InT vn[UL];
         IdxT in[UL];
@@ -86,31 +251,20 @@ __global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCounts
             vn[u] = k < k1 ? data[k] : (InT)0;
             in[u] = k < k1 ? indices[k] : (IdxT)0;
         }
-        {
-            uint4 *h4 = (uint4 *)cscc_h;
-            const int n4 = (G * WPG) >> 2;
-            for (int i = tid; i < n4; i += NT) h4[i] = make_uint4(0u, 0u, 0u, 0u);
-            for (int i = (n4 << 2) + tid; i < G * WPG; i += NT) cscc_h[i] = 0;
-        }
-        if (tid < RT) hsel[tid] = 0;
-        if (HAS_BIG) {
-            for (int i = tid; i < CSCC_MAX_BIG * RT; i += NT) hbig[i] = 0;
-            for (int i = tid; i < G; i += NT) slot[i] = P.big_slot[i];
-        }
-        if (tid == 0) { s_bad = 0; s_entries = 0; s_cells = 0; }
+        zero_tables();
         __syncthreads();
-        bool bad = false;
-        u32 n_ent = 0; // MIXED: entries this thread put into the packed group tables
+        if ((ABL & 64) && tid >= NT / 2) __builtin_amdgcn_s_sleep(32);  // experiment: the second half of the wavefronts half a round behind
+        if ((ABL & 128) && tid >= NT / 2) __builtin_amdgcn_s_sleep(96);
         // two-stage pipeline over the gene's entries: the values / row indices of round i + 1 are requested before round
         // i's group codes (a dependent gather) and LDS atomics, so one HBM round trip per round is off the critical path
         {
-            for (long long kb = k0; kb < k1; kb += (long long)NT * UL) {
+            for (long long kb = k0; kb < ((ABL & 16) ? k0 : k1); kb += (long long)NT * UL) {
                 InT v[UL];
                 int cd[UL];
 #pragma unroll
                 for (int u = 0; u < UL; ++u) {
                     v[u] = vn[u];
-                    cd[u] = C16 ? (int)P.codes16[(long long)in[u]] : (int)in[u]; // (entries past k1: row 0, value 0 -> ignored)
+                    cd[u] = code_of(in[u]);
                 }
                 const long long kn = kb + (long long)NT * UL;
                 if (kn < k1) { // uniform
@@ -122,25 +276,9 @@ __global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCounts
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < UL; ++u)
-                    if (v[u] != (InT)0) {
-                        const int c = (v[u] > (InT)0 && v[u] < (InT)RT) ? (int)v[u] : 0;
-                        if (c == 0 || (InT)c != v[u]) bad = true; // negative, fractional, NaN or beyond the table
-                        else {
-                            const int bs = HAS_BIG ? (int)slot[cd[u]] : -1;
-                            if (bs >= 0) atomicAdd(&hbig[bs * RT + c], 1u);
-                            else if (OVR || cd[u] != ref) {
-                                if (MIXED) {
-                                    const int wi = c < 8 ? (c >> 2) : 2 + ((c - 8) >> 3);
-                                    const int sh = c < 8 ? (c & 3) * 8 : ((c - 8) & 7) * 4;
-                                    atomicAdd(&cscc_h[wi * G + cd[u]], 1u << sh);
-                                    ++n_ent;
-                                } else atomicAdd(&cscc_h[(c >> 2) * G + cd[u]], 1u << ((c & 3) * 8));
-                            }
-                            if (OVR || cd[u] == ref) atomicAdd(&hsel[c], 1u);
-                        }
-                    }
+                for (int u = 0; u < UL; ++u) put(v[u], cd[u]);
             }
+        }
         }
         if (MIXED) {
             n_ent = (u32)wave_sum((int)n_ent);
@@ -153,6 +291,31 @@ __global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCounts
             __syncthreads();
             continue;
         }
+        if (WT) { // wave 0: prefix counts, tie term and value sum of the selected histogram by lane = value; the weight words
+            if (tid < 64) {
+                const int c = tid;
+                const u32 t = (c >= 1 && c < RT) ? hsel[c] : 0u;
+                u32 inc = t; // inclusive scan over the values
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const u32 o = (u32)__shfl_up((int)inc, d);
+                    if (lane >= d) inc += o;
+                }
+                const u32 lo = inc - t, run = (u32)__shfl((int)inc, 63);
+                const u64 t64 = t;
+                const u64 T = wave_sum<u64>(t64 * t64 * t64 - t64), sum = wave_sum<u64>(t64 * (u64)c);
+                const long long n_sel = OVR ? P.n_cells : (long long)P.counts[OVR ? 0 : ref];
+                const u32 z2 = 2u * (u32)(n_sel - (long long)run); // 2 zA (OVO) or 2 n0 (OVR)
+                if (c < RT) {
+                    wtab[c] = make_uint4(z2 + 2u * lo + t + (OVR ? 1u : 0u), 3u * t * t - 1u, 3u * t, 0u);
+                    if (HAS_BIG) cum[c] = lo;
+                }
+                if (c == 0) {
+                    s_nnz = run; s_T = T; s_sum = sum;
+                    if (OVR && P.gene_total) P.gene_total[gene] = (double)sum; // integer sums: exact whatever the order of addition
+                }
+            }
+        } else
         if (tid == 0) {
             u32 run = 0;
             u64 T = 0, sum = 0;
@@ -190,20 +353,37 @@ __global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCounts
             u32 nnz_g = 0, vsum = 0;
             const int bs = HAS_BIG ? (int)slot[g] : -1;
             auto cell = [&](int c, u32 tB) {
-                const u32 tS = hsel[c], lo = cum[c];
                 nnz_g += tB;
                 vsum += tB * (u32)c;
+                if (WT) { // A = 2 zsel + 2 cum[c] + tS (+ 1), B = 3 tS^2 - 1, C = 3 tS: tB (3 tS (tS + tB) + tB^2 - 1) = tB (B + tB (C + tB))
+                    const uint4 w = wtab[c];
+                    acc += (u64)tB * w.x;
+                    if (!OVR) tie += (u64)tB * (u32)(w.y + tB * (w.z + tB));
+                    return;
+                }
+                const u32 tS = hsel[c], lo = cum[c];
                 if (OVR) acc += (u64)tB * (u32)(2u * (u32)zsel + 2u * lo + tS + 1u);
                 else {
                     acc += (u64)tB * (u32)(2u * (u32)zsel + 2u * lo + tS);
                     tie += (u64)tB * (u32)(3u * tS * (tS + tB) + tB * tB - 1u);
                 }
             };
-            if (HAS_BIG && bs >= 0) {
+            if (HAS_BIG && bs >= 0) { // 32-bit cells of a group of any size: 64-bit terms (3 tS (tS + tB) + tB^2 leaves 32 bits)
 #pragma unroll 1
-                for (int c = 1; c < RT; ++c) cell(c, hbig[bs * RT + c]);
+                for (int c = 1; c < RT; ++c) {
+                    const u64 tB = hbig[bs * RT + c], tS = hsel[c], lo = cum[c];
+                    nnz_g += (u32)tB;
+                    vsum += (u32)tB * (u32)c;
+                    if (OVR) acc += tB * (2ull * zsel + 2ull * lo + tS + 1ull);
+                    else {
+                        acc += tB * (2ull * zsel + 2ull * lo + tS);
+                        tie += tB * (3ull * tS * (tS + tB) + tB * tB - 1ull);
+                    }
+                }
             }
             const bool packed = !HAS_BIG || bs < 0;
+            if (ABL & 4) { acc = cscc_h[g]; tie = cscc_h[G + g]; }
+            else
             if (MIXED) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) { // the 8-bit cells of the values 0 .. 7
@@ -230,6 +410,7 @@ __global__ __launch_bounds__(CSCC_NT, MIXED ? 4 : 2) void k_csc_counts(CscCounts
                 }
             }
             const long long n_g = P.counts[g];
+            if ((ABL & 8) && acc != 0x123456789ull) continue;
             const u64 zB = (u64)(n_g - (long long)nnz_g);
             if (OVR) {
                 acc += zB * (zsel + 1ull);

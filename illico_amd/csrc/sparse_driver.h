@@ -57,7 +57,7 @@ static int launch_csc_counts(illico_ctx *c, const CscCountsParams &P, int rt, bo
     ProfScope ps(c, KID_CSC_COUNTS);
 #define CSCC_LAUNCH1(OVRF, RTV, BIG, C16F)                                                                                 \
     do {                                                                                                                   \
-        auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, BIG, MIXED && RTV == 64, C16F>;                                     \
+        auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, BIG, MIXED && RTV == 64, C16F, CSCC_WT, 0, CSCC_NT, CSCC_LEAN, CSCC_PUTB(OVRF)>; \
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
         hipLaunchKernelGGL(kern, dim3(P.nb), dim3(CSCC_NT), lds, c->stream, P);                                            \
     } while (0)
@@ -127,6 +127,7 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
             P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes16 = codes16; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref;
             P.n_cells = n_rows; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot;
             P.gene_total = ovr ? gtot : nullptr;
+            P.verdict = nullptr;
             if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
             else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds))) return rc;
             if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0))) return rc; }
@@ -149,6 +150,82 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
     }
     std::sort(left.begin(), left.end());
     cols.swap(left);
+    return ILLICO_OK;
+}
+
+// ILLICO_FLAG_DEFER on device-resident CSC arrays with device planes: the count-valued pass (value sample, k_csc_counts,
+// k_finalize) is enqueued and the call returns -- no host wait at all.  Whether the window is count-valued is decided on the
+// device from the sample; which genes the pass could not take (values outside the table, 4-bit cells that overflowed) travels
+// to pinned memory behind an event and is looked at by the next call on the context / illico_ctx_synchronize
+// (resolve_pending_csc), which recomputes exactly those columns through the ordinary routes.
+template <typename InT, typename IdxT>
+static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *indices, const void *indptr, int dtype, int idx_dtype,
+                                   int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                                   const OutPlanes &o) {
+    const int G = (int)c->n_groups;
+    const bool ovr = c->ref < 0;
+    const int64_t W = col_ub - col_lb;
+    int rc;
+    void *v;
+    std::vector<signed char> h_slot(G, (signed char)-1);
+    int n_big = 0;
+    for (int g = 0; g < G; ++g)
+        if (g != c->ref && c->h_counts[g] > 255) h_slot[g] = (signed char)n_big++;
+    const signed char *d_slot = nullptr;
+    if (n_big) { // (rare: a one-off upload + wait; a context keeps its groups for many calls)
+        if ((rc = get_scratch(c, "cscc_slot", (size_t)G, &v))) return rc;
+        HIPCHK(c, hipMemcpyAsync(v, h_slot.data(), (size_t)G, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        d_slot = (const signed char *)v;
+    }
+    if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
+    u32 *d_cnt = (u32 *)v;
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
+    hipLaunchKernelGGL((k_sample_noncount_cols<InT, IdxT>), dim3((1 << 16) / 256), dim3(256), 0, c->stream, (const InT *)data,
+                       (const IdxT *)indptr, (long long)col_lb, (long long)col_ub, 1 << 16, CSCC_RT, d_cnt);
+    HIPCHK(c, hipGetLastError());
+    const int rt8 = cscc_lds_bytes(G, 64) + 8192 <= kMaxLds ? 64 : 32;
+    const bool mixed = !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(G, 0) + 4096) <= kMaxLds ||
+                                                   (rt8 == 32 && cscc_lds_bytes(G, 0) + 8192 <= kMaxLds));
+    const int rt = mixed ? 64 : rt8;
+    const size_t lds = cscc_lds_bytes(G, mixed ? 0 : rt);
+    const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(W, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
+    if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
+    long long *s2u = (long long *)v;
+    u64 *stie = (u64 *)(s2u + (size_t)nb_max * G);
+    double *ssum = (double *)(stie + (size_t)nb_max * G);
+    double *gtot = ssum + (size_t)nb_max * G;
+    if ((rc = get_scratch(c, "sp_defer_flags", (size_t)W * 4, &v))) return rc;
+    u32 *fb = (u32 *)v;
+    HIPCHK(c, hipMemsetAsync(fb, 0, (size_t)W * 4, c->stream));
+    for (int64_t b0 = 0; b0 < W; b0 += nb_max) {
+        const int nb = (int)std::min<int64_t>(nb_max, W - b0);
+        CscCountsParams P;
+        P.data = data; P.indices = indices; P.indptr = indptr; P.kshift = 0; P.col0 = col_lb + b0; P.gene_cols = nullptr; P.nb = nb;
+        P.codes16 = c->d_codes16; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref; P.n_cells = n_rows; P.fallback = fb + b0;
+        P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot; P.gene_total = ovr ? gtot : nullptr; P.verdict = d_cnt;
+        if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
+        else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds))) return rc;
+        if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0))) return rc;
+    }
+    const int slot = c->pend_next;
+    void *&pin = c->pend_pinned[slot];
+    if (c->pend_pinned_bytes[slot] < (size_t)W * 4) {
+        if (pin) hipHostFree(pin);
+        pin = nullptr;
+        c->pend_pinned_bytes[slot] = 0;
+        HIPCHK(c, hipHostMalloc(&pin, (size_t)W * 4 + 4096, hipHostMallocDefault));
+        c->pend_pinned_bytes[slot] = (size_t)W * 4 + 4096;
+    }
+    if (!c->pend_event[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->pend_event[slot], hipEventDisableTiming));
+    HIPCHK(c, hipMemcpyAsync(pin, fb, (size_t)W * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->pend_event[slot], c->stream));
+    c->pend_next ^= 1;
+    PendingDense &q = c->pend;
+    q = PendingDense();
+    q.on = true; q.kind = 1; q.sp_data = data; q.sp_indices = indices; q.sp_indptr = indptr; q.idx_dtype = idx_dtype; q.n_cols = n_cols;
+    q.dtype = dtype; q.flags = flags & ~ILLICO_FLAG_DEFER; q.alternative = alternative; q.slot = slot; q.N = n_rows;
+    q.col_lb = col_lb; q.col_ub = col_ub; q.out_ld = o.ld; q.p = o.p; q.u = o.u; q.fc = o.fc;
     return ILLICO_OK;
 }
 
@@ -309,6 +386,10 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
                               (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes;
     u32 h_sample[4] = {0, 0, 0, 0}; // non-integers, integers beyond the table, samples taken
     bool sampled = false;
+    if ((flags & ILLICO_FLAG_DEFER) && in_dev && (flags & ILLICO_FLAG_OUTPUT_DEVICE) && !o.staged && counts_route && W > 0 &&
+        !indices_are_codes && c->d_codes16 && !c->tap)
+        return run_csc_counts_deferred<InT, IdxT>(c, data, indices, indptr, dtype, (int)(sizeof(IdxT) == 4 ? ILLICO_IDX_I32 : ILLICO_IDX_I64),
+                                                  n_rows, n_cols, col_lb, col_ub, flags, alternative, o);
 
     // what the host needs of indptr: all of it for CSC (batch planning), its two ends for CSR (total stored entries)
     std::vector<IdxT> h_indptr;
@@ -721,22 +802,11 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     return ILLICO_OK;
 }
 
-static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr,
-                      int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                      double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
-    if (!c) return ILLICO_ERR_ARG;
-    CTX_LOCK(c);
-    int rc = check_common(c, n_rows, n_cols, col_lb, col_ub, alternative, out_p, out_u, out_fc, out_ld);
-    if (rc) return rc;
-    if (!data || !indices || !indptr) return fail(c, ILLICO_ERR_ARG, "null sparse array");
-    if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
-    if (idx_dtype != ILLICO_IDX_I32 && idx_dtype != ILLICO_IDX_I64) return fail(c, ILLICO_ERR_DTYPE, "unsupported index dtype code %d", idx_dtype);
-    HIPCHK(c, hipSetDevice(c->device));
-    if ((rc = resolve_pending(c))) return rc;
-    const int64_t W = col_ub - col_lb;
-    if (W == 0) return ILLICO_OK;
-    OutPlanes o;
-    if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) return rc;
+// dispatch on the value / index types (no argument checks, no deferred-call bookkeeping: run_sparse does both)
+static int run_sparse_inner(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr,
+                            int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                            const OutPlanes &o) {
+    int rc;
 #ifndef ILLICO_DEV_F32_ONLY
 #define SP_CALL(InT, KeyT)                                                                                                 \
     (idx_dtype == ILLICO_IDX_I32                                                                                           \
@@ -754,6 +824,63 @@ static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, c
         rc = run_sparse_t<float, int32_t, u32>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o);
     else rc = fail(c, ILLICO_ERR_DTYPE, "this development build holds the float32 / int32-index kernels only");
 #endif
+    return rc;
+}
+
+// the columns a deferred count-valued CSC pass could not take, through the ordinary routes
+static int resolve_pending_csc(illico_ctx *c, const PendingDense &q) {
+    const u32 *hf = (const u32 *)c->pend_pinned[q.slot];
+    const int64_t W = q.col_ub - q.col_lb;
+    for (int64_t j = 0; j < W;) {
+        if (!hf[j]) { ++j; continue; }
+        int64_t e = j;
+        while (e < W && hf[e]) ++e;
+        const OutPlanes o{q.p + j, q.u + j, q.fc + j, q.out_ld, false};
+        const int rc = run_sparse_inner(c, false, q.sp_data, q.dtype, q.sp_indices, q.sp_indptr, q.idx_dtype, q.N, q.n_cols, q.col_lb + j,
+                                        q.col_lb + e, q.flags, q.alternative, o);
+        if (rc) return rc;
+        j = e;
+    }
+    return ILLICO_OK;
+}
+
+static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr,
+                      int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                      double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
+    if (!c) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
+    int rc = check_common(c, n_rows, n_cols, col_lb, col_ub, alternative, out_p, out_u, out_fc, out_ld);
+    if (rc) return rc;
+    if (!data || !indices || !indptr) return fail(c, ILLICO_ERR_ARG, "null sparse array");
+    if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    if (idx_dtype != ILLICO_IDX_I32 && idx_dtype != ILLICO_IDX_I64) return fail(c, ILLICO_ERR_DTYPE, "unsupported index dtype code %d", idx_dtype);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t W = col_ub - col_lb;
+    // A deferred call still in flight: as in illico_run_dense, a deferred call that writes OTHER planes is enqueued first and
+    // the earlier one completed after (the GPU goes from one pass to the next without waiting for the host); otherwise the
+    // earlier call is completed before anything else happens.
+    PendingDense prev = c->pend;
+    c->pend.on = false;
+    bool later = false;
+    if (prev.on && (flags & ILLICO_FLAG_DEFER) && (flags & ILLICO_FLAG_OUTPUT_DEVICE) && (flags & ILLICO_FLAG_INPUT_DEVICE) && W > 0) {
+        const size_t span = (size_t)(c->n_groups - 1) * (size_t)out_ld + (size_t)W, pspan = (size_t)(c->n_groups - 1) * (size_t)prev.out_ld + (size_t)(prev.col_ub - prev.col_lb);
+        auto apart = [](const double *a, size_t na, const double *b, size_t nb) { return a + na <= b || b + nb <= a; };
+        later = true;
+        for (const double *a : {out_p, out_u, out_fc})
+            for (const double *b : {prev.p, prev.u, prev.fc}) later = later && apart(a, span, b, pspan);
+    }
+    if (!later && (rc = resolve_pending(c, prev))) return rc;
+    if (W == 0) return later ? resolve_pending(c, prev) : ILLICO_OK;
+    OutPlanes o;
+    if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) { if (later) resolve_pending(c, prev); return rc; }
+    rc = run_sparse_inner(c, is_csr, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o);
+    if (later) { // (the earlier call's leftovers run on the ordinary routes; this call's own pending state must survive them)
+        const PendingDense mine = c->pend;
+        c->pend.on = false;
+        const int rc2 = resolve_pending(c, prev);
+        c->pend = mine;
+        if (!rc) rc = rc2;
+    }
     if (rc) return rc;
     return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
 }

@@ -1,9 +1,13 @@
 """Gene sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is RCCL).
 
 Genes are independent units (every reference kernel takes an arbitrary contiguous gene range,
-illico/asymptotic_wilcoxon.py:213-241), so rank r of R computes genes [r*M/R, (r+1)*M/R) with no input
+illico/asymptotic_wilcoxon.py:213-241), so rank r of R computes a contiguous gene range with no input
 exchange; the only collective is the gather of the three float64 result planes to rank 0, issued per
 gene block so that it overlaps the next block's compute.
+
+Ranges are balanced by gene COUNT for dense input and by STORED ENTRIES for sparse input (SURVEY.md 8e:
+"for sparse inputs balance by nnz rather than gene count"; the unit of work of the reference's sparse
+kernels is the stored entry, illico/ovo/sparse_ovo.py:163-210).
 """
 from __future__ import annotations
 
@@ -20,6 +24,56 @@ def shard_bounds(n: int, parts: int) -> list[tuple[int, int]]:
 
 def rank_gene_range(n_genes: int, rank: int, world: int) -> tuple[int, int]:
     return ((n_genes * rank) // world, (n_genes * (rank + 1)) // world)
+
+
+def balanced_gene_ranges(weights, world: int) -> list[tuple[int, int]]:
+    """Contiguous gene ranges, one per rank, whose weight sums are as equal as contiguity allows.
+
+    ``weights[j]`` is gene j's cost (stored entries, plus a constant per gene if the caller wants one).  Rank r's range
+    ends at the first gene where the running weight reaches r+1 shares of the total -- every rank computes the same
+    edges from the same array, no communication.  Zero total weight falls back to the split by gene count.
+    """
+    w = np.asarray(weights, dtype=np.float64)
+    m = int(w.size)
+    world = max(1, int(world))
+    total = float(w.sum())
+    if m == 0 or total <= 0.0:
+        return [rank_gene_range(m, r, world) for r in range(world)]
+    cum = np.cumsum(w)
+    # edge r = number of genes whose running weight stays at or below r shares (the gene that crosses a share goes to
+    # whichever side leaves the smaller error)
+    targets = total * np.arange(1, world, dtype=np.float64) / world
+    hi = np.searchsorted(cum, targets, side="left")  # first gene with cum >= target
+    edges = [0]
+    for t, j in zip(targets, hi.tolist()):
+        j = min(j, m - 1)
+        below = cum[j - 1] if j > 0 else 0.0
+        e = j + 1 if (cum[j] - t) <= (t - below) else j
+        edges.append(int(min(max(e, edges[-1]), m)))
+    edges.append(m)
+    return [(edges[r], edges[r + 1]) for r in range(world)]
+
+
+def sparse_gene_weights(X, per_gene_cost: float = 0.0) -> np.ndarray:
+    """Stored entries per gene (column) of a scipy CSC / CSR matrix (or anything with indptr / indices / shape / format),
+    plus ``per_gene_cost``.  CSC: differences of ``indptr`` (no pass over the entries); CSR: one ``bincount`` of the
+    column indices."""
+    fmt = getattr(X, "format", None)
+    n_genes = int(X.shape[1])
+    if fmt == "csc":
+        w = np.diff(np.asarray(X.indptr, dtype=np.int64))
+    elif fmt == "csr":
+        w = np.bincount(np.asarray(X.indices), minlength=n_genes)[:n_genes]
+    else:
+        raise TypeError(f"sparse_gene_weights: expected a CSC or CSR matrix, got {type(X).__name__}")
+    return w.astype(np.float64) + float(per_gene_cost)
+
+
+def gene_ranges_for(X, world: int) -> list[tuple[int, int]]:
+    """The ranges `asymptotic_wilcoxon_sharded` uses: by stored entries for scipy sparse input, by gene count otherwise."""
+    if getattr(X, "format", None) in ("csc", "csr") and hasattr(X, "indptr"):
+        return balanced_gene_ranges(sparse_gene_weights(X), world)
+    return [rank_gene_range(int(X.shape[1]), r, world) for r in range(world)]
 
 
 def gather_block_async(stage, recv_list, rank: int, world: int, dst: int = 0, group=None):
@@ -52,12 +106,24 @@ def torch_empty_like_cpu(t):
 
 def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, reference=None, *, alternative="two-sided",
                                 use_continuity=True, tie_correct=True, layer=None, n_blocks: int = 4, group=None,
-                                compute_planes=None):
-    """Gene-sharded drop-in: every rank passes the same ``adata``; rank 0 returns the DataFrame, the others None.
+                                compute_planes=None, column_loader=None, n_genes=None, var_names=None, groups=None,
+                                gene_weights=None):
+    """Gene-sharded drop-in: rank 0 returns the DataFrame, the others None.
+
+    Two ways to hand over the data:
+
+    * every rank passes the same ``adata`` (the reference's argument, asymptotic_wilcoxon.py:71-83); a rank only ever
+      touches the columns of its own range;
+    * ``column_loader(lb, ub) -> X[:, lb:ub]`` (dense ndarray / device tensor / scipy CSC or CSR holding ONLY those
+      columns) with ``n_genes``, ``groups`` (the per-cell labels, what ``adata.obs[group_keys]`` would hold) and, on
+      rank 0, ``var_names``: a rank then never holds another rank's genes -- at BASELINE configs[4] the whole matrix is
+      120 GB, a rank's shard 15 GB.  ``adata`` may be None.  ``gene_weights`` (one number per gene, e.g. stored entries,
+      identical on every rank) balances the ranges; without it they are balanced by gene count.
 
     ``compute_planes(X, grpc, lb, ub, **opts) -> (p, u, fc)`` defaults to the HIP engine of this rank's GPU
     (planes stay on the device until gathered over RCCL); tests inject a CPU function to cover the sharding
-    and gather logic with the gloo backend.
+    and gather logic with the gloo backend.  With a loader, ``X`` is the loaded block and ``(lb, ub)`` are relative
+    to it.
     """
     import pandas as pd
     import torch
@@ -67,10 +133,25 @@ def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, referenc
     from illico_amd.utils.registry import data_handler_registry
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    X = adata.layers[layer] if layer is not None else adata.X
-    handler = data_handler_registry.get(X)
-    unique, grpc = encode_and_count_groups(np.asarray(adata.obs[group_keys]), reference)
-    n_genes, G = X.shape[1], int(grpc.counts.size)
+    if column_loader is None:
+        X = adata.layers[layer] if layer is not None else adata.X
+        n_genes = int(X.shape[1])
+        labels = np.asarray(adata.obs[group_keys])
+        ranges = balanced_gene_ranges(gene_weights, world) if gene_weights is not None else gene_ranges_for(X, world)
+        if rank == 0:
+            var_names = np.asarray(adata.var_names)
+    else:
+        if n_genes is None or groups is None:
+            raise ValueError("column_loader needs n_genes= and groups= (the per-cell labels)")
+        X, n_genes, labels = None, int(n_genes), np.asarray(groups)
+        ranges = (balanced_gene_ranges(gene_weights, world) if gene_weights is not None
+                  else [rank_gene_range(n_genes, r, world) for r in range(world)])
+        if rank == 0 and var_names is None:
+            var_names = np.arange(n_genes).astype(str)
+    if len(ranges) != world or ranges[0][0] != 0 or ranges[-1][1] != n_genes:
+        raise ValueError("gene ranges do not cover the genes")
+    unique, grpc = encode_and_count_groups(labels, reference)
+    G = int(grpc.counts.size)
     opts = dict(is_log1p=is_log1p, use_continuity=use_continuity, tie_correct=tie_correct, alternative=alternative)
 
     on_gpu = compute_planes is None
@@ -80,32 +161,34 @@ def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, referenc
         eng = get_engine()
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         eng.set_groups(grpc)
-        fmt = handler.kernel_data_format()
         dev = torch.device("cuda", eng.device)
 
-        def compute_planes(X, grpc, lb, ub, **o):  # noqa: F811
+        def compute_planes(Xb, grpc, lb, ub, **o):  # noqa: F811
+            h = data_handler_registry.get(Xb)
+            fmt = h.kernel_data_format()
             if fmt == KernelDataFormat.DENSE:
-                return eng.run_dense(X, lb, ub, device_out=True, **o)
-            return eng.run_sparse(fmt.value, X.data, X.indices, X.indptr, X.shape, lb, ub, device_out=True, **o)
+                return eng.run_dense(Xb, lb, ub, device_out=True, **o)
+            return eng.run_sparse(fmt.value, Xb.data, Xb.indices, Xb.indptr, Xb.shape, lb, ub, device_out=True, **o)
     else:
         dev = torch.device("cpu")
 
     # every rank must issue the same number of gathers: blocks are defined per rank on its own range
-    ranges = [rank_gene_range(n_genes, r, world) for r in range(world)]
     my_lb, my_ub = ranges[rank]
+    if column_loader is not None:  # this rank's genes, and nothing else
+        Xmine = column_loader(my_lb, my_ub) if my_ub > my_lb else None
+        if Xmine is not None and int(Xmine.shape[1]) != my_ub - my_lb:
+            raise ValueError(f"column_loader({my_lb}, {my_ub}) returned {Xmine.shape[1]} columns")
     handles, stages, recvs = [], [], []
     for b in range(n_blocks):
-        lb, ub = shard_bounds(my_ub - my_lb, n_blocks)[b] if my_ub > my_lb else (0, 0)
-        lb, ub = my_lb + lb, my_lb + ub
-        widths = []
-        for r in range(world):
-            rl, ru = ranges[r]
-            bl, bu = shard_bounds(ru - rl, n_blocks)[b] if ru > rl else (0, 0)
-            widths.append(bu - bl)
+        lb, ub = shard_bounds(my_ub - my_lb, n_blocks)[b]
+        widths = [shard_bounds(ru - rl, n_blocks)[b][1] - shard_bounds(ru - rl, n_blocks)[b][0] for rl, ru in ranges]
         wmax = max(widths)
         stage = torch.zeros((3, G, wmax), dtype=torch.float64, device=dev)
         if ub > lb:
-            p, u, fc = compute_planes(X, grpc, lb, ub, **opts)
+            if column_loader is not None:
+                p, u, fc = compute_planes(Xmine, grpc, lb, ub, **opts)
+            else:
+                p, u, fc = compute_planes(X, grpc, my_lb + lb, my_lb + ub, **opts)
             for k, a in enumerate((p, u, fc)):
                 stage[k, :, : ub - lb] = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
         recv = [torch.empty_like(stage) for _ in range(world)] if rank == 0 else None
@@ -120,10 +203,10 @@ def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, referenc
     for b, (recv, widths) in enumerate(recvs):
         for r in range(world):
             rl, ru = ranges[r]
-            bl, bu = shard_bounds(ru - rl, n_blocks)[b] if ru > rl else (0, 0)
+            bl, bu = shard_bounds(ru - rl, n_blocks)[b]
             if bu > bl:
                 planes[:, :, rl + bl: rl + bu] = recv[r][:, :, : bu - bl].cpu().numpy()
-    cols = pd.Series(np.asarray(adata.var_names), name="feature", dtype=str)
+    cols = pd.Series(np.asarray(var_names), name="feature", dtype=str)
     rows = pd.Series(unique, name="pert", dtype=str)
     return pd.DataFrame(
         {"p_value": planes[0].reshape(-1), "statistic": planes[1].reshape(-1), "fold_change": planes[2].reshape(-1)},

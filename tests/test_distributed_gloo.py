@@ -88,3 +88,105 @@ def test_sharded_gather_fewer_genes_than_blocks(tmp_path, world, n_genes, n_bloc
     np.testing.assert_array_equal(got[:, :, 0], p)
     np.testing.assert_array_equal(got[:, :, 1], u)
     np.testing.assert_array_equal(got[:, :, 2], fc)
+
+
+# ---- nnz-balanced ranges ("for sparse inputs balance by nnz rather than gene count") and the per-rank loader ----
+def _skewed_counts(seed, n_cells, n_genes):
+    """A count matrix whose genes differ 50-fold in stored entries, densest first (what sorting genes by expression gives)."""
+    rng = np.random.RandomState(seed)
+    dens = np.geomspace(0.5, 0.01, n_genes)
+    X = rng.poisson(3.0, size=(n_cells, n_genes)).astype(np.float32) + 1.0
+    X[rng.rand(n_cells, n_genes) >= dens] = 0
+    return X, rng
+
+
+def test_balanced_gene_ranges_by_stored_entries():
+    from scipy import sparse
+    from illico_amd.distributed import balanced_gene_ranges, gene_ranges_for, rank_gene_range, sparse_gene_weights
+    X, _ = _skewed_counts(0, 2000, 400)
+    for M in (sparse.csc_matrix(X), sparse.csr_matrix(X)):
+        w = sparse_gene_weights(M)
+        np.testing.assert_array_equal(w, (X != 0).sum(axis=0))
+        for world in (2, 3, 8):
+            rg = gene_ranges_for(M, world)
+            assert rg[0][0] == 0 and rg[-1][1] == 400 and all(a[1] == b[0] for a, b in zip(rg, rg[1:]))
+            per = np.array([w[lb:ub].sum() for lb, ub in rg])
+            assert per.max() <= 1.10 * per.mean() and per.min() >= 0.90 * per.mean(), (world, per)
+            by_count = np.array([w[slice(*rank_gene_range(400, r, world))].sum() for r in range(world)])
+            assert by_count.max() > 1.5 * by_count.mean()  # what the split by gene count would have given
+    # dense input: by gene count
+    assert gene_ranges_for(X, 3) == [rank_gene_range(400, r, 3) for r in range(3)]
+    # degenerate inputs: no genes, no weight, more ranks than genes, one gene holding everything
+    assert balanced_gene_ranges([], 3) == [(0, 0)] * 3
+    assert balanced_gene_ranges([0, 0, 0, 0], 2) == [(0, 2), (2, 4)]
+    rg = balanced_gene_ranges([5.0, 1.0], 4)
+    assert rg[0][0] == 0 and rg[-1][1] == 2 and all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(rg, rg[1:]))
+    rg = balanced_gene_ranges([0, 0, 100, 0, 0], 3)
+    assert sum(1 for lb, ub in rg if lb <= 2 < ub) == 1 and rg[-1][1] == 5
+
+
+def _worker_loader(rank, world, port, fmt, out_path, log_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from scipy import sparse
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from conftest import make_labels
+    from illico_amd.distributed import asymptotic_wilcoxon_sharded, sparse_gene_weights
+
+    X, rng = _skewed_counts(5, 500, 41)
+    labels = make_labels(rng, 500, 5, n_ref=50)
+    full = {"dense": X, "csc": sparse.csc_matrix(X), "csr": sparse.csr_matrix(X)}[fmt]
+    asked = []
+
+    def loader(lb, ub):  # a rank's own columns only (a real loader would read them from storage)
+        asked.append((lb, ub))
+        return full[:, lb:ub] if fmt == "dense" else full[:, lb:ub].asformat(fmt)
+
+    def compute(Xb, grpc, lb, ub, **o):
+        assert Xb.shape[1] <= 41 and (world == 1 or Xb.shape[1] < 41)  # never the whole matrix
+        return oracle.run(Xb, grpc, col_lb=lb, col_ub=ub, **o)
+
+    weights = sparse_gene_weights(full) if fmt != "dense" else None
+    df = asymptotic_wilcoxon_sharded(None, False, "pert", "non-targeting", n_blocks=3, compute_planes=compute,
+                                     column_loader=loader, n_genes=41, groups=labels, gene_weights=weights,
+                                     var_names=[f"g{j}" for j in range(41)] if rank == 0 else None)
+    with open(os.path.join(log_dir, f"asked_{rank}.txt"), "w") as f:
+        f.write(repr(asked))
+    if rank == 0:
+        df.to_pickle(out_path)
+    else:
+        assert df is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fmt", ["dense", "csc", "csr"])
+def test_sharded_with_a_per_rank_column_loader(tmp_path, fmt):
+    """A rank loads its own gene range once and nothing else; sparse ranges are balanced by stored entries."""
+    import oracle
+    from scipy import sparse
+    from conftest import make_labels
+    from illico_amd.distributed import balanced_gene_ranges, rank_gene_range, sparse_gene_weights
+    out = tmp_path / "df.pkl"
+    mp.spawn(_worker_loader, args=(2, _free_port(), fmt, str(out), str(tmp_path)), nprocs=2, join=True)
+    df = pd.read_pickle(out)
+    X, rng = _skewed_counts(5, 500, 41)
+    labels = make_labels(rng, 500, 5, n_ref=50)
+    uniq, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    p, u, fc = oracle.run(X, g)
+    got = df.values.reshape(len(uniq), 41, 3)
+    np.testing.assert_array_equal(got[:, :, 0], p)
+    np.testing.assert_array_equal(got[:, :, 1], u)
+    np.testing.assert_array_equal(got[:, :, 2], fc)
+    assert list(df.index.get_level_values(1)[:41]) == [f"g{j}" for j in range(41)]
+    want = (balanced_gene_ranges(sparse_gene_weights(sparse.csc_matrix(X)), 2) if fmt != "dense"
+            else [rank_gene_range(41, r, 2) for r in range(2)])
+    for r in range(2):
+        asked = eval((tmp_path / f"asked_{r}.txt").read_text())
+        assert asked == [want[r]], (r, asked, want)
+    if fmt != "dense":
+        assert want[0][1] < 41 // 2  # the dense genes come first: rank 0 takes fewer genes than half

@@ -475,3 +475,49 @@ def test_sparse_type_extremes(engine, fmt, test, dtype, route):
     M = (sparse.csc_matrix if fmt == "csc" else sparse.csr_matrix)(X)
     got = _run(engine, M, g)
     assert_planes_match(got, want, ref_row=g.encoded_ref_group if test == "ovo" else None, what=f"{fmt} {test} {np.dtype(dtype).name} {route}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_deferred_csc_calls_complete_their_leftover_genes(engine, test):
+    """ILLICO_FLAG_DEFER on device-resident CSC arrays: the count-valued pass is enqueued without a host wait; the genes it
+    cannot take (values beyond the table, fractional values, 4-bit cells that overflow) are recomputed when the next call or
+    synchronize() looks at their flags -- and a matrix that is no count matrix at all is sent on from the device-side sample."""
+    import torch
+    X, rng = make_counts(31, 6000, 96, 0.85)
+    X[:, 7] *= 9.0                          # values beyond 63 in one gene
+    X[::3, 40] += 0.5                       # fractional values in another
+    X[:, 41] = np.where(rng.rand(6000) < 0.9, 9.0, 0.0)  # sixteen and more equal values of 9 per group: the 4-bit cells overflow
+    labels = make_labels(rng, 6000, 9, n_ref=400)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    want = oracle.run(X, g)
+    Xc, rng2 = make_counts(32, 6000, 96, 0.85)
+    Xc = np.log1p(Xc * rng2.uniform(0.5, 1.5, size=Xc.shape)).astype(np.float32)  # continuous: the sample sends every gene on
+    want_c = oracle.run(Xc, g)
+    engine.set_groups(g)
+    dev = torch.device("cuda", engine.device)
+
+    def up(M):
+        M = sparse.csc_matrix(M)
+        return tuple(torch.from_numpy(a).to(dev) for a in (M.data, M.indices, M.indptr)), M.shape
+
+    (d, i, p), shape = up(X)
+    (dc, ic, pc), _ = up(Xc)
+    G = g.counts.size
+    A = tuple(torch.full((G, 96), -7.0, dtype=torch.float64, device=dev) for _ in range(3))
+    B = tuple(torch.full((G, 96), -7.0, dtype=torch.float64, device=dev) for _ in range(3))
+    engine.run_sparse("csc", d, i, p, shape, 0, 96, out=A, defer=True)
+    engine.run_sparse("csc", dc, ic, pc, shape, 0, 96, out=B, defer=True)   # other planes: enqueued before A is completed
+    engine.run_sparse("csc", d, i, p, shape, 0, 96, out=A, defer=True)      # the same planes again
+    engine.synchronize()
+    ref_row = g.encoded_ref_group
+    assert_planes_match(tuple(t.cpu().numpy() for t in A), want, ref_row=ref_row, what=f"deferred csc {test}")
+    assert_planes_match(tuple(t.cpu().numpy() for t in B), want_c, ref_row=ref_row, what=f"deferred csc {test} continuous")
+    # a window, then a non-deferred call while one is pending
+    C = tuple(torch.full((G, 96), -7.0, dtype=torch.float64, device=dev) for _ in range(3))
+    engine.run_sparse("csc", d, i, p, shape, 32, 80, out=tuple(t[:, 32:80] for t in C), defer=True)
+    got = engine.run_sparse("csc", d, i, p, shape, 0, 96)
+    assert_planes_match(got, want, ref_row=ref_row, what=f"csc {test} after a deferred call")
+    engine.synchronize()
+    assert_planes_match(tuple(t[:, 32:80].cpu().numpy() for t in C), tuple(w[:, 32:80] for w in want), ref_row=ref_row,
+                        what=f"deferred csc window {test}")
+    assert all(float(t[:, :32].min()) == -7.0 and float(t[:, 80:].max()) == -7.0 for t in C)
