@@ -29,7 +29,8 @@ SYMBOLS = [
     "illico_ctx_create", "illico_ctx_destroy", "illico_ctx_set_stream", "illico_ctx_set_option",
     "illico_last_error", "illico_ctx_synchronize", "illico_set_groups", "illico_run_dense", "illico_run_csc",
     "illico_run_csr", "illico_csr_indices_sorted", "illico_rank_statistics", "illico_profile_num_kernels", "illico_profile_kernel_name",
-    "illico_profile_get", "illico_profile_reset", "illico_version",
+    "illico_profile_get", "illico_profile_reset", "illico_version", "illico_csr_bind", "illico_csc_bind", "illico_run_bound",
+    "illico_matrix_release", "illico_profile_input_bytes",
 ]
 
 _lib = None
@@ -67,6 +68,11 @@ def load() -> ctypes.CDLL:
         lib.illico_profile_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
         lib.illico_profile_reset.argtypes = [vp]
         lib.illico_version.restype = ctypes.c_char_p
+        for f in (lib.illico_csr_bind, lib.illico_csc_bind):
+            f.argtypes = [vp, vp, ci, vp, vp, ci, i64, i64, ci, ctypes.POINTER(vp)]
+        lib.illico_run_bound.argtypes = [vp, vp, i64, i64, ci, ci, vp, vp, vp, i64]
+        lib.illico_matrix_release.argtypes = [vp, vp]
+        lib.illico_profile_input_bytes.argtypes = [vp, ctypes.POINTER(i64)]
         for name in SYMBOLS:  # fail at load time, not at first use, if the library and the header have drifted
             getattr(lib, name)
         _lib = lib
@@ -312,6 +318,33 @@ class Engine:
                        n_rows, n_cols, col_lb, col_ub, flags, alt, ptrs[0], ptrs[1], ptrs[2], out_ld))
         return planes
 
+    def bind_sparse(self, fmt, data, indices, indptr, shape):
+        """Upload a host CSR / CSC matrix once (or adopt device tensors) -- illico_csr_bind / illico_csc_bind; returns a
+        ``BoundMatrix`` whose ``run(col_lb, col_ub, ...)`` computes chunks without moving the matrix again."""
+        n_rows, n_cols = int(shape[0]), int(shape[1])
+        if _is_torch_tensor(data):
+            d, i, p = _Buf(data), _Buf(indices), _Buf(indptr)
+        else:
+            d = _Buf(normalize_values(np.asarray(data)))
+            idt = np.int32 if (np.asarray(indices).dtype == np.int32 and np.asarray(indptr).dtype == np.int32) else np.int64
+            i, p = _Buf(indices, idt), _Buf(indptr, idt)
+        if i.np_dtype != p.np_dtype or i.np_dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
+            raise KeyError(f"Support for index dtypes {i.np_dtype}/{p.np_dtype} is not implemented.")
+        if not (d.on_device == i.on_device == p.on_device):
+            raise ValueError("data, indices and indptr must live on the same side (host or device)")
+        h = ctypes.c_void_p()
+        fn = self.lib.illico_csc_bind if fmt == "csc" else self.lib.illico_csr_bind
+        self._bind_torch_stream(d.keep, i.keep, p.keep)
+        self._check(fn(self.h, d.ptr, dtype_code(d.np_dtype), i.ptr, p.ptr, IDX_I32 if i.np_dtype == np.int32 else IDX_I64,
+                       n_rows, n_cols, FLAG_INPUT_DEVICE if d.on_device else 0, ctypes.byref(h)))
+        return BoundMatrix(self, h, (n_rows, n_cols), (d.keep, i.keep, p.keep) if d.on_device else None)
+
+    def input_bytes(self) -> int:
+        """Matrix bytes copied host -> device by this context so far (illico_profile_input_bytes)."""
+        n = ctypes.c_int64(0)
+        self._check(self.lib.illico_profile_input_bytes(self.h, ctypes.byref(n)))
+        return int(n.value)
+
     def rank_statistics(self, X, col_lb, col_ub, *, is_log1p=False):
         """The ranking primitives before finalisation (include/illico_hip.h: illico_rank_statistics):
         ``(two_u int64 [W, G], tie_sum uint64 [W, G], value_sum float64 [W, G])`` for the dense columns [col_lb, col_ub)."""
@@ -368,6 +401,40 @@ class Engine:
             if n.value:
                 out[self.lib.illico_profile_kernel_name(k).decode()] = {"ms": ms.value, "launches": n.value}
         return out
+
+
+class BoundMatrix:
+    """Handle of illico_csr_bind / illico_csc_bind; ``release()`` (or garbage collection) frees the device copy."""
+
+    def __init__(self, engine, handle, shape, keep):
+        self.engine, self.h, self.shape, self._keep = engine, handle, shape, keep
+
+    def run(self, col_lb, col_ub, *, is_log1p=False, use_continuity=True, tie_correct=True, alternative="two-sided", out=None,
+            device_out=False, defer=False):
+        eng = self.engine
+        alt = eng._alt(alternative)
+        n_cols = self.shape[1]
+        if col_lb < 0 or col_ub > n_cols or col_lb > col_ub:
+            raise ValueError(f"Invalid chunk bounds: {(col_lb, col_ub)} for data with {n_cols} columns.")
+        G, W = eng.n_groups, col_ub - col_lb
+        planes, ptrs, oflag, out_ld = eng._outputs(out, G, W, device_out)
+        if ptrs is None:
+            return planes
+        flags = eng._flags(is_log1p, use_continuity, tie_correct) | oflag | (FLAG_DEFER if defer else 0)
+        eng._bind_torch_stream(*planes)
+        eng._check(eng.lib.illico_run_bound(eng.h, self.h, col_lb, col_ub, flags, alt, ptrs[0], ptrs[1], ptrs[2], out_ld))
+        return planes
+
+    def release(self):
+        if self.h is not None and self.h.value and getattr(self.engine, "h", None) is not None and self.engine.h.value:
+            self.engine.lib.illico_matrix_release(self.engine.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 def _current_device() -> int:

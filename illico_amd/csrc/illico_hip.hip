@@ -66,6 +66,15 @@ struct PendingDense {
     double *p = nullptr, *u = nullptr, *fc = nullptr;
 };
 
+// a sparse matrix bound to a context (illico_csr_bind / illico_csc_bind): device arrays, owned or adopted
+struct illico_matrix {
+    illico_ctx *owner = nullptr;
+    bool is_csr = false, owns = false;
+    int dtype = 0, idx_dtype = 0;
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    void *d_data = nullptr, *d_indices = nullptr, *d_indptr = nullptr;
+};
+
 struct ProfEvent {
     int kid;
     hipEvent_t a, b;
@@ -131,6 +140,8 @@ struct illico_ctx {
     int pend_next = 0;
     void *pinned = nullptr;       // pinned host staging for small device -> host results
     size_t pinned_bytes = 0;
+    int64_t h2d_input_bytes = 0;  // matrix bytes copied host -> device (illico_profile_input_bytes)
+    std::vector<illico_matrix *> bound; // matrices bound to this context and not yet released
     std::vector<ProfEvent> events;
     std::vector<hipEvent_t> event_pool;
     double prof_ms[KID_COUNT] = {0};
@@ -293,6 +304,10 @@ int illico_ctx_destroy(illico_ctx *c) {
         if (c->pend_event[k]) hipEventDestroy(c->pend_event[k]);
     }
     free_groups(c);
+    for (illico_matrix *m : c->bound) {
+        if (m->owns) { hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr); }
+        delete m;
+    }
     for (auto &kv : c->scratch)
         if (kv.second.first) hipFree(kv.second.first);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -372,6 +387,12 @@ int illico_profile_get(illico_ctx *c, int k, double *total_ms, int64_t *launches
     drain_events(c);
     if (total_ms) *total_ms = c->prof_ms[k];
     if (launches) *launches = c->prof_n[k];
+    return ILLICO_OK;
+}
+int illico_profile_input_bytes(illico_ctx *c, int64_t *h2d_bytes) {
+    if (!c || !h2d_bytes) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
+    *h2d_bytes = c->h2d_input_bytes;
     return ILLICO_OK;
 }
 int illico_profile_reset(illico_ctx *c) {
@@ -736,9 +757,10 @@ static bool fused_path_allowed(const illico_ctx *c, int flags) {
 
 static int launch_finalize(illico_ctx *c, const long long *s2u, const u64 *stie, const double *ssum, const double *gene_total,
                            int nb, int flags, int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld,
-                           int64_t col_off, const int *col_map = nullptr) {
+                           int64_t col_off, const int *col_map = nullptr, bool packed = false) {
     FinalizeParams F;
     F.col_map = col_map;
+    F.packed = packed ? 1 : 0;
     F.in_2u = s2u; F.in_tie = stie; F.in_sum = ssum; F.gene_total = gene_total;
     F.counts = c->d_counts; F.G = (int)c->n_groups; F.ref = (int)c->ref; F.nb = nb; F.n_cells = c->n_cells;
     F.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;
@@ -1077,6 +1099,7 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
             if ((rc = get_scratch(c, "xin", (size_t)wn * N * sizeof(InT), &v))) return rc;
             HIPCHK(c, hipMemcpy2DAsync(v, (size_t)wn * sizeof(InT), (const InT *)X + w0, (size_t)ld * sizeof(InT), (size_t)wn * sizeof(InT),
                                        (size_t)N, hipMemcpyHostToDevice, c->stream));
+            c->h2d_input_bytes += (int64_t)((size_t)wn * sizeof(InT) * (size_t)N);
             if ((rc = run_fused_ovo<InT>(c, v, wn, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc;
             flagged_runs(hf.data(), wn, w0, runs);
         }

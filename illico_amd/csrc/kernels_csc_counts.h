@@ -53,6 +53,8 @@ struct CscCountsParams {
     u64 *out_tie;
     double *out_sum;
     double *gene_total;                  // OVR: [nb] the column's value sum (what k_gene_totals would add up from out_sum), or nullptr
+    int pack16;                          // statistics as 16 bytes per test: out_2u = value sum << 40 | 2U (40 bits; all ones: the OVO reference
+                                         // row), out_tie; out_sum unused.  Host-checked: no group beyond 255 cells (sums < 2^24, 2U < 2^40)
     const u32 *verdict;                  // deferred calls: {non-integers, -, samples} of k_sample_noncount_cols, looked at on the device
                                          // (more than 2 % non-integers: not a count matrix, every gene is left to the general routes); or nullptr
 };
@@ -338,12 +340,16 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
         const long long n_ref = OVR ? 0 : P.counts[OVR ? 0 : ref];
         const u64 zsel = (u64)((OVR ? P.n_cells : n_ref) - (long long)nnz_sel); // zA (OVO) or n0 (OVR)
         u32 cells_seen = 0;
-        for (int g = tid; g < G; g += NT) {
+        auto emit = [&](int g, long long two_u, u64 tie_sum, u64 sum_g) { // (integer value sums: counts)
             const size_t o = (size_t)gene * G + g;
+            if (P.pack16) { // (uniform) 16 bytes per test: a third less for this kernel to write and for k_finalize to read
+                P.out_2u[o] = (long long)(((u64)sum_g << 40) | ((u64)two_u & 0xFFFFFFFFFFull));
+                P.out_tie[o] = tie_sum;
+            } else { P.out_2u[o] = two_u; P.out_tie[o] = tie_sum; P.out_sum[o] = (double)sum_g; }
+        };
+        for (int g = tid; g < G; g += NT) {
             if (!OVR && g == ref) {
-                P.out_2u[o] = -2;
-                P.out_tie[o] = 0;
-                P.out_sum[o] = (double)s_sum;
+                emit(g, -2, 0, s_sum);
                 continue;
             }
             // 32-bit inner terms (host-checked: n_ref < 30000 for OVO, n_cells < 2^30), one 32 x 32 -> 64 multiply-add each;
@@ -414,15 +420,12 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
             const u64 zB = (u64)(n_g - (long long)nnz_g);
             if (OVR) {
                 acc += zB * (zsel + 1ull);
-                P.out_2u[o] = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)acc;
-                P.out_tie[o] = T_sel + (zsel * zsel * zsel - zsel);
+                emit(g, 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)acc, T_sel + (zsel * zsel * zsel - zsel), (u64)vsum);
             } else {
                 acc += zB * zsel;
                 const u64 t0 = zsel + zB;
-                P.out_2u[o] = 2ll * n_ref * n_g - (long long)acc;
-                P.out_tie[o] = T_sel + tie + (t0 * t0 * t0 - t0);
+                emit(g, 2ll * n_ref * n_g - (long long)acc, T_sel + tie + (t0 * t0 * t0 - t0), (u64)vsum);
             }
-            P.out_sum[o] = (double)vsum;
         }
         if (MIXED) {
             cells_seen = (u32)wave_sum((int)cells_seen);

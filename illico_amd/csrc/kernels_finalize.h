@@ -18,6 +18,7 @@ struct FinalizeParams {
     double *out_p, *out_u, *out_fc; // [G][out_ld], column offset already applied
     long long out_ld;
     const int *col_map;       // optional: output column of batch gene j (relative to the offset); nullptr = j
+    int packed;               // 16-byte statistics (k_csc_counts): in_2u = value sum << 40 | 2U (40 bits, all ones = the OVO reference row); no in_sum
 };
 
 __device__ __forceinline__ double pval_device(long long n_ref, long long n_tgt, long long n, double tie_sum, double U,
@@ -68,8 +69,21 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
         const size_t o = ok ? (size_t)gene * P.G + g : 0;
         in2u[k] = ok ? P.in_2u[o] : 0;
         intie[k] = (ok && P.tie_correct) ? P.in_tie[o] : 0ull;
-        insum[k] = ok ? P.in_sum[o] : 0.0;
-        inref[k] = !ok ? 1.0 : (ovr ? P.gene_total[gene] : P.in_sum[(size_t)gene * P.G + P.ref]);
+        if (P.packed) { // (uniform)
+            insum[k] = 0.0;
+            inref[k] = !ok ? 1.0 : (ovr ? P.gene_total[gene] : (double)((u64)P.in_2u[(size_t)gene * P.G + P.ref] >> 40));
+        } else {
+            insum[k] = ok ? P.in_sum[o] : 0.0;
+            inref[k] = !ok ? 1.0 : (ovr ? P.gene_total[gene] : P.in_sum[(size_t)gene * P.G + P.ref]);
+        }
+    }
+    if (P.packed) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u64 w = (u64)in2u[k], lo = w & 0xFFFFFFFFFFull;
+            insum[k] = (double)(w >> 40);
+            in2u[k] = lo == 0xFFFFFFFFFFull ? -2ll : (long long)lo;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

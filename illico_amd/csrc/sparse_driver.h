@@ -128,10 +128,11 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
             P.n_cells = n_rows; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot;
             P.gene_total = ovr ? gtot : nullptr;
             P.verdict = nullptr;
+            P.pack16 = n_big == 0 ? 1 : 0; // 16-byte statistics while every ranked group has at most 255 cells
             if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
             else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds))) return rc;
-            if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0))) return rc; }
-            else if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb))) return rc;
+            if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0, n_big == 0))) return rc; }
+            else if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb, nullptr, n_big == 0))) return rc;
             if (c->pinned_bytes < (size_t)nb * 4) {
                 if (c->pinned) hipHostFree(c->pinned);
                 c->pinned = nullptr; c->pinned_bytes = 0;
@@ -204,9 +205,10 @@ static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *
         P.data = data; P.indices = indices; P.indptr = indptr; P.kshift = 0; P.col0 = col_lb + b0; P.gene_cols = nullptr; P.nb = nb;
         P.codes16 = c->d_codes16; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref; P.n_cells = n_rows; P.fallback = fb + b0;
         P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot; P.gene_total = ovr ? gtot : nullptr; P.verdict = d_cnt;
+        P.pack16 = n_big == 0 ? 1 : 0;
         if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
         else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds))) return rc;
-        if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0))) return rc;
+        if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0, nullptr, n_big == 0))) return rc;
     }
     const int slot = c->pend_next;
     void *&pin = c->pend_pinned[slot];
@@ -443,6 +445,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         if ((rc = get_scratch(c, "sp_indices", cnt * sizeof(IdxT), &v))) return rc;
         HIPCHK(c, hipMemcpyAsync(v, (const IdxT *)indices + k0, (size_t)(k1 - k0) * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
         d_indices = (const IdxT *)v;
+        c->h2d_input_bytes += (int64_t)(n_ptr * sizeof(IdxT) + (size_t)(k1 - k0) * (sizeof(InT) + sizeof(IdxT)));
     }
 
     // ---- CSR, count-valued, not too sparse: dense float32 windows + the fused single-pass kernels (k_csr_densify) ----
@@ -896,6 +899,88 @@ extern "C" int illico_run_csr(illico_ctx *c, const void *data, int dtype, const 
                               int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
     return run_sparse(c, true, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative,
                       out_p, out_u, out_fc, out_ld);
+}
+
+// ---- bound matrices -------------------------------------------------------------------------
+static int sparse_bind(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr, int idx_dtype,
+                       int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out) {
+    if (!c || !out) return ILLICO_ERR_ARG;
+    *out = nullptr;
+    CTX_LOCK(c);
+    if (!data || !indices || !indptr) return fail(c, ILLICO_ERR_ARG, "null sparse array");
+    if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    if (idx_dtype != ILLICO_IDX_I32 && idx_dtype != ILLICO_IDX_I64) return fail(c, ILLICO_ERR_DTYPE, "unsupported index dtype code %d", idx_dtype);
+    if (n_rows <= 0 || n_cols < 0) return fail(c, ILLICO_ERR_ARG, "bad matrix shape");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t isz = idx_dtype == ILLICO_IDX_I32 ? 4 : 8, vsz = dtype_size(dtype);
+    const int64_t n_ptr = (is_csr ? n_rows : n_cols) + 1;
+    illico_matrix *m = new illico_matrix();
+    m->owner = c; m->is_csr = is_csr; m->dtype = dtype; m->idx_dtype = idx_dtype; m->n_rows = n_rows; m->n_cols = n_cols;
+    if (flags & ILLICO_FLAG_INPUT_DEVICE) { // adopt: nothing is copied, the caller keeps the arrays alive
+        m->d_data = const_cast<void *>(data); m->d_indices = const_cast<void *>(indices); m->d_indptr = const_cast<void *>(indptr);
+        m->nnz = -1;
+    } else {
+        const int64_t nnz = idx_dtype == ILLICO_IDX_I32 ? (int64_t)((const int32_t *)indptr)[n_ptr - 1] : ((const int64_t *)indptr)[n_ptr - 1];
+        const int64_t first = idx_dtype == ILLICO_IDX_I32 ? (int64_t)((const int32_t *)indptr)[0] : ((const int64_t *)indptr)[0];
+        if (first != 0 || nnz < 0) { delete m; return fail(c, ILLICO_ERR_ARG, "indptr[0] must be 0 and indptr[-1] >= 0"); }
+        m->nnz = nnz;
+        m->owns = true;
+        const size_t cnt = (size_t)std::max<int64_t>(nnz, 1);
+        hipError_t e;
+        if ((e = hipMalloc(&m->d_data, cnt * vsz)) != hipSuccess || (e = hipMalloc(&m->d_indices, cnt * isz)) != hipSuccess ||
+            (e = hipMalloc(&m->d_indptr, (size_t)n_ptr * isz)) != hipSuccess) {
+            hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr);
+            delete m;
+            return fail(c, ILLICO_ERR_OOM, "hipMalloc for a bound matrix of %lld stored entries failed: %s", (long long)nnz, hipGetErrorString(e));
+        }
+        hipError_t e1 = hipMemcpyAsync(m->d_data, data, (size_t)nnz * vsz, hipMemcpyHostToDevice, c->stream);
+        hipError_t e2 = hipMemcpyAsync(m->d_indices, indices, (size_t)nnz * isz, hipMemcpyHostToDevice, c->stream);
+        hipError_t e3 = hipMemcpyAsync(m->d_indptr, indptr, (size_t)n_ptr * isz, hipMemcpyHostToDevice, c->stream);
+        hipError_t e4 = hipStreamSynchronize(c->stream); // the caller's arrays are free to go once bind returns
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+            hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr);
+            delete m;
+            return fail(c, ILLICO_ERR_HIP, "upload of a bound matrix failed");
+        }
+        c->h2d_input_bytes += (int64_t)((size_t)nnz * (vsz + isz) + (size_t)n_ptr * isz);
+    }
+    c->bound.push_back(m);
+    *out = m;
+    return ILLICO_OK;
+}
+
+extern "C" int illico_csr_bind(illico_ctx *c, const void *data, int dtype, const void *indices, const void *indptr, int idx_dtype,
+                               int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out) {
+    return sparse_bind(c, true, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, flags, out);
+}
+extern "C" int illico_csc_bind(illico_ctx *c, const void *data, int dtype, const void *indices, const void *indptr, int idx_dtype,
+                               int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out) {
+    return sparse_bind(c, false, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, flags, out);
+}
+extern "C" int illico_run_bound(illico_ctx *c, const illico_matrix *m, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                                double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
+    if (!c || !m) return ILLICO_ERR_ARG;
+    {
+        CTX_LOCK(c);
+        if (m->owner != c || std::find(c->bound.begin(), c->bound.end(), m) == c->bound.end())
+            return fail(c, ILLICO_ERR_ARG, "the matrix handle does not belong to this context (or was released)");
+    }
+    const int keep = ILLICO_FLAG_LOG1P | ILLICO_FLAG_CONTINUITY | ILLICO_FLAG_TIE_CORRECT | ILLICO_FLAG_OUTPUT_DEVICE | ILLICO_FLAG_DEFER;
+    return run_sparse(c, m->is_csr, m->d_data, m->dtype, m->d_indices, m->d_indptr, m->idx_dtype, m->n_rows, m->n_cols, col_lb, col_ub,
+                      (flags & keep) | ILLICO_FLAG_INPUT_DEVICE, alternative, out_p, out_u, out_fc, out_ld);
+}
+extern "C" int illico_matrix_release(illico_ctx *c, illico_matrix *m) {
+    if (!c || !m) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
+    auto it = std::find(c->bound.begin(), c->bound.end(), m);
+    if (it == c->bound.end() || m->owner != c) return fail(c, ILLICO_ERR_ARG, "the matrix handle does not belong to this context (or was released)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = resolve_pending(c); // a deferred call may still read the arrays
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bound.erase(it);
+    if (m->owns) { hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr); }
+    delete m;
+    return rc;
 }
 
 template <typename IdxT> static int csr_sorted_host(const IdxT *indices, const IdxT *indptr, int64_t n_rows) {

@@ -62,7 +62,10 @@ enum {
      * waiting for it.  The few genes that route cannot take (values outside its table) are recomputed when their flags have
      * arrived -- by the next call on the context or by illico_ctx_synchronize, after which the planes are complete.  X and
      * the planes must stay valid until then.  A following deferred call that writes OTHER planes is enqueued before the
-     * earlier one is completed, so back-to-back passes run without a host round trip in between.  Ignored elsewhere. */
+     * earlier one is completed, so back-to-back passes run without a host round trip in between.
+     * illico_run_csc / illico_run_bound on device-resident CSC arrays with device planes honour it too: the count-valued pass
+     * (whether the window holds counts at all is decided on the device, from a sample of its stored values) is enqueued and the
+     * columns it cannot take are recomputed the same way, later.  Ignored elsewhere (host arrays, host planes, CSR). */
     ILLICO_FLAG_DEFER = 32
 };
 
@@ -123,6 +126,24 @@ int illico_run_csc(illico_ctx *ctx, const void *data, int dtype, const void *ind
 int illico_run_csr(illico_ctx *ctx, const void *data, int dtype, const void *indices, const void *indptr,
                    int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags,
                    int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld);
+/* ---- a sparse matrix bound once, computed chunk by chunk -------------------------------------
+ * The reference's driver calls a dispatcher once per gene chunk with the SAME matrix (illico/asymptotic_wilcoxon.py:236-241:
+ * 32 calls at 8000 genes and batch_size 256); CSR rows span every gene, so illico_run_csr on HOST arrays has to move the whole
+ * matrix to the device in every call.  illico_csr_bind / illico_csc_bind upload the arrays ONCE (or, with
+ * ILLICO_FLAG_INPUT_DEVICE, adopt device arrays without copying) and return a handle; illico_run_bound then computes any
+ * column chunk of it like illico_run_csr / illico_run_csc on device-resident arrays (flags: LOG1P / CONTINUITY / TIE_CORRECT /
+ * OUTPUT_DEVICE / DEFER).  The caller may free or modify its host arrays as soon as bind returns.  A handle belongs to the
+ * context that made it; illico_matrix_release frees the device copy (illico_ctx_destroy releases what is left).  An explicit
+ * handle, not a cache keyed on pointers: nothing about a matrix is remembered behind the caller's back. */
+typedef struct illico_matrix illico_matrix;
+int illico_csr_bind(illico_ctx *ctx, const void *data, int dtype, const void *indices, const void *indptr, int idx_dtype,
+                    int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out_matrix);
+int illico_csc_bind(illico_ctx *ctx, const void *data, int dtype, const void *indices, const void *indptr, int idx_dtype,
+                    int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out_matrix);
+int illico_run_bound(illico_ctx *ctx, const illico_matrix *matrix, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                     double *out_p, double *out_u, double *out_fc, int64_t out_ld);
+int illico_matrix_release(illico_ctx *ctx, illico_matrix *matrix);
+
 /* replaces check_indices_sorted_per_parcel (utils/ranking.py:245-273); *out_sorted = 1/0. */
 int illico_csr_indices_sorted(illico_ctx *ctx, const void *indices, const void *indptr, int idx_dtype,
                               int64_t n_rows, int flags, int *out_sorted);
@@ -142,12 +163,21 @@ int illico_rank_statistics(illico_ctx *ctx, const void *X, int dtype, int64_t n_
                            int64_t col_lb, int64_t col_ub, int flags, int64_t *out_two_u, uint64_t *out_tie_sum,
                            double *out_value_sum);
 
+/* ---- multi-GPU ----------------------------------------------------------------------------
+ * Gene sharding is host-side: one context per GPU and process, each computing its own column range with the entry points
+ * above (no input is exchanged); the one collective of the path -- the gather of the planes to rank 0 -- is issued by the
+ * host over RCCL (illico_amd/distributed.py: torch.distributed.gather on device planes, backend "nccl").  The C-ABI has no
+ * illico_gather entry: a binding that wants several GPUs brings its own process group, as the Python host does. */
+
 /* ---- measurement hooks (bench.py roofline leg) ------------------------------------------- */
 int illico_profile_num_kernels(void);
 const char *illico_profile_kernel_name(int kernel_id);
 /* Sums HIP-event durations of kernel `kernel_id` since the last reset (synchronises the stream). */
 int illico_profile_get(illico_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 int illico_profile_reset(illico_ctx *ctx);
+/* Bytes of INPUT (matrix values / indices / index pointers) copied host -> device since the context was created: what a test
+ * of "one upload per matrix" looks at. */
+int illico_profile_input_bytes(illico_ctx *ctx, int64_t *h2d_bytes);
 
 const char *illico_version(void);
 

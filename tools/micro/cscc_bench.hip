@@ -82,7 +82,7 @@ int main(int argc, char **argv) {
 
     CscCountsParams P;
     P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = 0; P.col0 = 0; P.gene_cols = nullptr; P.nb = M; P.codes16 = d_codes16;
-    P.counts = d_counts; P.G = G; P.n_cells = N; P.big_slot = nullptr; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.gene_total = nullptr; P.verdict = nullptr;
+    P.counts = d_counts; P.G = G; P.n_cells = N; P.big_slot = nullptr; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.gene_total = nullptr; P.verdict = nullptr; P.pack16 = 0;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     auto time_it = [&](const char *name, auto launch) {
         launch(); CK(hipDeviceSynchronize());
@@ -156,17 +156,25 @@ if (ovr) { VAR("stagger32-wt", true, true, 64) VAR("stagger96-wt", true, true, 1
             CK(hipMalloc(&op, (size_t)M * G * 8)); CK(hipMalloc(&ou, (size_t)M * G * 8)); CK(hipMalloc(&ofc, (size_t)M * G * 8));
             FinalizeParams F;
             F.in_2u = s2u; F.in_tie = stie; F.in_sum = ssum; F.gene_total = nullptr; F.counts = d_cnt32; F.G = G; F.ref = 0; F.nb = M; F.n_cells = N;
-            F.use_continuity = 1; F.tie_correct = 1; F.alternative = 0; F.out_p = op; F.out_u = ou; F.out_fc = ofc; F.out_ld = M; F.col_map = nullptr;
+            F.use_continuity = 1; F.tie_correct = 1; F.alternative = 0; F.packed = 0; F.out_p = op; F.out_u = ou; F.out_fc = ofc; F.out_ld = M; F.col_map = nullptr;
             time_it("k_finalize alone", [&] { hipLaunchKernelGGL(k_finalize, dim3((M + 31) / 32, (G + 31) / 32), dim3(256), 0, 0, F); });
-            auto kern = k_csc_counts<float, int, false, 64, false, true, true, true, 0>;
+            auto kern = k_csc_counts<float, int, false, 64, false, true, true, true, 0, CSCC_NT, true, false>;
             CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             time_it("counts+finalize serial", [&] {
                 hipLaunchKernelGGL(kern, dim3(M), dim3(CSCC_NT), lds, 0, P);
                 hipLaunchKernelGGL(k_finalize, dim3((M + 31) / 32, (G + 31) / 32), dim3(256), 0, 0, F);
             });
+            { // 16-byte statistics
+                CscCountsParams Pp = P; Pp.pack16 = 1;
+                FinalizeParams Fp = F; Fp.packed = 1;
+                time_it("counts+finalize, 16-byte statistics", [&] {
+                    hipLaunchKernelGGL(kern, dim3(M), dim3(CSCC_NT), lds, 0, Pp);
+                    hipLaunchKernelGGL(k_finalize, dim3((M + 31) / 32, (G + 31) / 32), dim3(256), 0, 0, Fp);
+                });
+            }
             hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
             hipStream_t s1; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
-            for (int NBATCH : {2, 4, 8, 16}) {
+            for (int NBATCH : {2}) {
                 std::vector<hipEvent_t> ev(NBATCH), evf(NBATCH);
                 for (auto &evt : ev) CK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
                 for (auto &evt : evf) CK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
