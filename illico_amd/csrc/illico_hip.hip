@@ -7,8 +7,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -138,10 +141,14 @@ struct illico_ctx {
     size_t pend_pinned_bytes[2] = {0, 0};
     hipEvent_t pend_event[2] = {nullptr, nullptr};
     int pend_next = 0;
+    void *out_pin[2] = {nullptr, nullptr}; // pinned buffers + events of end_outputs (host planes)
+    size_t out_pin_bytes = 0;
+    hipEvent_t out_ev[2] = {nullptr, nullptr};
     void *pinned = nullptr;       // pinned host staging for small device -> host results
     size_t pinned_bytes = 0;
     int64_t h2d_input_bytes = 0;  // matrix bytes copied host -> device (illico_profile_input_bytes)
     std::vector<illico_matrix *> bound; // matrices bound to this context and not yet released
+    struct HostStage *host_stage = nullptr; // pinned slots / copy stream of the host-window pipeline (dense driver)
     std::vector<ProfEvent> events;
     std::vector<hipEvent_t> event_pool;
     double prof_ms[KID_COUNT] = {0};
@@ -252,6 +259,7 @@ static void drain_events(illico_ctx *c) {
 }
 
 static int resolve_pending(illico_ctx *c); // completes a deferred dense call (defined with the dense driver)
+static void free_host_stage(illico_ctx *c); // (dense driver)
 
 // ============================================================================================
 extern "C" {
@@ -300,10 +308,13 @@ int illico_ctx_destroy(illico_ctx *c) {
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     if (c->pinned) hipHostFree(c->pinned);
     for (int k = 0; k < 2; ++k) {
+        if (c->out_pin[k]) hipHostFree(c->out_pin[k]);
+        if (c->out_ev[k]) hipEventDestroy(c->out_ev[k]);
         if (c->pend_pinned[k]) hipHostFree(c->pend_pinned[k]);
         if (c->pend_event[k]) hipEventDestroy(c->pend_event[k]);
     }
     free_groups(c);
+    free_host_stage(c);
     for (illico_matrix *m : c->bound) {
         if (m->owns) { hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr); }
         delete m;
@@ -796,13 +807,72 @@ static int begin_outputs(illico_ctx *c, int flags, int64_t W, double *out_p, dou
     return ILLICO_OK;
 }
 
+// Host planes: the device staging planes come back through two pinned 32-MB buffers (row blocks of the three planes in turn:
+// block i is copied down at the link's rate while block i - 1 is scattered into the caller's planes by a few host threads).  A
+// pageable destination made the driver stage the 24 bytes per test itself: 20 - 40 ms for C2's 384 MB, against ~10 ms.
 static int end_outputs(illico_ctx *c, const OutPlanes &o, int64_t W, double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
     if (!o.staged) return ILLICO_OK;
-    size_t G = (size_t)c->n_groups;
-    HIPCHK(c, hipMemcpy2DAsync(out_p, out_ld * 8, o.p, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(out_u, out_ld * 8, o.u, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(out_fc, out_ld * 8, o.fc, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t G = (size_t)c->n_groups, row = (size_t)W * 8;
+    const size_t total = 3 * G * row;
+    if (total < ((size_t)8 << 20)) { // small results: three strided copies
+        HIPCHK(c, hipMemcpy2DAsync(out_p, out_ld * 8, o.p, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(out_u, out_ld * 8, o.u, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(out_fc, out_ld * 8, o.fc, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return ILLICO_OK;
+    }
+    const size_t buf = (size_t)32 << 20;
+    if (c->out_pin_bytes < buf) {
+        for (int k = 0; k < 2; ++k) { if (c->out_pin[k]) hipHostFree(c->out_pin[k]); c->out_pin[k] = nullptr; }
+        c->out_pin_bytes = 0;
+        for (int k = 0; k < 2; ++k) HIPCHK(c, hipHostMalloc(&c->out_pin[k], buf, hipHostMallocDefault));
+        for (int k = 0; k < 2; ++k) if (!c->out_ev[k]) HIPCHK(c, hipEventCreateWithFlags(&c->out_ev[k], hipEventDisableTiming));
+        c->out_pin_bytes = buf;
+    }
+    const size_t rows_per = std::max<size_t>(1, buf / row), n_rows = 3 * G; // rows of the three planes, one after the other
+    if (row > buf) { // (a window too wide for the buffers: the plain copies)
+        HIPCHK(c, hipMemcpy2DAsync(out_p, out_ld * 8, o.p, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(out_u, out_ld * 8, o.u, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(out_fc, out_ld * 8, o.fc, W * 8, W * 8, G, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return ILLICO_OK;
+    }
+    const double *src[3] = {o.p, o.u, o.fc};
+    double *dst[3] = {out_p, out_u, out_fc};
+    auto scatter = [&](int k, size_t r0, size_t r1) { // rows [r0, r1) of the concatenated planes, from pinned buffer k
+        const char *from = (const char *)c->out_pin[k];
+        const int T = (r1 - r0) * row >= ((size_t)4 << 20) ? 4 : 1;
+        std::vector<std::thread> pool;
+        auto part = [&](int t) {
+            for (size_t r = r0 + (r1 - r0) * t / T; r < r0 + (r1 - r0) * (t + 1) / T; ++r)
+                memcpy(dst[r / G] + (r % G) * (size_t)out_ld, from + (r - r0) * row, row);
+        };
+        for (int t = 1; t < T; ++t) pool.emplace_back(part, t);
+        part(0);
+        for (auto &th : pool) th.join();
+    };
+    size_t prev0 = 0, prev1 = 0;
+    int i = 0;
+    for (size_t r0 = 0; r0 < n_rows; r0 += rows_per, ++i) {
+        const size_t r1 = std::min(n_rows, r0 + rows_per);
+        const int k = i & 1;
+        // a block may straddle two planes: one contiguous device range per plane it touches (the staging planes are [G][W], dense)
+        for (size_t r = r0; r < r1;) {
+            const size_t pl = r / G, e = std::min(r1, (pl + 1) * G);
+            HIPCHK(c, hipMemcpyAsync((char *)c->out_pin[k] + (r - r0) * row, src[pl] + (r % G) * (size_t)W, (e - r) * row, hipMemcpyDeviceToHost, c->stream));
+            r = e;
+        }
+        HIPCHK(c, hipEventRecord(c->out_ev[k], c->stream));
+        if (i > 0) {
+            HIPCHK(c, hipEventSynchronize(c->out_ev[k ^ 1]));
+            scatter(k ^ 1, prev0, prev1);
+        }
+        prev0 = r0; prev1 = r1;
+    }
+    if (i > 0) {
+        HIPCHK(c, hipEventSynchronize(c->out_ev[(i - 1) & 1]));
+        scatter((i - 1) & 1, prev0, prev1);
+    }
     return ILLICO_OK;
 }
 
@@ -1052,6 +1122,143 @@ template <typename InT> static bool host_window_is_count_valued(const InT *X, in
     return (double)bad <= 0.02 * (double)n_samples;
 }
 
+// ---- host-resident dense input: a three-stage pipeline over column windows ----------------------------------------------
+// A pageable 2-D copy of the whole window (what this path did before) moves 9.6 GB at ~43 GB/s through the driver's own
+// staging and nothing overlaps it.  Here: (1) HS_THREADS host threads copy window k + 1's row pieces out of the caller's
+// matrix into a PINNED slot, (2) the copy stream moves window k's slot to the device at the link's rate, (3) the context's
+// stream runs the fused pass on window k - 1 -- all three at once, three slots deep.  Slot j serves the windows k = j mod 3: its
+// pinned half is free once its upload has completed, its device half once the pass over it has (events both ways).
+#define HS_SLOTS 3
+#define HS_THREADS 12
+struct HostStage {
+    void *pin[HS_SLOTS] = {nullptr, nullptr, nullptr};
+    size_t pin_bytes = 0;
+    hipStream_t copy = nullptr;
+    hipEvent_t up[HS_SLOTS] = {nullptr, nullptr, nullptr}, done[HS_SLOTS] = {nullptr, nullptr, nullptr};
+};
+static HostStage *host_stage_of(illico_ctx *c) { // (one per context, freed with it)
+    if (!c->host_stage) c->host_stage = new HostStage();
+    return c->host_stage;
+}
+static void free_host_stage(illico_ctx *c) {
+    HostStage *hs = c->host_stage;
+    if (!hs) return;
+    if (hs->copy) { hipStreamSynchronize(hs->copy); hipStreamDestroy(hs->copy); }
+    for (int j = 0; j < HS_SLOTS; ++j) {
+        if (hs->pin[j]) hipHostFree(hs->pin[j]);
+        if (hs->up[j]) hipEventDestroy(hs->up[j]);
+        if (hs->done[j]) hipEventDestroy(hs->done[j]);
+    }
+    delete hs;
+    c->host_stage = nullptr;
+}
+
+template <typename InT>
+static int host_windows_pipeline(illico_ctx *c, const InT *X, int64_t ld, int64_t N, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                                 const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> &runs) {
+    int rc;
+    void *v;
+    // windows of ~256 MB (a multiple of 64 genes): long enough for the link's rate, short enough that the first pass starts early
+    int64_t wmax = std::max<int64_t>(64, (int64_t)(((size_t)256 << 20) / ((size_t)N * sizeof(InT))) & ~63ll);
+    wmax = std::min<int64_t>(wmax, std::max<int64_t>(64, (int64_t)((size_t)c->scratch_bytes / HS_SLOTS / ((size_t)N * sizeof(InT))) & ~63ll));
+    if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, std::max<int64_t>(1, c->gene_batch));
+    const int64_t n_win = (col_ub - col_lb + wmax - 1) / wmax;
+    const size_t slot_bytes = (size_t)wmax * (size_t)N * sizeof(InT);
+    HostStage *hs = host_stage_of(c);
+    if (!hs->copy) HIPCHK(c, hipStreamCreateWithFlags(&hs->copy, hipStreamNonBlocking));
+    for (int j = 0; j < HS_SLOTS; ++j) {
+        if (!hs->up[j]) HIPCHK(c, hipEventCreateWithFlags(&hs->up[j], hipEventDisableTiming));
+        if (!hs->done[j]) HIPCHK(c, hipEventCreateWithFlags(&hs->done[j], hipEventDisableTiming));
+    }
+    if (hs->pin_bytes < slot_bytes) {
+        for (int j = 0; j < HS_SLOTS; ++j) { if (hs->pin[j]) hipHostFree(hs->pin[j]); hs->pin[j] = nullptr; }
+        hs->pin_bytes = 0;
+        for (int j = 0; j < HS_SLOTS; ++j) HIPCHK(c, hipHostMalloc(&hs->pin[j], slot_bytes, hipHostMallocDefault));
+        hs->pin_bytes = slot_bytes;
+    }
+    InT *dev[HS_SLOTS];
+    static const char *names[HS_SLOTS] = {"xin0", "xin1", "xin2"};
+    for (int j = 0; j < HS_SLOTS; ++j) {
+        if ((rc = get_scratch(c, names[j], slot_bytes, &v))) return rc;
+        dev[j] = (InT *)v;
+    }
+    // producer: fills and uploads the slots; the calling thread consumes them.  `ready` = windows whose upload is enqueued.
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t ready = 0, consumed = 0;
+    int err = 0; // hipError_t of the producer, if any
+    double t_fill = 0.0, t_wait = 0.0; // (ILLICO_HS_DEBUG=1 prints them: seconds the producer spent filling slots / the consumer waiting for one)
+    const int device = c->device;
+    hipStream_t compute = c->stream;
+    std::thread producer([&] {
+        hipSetDevice(device);
+        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(HS_THREADS, N / 4096 + 1));
+        for (int64_t k = 0; k < n_win; ++k) {
+            const int j = (int)(k % HS_SLOTS);
+            const int64_t w0 = col_lb + k * wmax, wn = std::min<int64_t>(wmax, col_ub - w0);
+            if (k >= HS_SLOTS) { // slot j still belongs to window k - HS_SLOTS until the pass over it is done
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return consumed > k - HS_SLOTS || err; });
+                if (err) return;
+                lk.unlock();
+                if (hipEventSynchronize(hs->done[j]) != hipSuccess) { std::lock_guard<std::mutex> g(mu); err = 1; cv.notify_all(); return; }
+            }
+            InT *dst = (InT *)hs->pin[j];
+            const size_t piece = (size_t)wn * sizeof(InT);
+            const auto t_a = std::chrono::steady_clock::now();
+            std::vector<std::thread> pool;
+            for (int t = 1; t < T; ++t)
+                pool.emplace_back([=] {
+                    for (int64_t r = N * t / T; r < N * (t + 1) / T; ++r) memcpy(dst + (size_t)r * wn, X + (size_t)r * ld + w0, piece);
+                });
+            for (int64_t r = 0; r < N / T; ++r) memcpy(dst + (size_t)r * wn, X + (size_t)r * ld + w0, piece);
+            for (auto &th : pool) th.join();
+            t_fill += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
+            hipError_t e = hipMemcpyAsync(dev[j], dst, piece * (size_t)N, hipMemcpyHostToDevice, hs->copy);
+            if (e == hipSuccess) e = hipEventRecord(hs->up[j], hs->copy);
+            std::lock_guard<std::mutex> g(mu);
+            if (e != hipSuccess) err = 1;
+            ready = k + 1;
+            cv.notify_all();
+            if (err) return;
+        }
+    });
+    std::vector<u32> hf;
+    rc = ILLICO_OK;
+    for (int64_t k = 0; k < n_win && !rc; ++k) {
+        const int j = (int)(k % HS_SLOTS);
+        const int64_t w0 = col_lb + k * wmax, wn = std::min<int64_t>(wmax, col_ub - w0);
+        {
+            const auto t_a = std::chrono::steady_clock::now();
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return ready > k || err; });
+            t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
+            if (err) { rc = fail(c, ILLICO_ERR_HIP, "staging a host window failed"); break; }
+        }
+        if (hipStreamWaitEvent(compute, hs->up[j], 0) != hipSuccess) { rc = fail(c, ILLICO_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        rc = run_fused_ovo<InT>(c, dev[j], wn, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf);
+        if (!rc && hipEventRecord(hs->done[j], compute) != hipSuccess) rc = fail(c, ILLICO_ERR_HIP, "hipEventRecord failed");
+        if (!rc) flagged_runs(hf.data(), wn, w0, runs);
+        c->h2d_input_bytes += (int64_t)((size_t)wn * sizeof(InT) * (size_t)N);
+        std::lock_guard<std::mutex> g(mu);
+        consumed = k + 1;
+        if (rc) err = 1;
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (rc) err = 1;
+        consumed = n_win + HS_SLOTS;
+        cv.notify_all();
+    }
+    producer.join();
+    hipStreamSynchronize(hs->copy);
+    if (getenv("ILLICO_HS_DEBUG"))
+        fprintf(stderr, "[illico] host windows: %lld x %lld genes, slot fill %.1f ms, consumer waited %.1f ms for uploads\n", (long long)n_win,
+                (long long)wmax, t_fill * 1e3, t_wait * 1e3);
+    return rc;
+}
+
 template <typename InT, typename KeyT>
 static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
                              int alternative, const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> runs);
@@ -1089,20 +1296,8 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
         flagged_runs(hf.data(), W, col_lb, runs);
         if (runs.empty()) return ILLICO_OK;
     } else if (!in_dev && try_fused && N > 0 && W > 0 && host_window_is_count_valued<InT>((const InT *)X, ld, col_lb, N, W)) {
-        // host matrix: column windows are copied up row-major (one 2-D copy each) and take the same fused pass
-        int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)N * sizeof(InT))) & ~63ll;
-        wmax = std::min<int64_t>(std::max<int64_t>(wmax, 64), (int64_t)((1ull << 32) / sizeof(InT)) - 64);
-        if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, c->gene_batch);
-        std::vector<u32> hf;
-        for (int64_t w0 = col_lb; w0 < col_ub; w0 += wmax) {
-            const int64_t wn = std::min<int64_t>(wmax, col_ub - w0);
-            if ((rc = get_scratch(c, "xin", (size_t)wn * N * sizeof(InT), &v))) return rc;
-            HIPCHK(c, hipMemcpy2DAsync(v, (size_t)wn * sizeof(InT), (const InT *)X + w0, (size_t)ld * sizeof(InT), (size_t)wn * sizeof(InT),
-                                       (size_t)N, hipMemcpyHostToDevice, c->stream));
-            c->h2d_input_bytes += (int64_t)((size_t)wn * sizeof(InT) * (size_t)N);
-            if ((rc = run_fused_ovo<InT>(c, v, wn, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc;
-            flagged_runs(hf.data(), wn, w0, runs);
-        }
+        // host matrix: column windows travel through pinned staging slots (host_windows_pipeline below) and take the same fused pass
+        if ((rc = host_windows_pipeline<InT>(c, (const InT *)X, ld, N, col_lb, col_ub, flags, alternative, o, runs))) return rc;
         if (runs.empty()) return ILLICO_OK;
     } else {
         runs.push_back({col_lb, col_ub});
