@@ -30,7 +30,9 @@
 #include "common.h"
 
 #define CSCC_NT 512
+#ifndef CSCC_UL
 #define CSCC_UL 16 // entries per thread and round
+#endif
 // the forms the library launches (tools/micro/cscc_bench.hip times the others against them)
 #define CSCC_WT true
 #define CSCC_LEAN true
