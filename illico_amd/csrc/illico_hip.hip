@@ -28,6 +28,7 @@
 #include "kernels_csc_counts.h"
 #include "kernels_csc_ovr.h"
 #include "kernels_sums.h"
+#include "kernels_leftover.h"
 
 // ---- profiled kernel ids ---------------------------------------------------------------------
 enum {
@@ -50,10 +51,12 @@ enum {
     KID_OVO_FUSED_WIDE,
     KID_GROUP_COMPACT,
     KID_OVO_RANK_COMPACT,
+    KID_OVR_COUNTS,
+    KID_GATHER_COLS,
     KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
-                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums", "k_ovo_fused_wide", "k_group_compact", "k_ovo_rank_compact"};
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums", "k_ovo_fused_wide", "k_group_compact", "k_ovo_rank_compact", "k_ovr_counts", "k_gather_columns"};
 
 // A dense call made with ILLICO_FLAG_DEFER whose fused pass is in flight: which genes it could not take is known only once
 // its route flags have reached the host; they are then recomputed by the two-pass routes (resolve_pending).
@@ -117,6 +120,7 @@ struct illico_ctx {
     bool no_ovr_packed_partition = false; // 1: dense OVR partitions the padded rows (every key) instead of the packed ones
     bool no_packed_dense = false;      // 1: dense OVO on continuous values takes the transpose + k_ovo_rank route (no group-wise packing)
     int packed_eq_buckets = -1;        // packed rank kernel: distribution-following bucket function; -1 = for references above 16384 cells
+    bool no_leftover_gather = false;   // 1: the genes the fused passes leave are recomputed as column runs of the input (no gather into a narrow matrix)
     bool no_fused_wide = false;        // 1: no second, 256-value pass of the fused OVO route (genes beyond 63 go to the two-pass routes)
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
@@ -350,6 +354,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_counts_path")) c->no_counts_path = value != 0;
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_fused_wide")) c->no_fused_wide = value != 0;
+    else if (!strcmp(key, "no_leftover_gather")) c->no_leftover_gather = value != 0;
     else if (!strcmp(key, "no_packed_dense")) c->no_packed_dense = value != 0;
     else if (!strcmp(key, "packed_eq_buckets")) c->packed_eq_buckets = (int)value;
     else if (!strcmp(key, "no_ovr_packed_partition")) c->no_ovr_packed_partition = value != 0;
@@ -741,17 +746,18 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
 }
 
 template <typename InT, typename KeyT>
-static int launch_transpose(illico_ctx *c, const void *X, int64_t ld, int64_t col0, int ncols, int N, KeyT *Xt, int64_t stride, u32 *flags) {
+static int launch_transpose(illico_ctx *c, const void *X, int64_t ld, int64_t col0, int ncols, int N, KeyT *Xt, int64_t stride, u32 *flags,
+                            int limit = COUNTS_R) { // flags[gene] != 0: a value that is no integer in [0, limit)
     ProfScope ps(c, KID_TRANSPOSE);
     dim3 grid((N + 63) / 64, (ncols + 63) / 64);
     constexpr int VEC = 16 / (int)sizeof(InT);
     const bool aligned = ((uintptr_t)X % 16 == 0) && (ld % VEC == 0) && (col0 % VEC == 0) && ((uintptr_t)Xt % 16 == 0) && (stride % 64 == 0);
     if (aligned)
         hipLaunchKernelGGL((k_transpose_permute_vec<InT, KeyT, VEC>), grid, dim3(256), 0, c->stream, (const InT *)X, (long long)ld,
-                           (long long)col0, ncols, (const int *)c->d_perm, N, Xt, (long long)stride, flags, COUNTS_R);
+                           (long long)col0, ncols, (const int *)c->d_perm, N, Xt, (long long)stride, flags, limit);
     else
         hipLaunchKernelGGL((k_transpose_permute<InT, KeyT>), grid, dim3(256), 0, c->stream, (const InT *)X, (long long)ld,
-                           (long long)col0, ncols, (const int *)c->d_perm, N, Xt, (long long)stride, flags, COUNTS_R);
+                           (long long)col0, ncols, (const int *)c->d_perm, N, Xt, (long long)stride, flags, limit);
     HIPCHK(c, hipGetLastError());
     return ILLICO_OK;
 }
@@ -1134,6 +1140,8 @@ template <typename InT> static bool host_window_is_count_valued(const InT *X, in
 struct HostStage {
     void *pin[HS_SLOTS] = {nullptr, nullptr, nullptr};
     size_t pin_bytes = 0;
+    int *lists = nullptr;        // pinned: column lists of the flagged genes, window after window (gathered leftovers)
+    size_t lists_ints = 0;
     hipStream_t copy = nullptr;
     hipEvent_t up[HS_SLOTS] = {nullptr, nullptr, nullptr}, done[HS_SLOTS] = {nullptr, nullptr, nullptr};
 };
@@ -1145,6 +1153,7 @@ static void free_host_stage(illico_ctx *c) {
     HostStage *hs = c->host_stage;
     if (!hs) return;
     if (hs->copy) { hipStreamSynchronize(hs->copy); hipStreamDestroy(hs->copy); }
+    if (hs->lists) hipHostFree(hs->lists);
     for (int j = 0; j < HS_SLOTS; ++j) {
         if (hs->pin[j]) hipHostFree(hs->pin[j]);
         if (hs->up[j]) hipEventDestroy(hs->up[j]);
@@ -1154,9 +1163,14 @@ static void free_host_stage(illico_ctx *c) {
     c->host_stage = nullptr;
 }
 
+struct HostLeftovers { // the flagged genes' columns, gathered on the device while their window is still there
+    void *xl = nullptr;    // [N][cap] values
+    int64_t cap = 0, n = 0;
+    int *d_dst = nullptr;  // [n] output column (relative to the call's planes) of gathered column j
+};
 template <typename InT>
 static int host_windows_pipeline(illico_ctx *c, const InT *X, int64_t ld, int64_t N, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                                 const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> &runs) {
+                                 const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> &runs, HostLeftovers &left) {
     int rc;
     void *v;
     // windows of ~256 MB (a multiple of 64 genes): long enough for the link's rate, short enough that the first pass starts early
@@ -1177,6 +1191,23 @@ static int host_windows_pipeline(illico_ctx *c, const InT *X, int64_t ld, int64_
         for (int j = 0; j < HS_SLOTS; ++j) HIPCHK(c, hipHostMalloc(&hs->pin[j], slot_bytes, hipHostMallocDefault));
         hs->pin_bytes = slot_bytes;
     }
+    // room for the genes the fused pass flags (a count matrix: few): they are gathered out of their window while it is on the device,
+    // so that no window travels twice
+    left.cap = c->no_leftover_gather ? 0 : std::min<int64_t>(((col_ub - col_lb) / 4 + 63) & ~63ll, (int64_t)((size_t)c->scratch_bytes / 4 / ((size_t)N * sizeof(InT))) & ~63ll);
+    int *d_src = nullptr;
+    if (left.cap >= 64) {
+        if ((rc = get_scratch(c, "xleft", (size_t)N * (size_t)left.cap * sizeof(InT), &v))) return rc;
+        left.xl = v;
+        HIPCHK(c, hipMemsetAsync(left.xl, 0, (size_t)N * (size_t)left.cap * sizeof(InT), c->stream));
+        if ((rc = get_scratch(c, "xleft_cols", (size_t)left.cap * 8, &v))) return rc;
+        d_src = (int *)v; left.d_dst = d_src + left.cap;
+        if (hs->lists_ints < (size_t)left.cap * 2) {
+            if (hs->lists) hipHostFree(hs->lists);
+            hs->lists = nullptr; hs->lists_ints = 0;
+            HIPCHK(c, hipHostMalloc((void **)&hs->lists, (size_t)left.cap * 8, hipHostMallocDefault));
+            hs->lists_ints = (size_t)left.cap * 2;
+        }
+    } else left.cap = 0;
     InT *dev[HS_SLOTS];
     static const char *names[HS_SLOTS] = {"xin0", "xin1", "xin2"};
     for (int j = 0; j < HS_SLOTS; ++j) {
@@ -1238,8 +1269,27 @@ static int host_windows_pipeline(illico_ctx *c, const InT *X, int64_t ld, int64_
         }
         if (hipStreamWaitEvent(compute, hs->up[j], 0) != hipSuccess) { rc = fail(c, ILLICO_ERR_HIP, "hipStreamWaitEvent failed"); break; }
         rc = run_fused_ovo<InT>(c, dev[j], wn, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf);
+        if (!rc) { // this window's flagged genes: out of the device window into the leftover matrix (else: column runs, uploaded again later)
+            int cnt = 0;
+            for (int64_t q = 0; q < wn; ++q) cnt += (hf[q] == 1u || hf[q] == 3u) ? 1 : 0;
+            if (cnt && left.n + cnt <= left.cap) {
+                int *ls = hs->lists + left.n, *ld_ = hs->lists + left.cap + left.n;
+                int e = 0;
+                for (int64_t q = 0; q < wn; ++q)
+                    if (hf[q] == 1u || hf[q] == 3u) { ls[e] = (int)q; ld_[e] = (int)(w0 - col_lb + q); ++e; }
+                if (hipMemcpyAsync(d_src + left.n, ls, (size_t)cnt * 4, hipMemcpyHostToDevice, compute) != hipSuccess ||
+                    hipMemcpyAsync(left.d_dst + left.n, ld_, (size_t)cnt * 4, hipMemcpyHostToDevice, compute) != hipSuccess)
+                    rc = fail(c, ILLICO_ERR_HIP, "uploading a column list failed");
+                if (!rc) {
+                    ProfScope ps(c, KID_GATHER_COLS);
+                    hipLaunchKernelGGL((k_gather_columns<InT>), dim3((unsigned)((N + 63) / 64)), dim3(256), 0, compute, (const InT *)dev[j], (long long)wn,
+                                       (int)N, (const int *)(d_src + left.n), cnt, cnt, (InT *)left.xl, (long long)left.cap, (long long)left.n);
+                    if (hipGetLastError() != hipSuccess) rc = fail(c, ILLICO_ERR_HIP, "k_gather_columns launch failed");
+                }
+                left.n += cnt;
+            } else if (cnt) flagged_runs(hf.data(), wn, w0, runs);
+        }
         if (!rc && hipEventRecord(hs->done[j], compute) != hipSuccess) rc = fail(c, ILLICO_ERR_HIP, "hipEventRecord failed");
-        if (!rc) flagged_runs(hf.data(), wn, w0, runs);
         c->h2d_input_bytes += (int64_t)((size_t)wn * sizeof(InT) * (size_t)N);
         std::lock_guard<std::mutex> g(mu);
         consumed = k + 1;
@@ -1262,7 +1312,45 @@ static int host_windows_pipeline(illico_ctx *c, const InT *X, int64_t ld, int64_
 
 template <typename InT, typename KeyT>
 static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
-                             int alternative, const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> runs);
+                             int alternative, const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> runs, const int *col_map = nullptr,
+                             bool prefer_counts = false);
+
+// The genes the fused passes of a DEVICE-resident window [col_lb, col_ub) left behind (hf[j] = 1 / 3).  Few and scattered (a count
+// matrix's highly expressed genes): gathered into a narrow matrix of their own and computed as ONE window whose results
+// k_finalize scatters back through a column map (kernels_leftover.h).  Many (normalised data: every gene): the column runs, as before.
+template <typename InT, typename KeyT>
+static int run_leftovers(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                         const OutPlanes &o, const u32 *hf) {
+    const int64_t W = col_ub - col_lb;
+    std::vector<int> src, dst;
+    for (int64_t j = 0; j < W; ++j)
+        if (hf[j] == 1u || hf[j] == 3u) { src.push_back((int)(col_lb + j)); dst.push_back((int)j); }
+    if (src.empty()) return ILLICO_OK;
+    const int64_t n = (int64_t)src.size(), n_pad = (n + 63) & ~63ll;
+    if (!(flags & ILLICO_FLAG_INPUT_DEVICE) || c->tap || c->no_leftover_gather || n * 2 > W || col_ub > 0x7FFFFFFFll ||
+        (size_t)N * (size_t)n_pad * sizeof(InT) > (size_t)c->scratch_bytes) {
+        std::vector<std::pair<int64_t, int64_t>> runs;
+        flagged_runs(hf, W, col_lb, runs);
+        return run_dense_twopass<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, runs);
+    }
+    int rc;
+    void *v;
+    if ((rc = get_scratch(c, "xleft", (size_t)N * (size_t)n_pad * sizeof(InT), &v))) return rc;
+    InT *xl = (InT *)v;
+    if ((rc = get_scratch(c, "xleft_cols", (size_t)n * 8, &v))) return rc;
+    int *d_src = (int *)v, *d_dst = d_src + n;
+    HIPCHK(c, hipMemcpyAsync(d_src, src.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_dst, dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, KID_GATHER_COLS);
+        hipLaunchKernelGGL((k_gather_columns<InT>), dim3((unsigned)((N + 63) / 64)), dim3(256), 0, c->stream, (const InT *)X, (long long)ld, (int)N,
+                           (const int *)d_src, (int)n, (int)n_pad, xl, (long long)n_pad, 0ll);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // (the host lists go out of scope)
+    std::vector<std::pair<int64_t, int64_t>> runs{{0, n}};
+    return run_dense_twopass<InT, KeyT>(c, xl, dtype, N, n_pad, 0, n, flags | ILLICO_FLAG_INPUT_DEVICE, alternative, o, runs, d_dst, true);
+}
 
 template <typename InT, typename KeyT>
 static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
@@ -1294,11 +1382,16 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
             return ILLICO_OK;
         }
         if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf, -1, ovr))) return rc;
-        flagged_runs(hf.data(), W, col_lb, runs);
-        if (runs.empty()) return ILLICO_OK;
+        return run_leftovers<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, hf.data());
     } else if (!in_dev && try_fused && N > 0 && W > 0 && host_window_is_count_valued<InT>((const InT *)X, ld, col_lb, N, W)) {
         // host matrix: column windows travel through pinned staging slots (host_windows_pipeline below) and take the same fused pass
-        if ((rc = host_windows_pipeline<InT>(c, (const InT *)X, ld, N, col_lb, col_ub, flags, alternative, o, runs))) return rc;
+        HostLeftovers left;
+        if ((rc = host_windows_pipeline<InT>(c, (const InT *)X, ld, N, col_lb, col_ub, flags, alternative, o, runs, left))) return rc;
+        if (left.n > 0) { // the gathered leftovers: one window of a device matrix, results scattered through the column map
+            std::vector<std::pair<int64_t, int64_t>> lr{{0, left.n}};
+            if ((rc = run_dense_twopass<InT, KeyT>(c, left.xl, dtype, N, left.cap, 0, left.n, flags | ILLICO_FLAG_INPUT_DEVICE, alternative, o, lr,
+                                                   left.d_dst, true))) return rc;
+        }
         if (runs.empty()) return ILLICO_OK;
     } else {
         runs.push_back({col_lb, col_ub});
@@ -1308,16 +1401,23 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
 
 // ---- routes 2-4 over the column runs the fused route left (or over everything) ----
 template <typename InT, typename KeyT>
+// col_map (device, one entry per column of X's window): the output column of each gene, relative to the planes (the gathered
+// leftover columns of a count matrix, kernels_leftover.h); prefer_counts: those genes are count-like -- the plain transposition
+// with per-gene histogram routes (k_ovo_counts / k_ovr_counts) first, the routes for continuous values only for what they leave.
 static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
-                             int alternative, const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> runs) {
+                             int alternative, const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> runs, const int *col_map,
+                             bool prefer_counts) {
     const int G = (int)c->n_groups;
     const bool ovr = c->ref < 0;
     const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
+    prefer_counts = prefer_counts && !(flags & ILLICO_FLAG_LOG1P) && !c->no_counts_path && (ovr || counts_path_allowed(c, flags));
     // dense OVO: group-wise packing + look-ups (kernels_ovo_compact.h) whenever the sizes allow; it has no histogram side path
-    // (count-valued genes reach this function only when the fused route is off) and holds ties exactly
-    const bool packed = !ovr && packed_route_fits<KeyT>(c);
+    // (count-valued genes reach this function only when the fused route is off, or as gathered leftovers: prefer_counts) and holds
+    // ties exactly
+    const bool packed = !ovr && !prefer_counts && packed_route_fits<KeyT>(c);
     // dense OVR: the transposition with the group sums folded in (k_group_compact keeping every key: padded dense layout)
-    const bool padded = ovr && !c->no_packed_dense && c->pk_nblk > 0 && c->max_nonref <= 65535 && c->pk_stride < (1ll << 31);
+    const bool padded = ovr && !prefer_counts && !c->no_packed_dense && c->pk_nblk > 0 && c->max_nonref <= 65535 && c->pk_stride < (1ll << 31);
+    const bool ovr_counts = ovr && prefer_counts && N < (1ll << 31);
     const int64_t stride = (packed || padded) ? c->pk_stride : ((N + 63) & ~63ll);
     int rc;
     void *v;
@@ -1352,10 +1452,11 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
     double *ssum = (double *)(stie + (size_t)nb_max * G);
     double *gtot = ssum + (size_t)nb_max * G;
     u32 *gflags = nullptr;
-    if (counts_path_allowed(c, flags) && !packed) {
+    if ((counts_path_allowed(c, flags) && !packed && !ovr) || ovr_counts) {
         if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
         gflags = (u32 *)v;
     }
+    const int *cmap = col_map; // (finalize: output column of batch gene j = cmap[b0 - col_lb + j])
     OvoGlobalBufs gb;
     if (need_glob) {
         if ((rc = get_scratch(c, "ovr_kb", (size_t)nb_max * stride * sizeof(KeyT), &v))) return rc;
@@ -1390,7 +1491,7 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 continue;
             }
-            if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
+            if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cmap ? 0 : b0 - col_lb, cmap ? cmap + (b0 - col_lb) : nullptr))) return rc;
             continue;
         }
         OvrPackedInput pki;
@@ -1419,7 +1520,7 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             if ((rc = launch_group_compact<InT, KeyT>(c, Q, nb, flags, ovr_packed))) return rc;
         } else {
         if (gflags) HIPCHK(c, hipMemsetAsync(gflags, 0, (size_t)nb * 4, c->stream));
-        if ((rc = launch_transpose<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, gflags))) return rc;
+        if ((rc = launch_transpose<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, gflags, ovr_counts ? OVRC_R : COUNTS_R))) return rc;
         }
         if (!ovr) {
             OvoParams P;
@@ -1435,7 +1536,36 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 continue;
             }
-            if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
+            if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cmap ? 0 : b0 - col_lb, cmap ? cmap + (b0 - col_lb) : nullptr))) return rc;
+        } else if (ovr_counts) {
+            // count-like leftovers: the column-histogram kernel takes every integer gene below OVRC_R; the value-range parts /
+            // the general route only see the runs of genes it flags
+            {
+                OvrCountsParams Q;
+                Q.Xt = Xt; Q.stride = stride; Q.pos_ptr = c->d_posptr; Q.counts = c->d_counts; Q.G = G; Q.n_genes = nb; Q.dt = dtype; Q.n_cells = N;
+                Q.gene_flags = gflags; Q.out_2u = s2u; Q.out_tie = stie; Q.out_sum = ssum; Q.gene_total = gtot;
+                ProfScope ps(c, KID_OVR_COUNTS);
+                auto kern = k_ovr_counts<KeyT>;
+                HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, OVRC_R * 4));
+                hipLaunchKernelGGL(kern, dim3(nb), dim3(OVRC_NT), OVRC_R * 4, c->stream, Q);
+                HIPCHK(c, hipGetLastError());
+            }
+            std::vector<u32> hg(nb);
+            HIPCHK(c, hipMemcpyAsync(hg.data(), gflags, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int j = 0; j < nb;) {
+                if (!hg[j]) { ++j; continue; }
+                int e = j;
+                while (e < nb && hg[e]) ++e;
+                const int sub = e - j;
+                bool done = false;
+                if ((rc = run_ovr_dense_parts<KeyT>(c, Xt + (size_t)j * stride, stride, sub, (int)N, dtype, flags, s2u + (size_t)j * G, stie + (size_t)j * G,
+                                                    ssum + (size_t)j * G, gtot + j, &done, false, nullptr))) return rc;
+                if (!done && (rc = run_ovr_dense_batch<KeyT>(c, Xt + (size_t)j * stride, stride, sub, (int)N, dtype, flags, s2u + (size_t)j * G,
+                                                             stie + (size_t)j * G, ssum + (size_t)j * G, gtot + j, false))) return rc;
+                j = e;
+            }
+            if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cmap ? 0 : b0 - col_lb, cmap ? cmap + (b0 - col_lb) : nullptr))) return rc;
         } else {
             bool done = false;
             if ((rc = run_ovr_dense_parts<KeyT>(c, Xt, stride, nb, (int)N, dtype, flags, s2u, stie, ssum, gtot, &done, padded, ovr_packed ? &pki : nullptr))) return rc;
@@ -1451,7 +1581,7 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 continue;
             }
-            if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0 - col_lb))) return rc;
+            if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cmap ? 0 : b0 - col_lb, cmap ? cmap + (b0 - col_lb) : nullptr))) return rc;
         }
     }
     return ILLICO_OK;
@@ -1466,16 +1596,14 @@ static int resolve_pending(illico_ctx *c, PendingDense q) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventSynchronize(c->pend_event[q.slot]));
     if (q.kind == 1) return resolve_pending_csc(c, q);
-    std::vector<std::pair<int64_t, int64_t>> runs;
-    flagged_runs((const u32 *)c->pend_pinned[q.slot], q.col_ub - q.col_lb, q.col_lb, runs);
-    if (runs.empty()) return ILLICO_OK;
+    const u32 *hf = (const u32 *)c->pend_pinned[q.slot];
     const OutPlanes o{q.p, q.u, q.fc, q.out_ld, false};
     switch (q.dtype) {
-    case ILLICO_F32: return run_dense_twopass<float, u32>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, runs);
+    case ILLICO_F32: return run_leftovers<float, u32>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf);
 #ifndef ILLICO_DEV_F32_ONLY
-    case ILLICO_F64: return run_dense_twopass<double, u64>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, runs);
-    case ILLICO_I32: return run_dense_twopass<int32_t, u32>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, runs);
-    default: return run_dense_twopass<int64_t, u64>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, runs);
+    case ILLICO_F64: return run_leftovers<double, u64>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf);
+    case ILLICO_I32: return run_leftovers<int32_t, u32>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf);
+    default: return run_leftovers<int64_t, u64>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf);
 #else
     default: return fail(c, ILLICO_ERR_DTYPE, "this development build holds the float32 kernels only");
 #endif

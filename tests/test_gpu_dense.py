@@ -385,3 +385,53 @@ def test_fused_route_second_pass_takes_counts_up_to_255(engine, test):
     M = sparse.csr_matrix(X[:, :120])
     got = engine.run_sparse("csr", M.data, M.indices, M.indptr, M.shape, 0, 120)
     assert_planes_match(got, tuple(a[:, :120] for a in want), ref_row=rr, what=f"csr byte window, counts up to 254 {test}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("where", ["device", "device-deferred", "host"])
+def test_scattered_big_count_genes_are_gathered_and_take_the_histogram_routes(engine, test, where):
+    """A count matrix whose highly expressed genes lie beyond the fused tables (64 .. 255: second pass; beyond: the genes are
+    gathered into a narrow matrix and take k_ovo_counts / k_ovr_counts, a fractional gene and one beyond every table the sort
+    routes) -- device-resident, deferred and host-resident input (the host windows gather their flagged columns on the device);
+    identical to recomputing the column runs (`no_leftover_gather`)."""
+    import torch
+    rng = np.random.RandomState(77)
+    n, m, G = 20000, 640, 40
+    means = np.exp(rng.normal(2.0, 1.8, size=m)).clip(0.05, 3000.0)
+    X = rng.poisson(means, size=(n, m)).astype(np.float32)
+    X[rng.rand(n, m) < 0.5] = 0
+    X[:, 100] = X[:, 100] * 0.5 + 0.25 * (X[:, 100] > 0)     # fractional values
+    X[:50, 200] = 40000.0 + np.arange(50)                     # beyond k_ovr_counts' table as well
+    mx = X.max(axis=0)
+    assert (mx > 63).sum() > 60 and (mx > 255).sum() > 10 and (mx > 2047).sum() >= 2 and ((mx > 63).sum() < m // 2)
+    labels = make_labels(rng, n, G, n_ref=1500)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    want = oracle.run(X, g)
+    engine.set_groups(g)
+    dev = torch.device("cuda", engine.device)
+
+    def run():
+        if where == "host":
+            return engine.run_dense(X, 0, m)
+        Xd = torch.from_numpy(X).to(dev)
+        if where == "device":
+            return engine.run_dense(Xd, 0, m)
+        out = tuple(torch.full((g.counts.size, m), -7.0, dtype=torch.float64, device=dev) for _ in range(3))
+        engine.run_dense(Xd, 0, m, out=out, defer=True)
+        engine.synchronize()
+        return tuple(t.cpu().numpy() for t in out)
+
+    engine.profile(True)
+    engine.profile_reset()
+    got = run()
+    prof = engine.profile_get()
+    engine.profile(False)
+    assert "k_gather_columns" in prof and ("k_ovo_counts" if test == "ovo" else "k_ovr_counts") in prof, prof
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"big counts {test} {where}")
+    engine.set_option("no_leftover_gather", 1)
+    try:
+        again = run()
+    finally:
+        engine.set_option("no_leftover_gather", 0)
+    for a, b in zip(got, again):
+        np.testing.assert_array_equal(a, b)
