@@ -521,3 +521,27 @@ def test_deferred_csc_calls_complete_their_leftover_genes(engine, test):
     assert_planes_match(tuple(t[:, 32:80].cpu().numpy() for t in C), tuple(w[:, 32:80] for w in want), ref_row=ref_row,
                         what=f"deferred csc window {test}")
     assert all(float(t[:, :32].min()) == -7.0 and float(t[:, 80:].max()) == -7.0 for t in C)
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_csc_counts_large_groups_with_one_dominant_value(engine, test):
+    """Groups of tens of thousands of cells whose stored values are nearly all the same count: the per-value tie terms
+    3 tS (tS + tB) + tB^2 of the 32-bit-cell rows leave 32 bits (25 000 reference cells and 30 000 group cells with the value 1:
+    5.0e9) -- they are formed in 64 bits."""
+    rng = np.random.RandomState(5)
+    sizes = [25000, 30000, 4000, 700, 200, 90]
+    codes = np.repeat(np.arange(len(sizes)), sizes)
+    rng.shuffle(codes)
+    n = codes.size
+    labels = np.array(["non-targeting" if c == 0 else f"pert_{c:05d}" for c in codes])
+    X = np.zeros((n, 6), dtype=np.float32)
+    X[:, 0] = 1.0                                   # every cell the same count
+    X[:, 1] = (rng.rand(n) < 0.97).astype(np.float32)   # nearly every cell
+    X[:, 2] = rng.poisson(0.3, size=n)
+    X[:, 3] = np.where(rng.rand(n) < 0.9, 7.0, 0.0)
+    X[:, 4] = rng.poisson(6.0, size=n)
+    X[:, 5] = np.where(codes == 1, 3.0, 1.0)        # one value per group
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    M = sparse.csc_matrix(X)
+    got = _run(engine, M, g)
+    assert_planes_match(got, oracle.run(X, g), ref_row=g.encoded_ref_group, what=f"csc large groups {test}")
