@@ -609,6 +609,10 @@ template <typename KeyT> static bool ovo_sort_route_fits(int64_t max_ref_nnz, in
     return max_grp_nnz <= 1024 && ovo_lds_bytes<KeyT>(ref_cap, runend, kOvoThreads) <= kMaxLds;
 }
 
+// table size of the two-pass histogram route (k_ovo_counts): 4096 values with 8-bit multiplicities while no ranked group exceeds 255
+// cells, else 2048 with 16-bit ones; the ingest kernels flag genes against the same limit
+static int ovo_counts_limit(const illico_ctx *c) { return c->max_nonref <= 255 ? COUNTS_R8 : COUNTS_R; }
+
 struct OvoGlobalBufs { // scratch of the global-sort fallback (same element count as the key buffer)
     void *kb = nullptr;
     u32 *va = nullptr, *vb = nullptr;
@@ -621,9 +625,10 @@ struct OvoGlobalBufs { // scratch of the global-sort fallback (same element coun
 template <typename KeyT>
 static int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz, const u32 *flags,
                       const OvoGlobalBufs *gb, bool sparse) {
-    if (flags) {
+    if (flags) { // (the ingest kernels flagged with the same limit: ovo_counts_limit)
         ProfScope ps(c, KID_OVO_COUNTS);
-        hipLaunchKernelGGL((k_ovo_counts<KeyT>), dim3(P.n_genes), dim3(COUNTS_NT), 0, c->stream, P, flags);
+        if (ovo_counts_limit(c) == COUNTS_R8) hipLaunchKernelGGL((k_ovo_counts<KeyT, COUNTS_R8, 8>), dim3(P.n_genes), dim3(COUNTS_NT), 0, c->stream, P, flags);
+        else hipLaunchKernelGGL((k_ovo_counts<KeyT, COUNTS_R, 16>), dim3(P.n_genes), dim3(COUNTS_NT), 0, c->stream, P, flags);
         HIPCHK(c, hipGetLastError());
     }
     if (!ovo_sort_route_fits<KeyT>(max_ref_nnz, max_grp_nnz)) {
@@ -747,7 +752,7 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
 
 template <typename InT, typename KeyT>
 static int launch_transpose(illico_ctx *c, const void *X, int64_t ld, int64_t col0, int ncols, int N, KeyT *Xt, int64_t stride, u32 *flags,
-                            int limit = COUNTS_R) { // flags[gene] != 0: a value that is no integer in [0, limit)
+                            int limit) { // flags[gene] != 0: a value that is no integer in [0, limit)
     ProfScope ps(c, KID_TRANSPOSE);
     dim3 grid((N + 63) / 64, (ncols + 63) / 64);
     constexpr int VEC = 16 / (int)sizeof(InT);
@@ -1520,7 +1525,7 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             if ((rc = launch_group_compact<InT, KeyT>(c, Q, nb, flags, ovr_packed))) return rc;
         } else {
         if (gflags) HIPCHK(c, hipMemsetAsync(gflags, 0, (size_t)nb * 4, c->stream));
-        if ((rc = launch_transpose<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, gflags, ovr_counts ? OVRC_R : COUNTS_R))) return rc;
+        if ((rc = launch_transpose<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, gflags, ovr_counts ? OVRC_R : ovo_counts_limit(c)))) return rc;
         }
         if (!ovr) {
             OvoParams P;

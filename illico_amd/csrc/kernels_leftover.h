@@ -13,7 +13,7 @@
 //                      illico/ovr/dense_ovr.py:46-75).  Count-like columns used to crowd the value buckets of the parts
 //                      route and fall through to the per-gene radix sort in HBM (0.64 ms per gene).
 //
-// OVO keeps k_ovo_counts (kernels_ovo_counts.h: integers below 2048) for these genes; what lies beyond takes the sort routes.
+// OVO keeps k_ovo_counts (kernels_ovo_counts.h: integers below 2048, or 4096 with groups of at most 255 cells) for these genes; what lies beyond takes the sort routes.
 #pragma once
 #include "common.h"
 #include "kernels_ovo_counts.h"

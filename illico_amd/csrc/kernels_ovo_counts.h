@@ -13,7 +13,8 @@
 #include "common.h"
 #include "kernels_ovo.h"
 
-#define COUNTS_R 2048      // table size: values 0 .. COUNTS_R-1
+#define COUNTS_R 2048      // table size: values 0 .. COUNTS_R-1 (16-bit running multiplicities: groups of any size up to 65535 cells)
+#define COUNTS_R8 4096     // ... with 8-bit multiplicities (every ranked group at most 255 cells): twice the values in less LDS
 #define COUNTS_NT 512
 
 // integer value of a key known to encode an integer in [0, COUNTS_R)
@@ -24,11 +25,12 @@ __device__ __forceinline__ u32 count_of_key(u64 k, int dt) {
     return dt == DT_F64 ? (u32)f64_of_key(k) : (u32)(k ^ 0x8000000000000000ull);
 }
 
-template <typename KeyT>
-__global__ __launch_bounds__(COUNTS_NT, 4) void k_ovo_counts(OvoParams P, const u32 *__restrict__ gene_flags) {
-    constexpr int NT = COUNTS_NT, NW = NT / 64, R = COUNTS_R;
+// R: table size; CB: bits of a group's running multiplicity (8: four bins per word; 16: two)
+template <typename KeyT, int R = COUNTS_R, int CB = 16>
+__global__ __launch_bounds__(COUNTS_NT, CB == 8 ? 3 : 4) void k_ovo_counts(OvoParams P, const u32 *__restrict__ gene_flags) {
+    constexpr int NT = COUNTS_NT, NW = NT / 64, PWB = 32 / CB, LGP = CB == 8 ? 2 : 1;
     __shared__ u32 cumA[R + 1];        // cumA[v] = # reference values < v (non-zeros only in the sparse layout)
-    __shared__ u32 hB[NW][R / 2];      // per-wave group histogram, two 16-bit bins per word
+    __shared__ u32 hB[NW][R / PWB];    // per-wave group histogram, PWB bins of CB bits per word
     __shared__ u64 s_red[NW];
     __shared__ u64 s_red2[NW];
     __shared__ u32 s_scan[NT];
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(COUNTS_NT, 4) void k_ovo_counts(OvoParams P, const 
 
         // ---- reference histogram -> cumA ----
         for (int i = tid; i <= R; i += NT) cumA[i] = 0;
-        for (int i = tid; i < R / 2 * NW; i += NT) (&hB[0][0])[i] = 0;
+        for (int i = tid; i < R / PWB * NW; i += NT) (&hB[0][0])[i] = 0;
         __syncthreads();
         u64 rsum = 0;
         for (u32 i0 = 0; i0 < nA; i0 += NT) {
@@ -162,8 +164,8 @@ __global__ __launch_bounds__(COUNTS_NT, 4) void k_ovo_counts(OvoParams P, const 
                                     o = zseen + (u32)__popcll(zb & lt_mask);
                                     lo = 0; hi = (u32)a0;
                                 } else {
-                                    const u32 sh = (c[r] & 1u) << 4;
-                                    o = __builtin_amdgcn_ubfe(atomicAdd(&hw[c[r] >> 1], 1u << sh), sh, 16);
+                                    const u32 sh = (c[r] & (u32)(PWB - 1)) * CB;
+                                    o = __builtin_amdgcn_ubfe(atomicAdd(&hw[c[r] >> LGP], 1u << sh), sh, CB);
                                     lo = cumA[c[r]]; hi = cumA[c[r] + 1];
                                 }
                                 a = hi - lo;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(COUNTS_NT, 4) void k_ovo_counts(OvoParams P, const 
                             if (i < nB) {
                                 const KeyT k = (i0 == 0) ? cur[r] : Xs[bstart + i];
                                 const u32 cc = count_of_key(k, P.dt);
-                                if (cc) hw[cc >> 1] = 0u;
+                                if (cc) hw[cc >> LGP] = 0u;
                             }
                         }
                     }

@@ -736,7 +736,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
                 HIPCHK(c, hipMemsetAsync(d_fb, 0, (size_t)nb * 4, c->stream));
                 CscRegroupParams R;
                 R.data = d_data; R.indices = d_indices; R.indptr = d_indptr; R.kshift = kshift; R.col0 = b.g0; R.gene_cols = d_cols;
-                R.gene_base = d_base; R.nb = nb; R.codes = d_codes; R.G = G; R.key_cap = key_cap; R.count_limit = COUNTS_R; R.Xs = Xs;
+                R.gene_base = d_base; R.nb = nb; R.codes = d_codes; R.G = G; R.key_cap = key_cap; R.count_limit = ovo_counts_limit(c); R.Xs = Xs;
                 R.vals = va; R.seg_ptr = seg; R.gene_flags = gflags; R.fallback = d_fb;
                 auto kern = k_csc_regroup<InT, IdxT, KeyT>;
                 const size_t lds = fixed + (size_t)key_cap * per_key;
@@ -748,7 +748,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
             size_t lds = seg_lds_bytes(G);
             HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(nb), dim3(SEG_NT), lds, c->stream, d_data, d_indices, d_indptr, (long long)b.g0, nb,
-                               d_codes, G, Xs, va, seg, gflags, COUNTS_R, d_cols, d_base, (long long)kshift, (const u32 *)d_fb);
+                               d_codes, G, Xs, va, seg, gflags, ovo_counts_limit(c), d_cols, d_base, (long long)kshift, (const u32 *)d_fb);
             HIPCHK(c, hipGetLastError());
         } else {
             if ((rc = get_scratch(c, "sp_cursor", (size_t)nb * (G + 1) * 4 + (size_t)nb * 8, &v))) return rc;
@@ -769,7 +769,7 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
                                (const u32 *)gene_base, G, nb);
             hipLaunchKernelGGL((k_csr_scatter<InT, IdxT, KeyT>), dim3(rows_grid), dim3(256), 0, c->stream, d_data, d_indices,
                                d_indptr, (int)n_rows, (long long)b.g0, (long long)b.g1, (const int *)c->d_codes, G, cursor, Xs, va,
-                               gflags, COUNTS_R);
+                               gflags, ovo_counts_limit(c));
             HIPCHK(c, hipGetLastError());
         }
 
