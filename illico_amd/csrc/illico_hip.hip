@@ -1028,9 +1028,11 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             P2.groups_per_wg = c->ovr_hist_groups_per_wg > 0 ? c->ovr_hist_groups_per_wg : 32;
             while (P2.groups_per_wg > 8 && (int64_t)tiles * ((c->n_groups + P2.groups_per_wg - 1) / P2.groups_per_wg) < 2048) P2.groups_per_wg >>= 1;
             const dim3 grid2(tiles, ((int)c->n_groups + P2.groups_per_wg - 1) / P2.groups_per_wg);
-            if (cbits == 8 && c->n_cells < (1ll << 23)) hipLaunchKernelGGL((k_ovr_from_hists<RT, 8, 3>), grid2, dim3(FUSED_NT), 0, c->stream, P2); // s < 2^24: three byte planes
+            const bool np3 = c->n_cells < (1ll << 23); // s < 2^24: three byte planes
+            if (cbits == 8 && np3) hipLaunchKernelGGL((k_ovr_from_hists<RT, 8, 3>), grid2, dim3(FUSED_NT), 0, c->stream, P2);
             else if (cbits == 8) hipLaunchKernelGGL((k_ovr_from_hists<RT, 8, 4>), grid2, dim3(FUSED_NT), 0, c->stream, P2);
-            else hipLaunchKernelGGL((k_ovr_from_hists<RT, 0>), grid2, dim3(FUSED_NT), 0, c->stream, P2);
+            else if (np3) hipLaunchKernelGGL((k_ovr_from_hists<RT, 0, 3>), grid2, dim3(FUSED_NT), 0, c->stream, P2);
+            else hipLaunchKernelGGL((k_ovr_from_hists<RT, 0, 4>), grid2, dim3(FUSED_NT), 0, c->stream, P2);
             HIPCHK(c, hipGetLastError());
         } else {
             {

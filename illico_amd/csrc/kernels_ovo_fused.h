@@ -681,49 +681,38 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_ovr_group_hists(FusedParams P) 
     if (act && bad && P.gene_flags[gene] != 3u) P.gene_flags[gene] = 1u;
 }
 
-// histograms -> rank sums, U, p, fold change.  grid (tiles, group chunks); lane = gene; s[c] = cum[c] + cum[c+1] sits
-// in registers for the workgroup's lifetime, a group costs BW coalesced word loads and RT multiply-adds per lane.
-// CB == 8 (every group at most 255 cells): s[c] is held as BYTE PLANES, four values per register, and a histogram word of four
-// 8-bit cells meets each plane in ONE v_dot4_u32_u8 -- 3 (NPL = 3: s < 2^24, i.e. fewer than 2^23 cells) or 4 dot products per
-// word instead of four field extractions and four 64-bit multiply-adds, and 48 instead of 64 table registers; the value sum is a
-// fifth dot product against the constant bytes (4 i .. 4 i + 3).  A plane's accumulator stays below 255 x 255.  168 registers:
-// three wavefronts per SIMD instead of two.  (At C4 the pass takes 0.38 ms either way: it is bound by the latency of its 4-KB
-// histogram reads and 512-byte result writes, not by this arithmetic.)
+// histograms -> rank sums, U, p, fold change.  grid (tiles, group chunks); lane = gene.  s[c] = cum[c] + cum[c+1] sits in
+// registers for the workgroup's lifetime as BYTE PLANES (four values per register): a histogram word of four 8-bit cells meets each
+// plane in ONE v_dot4_u32_u8 -- 3 (NPL = 3: s < 2^24, i.e. fewer than 2^23 cells) or 4 dot products per word; the value sum is one
+// more dot product against the constant bytes (4 i .. 4 i + 3).  A plane's accumulator stays below 255 x 255 x 64.  The next group's
+// 16 histogram words are requested BEFORE this group's p-value is evaluated (~900 instructions with nothing in flight otherwise).
+// CB == 0: histogram width per group; a group of more than 255 cells (16-bit cells, 32 words) is the rare case and reads s[c] back
+// from the cumulative table in global memory instead of keeping a second register copy.
 template <int RT, int CB, int NPL = 4>
-__global__ __launch_bounds__(FUSED_NT, CB == 8 ? (NPL == 3 ? 3 : 2) : 1) void k_ovr_from_hists(FusedParams P) {
-    constexpr int NW = FUSED_NT / 64, CSTR = RT + 1;
-    constexpr bool DOT = CB == 8;
+__global__ __launch_bounds__(FUSED_NT, NPL == 3 ? 3 : 2) void k_ovr_from_hists(FusedParams P) {
+    static_assert(CB == 8 || CB == 0, "8-bit cells throughout, or the width per group");
+    constexpr int NW = FUSED_NT / 64, CSTR = RT + 1, BW8 = RT / 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene = blockIdx.x * 64 + lane;
     const bool act = gene < P.ncols;
     if (!act || P.gene_flags[gene] != 0) return; // flagged genes are recomputed by the slower routes
-    u32 s[DOT ? 1 : RT];
-    u32 bp[DOT ? NPL : 1][DOT ? RT / 4 : 1]; // bp[k][i]: byte k of s[4 i .. 4 i + 3]
+    const u32 *cum = P.ref_cum + (size_t)blockIdx.x * (64 * CSTR) + lane;
+    u32 bp[NPL][BW8]; // bp[k][i]: byte k of s[4 i .. 4 i + 3]
     {
-        const u32 *cum = P.ref_cum + (size_t)blockIdx.x * (64 * CSTR) + lane;
         u32 prev = cum[0];
-        if constexpr (DOT) {
 #pragma unroll
-            for (int i = 0; i < RT / 4; ++i) {
-                u32 sv[4];
+        for (int i = 0; i < BW8; ++i) {
+            u32 sv[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u32 nxt = cum[(4 * i + j + 1) * 64];
-                    sv[j] = prev + nxt;
-                    prev = nxt;
-                }
-#pragma unroll
-                for (int k = 0; k < NPL; ++k)
-                    bp[k][i] = ((sv[0] >> (8 * k)) & 0xFFu) | (((sv[1] >> (8 * k)) & 0xFFu) << 8) | (((sv[2] >> (8 * k)) & 0xFFu) << 16) |
-                               (((sv[3] >> (8 * k)) & 0xFFu) << 24);
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < RT; ++c) {
-                const u32 nxt = cum[(c + 1) * 64];
-                s[c] = prev + nxt;
+            for (int j = 0; j < 4; ++j) {
+                const u32 nxt = cum[(4 * i + j + 1) * 64];
+                sv[j] = prev + nxt;
                 prev = nxt;
             }
+#pragma unroll
+            for (int k = 0; k < NPL; ++k)
+                bp[k][i] = ((sv[0] >> (8 * k)) & 0xFFu) | (((sv[1] >> (8 * k)) & 0xFFu) << 8) | (((sv[2] >> (8 * k)) & 0xFFu) << 16) |
+                           (((sv[3] >> (8 * k)) & 0xFFu) << 24);
         }
     }
     const u64 T_A = P.ref_TA[gene];
@@ -731,43 +720,57 @@ __global__ __launch_bounds__(FUSED_NT, CB == 8 ? (NPL == 3 ? 3 : 2) : 1) void k_
     const double tie = P.tie_correct ? (double)T_A : 0.0;
     const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
     const size_t tiles = gridDim.x;
+    auto narrow = [&](int g) { return CB == 8 || P.counts[g] <= 255; }; // uniform
+    auto hist_of = [&](int g, int bw) {
+        const size_t base = CB ? ((size_t)g * tiles + blockIdx.x) * (BW8 * 64) : ((size_t)P.hist_off[g] * tiles + (size_t)blockIdx.x * bw) * 64;
+        return P.group_hist + base + lane;
+    };
+    u32 wpre[BW8];
+    auto prefetch = [&](int g) {
+        if (g < gend && narrow(g)) {
+            const u32 *h = hist_of(g, BW8);
+#pragma unroll
+            for (int i = 0; i < BW8; ++i) wpre[i] = h[i * 64];
+        }
+    };
+    prefetch(gbeg + wave);
     for (int g = gbeg + wave; g < gend; g += NW) {
         const long long n_tgt = P.counts[g];
         u64 R2 = 0;
         u32 vsum = 0;
-        auto one_group = [&](auto cbt) {
-            constexpr int CBG = decltype(cbt)::value, BW = RT * CBG / 32, PW = 32 / CBG;
-            const size_t base = CB ? ((size_t)g * tiles + blockIdx.x) * (BW * 64) : ((size_t)P.hist_off[g] * tiles + (size_t)blockIdx.x * BW) * 64;
-            const u32 *h = P.group_hist + base + lane;
-            u32 w[BW];
+        if (narrow(g)) {
+            u32 w[BW8];
 #pragma unroll
-            for (int i = 0; i < BW; ++i) w[i] = h[i * 64];
-            if constexpr (DOT) {
-                u32 acc[NPL];
+            for (int i = 0; i < BW8; ++i) w[i] = wpre[i];
+            prefetch(g + NW);
+            u32 acc[NPL];
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) acc[k] = 0;
+            for (int k = 0; k < NPL; ++k) acc[k] = 0;
 #pragma unroll
-                for (int i = 0; i < BW; ++i) {
+            for (int i = 0; i < BW8; ++i) {
 #pragma unroll
-                    for (int k = 0; k < NPL; ++k) acc[k] = __builtin_amdgcn_udot4(w[i], bp[k][i], acc[k], false);
-                    vsum = __builtin_amdgcn_udot4(w[i], (u32)(4 * i) * 0x01010101u + 0x03020100u, vsum, false);
-                }
-#pragma unroll
-                for (int k = 0; k < NPL; ++k) R2 += (u64)acc[k] << (8 * k);
-            } else {
-#pragma unroll
-                for (int i = 0; i < BW; ++i)
-#pragma unroll
-                    for (int k = 0; k < PW; ++k) {
-                        const u32 cnt = __builtin_amdgcn_ubfe(w[i], k * CBG, CBG);
-                        R2 += (u64)cnt * s[i * PW + k];
-                        vsum += cnt * (u32)(i * PW + k);
-                    }
+                for (int k = 0; k < NPL; ++k) acc[k] = __builtin_amdgcn_udot4(w[i], bp[k][i], acc[k], false);
+                vsum = __builtin_amdgcn_udot4(w[i], (u32)(4 * i) * 0x01010101u + 0x03020100u, vsum, false);
             }
-        };
-        if constexpr (CB != 0) one_group(std::integral_constant<int, CB>());
-        else if (n_tgt <= 255) one_group(std::integral_constant<int, 8>()); // uniform
-        else one_group(std::integral_constant<int, 16>());
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) R2 += (u64)acc[k] << (8 * k);
+        } else {
+            prefetch(g + NW);
+            const u32 *h = hist_of(g, RT / 2);
+            u32 prev = cum[0];
+#pragma unroll 4
+            for (int i = 0; i < RT / 2; ++i) {
+                const u32 wv = h[i * 64];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const u32 nxt = cum[(2 * i + k + 1) * 64];
+                    const u32 cnt = __builtin_amdgcn_ubfe(wv, k * 16, 16);
+                    R2 += (u64)cnt * (prev + nxt);
+                    vsum += cnt * (u32)(2 * i + k);
+                    prev = nxt;
+                }
+            }
+        }
         // dense_ovr.py:57-75, as in k_ovo_fused<OVR>
         const long long n_rest = P.n_cells - n_tgt;
         const long long two_u = 2ll * n_rest * n_tgt + n_tgt * (n_tgt + 1) - ((long long)R2 + n_tgt);
