@@ -9,7 +9,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 SO = HERE / "libillico_hip.so"
 SOURCES = ["illico_hip.hip"]
-HEADERS = ["common.h", "kernels_ovo.h", "kernels_ovo_compact.h", "kernels_ovo_counts.h", "kernels_ovo_fused.h", "kernels_ovr.h", "kernels_finalize.h", "kernels_sparse.h", "kernels_csc_gene.h", "kernels_csc_counts.h", "kernels_csc_ovr.h", "kernels_sums.h", "ovr_driver.h",
+HEADERS = ["common.h", "kernels_ovo.h", "kernels_ovo_compact.h", "kernels_ovo_counts.h", "kernels_ovo_fused.h", "kernels_ovr.h", "kernels_finalize.h", "kernels_sparse.h", "kernels_csc_gene.h", "kernels_csc_counts.h", "kernels_csc_ovr.h", "kernels_ovr_parts.h", "kernels_sums.h", "kernels_leftover.h", "ovr_driver.h",
            "sparse_driver.h", "../../include/illico_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"]
 

@@ -27,6 +27,7 @@
 #include "kernels_csc_gene.h"
 #include "kernels_csc_counts.h"
 #include "kernels_csc_ovr.h"
+#include "kernels_ovr_parts.h"
 #include "kernels_sums.h"
 #include "kernels_leftover.h"
 

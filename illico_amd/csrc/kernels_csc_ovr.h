@@ -20,10 +20,9 @@
 //
 // DENSE columns (and whatever else exceeds the LDS key buffer) take the same rank kernel in pieces: k_ovr_partition splits
 // a gene's non-zero keys by VALUE into parts of at most key_cap keys (histogram over 8192 value buckets, scan, part =
-// cumulative count / quota, (key, group code) records appended per part in HBM), k_csc_ovr_gene<..., PARTS = true> ranks
-// each part in LDS exactly as it ranks a CSC column -- a key's rank is the number of keys in lower parts plus its rank
-// inside its own part -- and adds the part's group sums to per-gene accumulators; k_ovr_parts_finish turns them into the
-// statistics.  Dense continuous OVR at C4 shape: 68 ms (segmented radix sort of (key, group) pairs in HBM) -> see DESIGN.
+// cumulative count / quota, (key, group code) records appended per part in HBM), k_ovr_rank_gene_parts (kernels_ovr_parts.h)
+// ranks each part in LDS exactly as a CSC column is ranked here -- a key's rank is the number of keys in lower parts plus its
+// rank inside its own part -- one workgroup per gene, its parts one after the other.  Dense continuous OVR at C4 shape: 68 ms (segmented radix sort of (key, group) pairs in HBM) -> see DESIGN.
 #pragma once
 #include "common.h"
 #include "kernels_sparse.h"
@@ -38,25 +37,13 @@
 #define OVRP_PMAX 128       // parts per gene at most (8-bit part ids)
 
 struct CscOvrParams {
-    // CSC source (PARTS = false)
+    // CSC source
     const void *data, *indices, *indptr; // CSC arrays (device); stored entry k lives at data[k - kshift], indices[k - kshift]
     long long kshift;
     long long col0;                      // first gene of the batch (contiguous batches)
     const int *gene_cols;                // or: the batch's genes as a column list (absolute indices); nullptr = contiguous
     const int *codes;                    // [n_cells] group code per cell; nullptr: `indices` already holds group codes
     const u16 *codes16;                  // the same as 16-bit values (fewer cache lines per gather), or nullptr
-    // part source (PARTS = true): records written by k_ovr_partition
-    const void *pkeys;                   // [nb][pstride] non-zero keys, part after part
-    const u16 *pcodes;                   // [nb][pstride] their group codes
-    long long pstride;
-    const u32 *part_start;               // [nb][OVRP_PMAX + 1] first record of each part, relative to the gene
-    const u32 *gene_info;                // [nb][4] non-zeros, negatives, parts, flag (1 = the gene left this route)
-    u64 *gacc;                           // [nb][G] packed rank sums / counts, accumulated over the parts
-    u64 *gtie;                           // [nb]
-    u32 *gflag;                          // [nb] set to 1 when a part cannot be ranked here
-    const u32 *unit_list;                // [*n_units] gene * OVRP_PMAX + part, the non-empty parts (k_ovr_partition)
-    const u32 *n_units;
-    u32 *unit_counter;                   // work queue head (zeroed by the host): resident workgroups draw units from it
     int nb;
     const int *counts;                   // [G]
     int G, dt, is_log1p;
@@ -96,21 +83,31 @@ template <typename KeyT> __device__ __forceinline__ KeyT wave_max_key(KeyT x) {
 __device__ __forceinline__ int key_bits(u32 r) { return r ? 32 - __clz(r) : 0; }
 __device__ __forceinline__ int key_bits(u64 r) { return r ? 64 - __clzll((long long)r) : 0; }
 
-// exclusive scan of the 16-bit counters arr[0..n) in place (n a multiple of NT; totals below 2^16).  tmp: [NT] words.
-template <int NT> __device__ __forceinline__ void block_excl_scan_u16(u16 *arr, int n, u32 *tmp, int tid) {
-    const int per = n / NT, b = tid * per;
+// exclusive scan of the 16-bit counters arr[0..n) in place; n = NT * per, per a multiple of 2; totals below 2^16.  tmp: [NT / 64] words.
+template <int NT> __device__ __forceinline__ void block_excl_scan_u16_waves(u16 *arr, int n, u32 *tmp, int tid) {
+    constexpr int NW = NT / 64;
+    const int per = n / NT, lane = tid & 63, wave = tid >> 6;
+    u32 *w = (u32 *)arr + (size_t)tid * (per / 2);
     u32 s = 0;
-    for (int i = 0; i < per; ++i) s += arr[b + i];
-    tmp[tid] = s;
+    for (int i = 0; i < per / 2; ++i) { const u32 x = w[i]; s += (x & 0xFFFFu) + (x >> 16); }
+    const u32 incl = (u32)wave_incl_scan_add((int)s);
+    if (lane == 63) tmp[wave] = incl;
     __syncthreads();
-    for (int d = 1; d < NT; d <<= 1) {
-        const u32 v = (tid >= d) ? tmp[tid - d] : 0u;
-        __syncthreads();
-        tmp[tid] += v;
-        __syncthreads();
+    if (wave == 0) {
+        const u32 t = lane < NW ? tmp[lane] : 0u;
+        const u32 ti = (u32)wave_incl_scan_add((int)t);
+        if (lane < NW) tmp[lane] = ti - t;
     }
-    u32 run = tmp[tid] - s;
-    for (int i = 0; i < per; ++i) { const u32 cnt = arr[b + i]; arr[b + i] = (u16)run; run += cnt; }
+    __syncthreads();
+    u32 run = tmp[wave] + incl - s;
+    for (int i = 0; i < per / 2; ++i) {
+        const u32 x = w[i];
+        const u32 lo = run;
+        run += x & 0xFFFFu;
+        const u32 hi = run;
+        run += x >> 16;
+        w[i] = (lo & 0xFFFFu) | (hi << 16);
+    }
     __syncthreads();
 }
 
@@ -184,7 +181,7 @@ __device__ __forceinline__ void ovr_for_entries(const Src &src, long long k0, lo
     }
 }
 
-template <typename InT, typename IdxT, typename KeyT, bool PARTS>
+template <typename InT, typename IdxT, typename KeyT>
 __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     constexpr int NT = CSCO_NT, NW = NT / 64, CH = 64 * CSCO_K;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
@@ -199,51 +196,20 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     u64 *s_red = (u64 *)(tab + NBKT / 2);                     // [NW]
     KeyT *s_k = (KeyT *)(s_red + NW);                         // [2] smallest / largest non-zero key
     u32 *s_misc = (u32 *)(s_red + NW + 2);                    // [0] stored zeros  [1] negatives  [2] largest bucket
-    KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G, P.lg_buckets, PARTS));
+    KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G, P.lg_buckets, false));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const IdxT *indptr = (const IdxT *)P.indptr;
     constexpr int UL = 8; // independent entries per thread in flight
-    // CSC: one gene per workgroup.  Parts: a launch of one workgroup per (gene, part slot) would be mostly empty slots, and
-    // every workgroup holds a whole CU's LDS; resident workgroups draw the non-empty parts from a queue instead (every
-    // wave leaves once the queue is empty).
-    for (int it = blockIdx.x;; it += gridDim.x) {
-        int unit;
-        if constexpr (PARTS) {
-            if (tid == 0) s_misc[3] = atomicAdd(P.unit_counter, 1u);
-            __syncthreads();
-            const u32 q = s_misc[3];
-            __syncthreads();
-            if (q >= *P.n_units) break;
-            unit = (int)P.unit_list[q];
-        } else {
-            if (it >= P.nb) break;
-            unit = it;
-        }
-        const int gene = PARTS ? unit / OVRP_PMAX : unit;
-        OvrSource<InT, IdxT, KeyT, PARTS> src;
-        long long k0, k1;
-        long long n0 = 0, nneg = 0, base = 0; // PARTS: column-level numbers come from k_ovr_partition
-        if constexpr (PARTS) {
-            const int part = unit % OVRP_PMAX;
-            const u32 *gi = P.gene_info + (size_t)gene * 4;
-            if (gi[3] != 0u || part >= (int)gi[2]) continue; // uniform
-            const u32 *ps = P.part_start + (size_t)gene * (OVRP_PMAX + 1);
-            base = ps[part];
-            k0 = (long long)gene * P.pstride + ps[part];
-            k1 = (long long)gene * P.pstride + ps[part + 1];
-            n0 = P.n_cells - (long long)gi[0];
-            nneg = gi[1];
-            src.pkeys = (const KeyT *)P.pkeys; src.pcodes = P.pcodes;
-            if (k1 == k0) continue;
-        } else {
-            const long long col = P.gene_cols ? (long long)P.gene_cols[gene] : P.col0 + gene;
-            k0 = (long long)indptr[col] - P.kshift; k1 = (long long)indptr[col + 1] - P.kshift;
-            src.data = (const InT *)P.data; src.indices = (const IdxT *)P.indices; src.codes = P.codes; src.codes16 = P.codes16;
-        }
+    // one gene per workgroup
+    for (int gene = blockIdx.x; gene < P.nb; gene += gridDim.x) {
+        OvrSource<InT, IdxT, KeyT, false> src;
+        const long long col = P.gene_cols ? (long long)P.gene_cols[gene] : P.col0 + gene;
+        const long long k0 = (long long)indptr[col] - P.kshift, k1 = (long long)indptr[col + 1] - P.kshift;
+        src.data = (const InT *)P.data; src.indices = (const IdxT *)P.indices; src.codes = P.codes; src.codes16 = P.codes16;
         const long long ns_ll = k1 - k0;
         if (ns_ll > (long long)P.key_cap) { // uniform: this gene takes the general route
-            if (tid == 0) { if constexpr (PARTS) { P.gflag[gene] = 1u; } else { P.fallback[gene] = 1u; } }
+            if (tid == 0) P.fallback[gene] = 1u;
             continue;
         }
         const int ns = (int)ns_ll;
@@ -270,10 +236,12 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         const bool have_range = s_k[1] >= s_k[0];
         const KeyT kmin = have_range ? s_k[0] : (KeyT)0, kmax = have_range ? s_k[1] : (KeyT)0;
         const int shift = max(0, key_bits((KeyT)(kmax - kmin)) - P.lg_buckets);
-        const KeyT last_bucket = (KeyT)(NBKT - 1);
-        auto bucket_of = [&](KeyT key) -> u32 {
+        // table entry of a key: 1 + its bucket (buckets 0 .. NBKT - 2).  Entry 0 stays 0, so that after the scan and the scattering
+        // pass bucket b is [entry b, entry b + 1): two neighbouring 16-bit reads, no special case for the first bucket.
+        const KeyT last_bucket = (KeyT)(NBKT - 2);
+        auto entry_of = [&](KeyT key) -> u32 {
             const KeyT d = key > kmin ? (KeyT)((KeyT)(key - kmin) >> shift) : (KeyT)0;
-            return (u32)(d < last_bucket ? d : last_bucket);
+            return (u32)(d < last_bucket ? d : last_bucket) + 1u;
         };
         bool sorted_form = P.force_sorted != 0;
         // ---- 1. stored zeros, negatives, bucket sizes ----
@@ -283,7 +251,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                 if (nz) {
                     my_neg += key < ZEROK ? 1u : 0u;
                     if (!sorted_form) {
-                        const u32 b = bucket_of(key);
+                        const u32 b = entry_of(key);
                         atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u); // no carry: a counter stays below 2^16
                     }
                 } else ++my_zero; // a stored zero is an implicit zero
@@ -297,10 +265,8 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         }
         __syncthreads();
         const int n = ns - (int)s_misc[0];                   // stored non-zeros
-        if constexpr (!PARTS) {
-            n0 = P.n_cells - n;                              // zeros of the column
-            nneg = (long long)s_misc[1];
-        }
+        const long long n0 = P.n_cells - n;                  // zeros of the column
+        const long long nneg = (long long)s_misc[1];
         u64 tie = 0;
         if (n > 0 && !sorted_form) {
             // ---- 2. how crowded are the buckets? ----
@@ -319,41 +285,43 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         }
         if (n > 0 && !sorted_form) {
             // ---- 3. bucket offsets, keys into their buckets ----
-            block_excl_scan_u16<NT>(tab16, NBKT, (u32 *)A, tid); // the key buffer is still free: scan scratch
+            block_excl_scan_u16_waves<NT>(tab16, NBKT, (u32 *)s_red, tid); // (s_red: NW 64-bit slots, the scan wants NW words)
             ovr_for_entries<false, NT, UL, decltype(src), KeyT>(src, k0, k1, tid, [&](int, long long, KeyT key, bool nz, int) {
                 if (nz) {
-                    const u32 b = bucket_of(key);
+                    const u32 b = entry_of(key);
                     const u32 old = atomicAdd(&tab[b >> 1], (b & 1u) ? 0x10000u : 1u);
                     A[(b & 1u) ? (old >> 16) : (old & 0xFFFFu)] = key;
                 }
             });
-            if (tid < 4) A[n + tid] = MAXK; // the bucket walk below reads up to 3 keys past a bucket's end
-            __syncthreads(); // now tab16[b] = one past bucket b; it starts at tab16[b - 1]
-            // ---- 4. every stored entry against its own bucket ----
+            if (tid < 4) A[n + tid] = MAXK; // the window below reads up to 3 keys past a bucket's end
+            __syncthreads(); // now bucket b = [tab16[b], tab16[b + 1])
+            // ---- 4. every stored entry against its bucket: the first four keys in straight-line code (the average bucket holds
+            // two); keys past a bucket's end belong to later buckets (larger than q) or are the MAXK pad and count for neither sum ----
+            const u64 c_neg = 1ull + CNT1, c_pos = c_neg + 2ull * (u64)n0;
+            u32 tie32 = 0; // a thread's share of the column's tie sum: at most 64 keys x 192^2
             ovr_for_entries<true, NT, UL, decltype(src), KeyT>(src, k0, k1, tid, [&](int, long long, KeyT q, bool nz, int cd) {
                 if (nz) {
-                    const u32 b = bucket_of(q);
-                    const u32 lo = b ? tab16[b - 1] : 0u, hi = tab16[b];
-                    u32 less = 0, eq = 0;
-                    // 4 keys per step; keys past the bucket's end belong to later buckets (larger than q) or are the MAXK
-                    // pad, so they count for neither sum
-                    for (u32 j = lo; j < hi; j += 4) {
-                        const KeyT a0 = A[j], a1 = A[j + 1], a2 = A[j + 2], a3 = A[j + 3];
-                        less += (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u) + (a3 < q ? 1u : 0u);
-                        eq += (a0 == q ? 1u : 0u) + (a1 == q ? 1u : 0u) + (a2 == q ? 1u : 0u) + (a3 == q ? 1u : 0u);
+                    const u32 e = entry_of(q);
+                    const u32 lo = tab16[e - 1], hi = tab16[e];
+                    const KeyT a0 = A[lo], a1 = A[lo + 1], a2 = A[lo + 2], a3 = A[lo + 3];
+                    u32 less = (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u) + (a3 < q ? 1u : 0u);
+                    u32 eq = (a0 == q ? 1u : 0u) + (a1 == q ? 1u : 0u) + (a2 == q ? 1u : 0u) + (a3 == q ? 1u : 0u);
+                    for (u32 j = lo + 4; j < hi; j += 4) { // rare
+                        const KeyT b0 = A[j], b1 = A[j + 1], b2 = A[j + 2], b3 = A[j + 3];
+                        less += (b0 < q ? 1u : 0u) + (b1 < q ? 1u : 0u) + (b2 < q ? 1u : 0u) + (b3 < q ? 1u : 0u);
+                        eq += (b0 == q ? 1u : 0u) + (b1 == q ? 1u : 0u) + (b2 == q ? 1u : 0u) + (b3 == q ? 1u : 0u);
                     }
                     if (q == MAXK) eq = (hi - lo) - less; // the largest key also matches the pad slots
-                    const u64 s = (u64)base + lo + less;
-                    const u64 add = 2ull * s + eq + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
-                    atomicAdd(&acc[cd], add + CNT1);
-                    tie += (u64)eq * eq - 1ull;
+                    atomicAdd(&acc[cd], ((q > ZEROK) ? c_pos : c_neg) + (u64)(2u * (lo + less) + eq));
+                    tie32 += eq * eq - 1u;
                 }
             });
+            tie += (u64)tie32;
         } else if (n > 0) {
             // ---- sorted form: keys -> LDS, sort, tie blocks, two look-ups per entry ----
             const int ncap = (ns + CH - 1) / CH * CH;
             if (ncap > P.key_cap) { // uniform
-                if (tid == 0) { if constexpr (PARTS) { P.gflag[gene] = 1u; } else { P.fallback[gene] = 1u; } }
+                if (tid == 0) P.fallback[gene] = 1u;
                 __syncthreads();
                 continue;
             }
@@ -376,7 +344,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                     const u32 s = lower_bound_pow2(A, un, top, q);
                     u32 e = s + 1;
                     if (e < un && A[e] == q) e = upper_bound_pow2(A, un, top, q);
-                    const u64 add = 2ull * (u64)base + (u64)s + (u64)e + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
+                    const u64 add = (u64)s + (u64)e + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
                     atomicAdd(&acc[cd], add + CNT1);
                 }
             });
@@ -387,23 +355,14 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         __syncthreads();
         u64 tie_total = 0;
         for (int w = 0; w < NW; ++w) tie_total += s_red[w];
-        if constexpr (PARTS) {
-            // this part's share of the gene's accumulators
-            for (int g = tid; g < G; g += NT) {
-                const u64 a = acc[g];
-                if (a) atomicAdd(&P.gacc[(size_t)gene * G + g], a);
-            }
-            if (tid == 0 && tie_total) atomicAdd(&P.gtie[gene], tie_total);
-        } else {
-            tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
-            for (int g = tid; g < G; g += NT) {
-                const long long n_g = P.counts[g];
-                const u64 a = acc[g];
-                const long long z = n_g - (long long)(a >> CSCO_CNT_SHIFT);
-                const u64 r2 = (a & R2MASK) + (u64)z * (u64)(2 * nneg + n0 + 1);
-                P.out_2u[(size_t)gene * G + g] = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;
-                P.out_tie[(size_t)gene * G + g] = tie_total;
-            }
+        tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
+        for (int g = tid; g < G; g += NT) {
+            const long long n_g = P.counts[g];
+            const u64 a = acc[g];
+            const long long z = n_g - (long long)(a >> CSCO_CNT_SHIFT);
+            const u64 r2 = (a & R2MASK) + (u64)z * (u64)(2 * nneg + n0 + 1);
+            P.out_2u[(size_t)gene * G + g] = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;
+            P.out_tie[(size_t)gene * G + g] = tie_total;
         }
         __syncthreads();
     }
@@ -423,7 +382,6 @@ struct OvrPartParams {
     u16 *out_codes;            // [n_genes][stride]
     u32 *part_start;           // [n_genes][OVRP_PMAX + 1]
     u32 *gene_info;            // [n_genes][4]: non-zeros, negatives, parts, flag
-    u32 *unit_list, *n_units;  // out: gene * OVRP_PMAX + part for every part, appended; counter zeroed by the host
 };
 
 static inline size_t ovrp_lds_bytes() { return ((size_t)4 << OVRP_LG) + OVRP_NT * 4 + (2 * OVRP_PMAX + 4) * 4 + 16 + ((size_t)1 << OVRP_LG); }
@@ -553,12 +511,7 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition(OvrPartParams P) {
             }
         }
         if (tid <= (int)n_parts) ps_out[tid] = pstart[tid];
-        if (tid == 0) {
-            gi[0] = n; gi[1] = nneg; gi[2] = n_parts; gi[3] = 0u;
-            s_mx[0] = n_parts ? atomicAdd(P.n_units, n_parts) : 0u;
-        }
-        __syncthreads();
-        if (tid < (int)n_parts) P.unit_list[s_mx[0] + tid] = (u32)gene * OVRP_PMAX + tid;
+        if (tid == 0) { gi[0] = n; gi[1] = nneg; gi[2] = n_parts; gi[3] = 0u; }
         __syncthreads();
     }
 }
@@ -580,7 +533,7 @@ struct OvrPartPackedParams {
     int cap;
     void *out_keys;
     u16 *out_codes;
-    u32 *part_start, *gene_info, *unit_list, *n_units; // as OvrPartParams
+    u32 *part_start, *gene_info; // as OvrPartParams
 };
 
 template <typename KeyT>
@@ -725,36 +678,5 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
     }
     __syncthreads();
     if (tid <= (int)n_parts) ps_out[tid] = pstart[tid];
-    if (tid == 0) {
-        gi[0] = n; gi[1] = nneg; gi[2] = n_parts; gi[3] = 0u;
-        s_mx[0] = n_parts ? atomicAdd(P.n_units, n_parts) : 0u;
-    }
-    __syncthreads();
-    if (tid < (int)n_parts) P.unit_list[s_mx[0] + tid] = (u32)gene * OVRP_PMAX + tid;
-}
-
-// per (gene, group): the accumulated parts -> 2 U and the tie term (the CSC epilogue of k_csc_ovr_gene)
-struct OvrPartsFinishParams {
-    u64 *gacc;               // in: packed rank sums / counts   (aliases out_2u: same element, read before written)
-    const u64 *gtie;
-    const u32 *gene_info, *gflag;
-    const int *counts;
-    int G, nb;
-    long long n_cells;
-    long long *out_2u;
-    u64 *out_tie;
-};
-__global__ __launch_bounds__(256) void k_ovr_parts_finish(OvrPartsFinishParams P) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)P.nb * P.G) return;
-    const int gene = (int)(i / P.G), g = (int)(i % P.G);
-    const u32 *gi = P.gene_info + (size_t)gene * 4;
-    if (gi[3] != 0u || P.gflag[gene] != 0u) return; // the general route recomputes this gene
-    const long long n0 = P.n_cells - (long long)gi[0], nneg = gi[1];
-    const u64 a = P.gacc[i];
-    const long long n_g = P.counts[g];
-    const long long z = n_g - (long long)(a >> CSCO_CNT_SHIFT);
-    const u64 r2 = (a & ((1ull << CSCO_CNT_SHIFT) - 1ull)) + (u64)z * (u64)(2 * nneg + n0 + 1);
-    P.out_2u[i] = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;
-    P.out_tie[i] = P.gtie[gene] + ((u64)n0 * (u64)n0 * (u64)n0 - (u64)n0);
+    if (tid == 0) { gi[0] = n; gi[1] = nneg; gi[2] = n_parts; gi[3] = 0u; }
 }

@@ -101,18 +101,14 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     void *pkeys = v;
     if ((rc = get_scratch(c, "ovr_va", (size_t)nb * stride * 4, &v))) return rc;
     u16 *pcodes = (u16 *)v;
-    const size_t meta = (size_t)nb * ((OVRP_PMAX + 1) * 4 + 16 + 8 + 4 + OVRP_PMAX * 4) + 64;
+    const size_t meta = (size_t)nb * ((OVRP_PMAX + 1) * 4 + 16 + 4) + 64;
     if ((rc = get_scratch(c, "ovr_parts_meta", meta, &v))) return rc;
-    u64 *gtie = (u64 *)v;
-    u32 *part_start = (u32 *)(gtie + nb);
+    u32 *part_start = (u32 *)v;
     u32 *gene_info = part_start + (size_t)nb * (OVRP_PMAX + 1);
     u32 *gflag = gene_info + (size_t)nb * 4;
-    u32 *unit_list = gflag + nb;
-    u32 *unit_ctr = unit_list + (size_t)nb * OVRP_PMAX; // [0] units written  [1] queue head
-    HIPCHK(c, hipMemsetAsync(gtie, 0, (size_t)nb * 8, c->stream));
+    u32 *gene_ctr = gflag + nb; // the rank kernel's queue head
     HIPCHK(c, hipMemsetAsync(gflag, 0, (size_t)nb * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(unit_ctr, 0, 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(s2u, 0, (size_t)nb * G * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(gene_ctr, 0, 4, c->stream));
     // per-group value sums from the group-contiguous key rows, in a fixed order (the parts see a group's values in an order
     // that depends on timing)
     if (!padded && (rc = launch_group_sums_rows<KeyT>(c, Xt, stride, nb, dtype, flags, ssum))) return rc;
@@ -120,7 +116,7 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
         OvrPartPackedParams Q;
         Q.Xt = Xt; Q.stride = stride; Q.n_genes = nb; Q.G = G; Q.nblk = c->pk_nblk; Q.nnz = packed->nnz; Q.blk_cnt = packed->blk_cnt;
         Q.blk_g0 = c->d_pk_blk; Q.blk_g1 = c->d_pk_blk + c->pk_nblk; Q.blk_out = c->d_pk_blk + 2 * c->pk_nblk; Q.cap = cap;
-        Q.out_keys = pkeys; Q.out_codes = pcodes; Q.part_start = part_start; Q.gene_info = gene_info; Q.unit_list = unit_list; Q.n_units = unit_ctr;
+        Q.out_keys = pkeys; Q.out_codes = pcodes; Q.part_start = part_start; Q.gene_info = gene_info;
         ProfScope ps(c, KID_OVR_PART);
         auto kern = k_ovr_partition_packed<KeyT>;
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovrp_lds_bytes()));
@@ -129,7 +125,7 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     } else {
         OvrPartParams Q;
         Q.Xt = Xt; Q.stride = stride; Q.n_genes = nb; Q.n_cells = padded ? (int)c->pk_len : N; Q.code_by_pos = padded ? c->d_pk_code : c->d_code_by_pos; Q.cap = cap;
-        Q.out_keys = pkeys; Q.out_codes = pcodes; Q.part_start = part_start; Q.gene_info = gene_info; Q.unit_list = unit_list; Q.n_units = unit_ctr;
+        Q.out_keys = pkeys; Q.out_codes = pcodes; Q.part_start = part_start; Q.gene_info = gene_info;
         ProfScope ps(c, KID_OVR_PART);
         auto kern = k_ovr_partition<KeyT>;
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovrp_lds_bytes()));
@@ -137,29 +133,21 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
         HIPCHK(c, hipGetLastError());
     }
     {
-        CscOvrParams P;
+        // one workgroup per gene (drawn from a queue), the gene's parts one after the other: kernels_ovr_parts.h
+        OvrRankGeneParams P;
         memset(&P, 0, sizeof P);
         P.pkeys = pkeys; P.pcodes = pcodes; P.pstride = stride; P.part_start = part_start; P.gene_info = gene_info;
-        P.gacc = (u64 *)s2u; P.gtie = gtie; P.gflag = gflag; P.unit_list = unit_list; P.n_units = unit_ctr; P.unit_counter = unit_ctr + 1; P.nb = nb; P.counts = c->d_counts; P.G = G; P.dt = dtype;
-        P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = N; P.key_cap = key_cap; P.lg_buckets = lg;
-        P.force_sorted = c->csc_ovr_sorted_form ? 1 : 0;
+        P.gflag = gflag; P.gene_counter = gene_ctr; P.nb = nb; P.G = G; P.counts = c->d_counts; P.n_cells = N;
+        P.key_cap = key_cap; P.lg_buckets = lg; P.force_sorted = c->csc_ovr_sorted_form ? 1 : 0;
+        P.out_2u = s2u; P.out_tie = stie;
         const size_t lds = csco_fixed_lds_bytes(G, lg, true) + (size_t)(key_cap + 4) * sizeof(KeyT);
         ProfScope ps(c, KID_OVR_RANK_PARTS);
-        auto kern = k_csc_ovr_gene<KeyT, int, KeyT, true>;
+        auto kern = k_ovr_rank_gene_parts<KeyT>;
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int n_cu = 256;
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-        const unsigned grid = (unsigned)std::min<long long>((long long)nb * OVRP_PMAX, std::max(n_cu, 1)); // one resident workgroup per CU (LDS)
+        const unsigned grid = (unsigned)std::min<long long>((long long)nb, std::max(n_cu, 1)); // one resident workgroup per CU (LDS)
         hipLaunchKernelGGL(kern, dim3(grid), dim3(CSCO_NT), lds, c->stream, P);
-        HIPCHK(c, hipGetLastError());
-    }
-    {
-        OvrPartsFinishParams F;
-        F.gacc = (u64 *)s2u; F.gtie = gtie; F.gene_info = gene_info; F.gflag = gflag; F.counts = c->d_counts; F.G = G; F.nb = nb;
-        F.n_cells = N; F.out_2u = s2u; F.out_tie = stie;
-        ProfScope ps(c, KID_OVR_RANK_PARTS);
-        const long long tot = (long long)nb * G;
-        hipLaunchKernelGGL(k_ovr_parts_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, F);
         HIPCHK(c, hipGetLastError());
     }
     // genes that left the route (a coarse bucket too full, a part that fits neither form): the general route, over the

@@ -322,7 +322,7 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
     double *gtot = ssum + (size_t)nb_max * G;
     if ((rc = get_scratch(c, "gene_flags", (size_t)nb_max * 4, &v))) return rc;
     u32 *fb = (u32 *)v;
-    auto kern = k_csc_ovr_gene<InT, IdxT, KeyT, false>;
+    auto kern = k_csc_ovr_gene<InT, IdxT, KeyT>;
     HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<int64_t> left;
     for (int64_t b0 = 0; b0 < n; b0 += nb_max) {
