@@ -389,6 +389,42 @@ def test_fused_route_second_pass_takes_counts_up_to_255(engine, test):
     assert_planes_match(got, tuple(a[:, :120] for a in want), ref_row=rr, what=f"csr byte window, counts up to 254 {test}")
 
 
+@pytest.mark.parametrize("big_group", [False, True])
+def test_ovo_counts_table_is_4096_values_while_groups_stay_below_256_cells(engine, big_group):
+    """k_ovo_counts keeps 8-bit multiplicities and a 4096-value table while no ranked group exceeds 255 cells, 16-bit ones and 2048
+    values otherwise: genes with counts in [2048, 4096) take the histogram kernel in the first case and the sort routes in the
+    second; both match the oracle bit for bit (tie-heavy values around the limits included)."""
+    rng = np.random.RandomState(91)
+    n, m = 6000, 12
+    sizes = [300] + ([400] if big_group else []) + [200] * 20
+    labels = np.concatenate([np.full(k, "non-targeting" if i == 0 else f"pert_{i:02d}") for i, k in enumerate(sizes)])
+    labels = np.concatenate([labels, [f"rest_{i % 30:02d}" for i in range(n - labels.size)]])
+    rng.shuffle(labels)
+    X = rng.poisson(3.0, size=(n, m)).astype(np.float32)
+    X[:, 2] = rng.poisson(3000.0, size=n)                          # [2048, 4096)
+    X[:, 3] = rng.randint(2040, 2056, size=n)                      # ties on both sides of 2048
+    X[:, 4] = rng.randint(4090, 4100, size=n)                      # ... and of 4096: beyond the table
+    X[:, 5] = np.where(rng.rand(n) < 0.7, 0, rng.randint(1, 4096, size=n))
+    X[:, 6] = 4095.0
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    want = oracle.run(X, g)
+    engine.set_groups(g)
+    engine.set_option("no_fused_path", 1)
+    engine.set_option("no_packed_dense", 1)
+    engine.profile(True)
+    engine.profile_reset()
+    try:
+        got = engine.run_dense(X, 0, m)
+    finally:
+        engine.set_option("no_fused_path", 0)
+        engine.set_option("no_packed_dense", 0)
+        prof = engine.profile_get()
+        engine.profile(False)
+    assert "k_ovo_counts" in prof, prof
+    assert ("k_ovo_rank" in prof or "k_ovr_gene" in prof), prof    # column 4 (and, with a big group, columns 2, 3, 5, 6 too)
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"4096-value table big_group={big_group}")
+
+
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
 @pytest.mark.parametrize("where", ["device", "device-deferred", "host"])
 def test_scattered_big_count_genes_are_gathered_and_take_the_histogram_routes(engine, test, where):
