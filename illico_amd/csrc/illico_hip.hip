@@ -819,6 +819,37 @@ static int begin_outputs(illico_ctx *c, int flags, int64_t W, double *out_p, dou
     return ILLICO_OK;
 }
 
+// Freshly allocated host planes (np.empty: 384 MB at C2) take their page faults when they are first written -- in end_outputs, after
+// the device is done, on the scatter threads: ~35 ms at C2.  PlaneTouch takes them early instead: a few threads touch one byte per
+// page of the three destination windows (read and written back: contents are preserved) while the uploads and the kernels run.
+struct PlaneTouch {
+    std::vector<std::thread> pool;
+    void start(double *const planes[3], size_t n_rows, size_t row_bytes, size_t pitch_bytes) {
+        if (3 * n_rows * row_bytes < ((size_t)64 << 20)) return;
+        const int T = 8;
+        double *p0 = planes[0], *p1 = planes[1], *p2 = planes[2];
+        const bool dbg = getenv("ILLICO_HS_DEBUG") != nullptr;
+        for (int t = 0; t < T; ++t)
+            pool.emplace_back([=]() {
+                const auto t0 = std::chrono::steady_clock::now();
+                double *const pl[3] = {p0, p1, p2};
+                for (size_t r = 3 * n_rows * t / T; r < 3 * n_rows * (t + 1) / T; ++r) {
+                    char *row = (char *)pl[r / n_rows] + (r % n_rows) * pitch_bytes; // (8-byte aligned: a row of doubles)
+                    // (volatile read + write-back: the page is faulted in for writing, its contents stay; an atomic add of 0 is
+                    // folded into a load by the compiler.  Nobody else touches the planes before join().)
+                    for (size_t b = 0; b < row_bytes; b += 4096) { volatile char *q = row + b; *q = *q; }
+                    { volatile char *q = row + row_bytes - 1; *q = *q; }
+                }
+                if (dbg && t == 0) fprintf(stderr, "[illico] plane touch thread 0: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            });
+    }
+    void join() {
+        for (auto &th : pool) th.join();
+        pool.clear();
+    }
+    ~PlaneTouch() { join(); }
+};
+
 // Host planes: the device staging planes come back through two pinned 32-MB buffers (row blocks of the three planes in turn:
 // block i is copied down at the link's rate while block i - 1 is scattered into the caller's planes by a few host threads).  A
 // pageable destination made the driver stage the 24 bytes per test itself: 20 - 40 ms for C2's 384 MB, against ~10 ms.
@@ -1666,9 +1697,12 @@ extern "C" int illico_run_dense(illico_ctx *c, const void *X, int dtype, int64_t
     if (W == 0) return later ? resolve_pending(c, prev) : ILLICO_OK;
     OutPlanes o;
     if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) { if (later) resolve_pending(c, prev); return rc; }
+    PlaneTouch touch; // (joined before the first result is scattered, and on every way out)
+    if (o.staged) { double *const dst[3] = {out_p, out_u, out_fc}; touch.start(dst, (size_t)c->n_groups, (size_t)W * 8, (size_t)out_ld * 8); }
     rc = run_dense_any(c, X, dtype, n_rows, ld, col_lb, col_ub, flags, alternative, o);
     if (later) { const int rc2 = resolve_pending(c, prev); if (!rc) rc = rc2; }
     if (rc) return rc;
+    touch.join();
     return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
 }
 

@@ -876,6 +876,8 @@ static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, c
     if (W == 0) return later ? resolve_pending(c, prev) : ILLICO_OK;
     OutPlanes o;
     if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) { if (later) resolve_pending(c, prev); return rc; }
+    PlaneTouch touch;
+    if (o.staged) { double *const dst[3] = {out_p, out_u, out_fc}; touch.start(dst, (size_t)c->n_groups, (size_t)W * 8, (size_t)out_ld * 8); }
     rc = run_sparse_inner(c, is_csr, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o);
     if (later) { // (the earlier call's leftovers run on the ordinary routes; this call's own pending state must survive them)
         const PendingDense mine = c->pend;
@@ -885,6 +887,7 @@ static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, c
         if (!rc) rc = rc2;
     }
     if (rc) return rc;
+    touch.join();
     return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
 }
 

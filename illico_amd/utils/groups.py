@@ -23,6 +23,10 @@ def encode_and_count_groups(groups, ref_group: Any):
     if cat is not None and not groups.isna().any():
         return _encode_categorical(groups, ref_group)
     groups = np.asarray(groups)
+    if groups.ndim == 1 and groups.dtype.kind in "USO" and groups.size >= 4096:
+        fast = _encode_hashed(groups, ref_group)  # strings: one hash pass instead of a sort of N labels
+        if fast is not None:
+            return fast
     if ref_group is not None and not np.any(groups == ref_group):
         raise ValueError(f"Reference group `{ref_group}` is not present in the group labels.")
     unique_groups, encoded_groups, group_counts = np.unique(groups, return_inverse=True, return_counts=True)
@@ -57,6 +61,41 @@ def _encode_categorical(col, ref_group: Any):
     if ref_group is not None and not np.any(unique_groups == ref_group):
         raise ValueError(f"Reference group `{ref_group}` is not present in the group labels.")
     remap = np.full(cats.size, -1, dtype=np.int64)
+    remap[order] = np.arange(order.size)
+    encoded_groups = remap[codes]
+    group_counts = np.bincount(encoded_groups, minlength=order.size).astype(np.int64)
+    group_indices = np.argsort(encoded_groups, kind="stable").astype(np.int64)
+    group_indptr = np.concatenate([[0], np.cumsum(group_counts)]).astype(np.int64)
+    encoded_ref = -1 if ref_group is None else int(np.flatnonzero(unique_groups == ref_group)[0])
+    return unique_groups, GroupContainer(encoded_groups, group_counts, group_indices, group_indptr, encoded_ref)
+
+
+def _encode_hashed(groups: np.ndarray, ref_group: Any):
+    """The container of ``encode_and_count_groups`` for a 1-D array of string labels: ``pandas.factorize`` (a hash table: one pass
+    over the N labels) finds the distinct labels, which are then ordered as ``np.unique`` orders them (a sort of G labels instead of
+    N).  Returns None -- the caller takes the ``np.unique`` path -- for anything that is not plainly strings (missing values, mixed
+    objects), so that errors and orderings of odd inputs stay exactly numpy's."""
+    try:
+        import pandas as pd
+    except ImportError:  # pragma: no cover
+        return None
+    if groups.dtype.kind == "O" and not all(isinstance(x, str) for x in groups[:: max(1, groups.size // 1024)]):
+        return None
+    codes, uniques = pd.factorize(groups, sort=False)
+    if codes.min(initial=0) < 0:
+        return None
+    uniques = np.asarray(uniques)
+    if groups.dtype.kind == "O":
+        if not all(isinstance(x, str) for x in uniques):
+            return None
+        uniques = np.array(uniques.tolist())  # np.unique of a list of str gives a '<U' array; same order either way
+    else:
+        uniques = uniques.astype(groups.dtype, copy=False)
+    order = np.argsort(uniques, kind="stable")
+    unique_groups = uniques[order]
+    if ref_group is not None and not np.any(unique_groups == ref_group):
+        raise ValueError(f"Reference group `{ref_group}` is not present in the group labels.")
+    remap = np.empty(order.size, dtype=np.int64)
     remap[order] = np.arange(order.size)
     encoded_groups = remap[codes]
     group_counts = np.bincount(encoded_groups, minlength=order.size).astype(np.int64)

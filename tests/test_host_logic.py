@@ -208,3 +208,55 @@ def test_out_of_core_handlers_are_duck_typed():
     finally:
         data_handler_registry.pop(Dense)
     assert H5pyBackedCSCDataHandler.streams and H5pyBackedCSCDataHandler(None).kernel_data_format() == KernelDataFormat.CSC
+
+
+@pytest.mark.parametrize("kind", ["U", "object", "series", "series-object"])
+def test_hashed_group_encoding_equals_np_unique(kind):
+    """Above 4096 string labels the codes come from one hash pass (pandas.factorize) and a sort of the DISTINCT labels; the container
+    must be the one np.unique gives (groups.py:18-58: labels in np.unique's order), missing reference and odd inputs included."""
+    from illico_amd.utils import groups as gm
+    rng = np.random.RandomState(5)
+    n, G = 20000, 300
+    codes = rng.randint(0, G, size=n)
+    labels = np.where(codes == 0, "non-targeting", np.char.add("pert_", np.char.zfill((codes * 7919 % 1000).astype(str), rng.randint(1, 6))))
+    labels = np.concatenate([labels, ["Zeta", "alpha", "10", "9", "pert_", ""]])   # code-point order, not locale or numeric order
+    inp = {"U": labels, "object": labels.astype(object), "series": pd.Series(labels), "series-object": pd.Series(labels.astype(object))}[kind]
+    uniq, g = gm.encode_and_count_groups(inp, "non-targeting")
+    want_u, want_inv, want_cnt = np.unique(labels, return_inverse=True, return_counts=True)
+    assert [str(x) for x in uniq] == [str(x) for x in want_u]
+    np.testing.assert_array_equal(g.encoded_groups, want_inv.reshape(-1))
+    np.testing.assert_array_equal(g.counts, want_cnt)
+    np.testing.assert_array_equal(g.indptr, np.concatenate([[0], np.cumsum(want_cnt)]))
+    np.testing.assert_array_equal(g.indices, np.argsort(want_inv.reshape(-1), kind="stable"))
+    assert g.encoded_ref_group == int(np.flatnonzero(want_u == "non-targeting")[0])
+    for a in (g.encoded_groups, g.counts, g.indices, g.indptr):
+        assert a.dtype == np.int64
+    assert gm.encode_and_count_groups(inp, None)[1].encoded_ref_group == -1
+    with pytest.raises(ValueError, match="is not present"):
+        gm.encode_and_count_groups(inp, "no-such-label")
+    # integer labels and labels with missing values keep numpy's path (and numpy's behaviour)
+    ints = rng.randint(0, 50, size=10000)
+    u2, g2 = gm.encode_and_count_groups(ints, 3)
+    np.testing.assert_array_equal(u2, np.unique(ints))
+    assert g2.encoded_ref_group == 3 and gm._encode_hashed(np.array(["a", None] * 3000, dtype=object), None) is None
+
+
+def test_product_index_equals_from_product():
+    """The (pert, feature) index of the result frame is built with narrow integer codes in one pass; it must be from_product's index
+    (asymptotic_wilcoxon.py:252-256): same sorted levels, same codes, same dtypes -- unsorted and duplicated names included."""
+    from illico_amd.asymptotic_wilcoxon import _product_index
+    rng = np.random.RandomState(2)
+    for G, M in [(1, 1), (3, 5), (130, 40), (40, 300)]:
+        perts = pd.Series(np.array([f"p{i}" for i in rng.permutation(G)]), name="pert", dtype=str)
+        genes = pd.Series(np.array([f"gene_{i}" for i in rng.permutation(M)]), name="feature", dtype=str)
+        a = pd.MultiIndex.from_product([perts, genes], names=["pert", "feature"])
+        b = _product_index(perts, genes)
+        assert a.equals(b) and list(a.names) == list(b.names)
+        for x, y in zip(a.levels, b.levels):
+            assert x.equals(y) and x.dtype == y.dtype
+        for x, y in zip(a.codes, b.codes):
+            np.testing.assert_array_equal(x, y)
+            assert x.dtype == y.dtype
+    dup = pd.Series(["x", "y", "x"], name="feature", dtype=str)
+    one = pd.Series(["b", "a"], name="pert", dtype=str)
+    assert _product_index(one, dup).equals(pd.MultiIndex.from_product([one, dup], names=["pert", "feature"]))

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Usage (on the GPU box, from the repo root): tools/round_bench.sh <round tag, e.g. r03>
+# The bench lines and rocprofv3 summaries a round commits under profiles/: every line into gpurun_out/<tag>_bench_*.json,
+# every profile into gpurun_out/<tag>_<workload>/ (tools/profile_bench.sh).  Prints a progress line per step.
+set -u
+T=$1
+O=gpurun_out
+mkdir -p $O
+b() { name=$1; shift; python3 bench.py "$@" > $O/${T}_bench_$name.json 2> $O/${T}_bench_$name.err; echo "bench $name rc=$?"; }
+b c2 
+b c3 --workload c3 --no-c5
+b c3_ovr --workload c3 --test ovr --no-c5
+b c4 --workload c4 --no-c5
+b c5shard --workload c5shard --no-c5
+b c5_one_gpu --workload c5 --no-c5 --steps 5 --warmup 1
+b c2_nb --workload c2 --values nb --no-c5
+b c2_nb_ovr --workload c2 --values nb --test ovr --no-c5
+b c2_cont_ovo --workload c2 --values continuous --no-c5 --steps 10
+b c2_cont_ovr --workload c2 --values continuous --test ovr --no-c5 --steps 10
+b c3_cont_ovo --workload c3 --values continuous --no-c5 --steps 10
+b c3_cont_ovr --workload c3 --values continuous --test ovr --no-c5 --steps 10
+b c3_csr --workload c3 --format csr --no-c5 --steps 10
+b c3_csr_ovr --workload c3 --format csr --test ovr --no-c5 --steps 10
+b c2_host --workload c2 --input host --no-c5 --steps 3 --warmup 1
+p() { name=$1; shift; bash tools/profile_bench.sh ${T}_$name "$@" > $O/prof_$name.log 2>&1; echo "profile $name rc=$?"; }
+p c2 --workload c2
+p c3 --workload c3
+p c3_ovr --workload c3 --test ovr
+p c4 --workload c4
+p c5shard --workload c5shard
+p c2_nb --workload c2 --values nb
+p c2_cont_ovr --workload c2 --values continuous --test ovr
+p c3_cont_ovr --workload c3 --values continuous --test ovr
