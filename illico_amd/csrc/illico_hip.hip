@@ -121,6 +121,7 @@ struct illico_ctx {
     bool no_ovr_packed_partition = false; // 1: dense OVR partitions the padded rows (every key) instead of the packed ones
     bool no_packed_dense = false;      // 1: dense OVO on continuous values takes the transpose + k_ovo_rank route (no group-wise packing)
     int packed_eq_buckets = -1;        // packed rank kernel: distribution-following bucket function; -1 = for references above 16384 cells
+    bool no_wide_gather = false;       // 1: the 256-value stage always runs over the window as it lies (never left to the host's gather)
     bool no_leftover_gather = false;   // 1: the genes the fused passes leave are recomputed as column runs of the input (no gather into a narrow matrix)
     bool no_fused_wide = false;        // 1: no second, 256-value pass of the fused OVO route (genes beyond 63 go to the two-pass routes)
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
@@ -356,6 +357,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_fused_path")) c->no_fused_path = value != 0;
     else if (!strcmp(key, "no_fused_wide")) c->no_fused_wide = value != 0;
     else if (!strcmp(key, "no_leftover_gather")) c->no_leftover_gather = value != 0;
+    else if (!strcmp(key, "no_wide_gather")) c->no_wide_gather = value != 0;
     else if (!strcmp(key, "no_packed_dense")) c->no_packed_dense = value != 0;
     else if (!strcmp(key, "packed_eq_buckets")) c->packed_eq_buckets = (int)value;
     else if (!strcmp(key, "no_ovr_packed_partition")) c->no_ovr_packed_partition = value != 0;
@@ -934,10 +936,13 @@ static int check_common(illico_ctx *c, int64_t n_rows, int64_t n_cols, int64_t c
 #define FUSED_RT 64
 
 // Fused single-pass route over genes [b0, b0+nb): writes final planes for every gene it can take and sets
-// h_flags[j] != 0 for the others.
+// h_flags[j] != 0 for the others (1 / 3: left to the two-pass routes; 2: done by the 256-value stage).  h_flags[nb] (also word nb of
+// the deferred call's pinned flags) != 0: the 256-value stage was left to the host (k_wide_decide; only with max_gather > 0).
+// init_flags (host, [nb]): the 256-value stage ALONE, for the genes marked 1 there (run_leftovers: a narrow matrix of gathered columns).
 template <typename InT>
 static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, int flags, int alternative,
-                         const OutPlanes &o, int64_t col_off, std::vector<u32> &h_flags, int defer_slot = -1, bool probe = false) {
+                         const OutPlanes &o, int64_t col_off, std::vector<u32> &h_flags, int defer_slot = -1, bool probe = false,
+                         int64_t max_gather = 0, const u32 *init_flags = nullptr) {
     constexpr int RT = FUSED_RT;
     const bool ovr = c->ref < 0;
     void *v;
@@ -957,6 +962,9 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.wide_tiles = nullptr;
     P.wide_bad = nullptr;
     P.hist_off = nullptr;
+    u32 *skipw = P.hist_all + (size_t)nb * RT; // (inside the 64 spare bytes of the allocation)
+    P.wide_skip = skipw;
+    const bool wide_only = init_flags != nullptr;
     P.n_cells = c->n_cells;
     P.rows_per_wg = (int)std::max<int64_t>(1024, (c->n_cells + 31) / 32);
     P.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;
@@ -971,8 +979,10 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
         while (gpw > 4 && (int64_t)tiles * ((c->n_groups + gpw - 1) / gpw) < 2048) gpw >>= 1;
     }
     P.groups_per_wg = gpw = std::min(gpw, 128); // (k_ovr_group_hists packs a workgroup's cells into 16-bit fields: 128 x 255 < 2^16)
-    HIPCHK(c, hipMemsetAsync(P.gene_flags, 0, (size_t)nb * 4, c->stream));
-    if (probe) { // OVR on device-resident input: which genes are count-valued at all is found on the device (the OVO pass has
+    HIPCHK(c, hipMemsetAsync(skipw, 0, 4, c->stream));
+    if (wide_only) HIPCHK(c, hipMemcpyAsync(P.gene_flags, init_flags, (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(c, hipMemsetAsync(P.gene_flags, 0, (size_t)nb * 4, c->stream));
+    if (probe && !wide_only) { // OVR on device-resident input: which genes are count-valued at all is found on the device (the OVO pass has
         // k_fused_ref, which reads every reference row first)
         ProfScope ps(c, KID_FUSED_REF);
         hipLaunchKernelGGL((k_fused_probe<InT, RT>), dim3(tiles), dim3(256), 0, c->stream, P);
@@ -981,8 +991,17 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     const dim3 main_grid(tiles, ((int)c->n_groups + P.groups_per_wg - 1) / P.groups_per_wg);
     const size_t lds8 = fused_main_lds_bytes<RT, false, 8>(), lds16 = fused_main_lds_bytes<RT, false, 16>(), lds_ovr = fused_main_lds_bytes<RT, true, 16>();
     (void)lds8; (void)lds16; (void)lds_ovr;
+    // is the 256-value stage left to the host?  (decided on the device, after the first pass: nothing waits for it here)
+    auto wide_decide = [&]() -> int {
+        if (wide_only || max_gather <= 0 || c->no_wide_gather) return ILLICO_OK;
+        ProfScope ps(c, KID_FUSED_REF);
+        hipLaunchKernelGGL(k_wide_decide, dim3(1), dim3(1024), 0, c->stream, (const u32 *)P.gene_flags, nb, (int)std::min<int64_t>(max_gather, 0x7FFFFFFF), skipw);
+        HIPCHK(c, hipGetLastError());
+        return ILLICO_OK;
+    };
     if (!ovr) {
-        if (tiles >= 100) { // one 1024-thread workgroup per tile builds the tables (C2: 125 tiles, 0.074 ms)
+        if (wide_only) {
+        } else if (tiles >= 100) { // one 1024-thread workgroup per tile builds the tables (C2: 125 tiles, 0.074 ms)
             ProfScope ps(c, KID_FUSED_REF);
             auto kern = k_fused_ref<InT, RT>;
             hipLaunchKernelGGL(kern, dim3(tiles), dim3(FUSED_REF_NT), fused_ref_lds_bytes(RT), c->stream, P);
@@ -999,7 +1018,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             hipLaunchKernelGGL((k_fused_tables_all<RT>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, P);
             HIPCHK(c, hipGetLastError());
         }
-        {
+        if (!wide_only) {
             ProfScope ps(c, KID_OVO_FUSED);
             if (c->max_nonref <= 255) // 8-bit running multiplicities: 34 KB of LDS per workgroup instead of 50 KB
                 hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8>), main_grid, dim3(FUSED_NT), lds8, c->stream, P);
@@ -1011,6 +1030,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
         // working through the list of such tiles that k_fused_ref<WIDE> builds on the device -- an empty list costs two
         // near-empty launches (0.005 ms at C2).  Flags after it: 1 = the host's two-pass routes, 0 / 2 = done.
         if (c->max_nonref <= 255 && !c->no_fused_wide) {
+            if ((rc = wide_decide())) return rc;
             constexpr int WRT = FUSED_WIDE_RT;
             const size_t wbytes = nb64 * (WRT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)(tiles + 1) * 4 + 64;
             if ((rc = get_scratch(c, "fused_tables_wide", wbytes, &v))) return rc;
@@ -1036,7 +1056,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
             hipLaunchKernelGGL(kern, dim3((unsigned)std::max(n_cu, 1)), dim3(FUSED_NT), lds, c->stream, Q); // resident workgroups over the listed tiles
             HIPCHK(c, hipGetLastError());
         }
-    } else {
+    } else if (!wide_only) {
         HIPCHK(c, hipMemsetAsync(P.hist_all, 0, (size_t)nb * RT * 4, c->stream));
         // one pass over X when the per-(group, gene) histograms fit the scratch cap (64 or 128 bytes each)
         // 8-bit cells when no group is larger than 255 cells, else the width per group (0): a few large groups do not double
@@ -1084,6 +1104,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     // tables, then k_ovo_fused<OVR, WIDE> with resident workgroups over the listed tiles.  No per-group state: 67 KB of LDS.
     // C4 shape with gene means up to 40: 97 ms (those genes through the general sort route) -> see DESIGN.md.
     if (ovr && !c->no_fused_wide) {
+        if ((rc = wide_decide())) return rc;
         constexpr int WRT = FUSED_WIDE_RT;
         const size_t wbytes = nb64 * (WRT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * WRT * 4 + (size_t)(nb + tiles) * 4 + (size_t)(tiles + 1) * 4 + 64;
         if ((rc = get_scratch(c, "fused_tables_wide", wbytes, &v))) return rc;
@@ -1116,7 +1137,7 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     // route flags back through a pinned staging buffer (a pageable destination makes the copy a blocking, staged one)
     if (defer_slot >= 0) { // deferred: the copy is enqueued, an event marks it, nobody waits here (resolve_pending does)
         void *&pin = c->pend_pinned[defer_slot];
-        if (c->pend_pinned_bytes[defer_slot] < (size_t)nb * 4) {
+        if (c->pend_pinned_bytes[defer_slot] < (size_t)nb * 4 + 4) {
             if (pin) hipHostFree(pin);
             pin = nullptr;
             c->pend_pinned_bytes[defer_slot] = 0;
@@ -1125,10 +1146,11 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
         }
         if (!c->pend_event[defer_slot]) HIPCHK(c, hipEventCreateWithFlags(&c->pend_event[defer_slot], hipEventDisableTiming));
         HIPCHK(c, hipMemcpyAsync(pin, P.gene_flags, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync((u32 *)pin + nb, skipw, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipEventRecord(c->pend_event[defer_slot], c->stream));
         return ILLICO_OK;
     }
-    if (c->pinned_bytes < (size_t)nb * 4) {
+    if (c->pinned_bytes < (size_t)nb * 4 + 4) {
         if (c->pinned) hipHostFree(c->pinned);
         c->pinned = nullptr;
         c->pinned_bytes = 0;
@@ -1136,8 +1158,9 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
         c->pinned_bytes = (size_t)nb * 4 + 4096;
     }
     HIPCHK(c, hipMemcpyAsync(c->pinned, P.gene_flags, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync((u32 *)c->pinned + nb, skipw, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    h_flags.assign((const u32 *)c->pinned, (const u32 *)c->pinned + nb);
+    h_flags.assign((const u32 *)c->pinned, (const u32 *)c->pinned + nb + 1);
     return ILLICO_OK;
 }
 
@@ -1357,27 +1380,47 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
 // The genes the fused passes of a DEVICE-resident window [col_lb, col_ub) left behind (hf[j] = 1 / 3).  Few and scattered (a count
 // matrix's highly expressed genes): gathered into a narrow matrix of their own and computed as ONE window whose results
 // k_finalize scatters back through a column map (kernels_leftover.h).  Many (normalised data: every gene): the column runs, as before.
+// wide_skipped: the device left the 256-value stage to us (k_wide_decide): it runs on the narrow matrix first (the genes flagged 1),
+// its finished columns are copied into the caller's planes, and what it leaves is gathered once more out of the narrow matrix.
+// outer (host, [W]): the window is itself such a narrow matrix -- column j of it is column outer[j] of the caller's planes.
 template <typename InT, typename KeyT>
 static int run_leftovers(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                         const OutPlanes &o, const u32 *hf) {
+                         const OutPlanes &o, const u32 *hf, bool wide_skipped = false, const int *outer = nullptr) {
     const int64_t W = col_ub - col_lb;
-    std::vector<int> src, dst;
-    for (int64_t j = 0; j < W; ++j)
-        if (hf[j] == 1u || hf[j] == 3u) { src.push_back((int)(col_lb + j)); dst.push_back((int)j); }
-    if (src.empty()) return ILLICO_OK;
-    const int64_t n = (int64_t)src.size(), n_pad = (n + 63) & ~63ll;
-    if (!(flags & ILLICO_FLAG_INPUT_DEVICE) || c->tap || c->no_leftover_gather || n * 2 > W || col_ub > 0x7FFFFFFFll ||
-        (size_t)N * (size_t)n_pad * sizeof(InT) > (size_t)c->scratch_bytes) {
-        std::vector<std::pair<int64_t, int64_t>> runs;
-        flagged_runs(hf, W, col_lb, runs);
-        return run_dense_twopass<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, runs);
-    }
+    const int G = (int)c->n_groups;
     int rc;
     void *v;
-    if ((rc = get_scratch(c, "xleft", (size_t)N * (size_t)n_pad * sizeof(InT), &v))) return rc;
+    std::vector<int> src, dst;
+    for (int64_t j = 0; j < W; ++j)
+        if (hf[j] == 1u || hf[j] == 3u) { src.push_back((int)(col_lb + j)); dst.push_back(outer ? outer[j] : (int)j); }
+    if (src.empty()) return ILLICO_OK;
+    const int64_t n = (int64_t)src.size(), n_pad = (n + 63) & ~63ll;
+    const bool can_gather = (flags & ILLICO_FLAG_INPUT_DEVICE) && !c->tap && !c->no_leftover_gather && n * 2 <= W && col_ub <= 0x7FFFFFFFll &&
+                            (size_t)N * (size_t)n_pad * sizeof(InT) <= (size_t)c->scratch_bytes;
+    if (!can_gather) {
+        std::vector<u32> merged(hf, hf + W);
+        if (wide_skipped) { // (k_wide_decide only leaves the stage to us when the gather is possible; an option changed in between)
+            std::vector<u32> init((size_t)W), hf2;
+            for (int64_t j = 0; j < W; ++j) init[j] = hf[j] == 1u ? 1u : 3u;
+            if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags & ~ILLICO_FLAG_DEFER, alternative, o, 0, hf2, -1, false, 0, init.data()))) return rc;
+            for (int64_t j = 0; j < W; ++j) merged[j] = ((hf[j] == 1u || hf[j] == 3u) && hf2[j] != 2u) ? 1u : 0u;
+        }
+        if (outer) { // a narrow matrix whose leftovers cannot be gathered again: all of it as one window, through the map
+            if ((rc = get_scratch(c, "xleft_outer", (size_t)W * 4, &v))) return rc;
+            HIPCHK(c, hipMemcpyAsync(v, outer, (size_t)W * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::vector<std::pair<int64_t, int64_t>> all{{col_lb, col_ub}};
+            return run_dense_twopass<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, all, (const int *)v, true);
+        }
+        std::vector<std::pair<int64_t, int64_t>> runs;
+        flagged_runs(merged.data(), W, col_lb, runs);
+        return run_dense_twopass<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, runs);
+    }
+    if ((rc = get_scratch(c, outer ? "xleft2" : "xleft", (size_t)N * (size_t)n_pad * sizeof(InT), &v))) return rc;
     InT *xl = (InT *)v;
-    if ((rc = get_scratch(c, "xleft_cols", (size_t)n * 8, &v))) return rc;
+    if ((rc = get_scratch(c, outer ? "xleft2_cols" : "xleft_cols", (size_t)n * 12, &v))) return rc;
     int *d_src = (int *)v, *d_dst = d_src + n;
+    u32 *d_flags2 = (u32 *)(d_dst + n);
     HIPCHK(c, hipMemcpyAsync(d_src, src.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_dst, dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     {
@@ -1387,8 +1430,32 @@ static int run_leftovers(illico_ctx *c, const void *X, int dtype, int64_t N, int
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); // (the host lists go out of scope)
+    const int lflags = (flags | ILLICO_FLAG_INPUT_DEVICE) & ~ILLICO_FLAG_DEFER;
+    if (wide_skipped) {
+        std::vector<u32> init((size_t)n), hf2;
+        bool any = false;
+        for (int64_t j = 0; j < n; ++j) { init[j] = hf[src[j] - col_lb] == 1u ? 1u : 3u; any = any || init[j] == 1u; }
+        if (any) {
+            if ((rc = get_scratch(c, "wide_tmp", (size_t)3 * G * (size_t)n_pad * 8, &v))) return rc;
+            double *tp = (double *)v;
+            const OutPlanes ot{tp, tp + (size_t)G * n_pad, tp + (size_t)2 * G * n_pad, n_pad, false};
+            if ((rc = run_fused_ovo<InT>(c, xl, n_pad, 0, (int)n, lflags, alternative, ot, 0, hf2, -1, false, 0, init.data()))) return rc;
+            HIPCHK(c, hipMemcpyAsync(d_flags2, hf2.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            {
+                ProfScope ps(c, KID_GATHER_COLS);
+                const dim3 grid((unsigned)((n + 255) / 256), (unsigned)std::min(G, 1024));
+                hipLaunchKernelGGL(k_scatter_planes, grid, dim3(256), 0, c->stream, (const double *)ot.p, (const double *)ot.u, (const double *)ot.fc, (long long)n_pad,
+                                   (const int *)d_dst, (const u32 *)d_flags2, 2u, (int)n, G, o.p, o.u, o.fc, (long long)o.ld);
+                HIPCHK(c, hipGetLastError());
+            }
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::vector<u32> hf3((size_t)n);
+            for (int64_t j = 0; j < n; ++j) hf3[j] = hf2[j] == 2u ? 0u : 1u;
+            return run_leftovers<InT, KeyT>(c, xl, dtype, N, n_pad, 0, n, lflags, alternative, o, hf3.data(), false, dst.data());
+        }
+    }
     std::vector<std::pair<int64_t, int64_t>> runs{{0, n}};
-    return run_dense_twopass<InT, KeyT>(c, xl, dtype, N, n_pad, 0, n, flags | ILLICO_FLAG_INPUT_DEVICE, alternative, o, runs, d_dst, true);
+    return run_dense_twopass<InT, KeyT>(c, xl, dtype, N, n_pad, 0, n, lflags, alternative, o, runs, d_dst, true);
 }
 
 template <typename InT, typename KeyT>
@@ -1411,17 +1478,20 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
         // ILLICO_FLAG_DEFER (device planes only): enqueue and return; the flags are looked at by resolve_pending
         const bool defer = (flags & ILLICO_FLAG_DEFER) && (flags & ILLICO_FLAG_OUTPUT_DEVICE) && !o.staged;
         std::vector<u32> hf;
+        // how many flagged columns run_leftovers could gather (0: it could not) -- the bound under which the device may leave the
+        // 256-value stage to it (k_wide_decide)
+        const int64_t max_gather = (c->no_leftover_gather || col_ub > 0x7FFFFFFFll) ? 0 : (int64_t)((size_t)c->scratch_bytes / ((size_t)N * sizeof(InT))) & ~63ll;
         if (defer) {
             const int slot = c->pend_next;
-            if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf, slot, ovr))) return rc;
+            if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf, slot, ovr, max_gather))) return rc;
             c->pend_next ^= 1;
             PendingDense &q = c->pend;
             q.on = true; q.kind = 0; q.X = X; q.dtype = dtype; q.flags = flags & ~ILLICO_FLAG_DEFER; q.alternative = alternative; q.slot = slot;
             q.N = N; q.ld = ld; q.col_lb = col_lb; q.col_ub = col_ub; q.out_ld = o.ld; q.p = o.p; q.u = o.u; q.fc = o.fc;
             return ILLICO_OK;
         }
-        if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf, -1, ovr))) return rc;
-        return run_leftovers<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, hf.data());
+        if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf, -1, ovr, max_gather))) return rc;
+        return run_leftovers<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, hf.data(), hf[W] != 0u);
     } else if (!in_dev && try_fused && N > 0 && W > 0 && host_window_is_count_valued<InT>((const InT *)X, ld, col_lb, N, W)) {
         // host matrix: column windows travel through pinned staging slots (host_windows_pipeline below) and take the same fused pass
         HostLeftovers left;
@@ -1636,13 +1706,14 @@ static int resolve_pending(illico_ctx *c, PendingDense q) {
     HIPCHK(c, hipEventSynchronize(c->pend_event[q.slot]));
     if (q.kind == 1) return resolve_pending_csc(c, q);
     const u32 *hf = (const u32 *)c->pend_pinned[q.slot];
+    const bool skipped = hf[q.col_ub - q.col_lb] != 0u; // the 256-value stage was left to run_leftovers (k_wide_decide)
     const OutPlanes o{q.p, q.u, q.fc, q.out_ld, false};
     switch (q.dtype) {
-    case ILLICO_F32: return run_leftovers<float, u32>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf);
+    case ILLICO_F32: return run_leftovers<float, u32>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf, skipped);
 #ifndef ILLICO_DEV_F32_ONLY
-    case ILLICO_F64: return run_leftovers<double, u64>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf);
-    case ILLICO_I32: return run_leftovers<int32_t, u32>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf);
-    default: return run_leftovers<int64_t, u64>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf);
+    case ILLICO_F64: return run_leftovers<double, u64>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf, skipped);
+    case ILLICO_I32: return run_leftovers<int32_t, u32>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf, skipped);
+    default: return run_leftovers<int64_t, u64>(c, q.X, q.dtype, q.N, q.ld, q.col_lb, q.col_ub, q.flags, q.alternative, o, hf, skipped);
 #else
     default: return fail(c, ILLICO_ERR_DTYPE, "this development build holds the float32 kernels only");
 #endif

@@ -6,6 +6,8 @@
 //   k_gather_columns   copies the flagged columns into a narrow row-major matrix of their own (one pass over the rows; the
 //                      flagged genes then form ONE contiguous window for the two-pass routes, whose results k_finalize scatters
 //                      back through a column map);
+//   k_scatter_planes   the 256-value stage run on that narrow matrix (run_leftovers, when k_wide_decide left the stage to the host) writes
+//                      planes of its own; the finished columns go from there into the caller's planes;
 //   k_ovr_counts       dense OVR for integer-valued genes below OVRC_R = 32768: the column's histogram in LDS (one 128-KB table,
 //                      one workgroup per gene), turned in place into the doubled-rank table 2 cum[v] + t[v] + 1, then one
 //                      wavefront per group sums the table entries of the group's cells.  No sort, no per-group histogram:
@@ -29,6 +31,21 @@ __global__ __launch_bounds__(256) void k_gather_columns(const InT *__restrict__ 
         const long long col = j < n ? (long long)cols[j] : -1;
         if (j < n_pad)
             for (int r = r0; r < r1; ++r) dst[(size_t)r * dst_ld + dst_col0 + j] = col >= 0 ? src[(size_t)r * ld + col] : (InT)0;
+    }
+}
+
+// columns j < n of three [G][ld] planes whose flags[j] == want -> column map[j] of the caller's planes.  grid (column blocks, group blocks)
+__global__ __launch_bounds__(256) void k_scatter_planes(const double *__restrict__ p, const double *__restrict__ u, const double *__restrict__ fc, long long ld,
+                                                        const int *__restrict__ map, const u32 *__restrict__ flags, u32 want, int n, int G,
+                                                        double *op, double *ou, double *ofc, long long out_ld) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n || flags[j] != want) return;
+    const long long dst = map[j];
+    for (int g = blockIdx.y; g < G; g += gridDim.y) {
+        const size_t i = (size_t)g * ld + j, o = (size_t)g * out_ld + dst;
+        op[o] = p[i];
+        ou[o] = u[i];
+        ofc[o] = fc[i];
     }
 }
 

@@ -50,6 +50,7 @@ struct FusedParams {
     u32 *group_hist;          // OVR one-pass form: [G][tiles][RT * CB / 32][64] words, per-(group, gene) value histograms
     u32 *wide_tiles;          // WIDE: [0] = number of tiles with candidates, [1 ..] = those tiles (k_fused_ref<WIDE> appends)
     u32 *wide_bad;            // OVR second stage: [ncols] set when a column shows a value outside the 256-value table too
+    const u32 *wide_skip;     // WIDE: *wide_skip != 0 (k_wide_decide): the 256-value stage is left to the host (every WIDE kernel returns at once)
     const u32 *hist_off;      // OVR one-pass form, mixed cell widths: [G + 1] words per lane before group g (16 for a group of <= 255 cells, else 32)
 };
 
@@ -224,6 +225,27 @@ __global__ __launch_bounds__(256) void k_fused_probe(FusedParams P) {
     if (bad) P.gene_flags[gene] = hopeless ? 3u : 1u; // 3: as 1 (the host's two-pass routes), and skipped by the 256-value stage
 }
 
+// After the 64-value pass: is the 256-value stage worth running over the window as it lies?  It reads every row of every tile that holds
+// a flagged gene again, at one or two workgroups per CU.  When most tiles hold one (a heavy-tailed count matrix: 20 % of the genes beyond
+// 63 put one in EVERY tile, and the stage re-reads the whole matrix at 2 TB/s) and the flagged genes are few enough to be gathered, the
+// stage is left to the host, which gathers the flagged columns into a narrow matrix and runs it there (run_leftovers).  One workgroup.
+__global__ __launch_bounds__(1024) void k_wide_decide(const u32 *__restrict__ gene_flags, int ncols, int max_gather, u32 *skip) {
+    __shared__ u32 s_tiles, s_genes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tiles = (ncols + 63) / 64;
+    if (tid == 0) { s_tiles = 0; s_genes = 0; }
+    __syncthreads();
+    u32 t_cnt = 0, g_cnt = 0;
+    for (int t = wave; t < tiles; t += 16) {
+        const int gene = t * 64 + lane;
+        const u32 f = gene < ncols ? gene_flags[gene] : 0u;
+        t_cnt += __any(f == 1u) ? 1u : 0u;
+        g_cnt += (u32)__popcll(__ballot(f == 1u || f == 3u));
+    }
+    if (lane == 0) { atomicAdd(&s_tiles, t_cnt); atomicAdd(&s_genes, g_cnt); }
+    __syncthreads();
+    if (tid == 0) *skip = (s_tiles >= 8u && s_tiles * 4u > (u32)tiles && s_genes * 2u <= (u32)ncols && s_genes <= (u32)max_gather) ? 1u : 0u;
+}
+
 // ---- reference tables: one 1024-thread workgroup per 64-gene tile; lane = gene.  All 16 wavefronts add into one
 // LDS histogram (columns are lane-private, so the only contention is between wavefronts), then wavefront 0 scans
 // each gene's bins into the cumulative table, T_A and the reference sum, and writes the reference group's row.
@@ -242,6 +264,7 @@ __global__ __launch_bounds__(FUSED_REF_NT) void k_fused_ref(FusedParams P) {
     const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
     const bool act = gene < P.ncols;
     if (WIDE) {
+        if (P.wide_skip && *P.wide_skip) return; // uniform
         if (wave == 0) {
             const bool want = act && P.gene_flags[gene] == 1u;
             const bool any = __any(want);
@@ -371,6 +394,7 @@ __global__ __launch_bounds__(FUSED_NT) void k_fused_hist_all(FusedParams P) {
     const int gene0 = blockIdx.x * 64, gene = gene0 + lane;
     const bool act = gene < P.ncols;
     if (WIDE) {
+        if (P.wide_skip && *P.wide_skip) return; // uniform
         if (wave == 0) {
             const bool want = act && P.gene_flags[gene] == 1u;
             const bool any = __any(want);
@@ -416,6 +440,7 @@ template <int RT, bool WIDE = false> __global__ void k_fused_tables_all(FusedPar
     const int gene = blockIdx.x * blockDim.x + threadIdx.x;
     if (gene >= P.ncols) return;
     if (WIDE) {
+        if (P.wide_skip && *P.wide_skip) return;
         if (P.gene_flags[gene] != 1u || P.wide_bad[gene] != 0u) return;
         P.gene_flags[gene] = 2u;
         u32 *tile_mark = P.wide_bad + P.ncols; // [tiles]
@@ -469,6 +494,7 @@ __global__ __launch_bounds__(FUSED_NT, WIDE ? (OVR ? 2 : 1) : ((OVR || CB == 8) 
     // every workgroup leaves at once.  A grid of one workgroup per item cost 0.08 ms at C2 for nothing: 31 250 workgroups
     // that each wait for a whole CU's LDS.
     const int n_chunks = (P.G + P.groups_per_wg - 1) / P.groups_per_wg;
+    if (WIDE && P.wide_skip && *P.wide_skip) return; // uniform
     const int n_items = WIDE ? (int)P.wide_tiles[0] * n_chunks : 1;
     for (int item = WIDE ? (int)blockIdx.x : 0; item < n_items; item += WIDE ? (int)gridDim.x : 1) {
     const int tile = WIDE ? __builtin_amdgcn_readfirstlane((int)P.wide_tiles[1 + item / n_chunks]) : (int)blockIdx.x; // (uniform: scalar row bases below)

@@ -430,8 +430,10 @@ def test_ovo_counts_table_is_4096_values_while_groups_stay_below_256_cells(engin
 def test_scattered_big_count_genes_are_gathered_and_take_the_histogram_routes(engine, test, where):
     """A count matrix whose highly expressed genes lie beyond the fused tables (64 .. 255: second pass; beyond: the genes are
     gathered into a narrow matrix and take k_ovo_counts / k_ovr_counts, a fractional gene and one beyond every table the sort
-    routes) -- device-resident, deferred and host-resident input (the host windows gather their flagged columns on the device);
-    identical to recomputing the column runs (`no_leftover_gather`)."""
+    routes) -- device-resident, deferred and host-resident input (the host windows gather their flagged columns on the device).  Most
+    tiles hold a flagged gene here, so on device-resident input the 256-value stage is left to the host and runs on the gathered
+    columns (k_wide_decide); identical to recomputing the column runs (`no_leftover_gather`) and to the stage run in place
+    (`no_wide_gather`)."""
     import torch
     rng = np.random.RandomState(77)
     n, m, G = 20000, 640, 40
@@ -466,10 +468,11 @@ def test_scattered_big_count_genes_are_gathered_and_take_the_histogram_routes(en
     engine.profile(False)
     assert "k_gather_columns" in prof and ("k_ovo_counts" if test == "ovo" else "k_ovr_counts") in prof, prof
     assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"big counts {test} {where}")
-    engine.set_option("no_leftover_gather", 1)
-    try:
-        again = run()
-    finally:
-        engine.set_option("no_leftover_gather", 0)
-    for a, b in zip(got, again):
-        np.testing.assert_array_equal(a, b)
+    for option in ("no_leftover_gather", "no_wide_gather"):  # ... and to running the 256-value stage over the window as it lies
+        engine.set_option(option, 1)
+        try:
+            again = run()
+        finally:
+            engine.set_option(option, 0)
+        for a, b in zip(got, again):
+            np.testing.assert_array_equal(a, b, err_msg=option)
