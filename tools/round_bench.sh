@@ -21,7 +21,6 @@ b c3_cont_ovo --workload c3 --values continuous --no-c5 --steps 10
 b c3_cont_ovr --workload c3 --values continuous --test ovr --no-c5 --steps 10
 b c3_csr --workload c3 --format csr --no-c5 --steps 10
 b c3_csr_ovr --workload c3 --format csr --test ovr --no-c5 --steps 10
-b c2_host --workload c2 --input host --no-c5 --steps 3 --warmup 1
 p() { name=$1; shift; bash tools/profile_bench.sh ${T}_$name "$@" > $O/prof_$name.log 2>&1; echo "profile $name rc=$?"; }
 p c2 --workload c2
 p c3 --workload c3
@@ -31,3 +30,4 @@ p c5shard --workload c5shard
 p c2_nb --workload c2 --values nb
 p c2_cont_ovr --workload c2 --values continuous --test ovr
 p c3_cont_ovr --workload c3 --values continuous --test ovr
+p c2_nb_ovr --workload c2 --values nb --test ovr
