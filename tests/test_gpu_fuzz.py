@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _env_seeds():
-    """ILLICO_FUZZ_SEEDS="40-99,106-130": more seeds for a one-off sweep (below 100: small cases, from 100: large ones)."""
+    """ILLICO_FUZZ_SEEDS="40-99,106-130,206-260": more seeds for a one-off sweep (below 100: small cases, from 100: large ones, from 200: heavy-tailed counts among them)."""
     out = []
     for part in filter(None, os.environ.get("ILLICO_FUZZ_SEEDS", "").split(",")):
         a, _, b = part.partition("-")
@@ -41,13 +41,17 @@ def _case(seed):
         n = int(rng.choice([37, 150, 600, 2500]))
         m = int(rng.choice([1, 7, 64, 65, 130, 300]))
         G = int(rng.randint(2, min(40, n // 2) + 1))
-    kind = rng.choice(["counts", "counts-large", "continuous", "mixed"])
+    # (from seed 200: also heavy-tailed counts -- log-normal gene means: most 64-gene tiles hold a gene beyond the 64-value table, a few
+    # genes go beyond 255 / 2047 / 4095: the 256-value stage on gathered columns, the histogram kernels, the sort routes)
+    kind = rng.choice(["counts", "counts-large", "continuous", "mixed"] + (["counts-heavy"] * 3 if seed >= 200 else []))
     density = float(rng.choice([0.02, 0.1, 0.5, 1.0]))
     mask = rng.rand(n, m) < density
     if kind == "counts":
         X = rng.poisson(rng.uniform(0.2, 8.0, size=m), size=(n, m)) * mask
     elif kind == "counts-large":
         X = rng.poisson(rng.uniform(0.2, 90.0, size=m), size=(n, m)) * mask
+    elif kind == "counts-heavy":
+        X = rng.poisson(np.exp(rng.normal(2.0, 1.9, size=m)).clip(0.05, 5000.0), size=(n, m)) * mask
     elif kind == "continuous":
         X = np.log1p(rng.poisson(3.0, size=(n, m)) * rng.uniform(0.5, 1.5, size=(n, m))) * mask
     else:
@@ -61,6 +65,8 @@ def _case(seed):
     X = X.astype(dtype).astype(np.float64)
     lb = int(rng.randint(0, m))
     ub = int(rng.randint(lb + 1, m + 1))
+    if kind == "counts-heavy":  # the whole width: enough tiles for the device to leave the 256-value stage to the gathered columns
+        lb, ub = 0, m
     opts = dict(use_continuity=bool(rng.randint(2)), tie_correct=bool(rng.randint(2)),
                 alternative=str(rng.choice(["two-sided", "less", "greater"])),
                 is_log1p=bool(kind == "continuous" and rng.rand() < 0.5))
@@ -68,7 +74,7 @@ def _case(seed):
     return X, dtype, labels, ref, lb, ub, opts, kind
 
 
-@pytest.mark.parametrize("seed", list(range(40)) + [100, 101, 102, 103, 104, 105] + _env_seeds())
+@pytest.mark.parametrize("seed", list(range(40)) + [100, 101, 102, 103, 104, 105, 200, 201, 202, 203, 204, 205] + _env_seeds())
 def test_random_case_all_input_paths(engine, seed):
     import torch
     X, dtype, labels, ref, lb, ub, opts, kind = _case(seed)
