@@ -90,6 +90,9 @@ int illico_ctx_set_stream(illico_ctx *ctx, void *hip_stream);
  * "no_ovo_ref_buckets" (OVO sort route: reference column in value buckets instead of sorted), "no_ovr_parts_path" (dense OVR, any values: value-range parts ranked in LDS; "ovr_parts_cap" > 0 caps the keys per part), "no_csc_gene_path" (CSC OVO single-kernel route), "no_csc_ovr_gene_path" (CSC OVR single-kernel route; "csc_ovr_sorted_form" = 1 makes it sort every
  * gene in LDS, the form tie-heavy columns take, instead of bucketing the keys), "no_csc_regroup_lds" (two-kernel CSC route: regroup with scattered
  * stores only),
+ * "no_fused_wide" (the 256-value second stage of the fused routes), "no_wide_gather" (that stage always over the window as it lies, never
+ * on the gathered columns), "no_leftover_gather" (the genes the fused passes leave are recomputed as column runs of the input instead
+ * of being gathered into a narrow matrix),
  * "no_dense_window_path" (CSR through dense windows; "dense_window_f32" = 1: float32 cells instead of bytes), "no_csr_transpose_path" / "no_csr_tile_gather"
  * (CSR -> CSC transposition on the device / its gather form for sorted rows).  Unknown keys return ILLICO_ERR_ARG. */
 int illico_ctx_set_option(illico_ctx *ctx, const char *key, int64_t value);
