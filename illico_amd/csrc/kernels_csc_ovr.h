@@ -142,41 +142,43 @@ template <typename InT, typename IdxT, typename KeyT, bool PARTS> struct OvrSour
     }
 };
 
-// for every entry k in [k0, k1), 8 per thread and round: body(u, k, key, nz, code).  Two-stage pipeline: the raw loads of
-// the next round are issued before this round's code gather and body.
+// for every entry k in [k0, k1), UL per thread and round: body(u, k, key, nz, code).  Two-stage pipeline: the raw loads of the next
+// round are issued before this round's code gather and bodies.  No load sits under a per-lane condition (hipcc gives each such load a
+// basic block of its own: `s_and_saveexec` + branch): a round's requests are clamped to the column's last entry, full rounds run
+// their bodies unconditionally, only the last, partial round checks each entry.
 template <bool WANT_CODE, int NT, int UL, typename Src, typename KeyT, typename Body>
 __device__ __forceinline__ void ovr_for_entries(const Src &src, long long k0, long long k1, int tid, Body &&body) {
+    constexpr int PER = NT * UL;
+    const int n = (int)(k1 - k0); // (a column / a part: at most key_cap entries)
+    if (n <= 0) return;
     typename Src::RawV vn[UL];
     typename Src::RawI in[UL];
+    auto request = [&](int base) {
 #pragma unroll
-    for (int u = 0; u < UL; ++u) {
-        const long long k = k0 + u * NT + tid;
-        vn[u] = src.raw_v(k, k < k1);
-        if (WANT_CODE) in[u] = src.raw_i(k, k < k1);
-    }
-    for (long long kb = k0; kb < k1; kb += (long long)NT * UL) {
+        for (int u = 0; u < UL; ++u) {
+            const long long k = k0 + min(base + u * NT + tid, n - 1);
+            vn[u] = src.raw_v(k, true);
+            if (WANT_CODE) in[u] = src.raw_i(k, true);
+        }
+    };
+    request(0);
+    for (int base = 0; base < n; base += PER) {
         KeyT key[UL];
         bool nz[UL];
         int cd[UL];
 #pragma unroll
         for (int u = 0; u < UL; ++u) {
-            const long long k = kb + u * NT + tid;
-            key[u] = src.key_from(vn[u], k < k1, nz[u]);
+            key[u] = src.key_from(vn[u], true, nz[u]);
             cd[u] = WANT_CODE ? src.code_from(in[u]) : 0;
         }
-        const long long kn = kb + (long long)NT * UL;
-        if (kn < k1) { // uniform
+        if (base + PER < n) request(base + PER); // uniform
+        if (base + PER <= n) { // uniform: a full round
 #pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                const long long k = kn + u * NT + tid;
-                vn[u] = src.raw_v(k, k < k1);
-                if (WANT_CODE) in[u] = src.raw_i(k, k < k1);
-            }
-        }
+            for (int u = 0; u < UL; ++u) body(u, k0 + base + u * NT + tid, key[u], nz[u], cd[u]);
+        } else {
 #pragma unroll
-        for (int u = 0; u < UL; ++u) {
-            const long long k = kb + u * NT + tid;
-            if (k < k1) body(u, k, key[u], nz[u], cd[u]);
+            for (int u = 0; u < UL; ++u)
+                if (base + u * NT + tid < n) body(u, k0 + base + u * NT + tid, key[u], nz[u], cd[u]);
         }
     }
 }
