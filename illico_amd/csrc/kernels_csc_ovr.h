@@ -634,6 +634,13 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
         int gcur = P.blk_g0[b];
         const int glast = P.blk_g1[b];
         int gend = gcur < glast ? (int)nnz[gcur] : 0; // offset (inside the block) where group gcur's keys end
+        // A block of at most 64 groups (the usual case: ~7 groups of ~150 cells per 1024 rows) keeps its group ends in ONE register,
+        // lane l = the offset where group g0 + l ends: the walks below then read a lane instead of loading nnz[g] from memory -- a
+        // chain of dependent loads per 64-key piece otherwise.
+        const int g0 = gcur, ng = glast - g0;
+        const bool ends_in_lanes = ng <= 64;
+        int endv = 0, gi = 0; // gi: gcur - g0
+        if (ends_in_lanes) endv = wave_incl_scan_add(lane < ng ? (int)nnz[g0 + lane] : 0);
         for (int o = 0; o < n_b; o += 64 * UL) {
             KeyT k[UL];
 #pragma unroll
@@ -644,7 +651,17 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
                 if (o + u * 64 >= n_b) break; // uniform
                 // group code: gcur + the group ends at or below this key's offset (empty groups repeat an end: skipped over)
                 int cd = gcur;
-                {
+                if (ends_in_lanes) { // uniform
+                    const int piece_end = o + u * 64 + 64;
+                    cd = g0 + gi;
+                    int j = gi, e = __builtin_amdgcn_readlane(endv, __builtin_amdgcn_readfirstlane(gi));
+                    while (e < piece_end && j + 1 < ng) { // uniform
+                        cd += off >= e ? 1 : 0;
+                        ++j;
+                        e = __builtin_amdgcn_readlane(endv, __builtin_amdgcn_readfirstlane(j));
+                    }
+                    while (gi + 1 < ng && __builtin_amdgcn_readlane(endv, __builtin_amdgcn_readfirstlane(gi)) <= piece_end) ++gi;
+                } else {
                     int g = gcur, e = gend;
                     while (e < o + u * 64 + 64 && g + 1 < glast) { // uniform
                         cd += off >= e ? 1 : 0;

@@ -121,10 +121,19 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
 
     // chunk cursors (uniform scalars): group, chunk inside it, the group's rows and first position -- one for the loads being
     // issued (i*), one for the chunk being packed (c*)
+    // a block of fewer than 64 groups (the usual case) keeps its group boundaries in one register, lane l = pos_ptr[gA + l]: moving to
+    // the next group then reads two lanes instead of waiting for two loads
+    const int ngb = gB - gA;
+    const bool pp_in_lanes = seg < 0 && ngb < 64;
+    const int ppv = pp_in_lanes ? P.pos_ptr[gA + min(lane, ngb)] : 0;
     auto grp_rows = [&](int g, int &n, int &row0) {
         if (g >= gB) { n = 0; row0 = 0; }
         else if (seg >= 0) { row0 = seg_row0; n = seg_n; }
-        else { row0 = P.pos_ptr[g]; n = P.pos_ptr[g + 1] - row0; }
+        else if (pp_in_lanes) {
+            const int l = __builtin_amdgcn_readfirstlane(g - gA);
+            row0 = __builtin_amdgcn_readlane(ppv, l);
+            n = __builtin_amdgcn_readlane(ppv, l + 1) - row0;
+        } else { row0 = P.pos_ptr[g]; n = P.pos_ptr[g + 1] - row0; }
     };
 #define GCMP_CUR_SKIP(g, c, n, row0) while (g < gB && n == 0) { ++g; c = 0; grp_rows(g, n, row0); }
 #define GCMP_CUR_NEXT(g, c, n, row0) { ++c; if (c * 64 >= n) { ++g; c = 0; grp_rows(g, n, row0); GCMP_CUR_SKIP(g, c, n, row0) } }
