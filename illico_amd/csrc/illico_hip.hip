@@ -121,6 +121,7 @@ struct illico_ctx {
     bool no_ovr_packed_partition = false; // 1: dense OVR partitions the padded rows (every key) instead of the packed ones
     bool no_packed_dense = false;      // 1: dense OVO on continuous values takes the transpose + k_ovo_rank route (no group-wise packing)
     int packed_eq_buckets = -1;        // packed rank kernel: distribution-following bucket function; -1 = for references above 16384 cells
+    bool ovr_full_dump = false;        // 1: the one-pass OVR route dumps whole group histograms (A/B of the shortened dump)
     bool no_wide_gather = false;       // 1: the 256-value stage always runs over the window as it lies (never left to the host's gather)
     bool no_leftover_gather = false;   // 1: the genes the fused passes leave are recomputed as column runs of the input (no gather into a narrow matrix)
     bool no_fused_wide = false;        // 1: no second, 256-value pass of the fused OVO route (genes beyond 63 go to the two-pass routes)
@@ -358,6 +359,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_fused_wide")) c->no_fused_wide = value != 0;
     else if (!strcmp(key, "no_leftover_gather")) c->no_leftover_gather = value != 0;
     else if (!strcmp(key, "no_wide_gather")) c->no_wide_gather = value != 0;
+    else if (!strcmp(key, "ovr_full_dump")) c->ovr_full_dump = value != 0;
     else if (!strcmp(key, "no_packed_dense")) c->no_packed_dense = value != 0;
     else if (!strcmp(key, "packed_eq_buckets")) c->packed_eq_buckets = (int)value;
     else if (!strcmp(key, "no_ovr_packed_partition")) c->no_ovr_packed_partition = value != 0;
@@ -962,6 +964,9 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     P.wide_tiles = nullptr;
     P.wide_bad = nullptr;
     P.hist_off = nullptr;
+    P.hist_words = nullptr;
+    P.hist_full = c->ovr_full_dump ? 1 : 0;
+    P.hist_total = (long long)c->hist_words;
     u32 *skipw = P.hist_all + (size_t)nb * RT; // (inside the 64 spare bytes of the allocation)
     P.wide_skip = skipw;
     const bool wide_only = init_flags != nullptr;
@@ -975,7 +980,9 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
     int gpw = c->fused_groups_per_wg;
     if (gpw <= 0) { // 8 groups per workgroup (two per wavefront) measured best at C2 (4: +2 %, 16: +1 %, 32: +3 %: shorter
         // workgroups leave a shorter tail at the end of the launch); keep >= ~2048 workgroups on smaller problems
-        gpw = 8;
+        // OVR (k_ovr_group_hists): a workgroup ends by adding its share of the column histogram to the global one -- same-process A/B
+        // at C4 (tools/ab.py): 8 / 16 / 32 groups per workgroup 2.601 / 2.589 / 2.614 ms; 4: +36 %
+        gpw = ovr ? 16 : 8;
         while (gpw > 4 && (int64_t)tiles * ((c->n_groups + gpw - 1) / gpw) < 2048) gpw >>= 1;
     }
     P.groups_per_wg = gpw = std::min(gpw, 128); // (k_ovr_group_hists packs a workgroup's cells into 16-bit fields: 128 x 255 < 2^16)
@@ -1066,6 +1073,8 @@ static int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, i
         if (!c->no_ovr_one_pass && hist_bytes <= (size_t)c->scratch_bytes) {
             if ((rc = get_scratch(c, "group_hist", hist_bytes, &v))) return rc;
             P.group_hist = (u32 *)v;
+            if ((rc = get_scratch(c, "group_hist_words", (size_t)c->n_groups * tiles, &v))) return rc;
+            P.hist_words = (unsigned char *)v;
             P.hist_off = c->d_hist_off;
             {
                 ProfScope ps(c, KID_OVR_FUSED);

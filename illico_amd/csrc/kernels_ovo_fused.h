@@ -47,9 +47,12 @@ struct FusedParams {
     double *out_p, *out_u, *out_fc; // [G][out_ld], already offset to column col0's slot
     long long out_ld;
     int groups_per_wg;
-    u32 *group_hist;          // OVR one-pass form: [G][tiles][RT * CB / 32][64] words, per-(group, gene) value histograms
+    u32 *group_hist;          // OVR one-pass form: [tiles][G][RT * CB / 32][64] words, per-(group, gene) value histograms
     u32 *wide_tiles;          // WIDE: [0] = number of tiles with candidates, [1 ..] = those tiles (k_fused_ref<WIDE> appends)
     u32 *wide_bad;            // OVR second stage: [ncols] set when a column shows a value outside the 256-value table too
+    long long hist_total;      // OVR one pass, width per group: words per lane of ALL groups (hist_off[G])
+    int hist_full;             // 1: k_ovr_group_hists writes every word of every histogram (option "ovr_full_dump", A/B)
+    unsigned char *hist_words; // OVR one pass: [G][tiles] words of a (group, tile) histogram that were written (the rest are zero)
     const u32 *wide_skip;     // WIDE: *wide_skip != 0 (k_wide_decide): the 256-value stage is left to the host (every WIDE kernel returns at once)
     const u32 *hist_off;      // OVR one-pass form, mixed cell widths: [G + 1] words per lane before group g (16 for a group of <= 255 cells, else 32)
 };
@@ -673,12 +676,30 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_ovr_group_hists(FusedParams P) 
             if constexpr (U > 16) { if (p + 16 <= p1) chunk(std::integral_constant<int, 16>(), full_t()); }
             if (p + 8 <= p1) chunk(std::integral_constant<int, 8>(), full_t());
             if (p < p1) chunk(std::integral_constant<int, 8>(), pred_t());
-            const size_t base = CB ? ((size_t)g * tiles + blockIdx.x) * (BW * 64) : ((size_t)P.hist_off[g] * tiles + (size_t)blockIdx.x * BW) * 64;
+            // layout [tile][group][word][lane]: the workgroup's wavefronts (consecutive groups) write neighbouring slots, and
+            // k_ovr_from_hists walks a tile's groups through consecutive memory
+            const size_t base = CB ? ((size_t)blockIdx.x * P.G + g) * (BW * 64) : ((size_t)blockIdx.x * P.hist_total + P.hist_off[g]) * 64;
             u32 *dst = P.group_hist + base + lane;
+            // Only the words up to the last one that is non-zero in ANY of the tile's 64 genes leave (in fours): a group of ~150 cells
+            // with Poisson means up to 15 reaches value ~30, half of the 64-value table -- the dump was 0.42 ms of this kernel's
+            // 2.14 at C4 (1.03 GB), the words beyond hold zeros that k_ovr_from_hists need not read either.  hist_words[g][tile] says
+            // how many were written.
+            u32 wv[BW];
+            u32 nzm = 0;
+#pragma unroll
+            for (int i = 0; i < BW; ++i) { wv[i] = cbw[i * 64 + lane]; nzm |= wv[i] ? (1u << i) : 0u; }
+            const int nwl = nzm ? 32 - __clz(nzm) : 0;
+            const int nw = P.hist_full ? BW : (__builtin_amdgcn_readlane(wave_incl_scan_max(nwl), 63) + 3) & ~3; // (hist_full: A/B switch)
+#pragma unroll
+            for (int q = 0; q < BW; q += 4)
+                if (q < nw) { // uniform
+#pragma unroll
+                    for (int i = q; i < q + 4; ++i) dst[i * 64] = wv[i];
+                }
+            if (lane == 0) P.hist_words[(size_t)blockIdx.x * P.G + g] = (unsigned char)nw;
 #pragma unroll
             for (int i = 0; i < BW; ++i) {
-                const u32 w = cbw[i * 64 + lane];
-                dst[i * 64] = w;
+                const u32 w = wv[i];
                 cbw[i * 64 + lane] = 0;
                 if (CBG == 8) { // four 8-bit cells: values 4 i .. 4 i + 3
                     const u32 x0 = w & 0x00FF00FFu, x1 = (w >> 8) & 0x00FF00FFu;
@@ -721,6 +742,13 @@ __global__ __launch_bounds__(FUSED_NT, NPL == 3 ? 3 : 2) void k_ovr_from_hists(F
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene = blockIdx.x * 64 + lane;
     const bool act = gene < P.ncols;
+    const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
+    const size_t tiles = gridDim.x;
+    // how many words each of this wavefront's groups left (k_ovr_group_hists): lane j <-> its j-th group, read once -- by every lane,
+    // before the lanes of flagged genes leave (the values are read back with v_readlane)
+    const int my_g = gbeg + wave + lane * NW;
+    int nwv = my_g < gend ? (int)P.hist_words[(size_t)blockIdx.x * P.G + my_g] : 0;
+    asm volatile("" : "+v"(nwv)); // (the load stays in front of the exit below: the compiler may otherwise sink it to the lanes that remain)
     if (!act || P.gene_flags[gene] != 0) return; // flagged genes are recomputed by the slower routes
     const u32 *cum = P.ref_cum + (size_t)blockIdx.x * (64 * CSTR) + lane;
     u32 bp[NPL][BW8]; // bp[k][i]: byte k of s[4 i .. 4 i + 3]
@@ -744,19 +772,31 @@ __global__ __launch_bounds__(FUSED_NT, NPL == 3 ? 3 : 2) void k_ovr_from_hists(F
     const u64 T_A = P.ref_TA[gene];
     const double total = (double)P.ref_sum[gene], cc = P.use_continuity ? 0.5 : 0.0;
     const double tie = P.tie_correct ? (double)T_A : 0.0;
-    const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
-    const size_t tiles = gridDim.x;
     auto narrow = [&](int g) { return CB == 8 || P.counts[g] <= 255; }; // uniform
     auto hist_of = [&](int g, int bw) {
-        const size_t base = CB ? ((size_t)g * tiles + blockIdx.x) * (BW8 * 64) : ((size_t)P.hist_off[g] * tiles + (size_t)blockIdx.x * bw) * 64;
+        const size_t base = CB ? ((size_t)blockIdx.x * P.G + g) * (BW8 * 64) : ((size_t)blockIdx.x * P.hist_total + P.hist_off[g]) * 64;
+        (void)bw;
         return P.group_hist + base + lane;
+    };
+    auto words_of = [&](int g) {
+        const int j = (g - gbeg - wave) / NW; // uniform
+        return j < 64 ? __builtin_amdgcn_readlane(nwv, __builtin_amdgcn_readfirstlane(j)) : (int)P.hist_words[(size_t)blockIdx.x * P.G + g];
     };
     u32 wpre[BW8];
     auto prefetch = [&](int g) {
         if (g < gend && narrow(g)) {
             const u32 *h = hist_of(g, BW8);
+            const int nw = words_of(g);
 #pragma unroll
-            for (int i = 0; i < BW8; ++i) wpre[i] = h[i * 64];
+            for (int q = 0; q < BW8; q += 4) {
+                if (q < nw) { // uniform
+#pragma unroll
+                    for (int i = q; i < q + 4; ++i) wpre[i] = h[i * 64];
+                } else {
+#pragma unroll
+                    for (int i = q; i < q + 4; ++i) wpre[i] = 0u;
+                }
+            }
         }
     };
     prefetch(gbeg + wave);
@@ -783,10 +823,11 @@ __global__ __launch_bounds__(FUSED_NT, NPL == 3 ? 3 : 2) void k_ovr_from_hists(F
         } else {
             prefetch(g + NW);
             const u32 *h = hist_of(g, RT / 2);
+            const int nw = words_of(g);
             u32 prev = cum[0];
 #pragma unroll 4
             for (int i = 0; i < RT / 2; ++i) {
-                const u32 wv = h[i * 64];
+                const u32 wv = i < nw ? h[i * 64] : 0u;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const u32 nxt = cum[(2 * i + k + 1) * 64];
