@@ -1474,7 +1474,6 @@ static int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64
     const bool ovr = c->ref < 0;
     const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
     int rc;
-    void *v;
 
     // ---- route 1 (dense, count-valued genes): fused single pass; it reports the genes it could not take ----
     // Which genes are count-valued is found by the kernels themselves (k_fused_ref reads the reference rows first, k_fused_probe

@@ -645,7 +645,6 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_ovr_group_hists(FusedParams P) 
     __syncthreads();
     bool bad = false;
     const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
-    const size_t tiles = gridDim.x;
     for (int g = gbeg + wave; g < gend; g += NW) {
         const int p0 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g]);
         const int p1 = __builtin_amdgcn_readfirstlane(P.pos_ptr[g + 1]);
@@ -743,7 +742,6 @@ __global__ __launch_bounds__(FUSED_NT, NPL == 3 ? 3 : 2) void k_ovr_from_hists(F
     const int gene = blockIdx.x * 64 + lane;
     const bool act = gene < P.ncols;
     const int gbeg = blockIdx.y * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
-    const size_t tiles = gridDim.x;
     // how many words each of this wavefront's groups left (k_ovr_group_hists): lane j <-> its j-th group, read once -- by every lane,
     // before the lanes of flagged genes leave (the values are read back with v_readlane)
     const int my_g = gbeg + wave + lane * NW;
