@@ -64,6 +64,7 @@ struct CscCountsParams {
 #define CSCM_WPG 9 // words per group of the mixed layout
 // cells + slot bytes; rt = 0: the mixed layout
 static inline size_t cscc_lds_bytes(int G, int rt) { return (size_t)G * (rt ? rt : CSCM_WPG * 4) + (((size_t)G + 15) & ~(size_t)15); }
+static inline size_t cscc_lds_bytes16(int G, int rt) { return (size_t)G * rt * 2 + 16; } // 16-bit cells (W16)
 
 #define CSCC_MAX_BIG 8
 
@@ -71,10 +72,13 @@ static inline size_t cscc_lds_bytes(int G, int rt) { return (size_t)G * (rt ? rt
 // 65 536 groups); else `indices` already holds the codes (the device CSR -> CSC transposition writes them).
 // WT: the sweep reads one precomputed {A, B, C} word triple per value instead of forming the terms per (group, value) cell.
 // ABL: ablation bits for tools/micro/cscc_bench.hip only (timing builds with wrong results; the library instantiates 0).
-template <typename InT, typename IdxT, bool OVR, int RT, bool HAS_BIG, bool MIXED, bool C16, bool WT = false, int ABL = 0, int NTT = CSCC_NT, bool LEAN = false, bool PUTB = true>
+// W16: 16-bit cells for every group (RT / 2 words per group): what the route takes when more than CSCC_MAX_BIG ranked groups exceed 255
+// cells -- a few hundred groups of a thousand cells each still fit LDS (300 groups x 128 bytes), and every term of the sweep is 64-bit.
+template <typename InT, typename IdxT, bool OVR, int RT, bool HAS_BIG, bool MIXED, bool C16, bool WT = false, int ABL = 0, int NTT = CSCC_NT, bool LEAN = false, bool PUTB = true, bool W16 = false>
 __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_counts(CscCountsParams P) { // (waves per SIMD: two workgroups per CU for the mixed form)
     static_assert(!MIXED || RT == 64, "the mixed layout holds the values 1 .. 63");
-    constexpr int NT = NTT, UL = ((HAS_BIG && MIXED) || NTT == 1024) ? CSCC_UL / 2 : CSCC_UL, WPG = MIXED ? CSCM_WPG : RT / 4; // words per group (UL halved where 16 entries in flight would spill)
+    static_assert(!W16 || (!MIXED && !HAS_BIG && !PUTB), "16-bit cells: one plain layout for every group");
+    constexpr int NT = NTT, UL = ((HAS_BIG && MIXED) || NTT == 1024) ? CSCC_UL / 2 : CSCC_UL, WPG = MIXED ? CSCM_WPG : (W16 ? RT / 2 : RT / 4); // words per group (UL halved where 16 entries in flight would spill)
     extern __shared__ __align__(16) u32 cscc_h[];             // [WPG][G] words
     __shared__ u32 hsel[RT];   // OVO: histogram of the reference group's stored values; OVR: of the whole column
     __shared__ u32 hbig[HAS_BIG ? CSCC_MAX_BIG * RT : 1]; // 32-bit cells of the few groups with more than 255 cells
@@ -114,7 +118,8 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
                             const int sh = c < 8 ? (c & 3) * 8 : ((c - 8) & 7) * 4;
                             atomicAdd(&cscc_h[wi * G + cd], 1u << sh);
                             ++n_ent;
-                        } else atomicAdd(&cscc_h[(c >> 2) * G + cd], 1u << ((c & 3) * 8));
+                        } else if (W16) atomicAdd(&cscc_h[(c >> 1) * G + cd], 1u << ((c & 1) * 16)); // (a group holds fewer than 65 536 cells)
+                        else atomicAdd(&cscc_h[(c >> 2) * G + cd], 1u << ((c & 3) * 8));
                     }
                     if (OVR || cd == ref) atomicAdd(&hsel[c], 1u);
                 }
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
                 const u32 z2 = 2u * (u32)(n_sel - (long long)run); // 2 zA (OVO) or 2 n0 (OVR)
                 if (c < RT) {
                     wtab[c] = make_uint4(z2 + 2u * lo + t + (OVR ? 1u : 0u), 3u * t * t - 1u, 3u * t, 0u);
-                    if (HAS_BIG) cum[c] = lo;
+                    if (HAS_BIG || W16) cum[c] = lo;
                 }
                 if (c == 0) {
                     s_nnz = run; s_T = T; s_sum = sum;
@@ -376,18 +381,19 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
                     tie += (u64)tB * (u32)(3u * tS * (tS + tB) + tB * tB - 1u);
                 }
             };
-            if (HAS_BIG && bs >= 0) { // 32-bit cells of a group of any size: 64-bit terms (3 tS (tS + tB) + tB^2 leaves 32 bits)
-#pragma unroll 1
-                for (int c = 1; c < RT; ++c) {
-                    const u64 tB = hbig[bs * RT + c], tS = hsel[c], lo = cum[c];
-                    nnz_g += (u32)tB;
-                    vsum += (u32)tB * (u32)c;
-                    if (OVR) acc += tB * (2ull * zsel + 2ull * lo + tS + 1ull);
-                    else {
-                        acc += tB * (2ull * zsel + 2ull * lo + tS);
-                        tie += tB * (3ull * tS * (tS + tB) + tB * tB - 1ull);
-                    }
+            auto cell64 = [&](int c, u64 tB) { // a cell of a group of any size: 64-bit terms (3 tS (tS + tB) + tB^2 leaves 32 bits)
+                const u64 tS = hsel[c], lo = cum[c];
+                nnz_g += (u32)tB;
+                vsum += (u32)tB * (u32)c;
+                if (OVR) acc += tB * (2ull * zsel + 2ull * lo + tS + 1ull);
+                else {
+                    acc += tB * (2ull * zsel + 2ull * lo + tS);
+                    tie += tB * (3ull * tS * (tS + tB) + tB * tB - 1ull);
                 }
+            };
+            if (HAS_BIG && bs >= 0) { // 32-bit cells of their own
+#pragma unroll 1
+                for (int c = 1; c < RT; ++c) cell64(c, (u64)hbig[bs * RT + c]);
             }
             const bool packed = !HAS_BIG || bs < 0;
             if (ABL & 4) { acc = cscc_h[g]; tie = cscc_h[G + g]; }
@@ -408,6 +414,14 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
                     for (int k = 0; k < 8; ++k) cell(8 + (i - 2) * 8 + k, (w >> (k * 4)) & 0xFu);
                 }
                 if (packed) cells_seen += nnz_g;
+            } else if (W16) {
+#pragma unroll 1
+                for (int i = 0; i < WPG; ++i) { // two 16-bit cells per word
+                    const u32 w = cscc_h[i * G + g];
+                    if (__ballot(w != 0) == 0ull) continue;
+                    if (w & 0xFFFFu) cell64(i * 2, (u64)(w & 0xFFFFu));
+                    if (w >> 16) cell64(i * 2 + 1, (u64)(w >> 16));
+                }
             } else {
 #pragma unroll 1
                 for (int i = 0; i < WPG; ++i) {

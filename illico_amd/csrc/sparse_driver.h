@@ -53,8 +53,23 @@ static int upload_cols(illico_ctx *c, const std::vector<int64_t> &cols, const in
 // genes where a 4-bit cell overflowed are redone with 8-bit cells; genes with values outside the table are left to the
 // general routes.
 template <typename InT, typename IdxT, bool MIXED>
-static int launch_csc_counts(illico_ctx *c, const CscCountsParams &P, int rt, bool has_big, bool ovr, size_t lds) {
+static int launch_csc_counts(illico_ctx *c, const CscCountsParams &P, int rt, bool has_big, bool ovr, size_t lds, bool w16 = false) {
     ProfScope ps(c, KID_CSC_COUNTS);
+    if (w16) { // 16-bit cells for every group (more than CSCC_MAX_BIG groups above 255 cells)
+#define CSCC_LAUNCH16(OVRF, RTV, C16F)                                                                                      \
+    do {                                                                                                                   \
+        auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, false, false, C16F, CSCC_WT, 0, CSCC_NT, CSCC_LEAN, false, true>;   \
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+        hipLaunchKernelGGL(kern, dim3(P.nb), dim3(CSCC_NT), lds, c->stream, P);                                            \
+    } while (0)
+#define CSCC_LAUNCH16B(OVRF, RTV) do { if (P.codes16) CSCC_LAUNCH16(OVRF, RTV, true); else CSCC_LAUNCH16(OVRF, RTV, false); } while (0)
+        if (ovr) { if (rt == 64) CSCC_LAUNCH16B(true, 64); else CSCC_LAUNCH16B(true, 32); }
+        else { if (rt == 64) CSCC_LAUNCH16B(false, 64); else CSCC_LAUNCH16B(false, 32); }
+#undef CSCC_LAUNCH16B
+#undef CSCC_LAUNCH16
+        HIPCHK(c, hipGetLastError());
+        return ILLICO_OK;
+    }
 #define CSCC_LAUNCH1(OVRF, RTV, BIG, C16F)                                                                                 \
     do {                                                                                                                   \
         auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, BIG, MIXED && RTV == 64, C16F, CSCC_WT, 0, CSCC_NT, CSCC_LEAN, CSCC_PUTB(OVRF)>; \
@@ -83,20 +98,24 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
     std::vector<signed char> h_slot(G, (signed char)-1);
     int n_big = 0;
     for (int g = 0; g < G; ++g)
-        if (g != c->ref && c->h_counts[g] > 255) h_slot[g] = (signed char)n_big++;
+        if (g != c->ref && c->h_counts[g] > 255) h_slot[g] = (signed char)std::min(n_big++, 127);
     const signed char *d_slot = nullptr;
-    if (n_big) {
+    if (n_big && n_big <= CSCC_MAX_BIG) {
         if ((rc = get_scratch(c, "cscc_slot", (size_t)G, &v))) return rc;
         HIPCHK(c, hipMemcpyAsync(v, h_slot.data(), (size_t)G, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         d_slot = (const signed char *)v;
     }
-    const int rt8 = cscc_lds_bytes(G, 64) + 8192 <= kMaxLds ? 64 : 32;
+    // more big groups than the side table holds: 16-bit cells for every group, one pass (the caller has checked that they fit)
+    const bool w16 = n_big > CSCC_MAX_BIG;
+    const int rt16 = cscc_lds_bytes16(G, 64) + 8192 <= kMaxLds ? 64 : 32;
+    if (w16) { n_big = 0; d_slot = nullptr; }
+    const int rt8 = w16 ? rt16 : (cscc_lds_bytes(G, 64) + 8192 <= kMaxLds ? 64 : 32);
     // the mixed layout pays when two workgroups fit a CU
     // (... or when 64 bytes per group do not fit at all: the mixed table still holds all 63 values where the 8-bit form
     //  would drop to 31)
-    const bool try_mixed = !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(G, 0) + 4096) <= kMaxLds ||
-                                                       (rt8 == 32 && cscc_lds_bytes(G, 0) + 8192 <= kMaxLds));
+    const bool try_mixed = !w16 && !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(G, 0) + 4096) <= kMaxLds ||
+                                                               (rt8 == 32 && cscc_lds_bytes(G, 0) + 8192 <= kMaxLds));
     const u16 *codes16 = d_codes ? c->d_codes16 : nullptr; // (sparse input holds fewer than 65 536 groups: the 16-bit table exists)
     if (d_codes && !codes16) return ILLICO_OK; // every gene stays in `cols`
     std::vector<int64_t> left;
@@ -105,7 +124,7 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
     for (int pass = try_mixed ? 0 : 1; pass < 2 && !cols.empty(); ++pass) {
         const bool mixed = pass == 0;
         const int rt = mixed ? 64 : rt8;
-        const size_t lds = cscc_lds_bytes(G, mixed ? 0 : rt);
+        const size_t lds = w16 ? cscc_lds_bytes16(G, rt) : cscc_lds_bytes(G, mixed ? 0 : rt);
         const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
         const int *d_cols = nullptr;
         if (!contiguous && (rc = upload_cols(c, cols, &d_cols))) return rc;
@@ -128,11 +147,12 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
             P.n_cells = n_rows; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot;
             P.gene_total = ovr ? gtot : nullptr;
             P.verdict = nullptr;
-            P.pack16 = n_big == 0 ? 1 : 0; // 16-byte statistics while every ranked group has at most 255 cells
+            const bool pack16 = n_big == 0 && !w16; // 16-byte statistics while every ranked group has at most 255 cells
+            P.pack16 = pack16 ? 1 : 0;
             if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
-            else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds))) return rc;
-            if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0, n_big == 0))) return rc; }
-            else if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb, nullptr, n_big == 0))) return rc;
+            else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds, w16))) return rc;
+            if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0, pack16))) return rc; }
+            else if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb, nullptr, pack16))) return rc;
             if (c->pinned_bytes < (size_t)nb * 4) {
                 if (c->pinned) hipHostFree(c->pinned);
                 c->pinned = nullptr; c->pinned_bytes = 0;
@@ -171,9 +191,9 @@ static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *
     std::vector<signed char> h_slot(G, (signed char)-1);
     int n_big = 0;
     for (int g = 0; g < G; ++g)
-        if (g != c->ref && c->h_counts[g] > 255) h_slot[g] = (signed char)n_big++;
+        if (g != c->ref && c->h_counts[g] > 255) h_slot[g] = (signed char)std::min(n_big++, 127);
     const signed char *d_slot = nullptr;
-    if (n_big) { // (rare: a one-off upload + wait; a context keeps its groups for many calls)
+    if (n_big && n_big <= CSCC_MAX_BIG) { // (rare: a one-off upload + wait; a context keeps its groups for many calls)
         if ((rc = get_scratch(c, "cscc_slot", (size_t)G, &v))) return rc;
         HIPCHK(c, hipMemcpyAsync(v, h_slot.data(), (size_t)G, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -185,11 +205,13 @@ static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *
     hipLaunchKernelGGL((k_sample_noncount_cols<InT, IdxT>), dim3((1 << 16) / 256), dim3(256), 0, c->stream, (const InT *)data,
                        (const IdxT *)indptr, (long long)col_lb, (long long)col_ub, 1 << 16, CSCC_RT, d_cnt);
     HIPCHK(c, hipGetLastError());
-    const int rt8 = cscc_lds_bytes(G, 64) + 8192 <= kMaxLds ? 64 : 32;
-    const bool mixed = !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(G, 0) + 4096) <= kMaxLds ||
-                                                   (rt8 == 32 && cscc_lds_bytes(G, 0) + 8192 <= kMaxLds));
+    const bool w16 = n_big > CSCC_MAX_BIG; // 16-bit cells for every group (run_csc_counts_route)
+    if (w16) { n_big = 0; d_slot = nullptr; }
+    const int rt8 = w16 ? (cscc_lds_bytes16(G, 64) + 8192 <= kMaxLds ? 64 : 32) : (cscc_lds_bytes(G, 64) + 8192 <= kMaxLds ? 64 : 32);
+    const bool mixed = !w16 && !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(G, 0) + 4096) <= kMaxLds ||
+                                                           (rt8 == 32 && cscc_lds_bytes(G, 0) + 8192 <= kMaxLds));
     const int rt = mixed ? 64 : rt8;
-    const size_t lds = cscc_lds_bytes(G, mixed ? 0 : rt);
+    const size_t lds = w16 ? cscc_lds_bytes16(G, rt) : cscc_lds_bytes(G, mixed ? 0 : rt);
     const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(W, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
     if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
     long long *s2u = (long long *)v;
@@ -205,10 +227,11 @@ static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *
         P.data = data; P.indices = indices; P.indptr = indptr; P.kshift = 0; P.col0 = col_lb + b0; P.gene_cols = nullptr; P.nb = nb;
         P.codes16 = c->d_codes16; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref; P.n_cells = n_rows; P.fallback = fb + b0;
         P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot; P.gene_total = ovr ? gtot : nullptr; P.verdict = d_cnt;
-        P.pack16 = n_big == 0 ? 1 : 0;
+        const bool pack16 = n_big == 0 && !w16;
+        P.pack16 = pack16 ? 1 : 0;
         if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
-        else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds))) return rc;
-        if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0, nullptr, n_big == 0))) return rc;
+        else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds, w16))) return rc;
+        if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0, nullptr, pack16))) return rc;
     }
     const int slot = c->pend_next;
     void *&pin = c->pend_pinned[slot];
@@ -379,9 +402,13 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     // CSC, count-valued, groups of at most 255 cells: per-group histograms in LDS (OVO and OVR) -- when a sample of the window's
     // stored values says they are counts at all
     int n_big_groups = 0;
-    for (int g = 0; g < G; ++g) n_big_groups += (g != c->ref && c->h_counts[g] > 255) ? 1 : 0;
-    const bool counts_route = !is_csr && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && n_big_groups <= CSCC_MAX_BIG &&
-                              cscc_lds_bytes(G, 32) + 8192 <= kMaxLds && n_rows < (1ll << 30) &&
+    int64_t max_ranked = 0;
+    for (int g = 0; g < G; ++g)
+        if (g != c->ref) { n_big_groups += c->h_counts[g] > 255 ? 1 : 0; max_ranked = std::max<int64_t>(max_ranked, c->h_counts[g]); }
+    // (more than CSCC_MAX_BIG groups above 255 cells: 16-bit cells for every group, while those fit LDS)
+    const bool cells_fit = n_big_groups <= CSCC_MAX_BIG ? cscc_lds_bytes(G, 32) + 8192 <= kMaxLds
+                                                        : (max_ranked <= 65535 && cscc_lds_bytes16(G, 32) + 8192 <= kMaxLds && !c->no_csc_counts_wide);
+    const bool counts_route = !is_csr && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && cells_fit && n_rows < (1ll << 30) &&
                               (ovr || c->h_counts[c->ref] < 30000); // 32-bit inner terms of the sweep
     // CSR, count-valued, not too sparse: dense windows + the fused single-pass kernels (below); the same question about the values
     const bool window_route = is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) &&

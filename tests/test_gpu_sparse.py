@@ -545,3 +545,57 @@ def test_csc_counts_large_groups_with_one_dominant_value(engine, test):
     M = sparse.csc_matrix(X)
     got = _run(engine, M, g)
     assert_planes_match(got, oracle.run(X, g), ref_row=g.encoded_ref_group, what=f"csc large groups {test}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("n_groups", [14, 1300])
+def test_csc_counts_many_groups_above_255_cells_take_16_bit_cells(engine, test, n_groups):
+    """More groups above 255 cells than the kernel's side table of 32-bit rows holds (8): the LDS-histogram kernel keeps 16-bit cells
+    for EVERY group (64 values while 128 bytes per group fit LDS, 32 values beyond: 1300 groups) instead of leaving the window to the
+    per-gene LDS sort (19 ms against 0.6 ms at 300k x 8k x 300).  Host CSC, and device arrays deferred; genes with values beyond the
+    table, fractional values and explicit zeros among them; identical to the other route (`no_csc_counts_wide`)."""
+    import torch
+    rng = np.random.RandomState(41)
+    sizes = [900] + [int(s) for s in rng.randint(260, 700 if n_groups < 100 else 290, size=n_groups - 3)] + [40, 3]
+    codes = np.repeat(np.arange(len(sizes)), sizes)
+    rng.shuffle(codes)
+    n, m = codes.size, 48
+    labels = np.array(["non-targeting" if c == 0 else f"pert_{c:05d}" for c in codes])
+    X = (rng.poisson(rng.uniform(0.3, 9.0, size=m), size=(n, m)) * (rng.rand(n, m) < 0.25)).astype(np.float32)
+    X[:, 5] = rng.poisson(25.0, size=n) * (rng.rand(n) < 0.3)          # values in [32, 64): beyond the 32-value table of 1300 groups
+    X[:, 9] = rng.poisson(80.0, size=n) * (rng.rand(n) < 0.3)          # beyond every table: another route
+    X[:, 11] = X[:, 11] * 0.5                                          # fractional
+    X[:, 13] = 1.0                                                     # every cell the same count
+    X[:, 17] = 0.0
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    want = oracle.run(X, g)
+    M = sparse.csc_matrix(X)
+    M.data[::97] = 0.0                                                 # explicit zeros
+    Xz = M.toarray()
+    want = oracle.run(Xz, g)
+    engine.set_groups(g)
+    engine.profile(True)
+    engine.profile_reset()
+    got = engine.run_sparse("csc", M.data, M.indices, M.indptr, M.shape, 0, m)
+    prof = engine.profile_get()
+    engine.profile(False)
+    assert "k_csc_counts" in prof, prof
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"csc 16-bit cells {test} G={n_groups}")
+    dev = torch.device("cuda", engine.device)
+    d, i, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (M.data, M.indices, M.indptr))
+    out = tuple(torch.full((g.counts.size, m), -7.0, dtype=torch.float64, device=dev) for _ in range(3))
+    engine.run_sparse("csc", d, i, p, M.shape, 0, m, out=out, defer=True)
+    engine.synchronize()
+    assert_planes_match(tuple(t.cpu().numpy() for t in out), want, ref_row=g.encoded_ref_group, what=f"csc 16-bit cells deferred {test} G={n_groups}")
+    engine.set_option("no_csc_counts_wide", 1)
+    try:
+        engine.profile(True)
+        engine.profile_reset()
+        again = engine.run_sparse("csc", M.data, M.indices, M.indptr, M.shape, 0, m)
+        prof2 = engine.profile_get()
+    finally:
+        engine.profile(False)
+        engine.set_option("no_csc_counts_wide", 0)
+    assert "k_csc_counts" not in prof2, prof2
+    for a, b in zip(got, again):
+        np.testing.assert_array_equal(a, b)
