@@ -121,6 +121,7 @@ struct illico_ctx {
     bool no_ovr_packed_partition = false; // 1: dense OVR partitions the padded rows (every key) instead of the packed ones
     bool no_packed_dense = false;      // 1: dense OVO on continuous values takes the transpose + k_ovo_rank route (no group-wise packing)
     int packed_eq_buckets = -1;        // packed rank kernel: distribution-following bucket function; -1 = for references above 16384 cells
+    bool no_csc_counts_windows = false; // 1: count-valued CSC with more groups than LDS holds tables for never takes k_csc_counts (windows of groups)
     bool no_csc_counts_wide = false;   // 1: count-valued CSC with more than 8 groups above 255 cells never takes k_csc_counts (16-bit cells)
     bool ovr_full_dump = false;        // 1: the one-pass OVR route dumps whole group histograms (A/B of the shortened dump)
     bool no_wide_gather = false;       // 1: the 256-value stage always runs over the window as it lies (never left to the host's gather)
@@ -360,6 +361,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_fused_wide")) c->no_fused_wide = value != 0;
     else if (!strcmp(key, "no_leftover_gather")) c->no_leftover_gather = value != 0;
     else if (!strcmp(key, "no_wide_gather")) c->no_wide_gather = value != 0;
+    else if (!strcmp(key, "no_csc_counts_windows")) c->no_csc_counts_windows = value != 0;
     else if (!strcmp(key, "no_csc_counts_wide")) c->no_csc_counts_wide = value != 0;
     else if (!strcmp(key, "ovr_full_dump")) c->ovr_full_dump = value != 0;
     else if (!strcmp(key, "no_packed_dense")) c->no_packed_dense = value != 0;

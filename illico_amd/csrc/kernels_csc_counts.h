@@ -47,7 +47,10 @@ struct CscCountsParams {
     int nb;
     const u16 *codes16;                  // [n_cells] group code per cell as 16-bit values (C16); else `indices` already holds group codes
     const int *counts;                   // [G]
-    int G, ref;                          // ref == -1: OVR
+    int G, ref;                          // ref == -1: OVR.  G: the groups THIS launch holds tables for (a window of the groups, below)
+    int g_lo, G_total;                   // groups [g_lo, g_lo + G) of G_total: more groups than LDS holds tables for are taken window by window,
+                                         // one launch each (entries of other groups only feed the selected histogram); codes, counts, big_slot,
+                                         // ref and the statistics are indexed by the group's number among all G_total
     long long n_cells;
     const signed char *big_slot;         // [G] -1, or the row of the group in the 32-bit table (groups of more than 255 cells)
     u32 *fallback;                       // [nb] set to 1 for genes this kernel cannot take
@@ -72,12 +75,14 @@ static inline size_t cscc_lds_bytes16(int G, int rt) { return (size_t)G * rt * 2
 // 65 536 groups); else `indices` already holds the codes (the device CSR -> CSC transposition writes them).
 // WT: the sweep reads one precomputed {A, B, C} word triple per value instead of forming the terms per (group, value) cell.
 // ABL: ablation bits for tools/micro/cscc_bench.hip only (timing builds with wrong results; the library instantiates 0).
+// WIN: this launch holds tables for the groups [g_lo, g_lo + G) only (CscCountsParams::g_lo).
 // W16: 16-bit cells for every group (RT / 2 words per group): what the route takes when more than CSCC_MAX_BIG ranked groups exceed 255
 // cells -- a few hundred groups of a thousand cells each still fit LDS (300 groups x 128 bytes), and every term of the sweep is 64-bit.
-template <typename InT, typename IdxT, bool OVR, int RT, bool HAS_BIG, bool MIXED, bool C16, bool WT = false, int ABL = 0, int NTT = CSCC_NT, bool LEAN = false, bool PUTB = true, bool W16 = false>
+template <typename InT, typename IdxT, bool OVR, int RT, bool HAS_BIG, bool MIXED, bool C16, bool WT = false, int ABL = 0, int NTT = CSCC_NT, bool LEAN = false, bool PUTB = true, bool W16 = false, bool WIN = false>
 __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_counts(CscCountsParams P) { // (waves per SIMD: two workgroups per CU for the mixed form)
     static_assert(!MIXED || RT == 64, "the mixed layout holds the values 1 .. 63");
     static_assert(!W16 || (!MIXED && !HAS_BIG && !PUTB), "16-bit cells: one plain layout for every group");
+    static_assert(!WIN || !PUTB, "group windows: the branching entry only");
     constexpr int NT = NTT, UL = ((HAS_BIG && MIXED) || NTT == 1024) ? CSCC_UL / 2 : CSCC_UL, WPG = MIXED ? CSCM_WPG : (W16 ? RT / 2 : RT / 4); // words per group (UL halved where 16 entries in flight would spill)
     extern __shared__ __align__(16) u32 cscc_h[];             // [WPG][G] words
     __shared__ u32 hsel[RT];   // OVO: histogram of the reference group's stored values; OVR: of the whole column
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
     __shared__ u32 s_nnz, s_entries, s_cells;
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int G = P.G, ref = P.ref;
+    const int G = P.G, ref = P.ref, g_lo = P.g_lo;
     const InT *data = (const InT *)P.data;
     const IdxT *indices = (const IdxT *)P.indices, *indptr = (const IdxT *)P.indptr;
 
@@ -110,16 +115,19 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
                 if (c == 0 || (InT)c != v) bad = true; // negative, fractional, NaN or beyond the table
                 else {
                     if (ABL & 2) { n_ent += (u32)(c + cd); return; }
-                    const int bs = HAS_BIG ? (int)slot[cd] : -1;
-                    if (bs >= 0) atomicAdd(&hbig[bs * RT + c], 1u);
-                    else if (OVR || cd != ref) {
-                        if (MIXED) {
-                            const int wi = c < 8 ? (c >> 2) : 2 + ((c - 8) >> 3);
-                            const int sh = c < 8 ? (c & 3) * 8 : ((c - 8) & 7) * 4;
-                            atomicAdd(&cscc_h[wi * G + cd], 1u << sh);
-                            ++n_ent;
-                        } else if (W16) atomicAdd(&cscc_h[(c >> 1) * G + cd], 1u << ((c & 1) * 16)); // (a group holds fewer than 65 536 cells)
-                        else atomicAdd(&cscc_h[(c >> 2) * G + cd], 1u << ((c & 3) * 8));
+                    const int cl = WIN ? cd - g_lo : cd; // the group's place in this launch's window (WIN: a window of the groups)
+                    if (!WIN || (unsigned)cl < (unsigned)G) {
+                        const int bs = HAS_BIG ? (int)slot[cl] : -1;
+                        if (bs >= 0) atomicAdd(&hbig[bs * RT + c], 1u);
+                        else if (OVR || cd != ref) {
+                            if (MIXED) {
+                                const int wi = c < 8 ? (c >> 2) : 2 + ((c - 8) >> 3);
+                                const int sh = c < 8 ? (c & 3) * 8 : ((c - 8) & 7) * 4;
+                                atomicAdd(&cscc_h[wi * G + cl], 1u << sh);
+                                ++n_ent;
+                            } else if (W16) atomicAdd(&cscc_h[(c >> 1) * G + cl], 1u << ((c & 1) * 16)); // (a group holds fewer than 65 536 cells)
+                            else atomicAdd(&cscc_h[(c >> 2) * G + cl], 1u << ((c & 3) * 8));
+                        }
                     }
                     if (OVR || cd == ref) atomicAdd(&hsel[c], 1u);
                 }
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
             if (tid < RT) hsel[tid] = 0;
             if (HAS_BIG) {
                 for (int i = tid; i < CSCC_MAX_BIG * RT; i += NT) hbig[i] = 0;
-                for (int i = tid; i < G; i += NT) slot[i] = P.big_slot[i];
+                for (int i = tid; i < G; i += NT) slot[i] = P.big_slot[g_lo + i];
             }
             if (tid == 0) { s_bad = 0; s_entries = 0; s_cells = 0; }
         };
@@ -348,15 +356,16 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
         const u64 zsel = (u64)((OVR ? P.n_cells : n_ref) - (long long)nnz_sel); // zA (OVO) or n0 (OVR)
         u32 cells_seen = 0;
         auto emit = [&](int g, long long two_u, u64 tie_sum, u64 sum_g) { // (integer value sums: counts)
-            const size_t o = (size_t)gene * G + g;
+            const size_t o = (size_t)gene * P.G_total + g; // (g: the group's number among all)
             if (P.pack16) { // (uniform) 16 bytes per test: a third less for this kernel to write and for k_finalize to read
                 P.out_2u[o] = (long long)(((u64)sum_g << 40) | ((u64)two_u & 0xFFFFFFFFFFull));
                 P.out_tie[o] = tie_sum;
             } else { P.out_2u[o] = two_u; P.out_tie[o] = tie_sum; P.out_sum[o] = (double)sum_g; }
         };
         for (int g = tid; g < G; g += NT) {
-            if (!OVR && g == ref) {
-                emit(g, -2, 0, s_sum);
+            const int gg = g_lo + g; // the group's number among all
+            if (!OVR && gg == ref) {
+                emit(gg, -2, 0, s_sum);
                 continue;
             }
             // 32-bit inner terms (host-checked: n_ref < 30000 for OVO, n_cells < 2^30), one 32 x 32 -> 64 multiply-add each;
@@ -431,16 +440,16 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
                     for (int k = 0; k < 4; ++k) cell(i * 4 + k, (w >> (k * 8)) & 0xFFu);
                 }
             }
-            const long long n_g = P.counts[g];
+            const long long n_g = P.counts[gg];
             if ((ABL & 8) && acc != 0x123456789ull) continue;
             const u64 zB = (u64)(n_g - (long long)nnz_g);
             if (OVR) {
                 acc += zB * (zsel + 1ull);
-                emit(g, 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)acc, T_sel + (zsel * zsel * zsel - zsel), (u64)vsum);
+                emit(gg, 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)acc, T_sel + (zsel * zsel * zsel - zsel), (u64)vsum);
             } else {
                 acc += zB * zsel;
                 const u64 t0 = zsel + zB;
-                emit(g, 2ll * n_ref * n_g - (long long)acc, T_sel + tie + (t0 * t0 * t0 - t0), (u64)vsum);
+                emit(gg, 2ll * n_ref * n_g - (long long)acc, T_sel + tie + (t0 * t0 * t0 - t0), (u64)vsum);
             }
         }
         if (MIXED) {

@@ -48,6 +48,16 @@ static int upload_cols(illico_ctx *c, const std::vector<int64_t> &cols, const in
     return ILLICO_OK;
 }
 
+// Groups per launch of k_csc_counts: all of them while their tables fit LDS the way the kernel likes it (mixed cells: two workgroups
+// per CU), else equal windows of about 2000 groups (16-bit cells: about 1100), one launch per window over the same entries.
+static int cscc_group_window(int G, bool w16) {
+    const bool one = w16 ? cscc_lds_bytes16(G, 32) + 8192 <= kMaxLds : cscc_lds_bytes(G, 32) + 8192 <= kMaxLds;
+    if (one) return G;
+    const int per = w16 ? 1100 : 2000;
+    const int k = (G + per - 1) / per;
+    return (G + k - 1) / k;
+}
+
 // Count-valued CSC genes with small groups: per-group value histograms in LDS (k_csc_counts), OVO and OVR.  `cols` in:
 // the genes to compute; out: the genes it could not take.  First the mixed 8- / 4-bit cells (two workgroups per CU); the
 // genes where a 4-bit cell overflowed are redone with 8-bit cells; genes with values outside the table are left to the
@@ -55,14 +65,16 @@ static int upload_cols(illico_ctx *c, const std::vector<int64_t> &cols, const in
 template <typename InT, typename IdxT, bool MIXED>
 static int launch_csc_counts(illico_ctx *c, const CscCountsParams &P, int rt, bool has_big, bool ovr, size_t lds, bool w16 = false) {
     ProfScope ps(c, KID_CSC_COUNTS);
+    const bool win = P.G != P.G_total; // a window of the groups (instantiated for 16-bit group codes only: the host's case)
+    if (win && !P.codes16) return fail(c, ILLICO_ERR_UNSUPPORTED, "group windows need the 16-bit code table");
     if (w16) { // 16-bit cells for every group (more than CSCC_MAX_BIG groups above 255 cells)
-#define CSCC_LAUNCH16(OVRF, RTV, C16F)                                                                                      \
+#define CSCC_LAUNCH16(OVRF, RTV, C16F, WINF)                                                                                    \
     do {                                                                                                                   \
-        auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, false, false, C16F, CSCC_WT, 0, CSCC_NT, CSCC_LEAN, false, true>;   \
+        auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, false, false, C16F, CSCC_WT, 0, CSCC_NT, CSCC_LEAN, false, true, WINF>; \
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
         hipLaunchKernelGGL(kern, dim3(P.nb), dim3(CSCC_NT), lds, c->stream, P);                                            \
     } while (0)
-#define CSCC_LAUNCH16B(OVRF, RTV) do { if (P.codes16) CSCC_LAUNCH16(OVRF, RTV, true); else CSCC_LAUNCH16(OVRF, RTV, false); } while (0)
+#define CSCC_LAUNCH16B(OVRF, RTV) do { if (win) CSCC_LAUNCH16(OVRF, RTV, true, true); else if (P.codes16) CSCC_LAUNCH16(OVRF, RTV, true, false); else CSCC_LAUNCH16(OVRF, RTV, false, false); } while (0)
         if (ovr) { if (rt == 64) CSCC_LAUNCH16B(true, 64); else CSCC_LAUNCH16B(true, 32); }
         else { if (rt == 64) CSCC_LAUNCH16B(false, 64); else CSCC_LAUNCH16B(false, 32); }
 #undef CSCC_LAUNCH16B
@@ -70,13 +82,13 @@ static int launch_csc_counts(illico_ctx *c, const CscCountsParams &P, int rt, bo
         HIPCHK(c, hipGetLastError());
         return ILLICO_OK;
     }
-#define CSCC_LAUNCH1(OVRF, RTV, BIG, C16F)                                                                                 \
+#define CSCC_LAUNCH1(OVRF, RTV, BIG, C16F, WINF)                                                                           \
     do {                                                                                                                   \
-        auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, BIG, MIXED && RTV == 64, C16F, CSCC_WT, 0, CSCC_NT, CSCC_LEAN, CSCC_PUTB(OVRF)>; \
+        auto kern = k_csc_counts<InT, IdxT, OVRF, RTV, BIG, MIXED && RTV == 64, C16F, CSCC_WT, 0, CSCC_NT, CSCC_LEAN, CSCC_PUTB(OVRF), false, WINF>; \
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
         hipLaunchKernelGGL(kern, dim3(P.nb), dim3(CSCC_NT), lds, c->stream, P);                                            \
     } while (0)
-#define CSCC_LAUNCH(OVRF, RTV, BIG) do { if (P.codes16) CSCC_LAUNCH1(OVRF, RTV, BIG, true); else CSCC_LAUNCH1(OVRF, RTV, BIG, false); } while (0)
+#define CSCC_LAUNCH(OVRF, RTV, BIG) do { if (win) CSCC_LAUNCH1(OVRF, RTV, BIG, true, true); else if (P.codes16) CSCC_LAUNCH1(OVRF, RTV, BIG, true, false); else CSCC_LAUNCH1(OVRF, RTV, BIG, false, false); } while (0)
 #define CSCC_LAUNCH2(OVRF, RTV) do { if (has_big) CSCC_LAUNCH(OVRF, RTV, true); else CSCC_LAUNCH(OVRF, RTV, false); } while (0)
     if (ovr) { if (rt == 64) CSCC_LAUNCH2(true, 64); else CSCC_LAUNCH2(true, 32); }
     else { if (rt == 64) CSCC_LAUNCH2(false, 64); else CSCC_LAUNCH2(false, 32); }
@@ -106,16 +118,18 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
         HIPCHK(c, hipStreamSynchronize(c->stream));
         d_slot = (const signed char *)v;
     }
-    // more big groups than the side table holds: 16-bit cells for every group, one pass (the caller has checked that they fit)
+    // more big groups than the side table holds: 16-bit cells for every group, one pass
     const bool w16 = n_big > CSCC_MAX_BIG;
-    const int rt16 = cscc_lds_bytes16(G, 64) + 8192 <= kMaxLds ? 64 : 32;
     if (w16) { n_big = 0; d_slot = nullptr; }
-    const int rt8 = w16 ? rt16 : (cscc_lds_bytes(G, 64) + 8192 <= kMaxLds ? 64 : 32);
+    // more groups than LDS holds tables for: windows of Gw groups, one launch each (CscCountsParams::g_lo)
+    const int Gw = cscc_group_window(G, w16);
+    const int rt16 = cscc_lds_bytes16(Gw, 64) + 8192 <= kMaxLds ? 64 : 32;
+    const int rt8 = w16 ? rt16 : (cscc_lds_bytes(Gw, 64) + 8192 <= kMaxLds ? 64 : 32);
     // the mixed layout pays when two workgroups fit a CU
     // (... or when 64 bytes per group do not fit at all: the mixed table still holds all 63 values where the 8-bit form
     //  would drop to 31)
-    const bool try_mixed = !w16 && !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(G, 0) + 4096) <= kMaxLds ||
-                                                               (rt8 == 32 && cscc_lds_bytes(G, 0) + 8192 <= kMaxLds));
+    const bool try_mixed = !w16 && !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(Gw, 0) + 4096) <= kMaxLds ||
+                                                               (rt8 == 32 && cscc_lds_bytes(Gw, 0) + 8192 <= kMaxLds));
     const u16 *codes16 = d_codes ? c->d_codes16 : nullptr; // (sparse input holds fewer than 65 536 groups: the 16-bit table exists)
     if (d_codes && !codes16) return ILLICO_OK; // every gene stays in `cols`
     std::vector<int64_t> left;
@@ -124,7 +138,7 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
     for (int pass = try_mixed ? 0 : 1; pass < 2 && !cols.empty(); ++pass) {
         const bool mixed = pass == 0;
         const int rt = mixed ? 64 : rt8;
-        const size_t lds = w16 ? cscc_lds_bytes16(G, rt) : cscc_lds_bytes(G, mixed ? 0 : rt);
+        const size_t lds = w16 ? cscc_lds_bytes16(Gw, rt) : cscc_lds_bytes(Gw, mixed ? 0 : rt);
         const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
         const int *d_cols = nullptr;
         if (!contiguous && (rc = upload_cols(c, cols, &d_cols))) return rc;
@@ -149,8 +163,12 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
             P.verdict = nullptr;
             const bool pack16 = n_big == 0 && !w16; // 16-byte statistics while every ranked group has at most 255 cells
             P.pack16 = pack16 ? 1 : 0;
-            if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
-            else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds, w16))) return rc;
+            P.G_total = G;
+            for (int g_lo = 0; g_lo < G; g_lo += Gw) { // (one window unless the groups outgrow LDS)
+                P.g_lo = g_lo; P.G = std::min(Gw, G - g_lo);
+                if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
+                else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds, w16))) return rc;
+            }
             if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0, pack16))) return rc; }
             else if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb, nullptr, pack16))) return rc;
             if (c->pinned_bytes < (size_t)nb * 4) {
@@ -207,11 +225,12 @@ static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *
     HIPCHK(c, hipGetLastError());
     const bool w16 = n_big > CSCC_MAX_BIG; // 16-bit cells for every group (run_csc_counts_route)
     if (w16) { n_big = 0; d_slot = nullptr; }
-    const int rt8 = w16 ? (cscc_lds_bytes16(G, 64) + 8192 <= kMaxLds ? 64 : 32) : (cscc_lds_bytes(G, 64) + 8192 <= kMaxLds ? 64 : 32);
-    const bool mixed = !w16 && !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(G, 0) + 4096) <= kMaxLds ||
-                                                           (rt8 == 32 && cscc_lds_bytes(G, 0) + 8192 <= kMaxLds));
+    const int Gw = cscc_group_window(G, w16); // windows of groups when they outgrow LDS (run_csc_counts_route)
+    const int rt8 = w16 ? (cscc_lds_bytes16(Gw, 64) + 8192 <= kMaxLds ? 64 : 32) : (cscc_lds_bytes(Gw, 64) + 8192 <= kMaxLds ? 64 : 32);
+    const bool mixed = !w16 && !c->no_csc_counts_mixed && (2 * (cscc_lds_bytes(Gw, 0) + 4096) <= kMaxLds ||
+                                                           (rt8 == 32 && cscc_lds_bytes(Gw, 0) + 8192 <= kMaxLds));
     const int rt = mixed ? 64 : rt8;
-    const size_t lds = w16 ? cscc_lds_bytes16(G, rt) : cscc_lds_bytes(G, mixed ? 0 : rt);
+    const size_t lds = w16 ? cscc_lds_bytes16(Gw, rt) : cscc_lds_bytes(Gw, mixed ? 0 : rt);
     const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(W, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
     if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
     long long *s2u = (long long *)v;
@@ -229,8 +248,12 @@ static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *
         P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot; P.gene_total = ovr ? gtot : nullptr; P.verdict = d_cnt;
         const bool pack16 = n_big == 0 && !w16;
         P.pack16 = pack16 ? 1 : 0;
-        if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
-        else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds, w16))) return rc;
+        P.G_total = G;
+        for (int g_lo = 0; g_lo < G; g_lo += Gw) {
+            P.g_lo = g_lo; P.G = std::min(Gw, G - g_lo);
+            if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
+            else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds, w16))) return rc;
+        }
         if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0, nullptr, pack16))) return rc;
     }
     const int slot = c->pend_next;
@@ -406,8 +429,11 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
     for (int g = 0; g < G; ++g)
         if (g != c->ref) { n_big_groups += c->h_counts[g] > 255 ? 1 : 0; max_ranked = std::max<int64_t>(max_ranked, c->h_counts[g]); }
     // (more than CSCC_MAX_BIG groups above 255 cells: 16-bit cells for every group, while those fit LDS)
-    const bool cells_fit = n_big_groups <= CSCC_MAX_BIG ? cscc_lds_bytes(G, 32) + 8192 <= kMaxLds
-                                                        : (max_ranked <= 65535 && cscc_lds_bytes16(G, 32) + 8192 <= kMaxLds && !c->no_csc_counts_wide);
+    // ... and more groups than LDS holds tables for: windows of groups, at most 8 launches over the same entries)
+    const bool w16_needed = n_big_groups > CSCC_MAX_BIG;
+    const int n_windows = (G + cscc_group_window(G, w16_needed) - 1) / std::max(1, cscc_group_window(G, w16_needed));
+    const bool cells_fit = (!w16_needed || (max_ranked <= 65535 && !c->no_csc_counts_wide)) && n_windows <= 8 &&
+                           (n_windows == 1 || (!c->no_csc_counts_windows && c->d_codes16 && !indices_are_codes));
     const bool counts_route = !is_csr && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && cells_fit && n_rows < (1ll << 30) &&
                               (ovr || c->h_counts[c->ref] < 30000); // 32-bit inner terms of the sweep
     // CSR, count-valued, not too sparse: dense windows + the fused single-pass kernels (below); the same question about the values
@@ -861,6 +887,19 @@ static int run_sparse_inner(illico_ctx *c, bool is_csr, const void *data, int dt
 static int resolve_pending_csc(illico_ctx *c, const PendingDense &q) {
     const u32 *hf = (const u32 *)c->pend_pinned[q.slot];
     const int64_t W = q.col_ub - q.col_lb;
+    // Many scattered flagged columns (a denser matrix: 4-bit cells overflowing in every other gene) are completed by ONE call over
+    // the range that covers them -- the route itself works on column lists and recomputes an unflagged column identically -- not by
+    // one call, with its value sample and host waits, per run of flagged columns (4000 runs: 250 ms at C3 shape with half the entries stored).
+    {
+        int64_t runs = 0, first = -1, last = -1;
+        for (int64_t j = 0; j < W; ++j)
+            if (hf[j]) { if (j == 0 || !hf[j - 1]) ++runs; if (first < 0) first = j; last = j; }
+        if (runs > 8) {
+            const OutPlanes o{q.p + first, q.u + first, q.fc + first, q.out_ld, false};
+            return run_sparse_inner(c, false, q.sp_data, q.dtype, q.sp_indices, q.sp_indptr, q.idx_dtype, q.N, q.n_cols, q.col_lb + first,
+                                    q.col_lb + last + 1, q.flags, q.alternative, o);
+        }
+    }
     for (int64_t j = 0; j < W;) {
         if (!hf[j]) { ++j; continue; }
         int64_t e = j;

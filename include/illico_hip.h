@@ -83,7 +83,8 @@ int illico_ctx_set_stream(illico_ctx *ctx, void *hip_stream);
  * "no_ovr_one_pass" (dense OVR in two passes over X; "ovr_full_dump" = 1: its one pass writes every word of every group histogram
  * instead of the leading non-zero ones), "no_csc_counts_path" (count-valued CSC on LDS histograms;
  * "no_csc_counts_mixed" = 1: its 8-bit cell form only; "no_csc_counts_wide" = 1: never its 16-bit-cell form, i.e. the route is off when
- * more than 8 ranked groups exceed 255 cells),
+ * more than 8 ranked groups exceed 255 cells; "no_csc_counts_windows" = 1: never in windows of groups, i.e. off when the groups' tables
+ * do not fit LDS at once),
  * "no_packed_dense" (dense two-pass routes: group-wise packing of the non-zero keys + look-ups in a counted bitmap of the reference
  * for OVO, the transposition with the group sums folded in for OVR; 1 = the plain transposition and the kernels behind it;
  * "no_ovr_packed_partition" = 1: dense OVR splits the padded key rows -- every key -- instead of the packed ones;

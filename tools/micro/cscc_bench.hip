@@ -81,6 +81,7 @@ int main(int argc, char **argv) {
     printf("nnz %lld (%.1f per gene), algorithmic bytes %.3f GB\n", nnz, (double)nnz / M, (nnz * 8.0 + (M + 1) * 4 + 4.0 * N + 24.0 * G * M) / 1e9);
 
     CscCountsParams P;
+    P.g_lo = 0; P.G_total = G; // (no group windows here)
     P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = 0; P.col0 = 0; P.gene_cols = nullptr; P.nb = M; P.codes16 = d_codes16;
     P.counts = d_counts; P.G = G; P.n_cells = N; P.big_slot = nullptr; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.gene_total = nullptr; P.verdict = nullptr; P.pack16 = 0;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
