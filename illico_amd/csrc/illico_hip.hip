@@ -552,7 +552,9 @@ static int launch_csc_value_sums(illico_ctx *c, const InT *d_data, const IdxT *d
     CscSumsParams P;
     P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = col0; P.gene_cols = d_cols; P.codes = d_codes; P.codes16 = d_codes ? c->d_codes16 : nullptr;
     P.nb = nb; P.G = (int)c->n_groups; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.acc_global = nullptr; P.out_sum = ssum;
-    const bool accg = csc_sums_lds_bytes(P.G, false) > kMaxLds / 2; // two workgroups per CU at least
+    // accumulators in LDS while they fit at all (one workgroup per CU beyond 5000 groups); in HBM through global atomics otherwise:
+    // 46 times slower at 10 000 groups (29 ms against 0.65 at C3 shape), which is where the threshold used to sit
+    const bool accg = csc_sums_lds_bytes(P.G, false) + 2048 > kMaxLds;
     const size_t lds = csc_sums_lds_bytes(P.G, accg);
     if (accg) {
         void *v;
