@@ -51,7 +51,8 @@ static int upload_cols(illico_ctx *c, const std::vector<int64_t> &cols, const in
 // Groups per launch of k_csc_counts: all of them while their tables fit LDS the way the kernel likes it (mixed cells: two workgroups
 // per CU), else equal windows of about 2000 groups (16-bit cells: about 1100), one launch per window over the same entries.
 static int cscc_group_window(int G, bool w16) {
-    const bool one = w16 ? cscc_lds_bytes16(G, 32) + 8192 <= kMaxLds : cscc_lds_bytes(G, 32) + 8192 <= kMaxLds;
+    // (16-bit cells: windows rather than a 32-value table -- genes with a value of 32 .. 63 would leave the route)
+    const bool one = w16 ? cscc_lds_bytes16(G, 64) + 8192 <= kMaxLds : cscc_lds_bytes(G, 32) + 8192 <= kMaxLds;
     if (one) return G;
     const int per = w16 ? 1100 : 2000;
     const int k = (G + per - 1) / per;
@@ -119,7 +120,8 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
         d_slot = (const signed char *)v;
     }
     // more big groups than the side table holds: 16-bit cells for every group, one pass
-    const bool w16 = n_big > CSCC_MAX_BIG;
+    // (... or an OVO reference of 30 000 cells or more: the sweep's 32-bit terms -- 3 tS^2 -- would overflow; the 16-bit form's are 64-bit)
+    const bool w16 = n_big > CSCC_MAX_BIG || (!ovr && c->h_counts[c->ref] >= 30000);
     if (w16) { n_big = 0; d_slot = nullptr; }
     // more groups than LDS holds tables for: windows of Gw groups, one launch each (CscCountsParams::g_lo)
     const int Gw = cscc_group_window(G, w16);
@@ -223,7 +225,7 @@ static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *
     hipLaunchKernelGGL((k_sample_noncount_cols<InT, IdxT>), dim3((1 << 16) / 256), dim3(256), 0, c->stream, (const InT *)data,
                        (const IdxT *)indptr, (long long)col_lb, (long long)col_ub, 1 << 16, CSCC_RT, d_cnt);
     HIPCHK(c, hipGetLastError());
-    const bool w16 = n_big > CSCC_MAX_BIG; // 16-bit cells for every group (run_csc_counts_route)
+    const bool w16 = n_big > CSCC_MAX_BIG || (!ovr && c->h_counts[c->ref] >= 30000); // 16-bit cells for every group (run_csc_counts_route)
     if (w16) { n_big = 0; d_slot = nullptr; }
     const int Gw = cscc_group_window(G, w16); // windows of groups when they outgrow LDS (run_csc_counts_route)
     const int rt8 = w16 ? (cscc_lds_bytes16(Gw, 64) + 8192 <= kMaxLds ? 64 : 32) : (cscc_lds_bytes(Gw, 64) + 8192 <= kMaxLds ? 64 : 32);
@@ -430,12 +432,12 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         if (g != c->ref) { n_big_groups += c->h_counts[g] > 255 ? 1 : 0; max_ranked = std::max<int64_t>(max_ranked, c->h_counts[g]); }
     // (more than CSCC_MAX_BIG groups above 255 cells: 16-bit cells for every group, while those fit LDS)
     // ... and more groups than LDS holds tables for: windows of groups, at most 8 launches over the same entries)
-    const bool w16_needed = n_big_groups > CSCC_MAX_BIG;
+    const bool w16_needed = n_big_groups > CSCC_MAX_BIG || (!ovr && c->h_counts[c->ref] >= 30000); // (64-bit sweep terms for a large reference)
     const int n_windows = (G + cscc_group_window(G, w16_needed) - 1) / std::max(1, cscc_group_window(G, w16_needed));
     const bool cells_fit = (!w16_needed || (max_ranked <= 65535 && !c->no_csc_counts_wide)) && n_windows <= 8 &&
                            (n_windows == 1 || (!c->no_csc_counts_windows && c->d_codes16 && !indices_are_codes));
     const bool counts_route = !is_csr && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && cells_fit && n_rows < (1ll << 30) &&
-                              (ovr || c->h_counts[c->ref] < 30000); // 32-bit inner terms of the sweep
+                              (ovr || c->h_counts[c->ref] < (1ll << 30));
     // CSR, count-valued, not too sparse: dense windows + the fused single-pass kernels (below); the same question about the values
     const bool window_route = is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) &&
                               (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes;

@@ -551,7 +551,7 @@ def test_csc_counts_large_groups_with_one_dominant_value(engine, test):
 @pytest.mark.parametrize("n_groups", [14, 1300])
 def test_csc_counts_many_groups_above_255_cells_take_16_bit_cells(engine, test, n_groups):
     """More groups above 255 cells than the kernel's side table of 32-bit rows holds (8): the LDS-histogram kernel keeps 16-bit cells
-    for EVERY group (64 values while 128 bytes per group fit LDS, 32 values beyond: 1300 groups) instead of leaving the window to the
+    for EVERY group (128 bytes per group: in one launch up to ~1180 groups, in windows of groups beyond: 1300 groups) instead of leaving the window to the
     per-gene LDS sort (19 ms against 0.6 ms at 300k x 8k x 300).  Host CSC, and device arrays deferred; genes with values beyond the
     table, fractional values and explicit zeros among them; identical to the other route (`no_csc_counts_wide`)."""
     import torch
@@ -562,7 +562,7 @@ def test_csc_counts_many_groups_above_255_cells_take_16_bit_cells(engine, test, 
     n, m = codes.size, 48
     labels = np.array(["non-targeting" if c == 0 else f"pert_{c:05d}" for c in codes])
     X = (rng.poisson(rng.uniform(0.3, 9.0, size=m), size=(n, m)) * (rng.rand(n, m) < 0.25)).astype(np.float32)
-    X[:, 5] = rng.poisson(25.0, size=n) * (rng.rand(n) < 0.3)          # values in [32, 64): beyond the 32-value table of 1300 groups
+    X[:, 5] = rng.poisson(25.0, size=n) * (rng.rand(n) < 0.3)          # values in [32, 64)
     X[:, 9] = rng.poisson(80.0, size=n) * (rng.rand(n) < 0.3)          # beyond every table: another route
     X[:, 11] = X[:, 11] * 0.5                                          # fractional
     X[:, 13] = 1.0                                                     # every cell the same count
@@ -643,3 +643,29 @@ def test_csc_counts_more_groups_than_lds_tables_are_taken_in_windows(engine, tes
         engine.set_option("no_csc_counts_windows", 0)
     for a, b in zip(got, again):
         np.testing.assert_array_equal(a, b)
+
+
+def test_csc_counts_with_a_reference_of_tens_of_thousands_of_cells(engine):
+    """An OVO reference of 30 000 cells or more (a tenth of a large screen's cells are controls): the sweep's 32-bit terms (3 tS^2)
+    would overflow, so the LDS-histogram kernel takes its 16-bit-cell form, whose terms are 64-bit, instead of leaving the window to
+    the per-gene sort.  Most reference cells share one value in some genes (tS ~ 40 000)."""
+    rng = np.random.RandomState(47)
+    sizes = [45000] + [int(s) for s in rng.randint(40, 400, size=60)]
+    codes = np.repeat(np.arange(len(sizes)), sizes)
+    rng.shuffle(codes)
+    n, m = codes.size, 16
+    labels = np.array(["non-targeting" if c == 0 else f"pert_{c:05d}" for c in codes])
+    X = (rng.poisson(rng.uniform(0.3, 6.0, size=m), size=(n, m)) * (rng.rand(n, m) < 0.3)).astype(np.float32)
+    X[:, 2] = 1.0                                        # tS = 45 000
+    X[:, 5] = (rng.rand(n) < 0.95) * 3.0
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    want = oracle.run(X, g)
+    M = sparse.csc_matrix(X)
+    engine.set_groups(g)
+    engine.profile(True)
+    engine.profile_reset()
+    got = engine.run_sparse("csc", M.data, M.indices, M.indptr, M.shape, 0, m)
+    prof = engine.profile_get()
+    engine.profile(False)
+    assert "k_csc_counts" in prof and "k_csc_gene" not in prof, prof
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what="csc counts, large reference")
