@@ -1,0 +1,5 @@
+// dense-input drivers and kernels for float values (u32 keys)
+#include "dense_driver.h"
+template int run_fused_ovo<float>(illico_ctx *, const void *, int64_t, int64_t, int, int, int, const OutPlanes &, int64_t, std::vector<u32> &, int, bool, int64_t, const u32 *);
+template int run_dense_t<float, u32>(illico_ctx *, const void *, int, int64_t, int64_t, int64_t, int64_t, int, int, const OutPlanes &);
+template int run_leftovers<float, u32>(illico_ctx *, const void *, int, int64_t, int64_t, int64_t, int64_t, int, int, const OutPlanes &, const u32 *, bool, const int *);

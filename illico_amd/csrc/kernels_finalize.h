@@ -46,7 +46,7 @@ __device__ __forceinline__ double pval_device(long long n_ref, long long n_tgt, 
 
 // 32 genes x 32 groups per block; stats are read coalesced along groups, results written coalesced
 // along genes.
-__global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
+static __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     __shared__ double tp[32][33], tu[32][33], tf[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // ty 0..7
     const int gene0 = blockIdx.x * 32, grp0 = blockIdx.y * 32;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
 // per-gene sum over groups, rows added in group order like group_agg_counts.sum(axis=0) (math.py:185).
 // One workgroup per 64 genes: [64 genes][64 groups] tiles of in_sum ([gene][G], so a gene's groups are contiguous) are
 // read coalesced along groups and handed through LDS to one thread per gene, which adds them in group order.
-__global__ __launch_bounds__(256) void k_gene_totals(const double *in_sum, int G, int nb, double *gene_total) {
+static __global__ __launch_bounds__(256) void k_gene_totals(const double *in_sum, int G, int nb, double *gene_total) {
     __shared__ double tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // ty 0..3
     const int gene0 = blockIdx.x * 64;

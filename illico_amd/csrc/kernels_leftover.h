@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_gather_columns(const InT *__restrict__ 
 }
 
 // columns j < n of three [G][ld] planes whose flags[j] == want -> column map[j] of the caller's planes.  grid (column blocks, group blocks)
-__global__ __launch_bounds__(256) void k_scatter_planes(const double *__restrict__ p, const double *__restrict__ u, const double *__restrict__ fc, long long ld,
+static __global__ __launch_bounds__(256) void k_scatter_planes(const double *__restrict__ p, const double *__restrict__ u, const double *__restrict__ fc, long long ld,
                                                         const int *__restrict__ map, const u32 *__restrict__ flags, u32 want, int n, int G,
                                                         double *op, double *ou, double *ofc, long long out_ld) {
     const int j = blockIdx.x * 256 + threadIdx.x;

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_fused_probe(FusedParams P) {
 // a flagged gene again, at one or two workgroups per CU.  When most tiles hold one (a heavy-tailed count matrix: 20 % of the genes beyond
 // 63 put one in EVERY tile, and the stage re-reads the whole matrix at 2 TB/s) and the flagged genes are few enough to be gathered, the
 // stage is left to the host, which gathers the flagged columns into a narrow matrix and runs it there (run_leftovers).  One workgroup.
-__global__ __launch_bounds__(1024) void k_wide_decide(const u32 *__restrict__ gene_flags, int ncols, int max_gather, u32 *skip) {
+static __global__ __launch_bounds__(1024) void k_wide_decide(const u32 *__restrict__ gene_flags, int ncols, int max_gather, u32 *skip) {
     __shared__ u32 s_tiles, s_genes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tiles = (ncols + 63) / 64;
     if (tid == 0) { s_tiles = 0; s_genes = 0; }

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_csr_count(const InT *__restrict__ data,
 }
 
 // CSR pass 2/3: per gene exclusive scan over groups (in place) + gene totals
-__global__ __launch_bounds__(SEG_NT) void k_seg_scan(u32 *__restrict__ seg, int G, int nb, u32 *__restrict__ gene_tot) {
+static __global__ __launch_bounds__(SEG_NT) void k_seg_scan(u32 *__restrict__ seg, int G, int nb, u32 *__restrict__ gene_tot) {
     extern __shared__ __align__(16) unsigned char smem[];
     u32 *hist = (u32 *)smem;
     u32 *tmp = hist + ((G + 3) & ~3);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(SEG_NT) void k_seg_scan(u32 *__restrict__ seg, int 
     }
 }
 // exclusive scan of the gene totals by one workgroup (nb is at most a few thousand)
-__global__ __launch_bounds__(1024) void k_gene_base_scan(const u32 *__restrict__ gene_tot, int nb, u32 *__restrict__ gene_base) {
+static __global__ __launch_bounds__(1024) void k_gene_base_scan(const u32 *__restrict__ gene_tot, int nb, u32 *__restrict__ gene_base) {
     __shared__ u32 tmp[1024];
     __shared__ u32 carry;
     const int tid = threadIdx.x;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(1024) void k_gene_base_scan(const u32 *__restrict__
     }
 }
 // seg[gene][g] += gene_base[gene]; cursor = copy
-__global__ void k_seg_add_base(u32 *__restrict__ seg, u32 *__restrict__ cursor, const u32 *__restrict__ gene_base, int G, int nb) {
+static __global__ void k_seg_add_base(u32 *__restrict__ seg, u32 *__restrict__ cursor, const u32 *__restrict__ gene_base, int G, int nb) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long tot = (long long)nb * (G + 1);
     if (i >= tot) return;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(TR_NT) void k_csr_block_count(const IdxT *__restric
     for (int i = tid; i < W; i += TR_NT) dst[i] = tr_cnt[i];
 }
 // per column: exclusive scan of the block counts (in place) and the column's total
-__global__ void k_col_block_scan(u32 *__restrict__ counts, int n_blocks, int W, u32 *__restrict__ col_total) {
+static __global__ void k_col_block_scan(u32 *__restrict__ counts, int n_blocks, int W, u32 *__restrict__ col_total) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= W) return;
     u32 run = 0;

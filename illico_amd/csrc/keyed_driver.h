@@ -1,0 +1,87 @@
+// Launchers that depend on the KEY type only (u32 for float32 / int32 values, u64 for float64 / int64): instantiated once per key
+// type in keyed_u32.hip / keyed_u64.hip; every other translation unit sees explicit-instantiation declarations.
+#pragma once
+#include "engine.h"
+#include <functional>
+
+template <typename KeyT> static size_t ovo_lds_bytes(int ref_cap, bool runend, int nt, bool buckets = false) {
+    size_t nw = nt / 64;
+    size_t b = ((((size_t)ref_cap + 4) * sizeof(KeyT)) + 15) & ~(size_t)15;
+    if (runend) b += ovo_runend_bytes(ref_cap, buckets);
+    b += nw * 256 * sizeof(KeyT) + nw * 256 * 4;
+    b += nw * 8 * 2 + 16 + 48;
+    return b;
+}
+// Does the in-LDS sort route (k_ovo_rank) hold these sizes?  (reference column in LDS, groups <= 1024 keys)
+template <typename KeyT> static bool ovo_sort_route_fits(int64_t max_ref_nnz, int64_t max_grp_nnz) {
+    int ref_cap = (int)std::max<int64_t>(max_ref_nnz, 1);
+    bool runend = ref_cap <= 65535 && ovo_lds_bytes<KeyT>(ref_cap, true, kOvoThreads) <= kMaxLds;
+    return max_grp_nnz <= 1024 && ovo_lds_bytes<KeyT>(ref_cap, runend, kOvoThreads) <= kMaxLds;
+}
+
+struct OvoGlobalBufs { // scratch of the global-sort fallback (same element count as the key buffer)
+    void *kb = nullptr;
+    u32 *va = nullptr, *vb = nullptr;
+};
+
+// ---- packed dense OVO route (kernels_ovo_compact.h) ----
+// LDS sizing of the packed rank kernel: key slots for the reference's NON-ZERO keys and the bucket count (2^lg, half a byte each).
+// A reference whose every cell fits beside 2^17 buckets gets one slot per cell; a larger one gets the slots that fit beside 2^16
+// buckets -- an expression matrix is mostly zeros, so the non-zeros of a 33 000-cell reference still fit -- and a gene whose
+// non-zeros exceed the slots is left to k_ovo_rank by the kernel (as the tie-heavy ones are).
+template <typename KeyT> static void packed_ref_sizing(int64_t n_ref, int *cap, int *lg) {
+    if (ocr_lds_bytes((int)n_ref, 17, sizeof(KeyT)) <= kMaxLds) { *cap = (int)n_ref; *lg = 17; return; }
+    // 2^17 buckets while 55 % of the reference's cells would still fit the slots left beside them, else 2^16 and more slots
+    const size_t fixed17 = ocr_lds_bytes(0, 17, sizeof(KeyT));
+    const int64_t cap17 = fixed17 < kMaxLds ? (int64_t)((kMaxLds - fixed17) / sizeof(KeyT)) - 8 : 0;
+    if (cap17 > 0 && n_ref * 55 <= cap17 * 100) { *lg = 17; *cap = (int)std::min<int64_t>(n_ref, cap17); return; }
+    *lg = 16;
+    const size_t fixed = ocr_lds_bytes(0, 16, sizeof(KeyT));
+    *cap = (int)std::min<int64_t>(n_ref, (int64_t)((kMaxLds - fixed) / sizeof(KeyT)) - 8);
+}
+// Sizes the route holds: reference of at most 65535 cells whose keys fit k_ovo_rank's LDS (it takes the tie-heavy genes and those
+// whose non-zeros exceed the packed kernel's key slots), other groups of at most 1024 cells (k_ovo_rank's register form).
+template <typename KeyT> static bool packed_route_fits(const illico_ctx *c) {
+    if (c->ref < 0 || c->no_packed_dense) return false;
+    const int64_t n_ref = c->h_counts[c->ref];
+    return n_ref >= 1 && n_ref <= 65535 && c->max_nonref <= 1024 && ovo_sort_route_fits<KeyT>(n_ref, c->max_nonref);
+}
+
+constexpr int kOvrThreads = 256; // several small workgroups per CU overlap each other's barriers (1024 measured the same)
+
+struct OvrPackedInput {
+    const u16 *nnz;
+    const u32 *blk_cnt;
+    std::function<int(int, int)> repad;
+};
+
+// ---- the launchers (keyed_impl.h; instantiated in keyed_u32.hip / keyed_u64.hip) ----
+template <typename KeyT> int launch_seg_value_sums(illico_ctx *c, const KeyT *Xs, const u32 *seg, int nb, int dtype, int flags, double *ssum);
+template <typename KeyT> int launch_group_sums_rows(illico_ctx *c, const KeyT *Xt, int64_t stride, int nb, int dtype, int flags, double *ssum);
+// Per-group accumulators in LDS when they fit, else in HBM (one [3*G] u64 block per gene of the batch).
+template <typename KeyT, bool SPARSE, bool OVO = false> int launch_ovr_gene(illico_ctx *c, OvrParams P);
+// padded = true: Xt is the padded dense layout of k_group_compact (slot codes c->d_pk_code, c->pk_stride slots per gene; the value
+// sums are in ssum already)
+template <typename KeyT>
+int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags, long long *s2u, u64 *stie, double *ssum,
+                        double *gtot, bool padded = false);
+template <typename KeyT>
+int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags, long long *s2u, u64 *stie, double *ssum,
+                        double *gtot, bool *done, bool padded = false, const OvrPackedInput *packed = nullptr);
+template <typename KeyT>
+int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz, const u32 *flags, const OvoGlobalBufs *gb, bool sparse);
+
+#define ILLICO_KEYED_INSTANCES(X, KeyT)                                                                                                  \
+    X template int launch_seg_value_sums<KeyT>(illico_ctx *, const KeyT *, const u32 *, int, int, int, double *);                            \
+    X template int launch_group_sums_rows<KeyT>(illico_ctx *, const KeyT *, int64_t, int, int, int, double *);                               \
+    X template int launch_ovr_gene<KeyT, true, false>(illico_ctx *, OvrParams);                                                             \
+    X template int launch_ovr_gene<KeyT, false, false>(illico_ctx *, OvrParams);                                                            \
+    X template int launch_ovr_gene<KeyT, true, true>(illico_ctx *, OvrParams);                                                              \
+    X template int launch_ovr_gene<KeyT, false, true>(illico_ctx *, OvrParams);                                                             \
+    X template int run_ovr_dense_batch<KeyT>(illico_ctx *, KeyT *, int64_t, int, int, int, int, long long *, u64 *, double *, double *, bool); \
+    X template int run_ovr_dense_parts<KeyT>(illico_ctx *, KeyT *, int64_t, int, int, int, int, long long *, u64 *, double *, double *, bool *, bool, const OvrPackedInput *); \
+    X template int launch_ovo<KeyT>(illico_ctx *, OvoParams, int64_t, int64_t, const u32 *, const OvoGlobalBufs *, bool);
+#ifndef ILLICO_KEYED_IMPL
+ILLICO_KEYED_INSTANCES(extern, u32)
+ILLICO_KEYED_INSTANCES(extern, u64)
+#endif

@@ -1,12 +1,27 @@
-// Host-side launch of the OVR per-gene kernel (included by illico_hip.hip after the context helpers).
+// Definitions of the key-type launchers declared in keyed_driver.h (included by keyed_u32.hip / keyed_u64.hip only).
 #pragma once
-#include <functional>
-
-constexpr int kOvrThreads = 256; // several small workgroups per CU overlap each other's barriers (1024 measured the same)
-
+#define ILLICO_KEYED_IMPL
+#include "keyed_driver.h"
+template <typename KeyT>
+int launch_seg_value_sums(illico_ctx *c, const KeyT *Xs, const u32 *seg, int nb, int dtype, int flags, double *ssum) {
+    SegSumsParams P;
+    P.Xs = Xs; P.seg_ptr = seg; P.nb = nb; P.G = (int)c->n_groups; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.out_sum = ssum;
+    ProfScope ps(c, KID_VALUE_SUMS);
+    hipLaunchKernelGGL((k_seg_value_sums<KeyT>), dim3(nb), dim3(SUMS_NT), 0, c->stream, P);
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+template <typename KeyT>
+int launch_group_sums_rows(illico_ctx *c, const KeyT *Xt, int64_t stride, int nb, int dtype, int flags, double *ssum) {
+    ProfScope ps(c, KID_VALUE_SUMS);
+    hipLaunchKernelGGL((k_group_sums_rows<KeyT>), dim3(nb), dim3(SUMS_NT), 0, c->stream, Xt, (long long)stride, nb, (const int *)c->d_posptr,
+                       (int)c->n_groups, dtype, (flags & ILLICO_FLAG_LOG1P) ? 1 : 0, ssum);
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
 // Per-group accumulators in LDS when they fit, else in HBM (one [3*G] u64 block per gene of the batch).
-template <typename KeyT, bool SPARSE, bool OVO = false>
-static int launch_ovr_gene(illico_ctx *c, OvrParams P) {
+template <typename KeyT, bool SPARSE, bool OVO>
+int launch_ovr_gene(illico_ctx *c, OvrParams P) {
     constexpr bool DC = !SPARSE && !OVO; // dense OVR: compact the zeros away inside the kernel
     const bool accg = ovr_lds_bytes(P.G, SPARSE || DC, OVO, kOvrThreads, false) > kMaxLds;
     const size_t lds = ovr_lds_bytes(P.G, SPARSE || DC, OVO, kOvrThreads, accg);
@@ -38,18 +53,11 @@ static int launch_ovr_gene(illico_ctx *c, OvrParams P) {
     return ILLICO_OK;
 }
 
-static int launch_gene_totals(illico_ctx *c, const double *ssum, int G, int nb, double *gtot) {
-    ProfScope ps(c, KID_GENE_TOTALS);
-    hipLaunchKernelGGL(k_gene_totals, dim3((nb + 63) / 64), dim3(256), 0, c->stream, ssum, G, nb, gtot);
-    HIPCHK(c, hipGetLastError());
-    return ILLICO_OK;
-}
-
 // padded = true: Xt is the padded dense layout of k_group_compact (slot codes c->d_pk_code, c->pk_stride slots per gene; the value
 // sums are in ssum already)
 template <typename KeyT>
-static int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags,
-                               long long *s2u, u64 *stie, double *ssum, double *gtot, bool padded = false) {
+int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags,
+                        long long *s2u, u64 *stie, double *ssum, double *gtot, bool padded) {
     void *v;
     int rc;
     if ((rc = get_scratch(c, "ovr_kb", (size_t)nb * stride * sizeof(KeyT), &v))) return rc;
@@ -74,15 +82,10 @@ static int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
 // them (run by run).  *done = false: the route does not apply (nothing was launched).
 // packed = non-null: Xt holds the PACKED rows of k_group_compact (non-zero keys only; nnz / blk_cnt beside them): the partition walks
 // those; genes that leave the route are first written again in the padded layout (repad(first gene, count)) for the general route.
-struct OvrPackedInput {
-    const u16 *nnz;
-    const u32 *blk_cnt;
-    std::function<int(int, int)> repad;
-};
 template <typename KeyT>
-static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags,
-                               long long *s2u, u64 *stie, double *ssum, double *gtot, bool *done, bool padded = false,
-                               const OvrPackedInput *packed = nullptr) {
+int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags,
+                        long long *s2u, u64 *stie, double *ssum, double *gtot, bool *done, bool padded,
+                        const OvrPackedInput *packed) {
     *done = false;
     const int G = (int)c->n_groups;
     if (c->no_ovr_parts_path || G > 65535 || c->max_nonref >= (1ll << 23) ||
@@ -171,4 +174,51 @@ static int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, 
     }
     *done = true;
     return launch_gene_totals(c, ssum, G, nb, gtot);
+}
+template <typename KeyT, int KMAX, bool RUNEND, bool LG>
+static int launch_ovo_t(illico_ctx *c, const OvoParams &P, size_t lds, const u32 *flags) {
+    auto kern = k_ovo_rank<KeyT, KMAX, RUNEND, kOvoThreads, LG>;
+    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps(c, KID_OVO_RANK);
+    hipLaunchKernelGGL(kern, dim3(P.n_genes), dim3(kOvoThreads), lds, c->stream, P, flags);
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+// flags: per-gene routing word written by the ingest kernels (0 = count-valued gene -> k_ovo_counts,
+// non-zero -> sort route); nullptr routes every gene through the sort route.  The sort route is k_ovo_rank when
+// the reference column and the groups fit LDS / registers, else the per-gene global radix sort (k_ovr_gene in
+// OVO mode), which has no size limit.
+template <typename KeyT>
+int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz, const u32 *flags,
+               const OvoGlobalBufs *gb, bool sparse) {
+    if (flags) { // (the ingest kernels flagged with the same limit: ovo_counts_limit)
+        ProfScope ps(c, KID_OVO_COUNTS);
+        if (ovo_counts_limit(c) == COUNTS_R8) hipLaunchKernelGGL((k_ovo_counts<KeyT, COUNTS_R8, 8>), dim3(P.n_genes), dim3(COUNTS_NT), 0, c->stream, P, flags);
+        else hipLaunchKernelGGL((k_ovo_counts<KeyT, COUNTS_R, 16>), dim3(P.n_genes), dim3(COUNTS_NT), 0, c->stream, P, flags);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (!ovo_sort_route_fits<KeyT>(max_ref_nnz, max_grp_nnz)) {
+        if (!gb || !gb->kb) return fail(c, ILLICO_ERR_UNSUPPORTED, "internal: global-sort scratch missing");
+        OvrParams Q;
+        Q.keys_a = (void *)P.Xs; Q.keys_b = gb->kb; Q.vals_a = gb->va; Q.vals_b = gb->vb;
+        Q.code_by_pos = sparse ? nullptr : c->d_code_by_pos; Q.seg_ptr = P.seg_ptr; Q.stride = P.gene_stride;
+        Q.pos_ptr = P.pos_ptr; Q.counts = P.counts; Q.G = P.G; Q.n_genes = P.n_genes; Q.dt = P.dt; Q.is_log1p = P.is_log1p;
+        Q.n_cells = c->n_cells; Q.ref = P.ref; Q.gene_flags = flags;
+        Q.out_2u = P.out_2u; Q.out_tie = P.out_tie; Q.out_sum = P.out_sum;
+        return sparse ? launch_ovr_gene<KeyT, true, true>(c, Q) : launch_ovr_gene<KeyT, false, true>(c, Q);
+    }
+    int ref_cap = (int)std::max<int64_t>(max_ref_nnz, 1);
+    bool runend = ref_cap <= 65535 && ovo_lds_bytes<KeyT>(ref_cap, true, kOvoThreads) <= kMaxLds;
+    // bucket form of the reference column (no sort, short look-ups): needs the 16-bit table beside the keys
+    const bool buckets = runend && !c->no_ovo_ref_buckets && ref_cap <= 65531 && ovo_lds_bytes<KeyT>(ref_cap, true, kOvoThreads, true) <= kMaxLds;
+    size_t lds = ovo_lds_bytes<KeyT>(ref_cap, runend, kOvoThreads, buckets);
+    P.ref_cap = ref_cap;
+    P.ref_buckets = buckets ? 1 : 0;
+    bool big = max_grp_nnz > 256;
+    if (sparse) { // sparse layouts get the lane-per-group form as well
+        if (big) return runend ? launch_ovo_t<KeyT, 16, true, true>(c, P, lds, flags) : launch_ovo_t<KeyT, 16, false, true>(c, P, lds, flags);
+        return runend ? launch_ovo_t<KeyT, 4, true, true>(c, P, lds, flags) : launch_ovo_t<KeyT, 4, false, true>(c, P, lds, flags);
+    }
+    if (big) return runend ? launch_ovo_t<KeyT, 16, true, false>(c, P, lds, flags) : launch_ovo_t<KeyT, 16, false, false>(c, P, lds, flags);
+    return runend ? launch_ovo_t<KeyT, 4, true, false>(c, P, lds, flags) : launch_ovo_t<KeyT, 4, false, false>(c, P, lds, flags);
 }

@@ -1,0 +1,3 @@
+// explicit instantiations of the key-type launchers for u64 keys
+#include "keyed_impl.h"
+ILLICO_KEYED_INSTANCES(, u64)

@@ -1,6 +1,39 @@
-// Host-side drivers of the CSC / CSR entry points (included at the end of illico_hip.hip).
+// Host-side drivers of the CSC / CSR routes, templated on the value / index types: instantiated in sparse_<type>.hip.
 #pragma once
 
+#include "keyed_driver.h"
+// ---- order-independent value sums (kernels_sums.h) ----
+template <typename InT, typename IdxT>
+static int launch_csc_value_sums(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, int64_t col0,
+                                 const int *d_cols, const int *d_codes, int nb, int dtype, int flags, double *ssum) {
+    CscSumsParams P;
+    P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.kshift = kshift; P.col0 = col0; P.gene_cols = d_cols; P.codes = d_codes; P.codes16 = d_codes ? c->d_codes16 : nullptr;
+    P.nb = nb; P.G = (int)c->n_groups; P.dt = dtype; P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.acc_global = nullptr; P.out_sum = ssum;
+    // accumulators in LDS while they fit at all (one workgroup per CU beyond 5000 groups); in HBM through global atomics otherwise:
+    // 46 times slower at 10 000 groups (29 ms against 0.65 at C3 shape), which is where the threshold used to sit
+    const bool accg = csc_sums_lds_bytes(P.G, false) + 2048 > kMaxLds;
+    const size_t lds = csc_sums_lds_bytes(P.G, accg);
+    if (accg) {
+        void *v;
+        int rc = get_scratch(c, "sums_acc", (size_t)nb * 2 * P.G * 8, &v);
+        if (rc) return rc;
+        P.acc_global = (long long *)v;
+        HIPCHK(c, hipMemsetAsync(v, 0, (size_t)nb * 2 * P.G * 8, c->stream));
+    }
+    ProfScope ps(c, KID_VALUE_SUMS);
+    if (accg) {
+        auto kern = k_csc_value_sums<InT, IdxT, true>;
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(CSUM_NT), lds, c->stream, P);
+    } else {
+        auto kern = k_csc_value_sums<InT, IdxT, false>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(CSUM_NT), lds, c->stream, P);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+// (run_fused_ovo<uint8_t> / <float> -- the fused kernels on the dense windows of count-valued CSR input -- are instantiated in
+// dense_u8.hip / dense_f32.hip: only their declaration, engine.h, is visible here)
 static size_t seg_lds_bytes(int G) { return (size_t)((G + 3) & ~3) * 4 + SEG_NT * 4; }
 
 struct SparseBatch {
@@ -409,9 +442,9 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
 }
 
 template <typename InT, typename IdxT, typename KeyT>
-static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indices, const void *indptr, int dtype,
-                        int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                        const OutPlanes &o, bool allow_dense_window = true, bool allow_transpose = true, bool indices_are_codes = false) {
+int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indices, const void *indptr, int dtype,
+                 int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                 const OutPlanes &o, bool allow_dense_window, bool allow_transpose, bool indices_are_codes) {
     // indices_are_codes: CSC whose `indices` hold the group code of each stored entry's cell (what the device CSR -> CSC
     // transposition writes: the per-entry lookup codes[row] is an uncoalesced gather the CSC kernels then skip)
     const int *d_codes = indices_are_codes ? nullptr : c->d_codes;
@@ -857,236 +890,5 @@ static int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void
         }
     }
     }
-    return ILLICO_OK;
-}
-
-// dispatch on the value / index types (no argument checks, no deferred-call bookkeeping: run_sparse does both)
-static int run_sparse_inner(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr,
-                            int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                            const OutPlanes &o) {
-    int rc;
-#ifndef ILLICO_DEV_F32_ONLY
-#define SP_CALL(InT, KeyT)                                                                                                 \
-    (idx_dtype == ILLICO_IDX_I32                                                                                           \
-         ? run_sparse_t<InT, int32_t, KeyT>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o) \
-         : run_sparse_t<InT, int64_t, KeyT>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o))
-    switch (dtype) {
-    case ILLICO_F32: rc = SP_CALL(float, u32); break;
-    case ILLICO_F64: rc = SP_CALL(double, u64); break;
-    case ILLICO_I32: rc = SP_CALL(int32_t, u32); break;
-    default: rc = SP_CALL(int64_t, u64); break;
-    }
-#undef SP_CALL
-#else // development build: float32 values, int32 indices only
-    if (dtype == ILLICO_F32 && idx_dtype == ILLICO_IDX_I32)
-        rc = run_sparse_t<float, int32_t, u32>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o);
-    else rc = fail(c, ILLICO_ERR_DTYPE, "this development build holds the float32 / int32-index kernels only");
-#endif
-    return rc;
-}
-
-// the columns a deferred count-valued CSC pass could not take, through the ordinary routes
-static int resolve_pending_csc(illico_ctx *c, const PendingDense &q) {
-    const u32 *hf = (const u32 *)c->pend_pinned[q.slot];
-    const int64_t W = q.col_ub - q.col_lb;
-    // Many scattered flagged columns (a denser matrix: 4-bit cells overflowing in every other gene) are completed by ONE call over
-    // the range that covers them -- the route itself works on column lists and recomputes an unflagged column identically -- not by
-    // one call, with its value sample and host waits, per run of flagged columns (4000 runs: 250 ms at C3 shape with half the entries stored).
-    {
-        int64_t runs = 0, first = -1, last = -1;
-        for (int64_t j = 0; j < W; ++j)
-            if (hf[j]) { if (j == 0 || !hf[j - 1]) ++runs; if (first < 0) first = j; last = j; }
-        if (runs > 8) {
-            const OutPlanes o{q.p + first, q.u + first, q.fc + first, q.out_ld, false};
-            return run_sparse_inner(c, false, q.sp_data, q.dtype, q.sp_indices, q.sp_indptr, q.idx_dtype, q.N, q.n_cols, q.col_lb + first,
-                                    q.col_lb + last + 1, q.flags, q.alternative, o);
-        }
-    }
-    for (int64_t j = 0; j < W;) {
-        if (!hf[j]) { ++j; continue; }
-        int64_t e = j;
-        while (e < W && hf[e]) ++e;
-        const OutPlanes o{q.p + j, q.u + j, q.fc + j, q.out_ld, false};
-        const int rc = run_sparse_inner(c, false, q.sp_data, q.dtype, q.sp_indices, q.sp_indptr, q.idx_dtype, q.N, q.n_cols, q.col_lb + j,
-                                        q.col_lb + e, q.flags, q.alternative, o);
-        if (rc) return rc;
-        j = e;
-    }
-    return ILLICO_OK;
-}
-
-static int run_sparse(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr,
-                      int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                      double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
-    if (!c) return ILLICO_ERR_ARG;
-    CTX_LOCK(c);
-    int rc = check_common(c, n_rows, n_cols, col_lb, col_ub, alternative, out_p, out_u, out_fc, out_ld);
-    if (rc) return rc;
-    if (!data || !indices || !indptr) return fail(c, ILLICO_ERR_ARG, "null sparse array");
-    if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
-    if (idx_dtype != ILLICO_IDX_I32 && idx_dtype != ILLICO_IDX_I64) return fail(c, ILLICO_ERR_DTYPE, "unsupported index dtype code %d", idx_dtype);
-    HIPCHK(c, hipSetDevice(c->device));
-    const int64_t W = col_ub - col_lb;
-    // A deferred call still in flight: as in illico_run_dense, a deferred call that writes OTHER planes is enqueued first and
-    // the earlier one completed after (the GPU goes from one pass to the next without waiting for the host); otherwise the
-    // earlier call is completed before anything else happens.
-    PendingDense prev = c->pend;
-    c->pend.on = false;
-    bool later = false;
-    if (prev.on && (flags & ILLICO_FLAG_DEFER) && (flags & ILLICO_FLAG_OUTPUT_DEVICE) && (flags & ILLICO_FLAG_INPUT_DEVICE) && W > 0) {
-        const size_t span = (size_t)(c->n_groups - 1) * (size_t)out_ld + (size_t)W, pspan = (size_t)(c->n_groups - 1) * (size_t)prev.out_ld + (size_t)(prev.col_ub - prev.col_lb);
-        auto apart = [](const double *a, size_t na, const double *b, size_t nb) { return a + na <= b || b + nb <= a; };
-        later = true;
-        for (const double *a : {out_p, out_u, out_fc})
-            for (const double *b : {prev.p, prev.u, prev.fc}) later = later && apart(a, span, b, pspan);
-    }
-    if (!later && (rc = resolve_pending(c, prev))) return rc;
-    if (W == 0) return later ? resolve_pending(c, prev) : ILLICO_OK;
-    OutPlanes o;
-    if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) { if (later) resolve_pending(c, prev); return rc; }
-    PlaneTouch touch;
-    if (o.staged) { double *const dst[3] = {out_p, out_u, out_fc}; touch.start(dst, (size_t)c->n_groups, (size_t)W * 8, (size_t)out_ld * 8); }
-    rc = run_sparse_inner(c, is_csr, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o);
-    if (later) { // (the earlier call's leftovers run on the ordinary routes; this call's own pending state must survive them)
-        const PendingDense mine = c->pend;
-        c->pend.on = false;
-        const int rc2 = resolve_pending(c, prev);
-        c->pend = mine;
-        if (!rc) rc = rc2;
-    }
-    if (rc) return rc;
-    touch.join();
-    return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
-}
-
-extern "C" int illico_run_csc(illico_ctx *c, const void *data, int dtype, const void *indices, const void *indptr,
-                              int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags,
-                              int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
-    return run_sparse(c, false, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative,
-                      out_p, out_u, out_fc, out_ld);
-}
-extern "C" int illico_run_csr(illico_ctx *c, const void *data, int dtype, const void *indices, const void *indptr,
-                              int idx_dtype, int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags,
-                              int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
-    return run_sparse(c, true, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative,
-                      out_p, out_u, out_fc, out_ld);
-}
-
-// ---- bound matrices -------------------------------------------------------------------------
-static int sparse_bind(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr, int idx_dtype,
-                       int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out) {
-    if (!c || !out) return ILLICO_ERR_ARG;
-    *out = nullptr;
-    CTX_LOCK(c);
-    if (!data || !indices || !indptr) return fail(c, ILLICO_ERR_ARG, "null sparse array");
-    if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
-    if (idx_dtype != ILLICO_IDX_I32 && idx_dtype != ILLICO_IDX_I64) return fail(c, ILLICO_ERR_DTYPE, "unsupported index dtype code %d", idx_dtype);
-    if (n_rows <= 0 || n_cols < 0) return fail(c, ILLICO_ERR_ARG, "bad matrix shape");
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t isz = idx_dtype == ILLICO_IDX_I32 ? 4 : 8, vsz = dtype_size(dtype);
-    const int64_t n_ptr = (is_csr ? n_rows : n_cols) + 1;
-    illico_matrix *m = new illico_matrix();
-    m->owner = c; m->is_csr = is_csr; m->dtype = dtype; m->idx_dtype = idx_dtype; m->n_rows = n_rows; m->n_cols = n_cols;
-    if (flags & ILLICO_FLAG_INPUT_DEVICE) { // adopt: nothing is copied, the caller keeps the arrays alive
-        m->d_data = const_cast<void *>(data); m->d_indices = const_cast<void *>(indices); m->d_indptr = const_cast<void *>(indptr);
-        m->nnz = -1;
-    } else {
-        const int64_t nnz = idx_dtype == ILLICO_IDX_I32 ? (int64_t)((const int32_t *)indptr)[n_ptr - 1] : ((const int64_t *)indptr)[n_ptr - 1];
-        const int64_t first = idx_dtype == ILLICO_IDX_I32 ? (int64_t)((const int32_t *)indptr)[0] : ((const int64_t *)indptr)[0];
-        if (first != 0 || nnz < 0) { delete m; return fail(c, ILLICO_ERR_ARG, "indptr[0] must be 0 and indptr[-1] >= 0"); }
-        m->nnz = nnz;
-        m->owns = true;
-        const size_t cnt = (size_t)std::max<int64_t>(nnz, 1);
-        hipError_t e;
-        if ((e = hipMalloc(&m->d_data, cnt * vsz)) != hipSuccess || (e = hipMalloc(&m->d_indices, cnt * isz)) != hipSuccess ||
-            (e = hipMalloc(&m->d_indptr, (size_t)n_ptr * isz)) != hipSuccess) {
-            hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr);
-            delete m;
-            return fail(c, ILLICO_ERR_OOM, "hipMalloc for a bound matrix of %lld stored entries failed: %s", (long long)nnz, hipGetErrorString(e));
-        }
-        hipError_t e1 = hipMemcpyAsync(m->d_data, data, (size_t)nnz * vsz, hipMemcpyHostToDevice, c->stream);
-        hipError_t e2 = hipMemcpyAsync(m->d_indices, indices, (size_t)nnz * isz, hipMemcpyHostToDevice, c->stream);
-        hipError_t e3 = hipMemcpyAsync(m->d_indptr, indptr, (size_t)n_ptr * isz, hipMemcpyHostToDevice, c->stream);
-        hipError_t e4 = hipStreamSynchronize(c->stream); // the caller's arrays are free to go once bind returns
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-            hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr);
-            delete m;
-            return fail(c, ILLICO_ERR_HIP, "upload of a bound matrix failed");
-        }
-        c->h2d_input_bytes += (int64_t)((size_t)nnz * (vsz + isz) + (size_t)n_ptr * isz);
-    }
-    c->bound.push_back(m);
-    *out = m;
-    return ILLICO_OK;
-}
-
-extern "C" int illico_csr_bind(illico_ctx *c, const void *data, int dtype, const void *indices, const void *indptr, int idx_dtype,
-                               int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out) {
-    return sparse_bind(c, true, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, flags, out);
-}
-extern "C" int illico_csc_bind(illico_ctx *c, const void *data, int dtype, const void *indices, const void *indptr, int idx_dtype,
-                               int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out) {
-    return sparse_bind(c, false, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, flags, out);
-}
-extern "C" int illico_run_bound(illico_ctx *c, const illico_matrix *m, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                                double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
-    if (!c || !m) return ILLICO_ERR_ARG;
-    {
-        CTX_LOCK(c);
-        if (m->owner != c || std::find(c->bound.begin(), c->bound.end(), m) == c->bound.end())
-            return fail(c, ILLICO_ERR_ARG, "the matrix handle does not belong to this context (or was released)");
-    }
-    const int keep = ILLICO_FLAG_LOG1P | ILLICO_FLAG_CONTINUITY | ILLICO_FLAG_TIE_CORRECT | ILLICO_FLAG_OUTPUT_DEVICE | ILLICO_FLAG_DEFER;
-    return run_sparse(c, m->is_csr, m->d_data, m->dtype, m->d_indices, m->d_indptr, m->idx_dtype, m->n_rows, m->n_cols, col_lb, col_ub,
-                      (flags & keep) | ILLICO_FLAG_INPUT_DEVICE, alternative, out_p, out_u, out_fc, out_ld);
-}
-extern "C" int illico_matrix_release(illico_ctx *c, illico_matrix *m) {
-    if (!c || !m) return ILLICO_ERR_ARG;
-    CTX_LOCK(c);
-    auto it = std::find(c->bound.begin(), c->bound.end(), m);
-    if (it == c->bound.end() || m->owner != c) return fail(c, ILLICO_ERR_ARG, "the matrix handle does not belong to this context (or was released)");
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = resolve_pending(c); // a deferred call may still read the arrays
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->bound.erase(it);
-    if (m->owns) { hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr); }
-    delete m;
-    return rc;
-}
-
-template <typename IdxT> static int csr_sorted_host(const IdxT *indices, const IdxT *indptr, int64_t n_rows) {
-    for (int64_t r = 0; r < n_rows; ++r)
-        for (int64_t k = (int64_t)indptr[r] + 1; k < (int64_t)indptr[r + 1]; ++k)
-            if (indices[k] < indices[k - 1]) return 0;
-    return 1;
-}
-
-extern "C" int illico_csr_indices_sorted(illico_ctx *c, const void *indices, const void *indptr, int idx_dtype,
-                                         int64_t n_rows, int flags, int *out_sorted) {
-    if (!c) return ILLICO_ERR_ARG;
-    CTX_LOCK(c);
-    if (!indices || !indptr || !out_sorted || n_rows < 0) return fail(c, ILLICO_ERR_ARG, "bad argument");
-    if (idx_dtype != ILLICO_IDX_I32 && idx_dtype != ILLICO_IDX_I64) return fail(c, ILLICO_ERR_DTYPE, "unsupported index dtype code %d", idx_dtype);
-    if (!(flags & ILLICO_FLAG_INPUT_DEVICE)) {
-        *out_sorted = idx_dtype == ILLICO_IDX_I32 ? csr_sorted_host((const int32_t *)indices, (const int32_t *)indptr, n_rows)
-                                                  : csr_sorted_host((const int64_t *)indices, (const int64_t *)indptr, n_rows);
-        return ILLICO_OK;
-    }
-    HIPCHK(c, hipSetDevice(c->device));
-    void *v;
-    int rc = get_scratch(c, "flag", 16, &v);
-    if (rc) return rc;
-    int *d_bad = (int *)v;
-    HIPCHK(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
-    const int grid = (int)std::min<int64_t>((n_rows + 3) / 4 + 1, 8192);
-    if (idx_dtype == ILLICO_IDX_I32)
-        hipLaunchKernelGGL((k_csr_sorted_check<int32_t>), dim3(grid), dim3(256), 0, c->stream, (const int32_t *)indices, (const int32_t *)indptr, (int)n_rows, d_bad);
-    else
-        hipLaunchKernelGGL((k_csr_sorted_check<int64_t>), dim3(grid), dim3(256), 0, c->stream, (const int64_t *)indices, (const int64_t *)indptr, (int)n_rows, d_bad);
-    HIPCHK(c, hipGetLastError());
-    int bad = 0;
-    HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    *out_sorted = bad ? 0 : 1;
     return ILLICO_OK;
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Host-side undefined-behaviour check of the drivers (illico_hip.hip, sparse_driver.h, ovr_driver.h: pointer arithmetic on scratch,
+# Host-side undefined-behaviour check of the drivers (core.hip, dense_driver.h, sparse_driver.h, keyed_impl.h: pointer arithmetic on scratch,
 # 64-bit size products, shifts).  The HOST half of the library is built with UBSan in trap mode (no runtime library needed in the
 # python process; the device code is compiled as usual: GPU sanitizers are not available on this pool), swapped in for the product
 # library on the GPU box's scratch copy, and the whole GPU suite runs against it: an undefined operation ends the run with SIGILL
@@ -10,9 +10,11 @@ set -eu
 R=$(cd "$(dirname "$0")/.." && pwd)
 case "${1:-}" in
 build)
+    # every translation unit of the library (illico_amd/csrc/build.py: UNITS) in one hipcc call
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -fPIC -shared -std=c++17 -ffp-contract=off -Wno-unused-value \
         -fsanitize=signed-integer-overflow,shift,bounds,alignment,null,pointer-overflow,integer-divide-by-zero,float-cast-overflow \
-        -fsanitize-trap=all -fno-gpu-sanitize -o "$R/tools/micro/libillico_ubsan.so" "$R/illico_amd/csrc/illico_hip.hip"
+        -fsanitize-trap=all -fno-gpu-sanitize -Wl,--version-script="$R/illico_amd/csrc/exports.map" \
+        -o "$R/tools/micro/libillico_ubsan.so" "$R"/illico_amd/csrc/*.hip
     ;;
 run)
     shift
