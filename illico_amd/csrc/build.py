@@ -20,7 +20,7 @@ UNITS = ["core", "keyed_u32", "keyed_u64", "dense_f32", "dense_f64", "dense_i32"
          "sparse_f32", "sparse_f64", "sparse_i32", "sparse_i64"]
 DEV_UNITS = ["core", "keyed_u32", "dense_f32", "dense_u8", "sparse_f32"]  # ILLICO_DEV_F32_ONLY=1: float32 values, int32 indices
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"]
-LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared", f"-Wl,--version-script={HERE / 'exports.map'}"]
+LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared", "-Wl,-z,defs", f"-Wl,--version-script={HERE / 'exports.map'}"]
 
 STAMP = HERE / "libillico_hip.stamp"  # the flags the library on disk was built with (a development build must not pass for a full one)
 

@@ -4,7 +4,7 @@
 #include "engine.h"
 
 const char *const kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
-                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums", "k_ovo_fused_wide", "k_group_compact", "k_ovo_rank_compact", "k_ovr_counts", "k_gather_columns"};
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums", "k_ovo_fused_wide", "k_group_compact", "k_ovo_rank_compact", "k_ovr_counts", "k_gather_columns", "k_csr_counts"};
 
 // The message of a failed call is kept per calling thread (and in the context, for single-threaded callers): a second
 // thread's failure must not replace the text the first is about to read through illico_last_error.
@@ -109,6 +109,9 @@ static void free_groups(illico_ctx *c) {
     c->d_codes16 = nullptr;
     if (c->d_hist_off) hipFree(c->d_hist_off);
     c->d_hist_off = nullptr;
+    if (c->d_csr_chunks) hipFree(c->d_csr_chunks);
+    c->d_csr_chunks = nullptr;
+    c->csr_n_chunks = c->csr_n_big = 0;
     c->has_groups = false;
 }
 
@@ -184,6 +187,8 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_csr_tile_gather")) c->no_csr_tile_gather = value != 0;
     else if (!strcmp(key, "no_csr_transpose_path")) c->no_csr_transpose_path = value != 0;
     else if (!strcmp(key, "dense_window_f32")) c->dense_window_f32 = value != 0;
+    else if (!strcmp(key, "no_csr_counts_path")) c->no_csr_counts_path = value != 0;
+    else if (!strcmp(key, "csr_counts_abl")) c->csr_counts_abl = (int)value;
     else if (!strcmp(key, "no_dense_window_path")) c->no_dense_window_path = value != 0;
     else if (!strcmp(key, "ovr_hist_groups_per_wg")) c->ovr_hist_groups_per_wg = (int)std::max<int64_t>(0, value);
     else if (!strcmp(key, "fused_groups_per_wg")) c->fused_groups_per_wg = (int)std::max<int64_t>(0, value);
@@ -330,6 +335,31 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
         std::vector<u16> c16(codes.begin(), codes.end());
         HIPCHK(c, hipMalloc((void **)&c->d_codes16, c16.size() * sizeof(u16)));
         HIPCHK(c, hipMemcpy(c->d_codes16, c16.data(), c16.size() * sizeof(u16), hipMemcpyHostToDevice));
+    }
+    { // row chunks of the group-major CSR pass (kernels_csr_counts.h)
+        std::vector<int> p0, nr, slab, big;
+        auto chunks = [&](int64_t first, int64_t rows, int s, bool natural) {
+            for (int64_t r = 0; r < rows; r += CSRH_ROWS) {
+                p0.push_back(natural ? (int)(-1 - (first + r)) : (int)(first + r));
+                nr.push_back((int)std::min<int64_t>(CSRH_ROWS, rows - r));
+                slab.push_back(s);
+            }
+        };
+        if (ref >= 0) chunks(indptr[ref], counts[ref], 0, false); // (OVR: the column histograms come out of the count pass itself)
+        for (int64_t g = 0; g < n_groups; ++g)
+            if (g != ref && counts[g] > 255) big.push_back((int)g);
+        c->csr_n_big = (int)big.size();
+        if (big.size() > CSRC_MAX_BIG) { c->csr_n_big = -1; big.clear(); }
+        for (size_t k = 0; k < big.size(); ++k) chunks(indptr[big[k]], counts[big[k]], 1 + (int)k, false);
+        c->csr_n_chunks = (int)p0.size();
+        std::vector<int> all;
+        all.insert(all.end(), p0.begin(), p0.end());
+        all.insert(all.end(), nr.begin(), nr.end());
+        all.insert(all.end(), slab.begin(), slab.end());
+        all.insert(all.end(), big.begin(), big.end());
+        if (all.empty()) all.push_back(0);
+        HIPCHK(c, hipMalloc((void **)&c->d_csr_chunks, all.size() * sizeof(int)));
+        HIPCHK(c, hipMemcpy(c->d_csr_chunks, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     c->h_counts = cnt;
     c->n_cells = n_cells;
@@ -658,10 +688,31 @@ int run_sparse_inner(illico_ctx *c, bool is_csr, const void *data, int dtype, co
     return rc;
 }
 
-// the columns a deferred count-valued CSC pass could not take, through the ordinary routes
+// the columns a deferred count-valued CSC / CSR pass could not take, through the ordinary routes
 static int resolve_pending_csc(illico_ctx *c, const PendingDense &q) {
     const u32 *hf = (const u32 *)c->pend_pinned[q.slot];
     const int64_t W = q.col_ub - q.col_lb;
+    if (q.is_csr) { // the group-major CSR pass: flags + 4 verdict words; its leftovers must not come back to it
+        struct Hold { illico_ctx *c; Hold(illico_ctx *c_) : c(c_) { c->hold_csr_counts = true; } ~Hold() { c->hold_csr_counts = false; } } hold(c);
+        const u32 *vd = hf + W;
+        int64_t n_flagged = 0;
+        for (int64_t j = 0; j < W; ++j) n_flagged += hf[j] ? 1 : 0;
+        if ((double)vd[0] > 0.02 * (double)vd[2] || (double)vd[1] > 0.005 * (double)vd[2] || vd[3] != 0u || n_flagged * 16 > W) { // not a matrix for the route (or many genes left it): all of it
+            const OutPlanes o{q.p, q.u, q.fc, q.out_ld, false};
+            return run_sparse_inner(c, true, q.sp_data, q.dtype, q.sp_indices, q.sp_indptr, q.idx_dtype, q.N, q.n_cols, q.col_lb, q.col_ub, q.flags, q.alternative, o);
+        }
+        for (int64_t j = 0; j < W;) { // runs of flagged genes (closer than 32 genes: one run)
+            if (!hf[j]) { ++j; continue; }
+            int64_t last = j;
+            for (int64_t e = j + 1; e < W && e - last <= 32; ++e) if (hf[e]) last = e;
+            const OutPlanes o{q.p + j, q.u + j, q.fc + j, q.out_ld, false};
+            const int rc = run_sparse_inner(c, true, q.sp_data, q.dtype, q.sp_indices, q.sp_indptr, q.idx_dtype, q.N, q.n_cols, q.col_lb + j, q.col_lb + last + 1,
+                                            q.flags, q.alternative, o);
+            if (rc) return rc;
+            j = last + 1;
+        }
+        return ILLICO_OK;
+    }
     // Many scattered flagged columns (a denser matrix: 4-bit cells overflowing in every other gene) are completed by ONE call over
     // the range that covers them -- the route itself works on column lists and recomputes an unflagged column identically -- not by
     // one call, with its value sample and host waits, per run of flagged columns (4000 runs: 250 ms at C3 shape with half the entries stored).
@@ -788,6 +839,20 @@ static int sparse_bind(illico_ctx *c, bool is_csr, const void *data, int dtype, 
         }
         c->h2d_input_bytes += (int64_t)((size_t)nnz * (vsz + isz) + (size_t)n_ptr * isz);
     }
+    if (is_csr && n_rows < (1ll << 31)) { // the rows' order, once: the group-major CSR pass of every later call relies on it
+        void *v;
+        int bad = 0;
+        if (get_scratch(c, "flag", 16, &v) == ILLICO_OK && hipMemsetAsync(v, 0, 4, c->stream) == hipSuccess) {
+            const unsigned grid = (unsigned)std::min<int64_t>((n_rows + 3) / 4 + 1, 8192);
+            if (idx_dtype == ILLICO_IDX_I32)
+                hipLaunchKernelGGL((k_csr_sorted_check<int32_t>), dim3(grid), dim3(256), 0, c->stream, (const int32_t *)m->d_indices, (const int32_t *)m->d_indptr, (int)n_rows, (int *)v);
+            else
+                hipLaunchKernelGGL((k_csr_sorted_check<int64_t>), dim3(grid), dim3(256), 0, c->stream, (const int64_t *)m->d_indices, (const int64_t *)m->d_indptr, (int)n_rows, (int *)v);
+            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, v, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                hipStreamSynchronize(c->stream) == hipSuccess)
+                m->sorted = bad ? 0 : 1;
+        }
+    }
     c->bound.push_back(m);
     *out = m;
     return ILLICO_OK;
@@ -804,14 +869,20 @@ extern "C" int illico_csc_bind(illico_ctx *c, const void *data, int dtype, const
 extern "C" int illico_run_bound(illico_ctx *c, const illico_matrix *m, int64_t col_lb, int64_t col_ub, int flags, int alternative,
                                 double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
     if (!c || !m) return ILLICO_ERR_ARG;
-    {
-        CTX_LOCK(c);
-        if (m->owner != c || std::find(c->bound.begin(), c->bound.end(), m) == c->bound.end())
-            return fail(c, ILLICO_ERR_ARG, "the matrix handle does not belong to this context (or was released)");
-    }
+    CTX_LOCK(c); // (recursive: held for the whole call, so that illico_matrix_release on another thread cannot free the arrays under it)
+    if (m->owner != c || std::find(c->bound.begin(), c->bound.end(), m) == c->bound.end())
+        return fail(c, ILLICO_ERR_ARG, "the matrix handle does not belong to this context (or was released)");
     const int keep = ILLICO_FLAG_LOG1P | ILLICO_FLAG_CONTINUITY | ILLICO_FLAG_TIE_CORRECT | ILLICO_FLAG_OUTPUT_DEVICE | ILLICO_FLAG_DEFER;
-    return run_sparse(c, m->is_csr, m->d_data, m->dtype, m->d_indices, m->d_indptr, m->idx_dtype, m->n_rows, m->n_cols, col_lb, col_ub,
-                      (flags & keep) | ILLICO_FLAG_INPUT_DEVICE, alternative, out_p, out_u, out_fc, out_ld);
+    // what was learnt about the rows' order when the matrix was bound: in order -- the group-major CSR pass need not ask again; not --
+    // it is not for that pass
+    const bool hold0 = c->hold_csr_counts;
+    c->cur_sorted_known = m->is_csr && m->sorted == 1;
+    if (m->is_csr && m->sorted == 0) c->hold_csr_counts = true;
+    const int rc = run_sparse(c, m->is_csr, m->d_data, m->dtype, m->d_indices, m->d_indptr, m->idx_dtype, m->n_rows, m->n_cols, col_lb, col_ub,
+                              (flags & keep) | ILLICO_FLAG_INPUT_DEVICE, alternative, out_p, out_u, out_fc, out_ld);
+    c->cur_sorted_known = false;
+    c->hold_csr_counts = hold0;
+    return rc;
 }
 extern "C" int illico_matrix_release(illico_ctx *c, illico_matrix *m) {
     if (!c || !m) return ILLICO_ERR_ARG;

@@ -32,6 +32,7 @@
 #include "kernels_ovr_parts.h"
 #include "kernels_sums.h"
 #include "kernels_leftover.h"
+#include "kernels_csr_counts.h"
 
 // ---- profiled kernel ids ---------------------------------------------------------------------
 enum {
@@ -56,6 +57,7 @@ enum {
     KID_OVO_RANK_COMPACT,
     KID_OVR_COUNTS,
     KID_GATHER_COLS,
+    KID_CSR_COUNTS,
     KID_COUNT
 };
 extern const char *const kKernelNames[KID_COUNT];
@@ -70,6 +72,7 @@ struct PendingDense {
     int64_t n_cols = 0;
     const void *X = nullptr;
     int dtype = 0, flags = 0, alternative = 0, slot = 0;
+    bool is_csr = false;          // kind 1: the arrays are CSR (the group-major count pass, kernels_csr_counts.h)
     int64_t N = 0, ld = 0, col_lb = 0, col_ub = 0, out_ld = 0;
     double *p = nullptr, *u = nullptr, *fc = nullptr;
 };
@@ -81,6 +84,7 @@ struct illico_matrix {
     int dtype = 0, idx_dtype = 0;
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     void *d_data = nullptr, *d_indices = nullptr, *d_indptr = nullptr;
+    int sorted = -1;              // CSR: 1 = every row's column indices ascend (looked at once, when the matrix is bound), 0 = not, -1 = not looked at
 };
 
 struct ProfEvent {
@@ -114,6 +118,13 @@ struct illico_ctx {
     u32 *d_hist_off = nullptr;    // [G+1] OVR one-pass histograms: words per lane before group g (16 per group of <= 255 cells, else 32)
     size_t hist_words = 0;        // d_hist_off[G]
     u16 *d_codes16 = nullptr;     // [N] d_codes as 16-bit values when G <= 65535 (half the cache lines per codes[row] gather), else null
+    // the group-major CSR pass (kernels_csr_counts.h): row chunks of its histogram pre-pass -- slab 0 = the reference group's rows (OVO; OVR:
+    // the column histograms come out of the count pass itself), slab 1 + k = the k-th group of more than 255 cells -- as [3][csr_n_chunks] {p0, rows, slab}, then [csr_n_big] group numbers
+    int *d_csr_chunks = nullptr;
+    int csr_n_chunks = 0, csr_n_big = 0; // csr_n_big < 0: more big groups than the route takes
+    bool cur_sorted_known = false;       // the running call is on a bound CSR matrix whose rows were found in order when it was bound
+    int csr_counts_abl = 0;              // timing experiments (CsrCountsParams::abl)
+    bool hold_csr_counts = false;        // set while a deferred call's leftover genes are recomputed (they must not come back to the route)
     // options
     int64_t gene_batch = 0;
     int64_t scratch_bytes = 24ll << 30; // (illico_ctx_create: min(64 GiB, a quarter of the device's memory))
@@ -141,6 +152,7 @@ struct illico_ctx {
     bool no_csr_tile_gather = false;    // 1: CSR -> CSC always by the scatter form (k_csr_block_scatter), as for unsorted rows
     bool no_csr_transpose_path = false; // 1: CSR is regrouped by (gene, group) with global atomics instead of being transposed to CSC
     bool dense_window_f32 = false;      // 1: CSR dense windows hold float32 cells instead of bytes
+    bool no_csr_counts_path = false;   // 1: count-valued CSR never takes the group-major single pass (k_csr_counts)
     bool no_dense_window_path = false; // 1: CSR never goes through dense float32 windows + the fused kernels
     int fused_groups_per_wg = 0; // 0 = auto
     int ovr_hist_groups_per_wg = 0; // k_ovr_from_hists; 0 = auto
@@ -256,7 +268,7 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
 template <typename InT, typename IdxT, typename KeyT>
 int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indices, const void *indptr, int dtype, int64_t n_rows, int64_t n_cols,
                  int64_t col_lb, int64_t col_ub, int flags, int alternative, const OutPlanes &o, bool allow_dense_window = true,
-                 bool allow_transpose = true, bool indices_are_codes = false);
+                 bool allow_transpose = true, bool indices_are_codes = false, bool allow_csr_counts = true);
 // the run_sparse_t of a type given by its codes (core.hip; what a deferred CSC pass's leftovers and the drivers' own re-entries call)
 int run_sparse_inner(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr, int idx_dtype, int64_t n_rows,
                      int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative, const OutPlanes &o);

@@ -21,13 +21,15 @@ struct FinalizeParams {
     int packed;               // 16-byte statistics (k_csc_counts): in_2u = value sum << 40 | 2U (40 bits, all ones = the OVO reference row); no in_sum
 };
 
-__device__ __forceinline__ double pval_device(long long n_ref, long long n_tgt, long long n, double tie_sum, double U,
-                                              double mu, double cc, int alternative) {
-    double tie_corr = 1.0 - tie_sum / (double)(n * (n - 1) * (n + 1));            // math.py:95
+// compute_pval with its per-(group) constants handed in -- nnn = (double)(n (n-1) (n+1)) (math.py:95), var0 = (double)(n_ref n_tgt
+// (n_ref + n_tgt + 1)) / 12.0 (:97, the part in front of "* tie_corr"), n12 = (double)(n_ref n_tgt) -- so that a kernel which computes
+// many genes of one group forms them once: the same operations on the same values, bit for bit
+__device__ __forceinline__ double pval_device_pre(double nnn, double var0, double n12, double tie_sum, double U, double mu, double cc, int alternative) {
+    double tie_corr = 1.0 - tie_sum / nnn;                                         // math.py:95
     if (tie_corr > 1.0e-9) {                                                       // :96
-        double sigma = sqrt((double)(n_ref * n_tgt * (n_ref + n_tgt + 1)) / 12.0 * tie_corr); // :97
+        double sigma = sqrt(var0 * tie_corr);                                      // :97
         if (alternative == 0) {                                                    // :99-104
-            double other = (double)(n_ref * n_tgt) - U;
+            double other = n12 - U;
             U = (U < other) ? U : other;
             double delta = U - mu;
             double sgn = (delta > 0.0) ? 1.0 : ((delta < 0.0) ? -1.0 : 0.0);
@@ -42,6 +44,11 @@ __device__ __forceinline__ double pval_device(long long n_ref, long long n_tgt, 
         }
     }
     return 1.0;                                                                    // :117-118
+}
+__device__ __forceinline__ double pval_device(long long n_ref, long long n_tgt, long long n, double tie_sum, double U,
+                                              double mu, double cc, int alternative) {
+    return pval_device_pre((double)(n * (n - 1) * (n + 1)), (double)(n_ref * n_tgt * (n_ref + n_tgt + 1)) / 12.0, (double)(n_ref * n_tgt), tie_sum, U, mu, cc,
+                           alternative);
 }
 
 // 32 genes x 32 groups per block; stats are read coalesced along groups, results written coalesced

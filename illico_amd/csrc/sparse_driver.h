@@ -441,10 +441,120 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
     return ILLICO_OK;
 }
 
+
+// ---- CSR, count-valued, rows in order: the group-major single pass (kernels_csr_counts.h) ----
+// A sample of the stored values and the order of the rows' column indices are looked at ON THE DEVICE (d_verdict: the kernels leave
+// every gene flagged when the matrix is not for them); then the row boundaries of the gene windows, the tables of the reference group
+// (OVO) / of the whole column (OVR), the histograms of the groups above 255 cells, k_csr_counts and k_csr_big_sweep: p-values straight
+// into the planes.  d_flags (device, [W] + 4 words for the verdict): the genes it could not take.  Nothing here waits for the host.
+template <typename InT, typename IdxT>
+static int launch_csr_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t n_rows, int64_t n_cols,
+                                   int64_t col_lb, int64_t col_ub, int flags, int alternative, const OutPlanes &o, u32 *d_flags) {
+    const int G = (int)c->n_groups;
+    const bool ovr = c->ref < 0;
+    const int64_t W = col_ub - col_lb, Wpad = (W + 63) & ~63ll;
+    const int n_big = c->csr_n_big, n_chunks = c->csr_n_chunks;
+    int rc;
+    void *v;
+    u32 *d_verdict = d_flags + W;
+    HIPCHK(c, hipMemsetAsync(d_flags, 0, (size_t)(W + 4) * 4, c->stream));
+    hipLaunchKernelGGL((k_sample_noncount_cols<InT, IdxT>), dim3((1 << 16) / 256), dim3(256), 0, c->stream, d_data, d_indptr, 0ll, (long long)n_rows,
+                       1 << 16, CSRC_RT, d_verdict);
+    hipLaunchKernelGGL((k_csr_density_verdict<IdxT>), dim3(1), dim3(1), 0, c->stream, d_indptr, (long long)n_rows, (long long)n_cols, 0.3, d_verdict);
+    // rows out of order: a call over every column finds them in its entry loops (a row's stretches then cover the row: an entry that
+    // is not where the boundaries put it shows up outside its window); a column window asks the whole index array first -- unless the
+    // matrix is a bound one, whose order was looked at when it was bound
+    if (!(col_lb == 0 && col_ub == n_cols) && !c->cur_sorted_known)
+        hipLaunchKernelGGL((k_csr_sorted_check<IdxT>), dim3((unsigned)std::min<int64_t>((n_rows + 3) / 4 + 1, 8192)), dim3(256), 0, c->stream, d_indices,
+                           d_indptr, (int)n_rows, (int *)(d_verdict + 3));
+    HIPCHK(c, hipGetLastError());
+    // windows of about 2048 genes: 72 KB of mixed cells, two workgroups per CU; equal widths
+    const int n_win = (int)((W + 2047) / 2048);
+    const int Wg = (int)((((W + n_win - 1) / n_win) + 63) & ~63ll);
+    const int n_bnd = n_win + 1;
+    if ((rc = get_scratch(c, "csrc_bounds", (size_t)n_bnd * n_rows * 4, &v))) return rc;
+    u32 *bounds = (u32 *)v;
+    const size_t slab = (size_t)Wpad * 64;
+    if ((rc = get_scratch(c, "csrc_tables", slab * 4 * (size_t)(2 + n_big) + (size_t)Wpad * (16 + 8), &v))) return rc;
+    u32 *hist = (u32 *)v, *tab = hist + slab * (size_t)(1 + n_big);
+    uint4 *ginfo = (uint4 *)(tab + slab);
+    double *gtot = (double *)(ginfo + Wpad);
+    HIPCHK(c, hipMemsetAsync(hist, 0, slab * 4 * (size_t)(1 + n_big), c->stream));
+    CsrCountsParams P;
+    memset(&P, 0, sizeof P);
+    P.data = d_data; P.indices = d_indices; P.indptr = d_indptr; P.perm = c->d_perm; P.pos_ptr = c->d_posptr; P.counts = c->d_counts;
+    P.G = G; P.ref = (int)c->ref; P.n_cells = n_rows; P.col_lb = col_lb; P.W = (int)W; P.Wg = Wg; P.bounds = bounds; P.bstep = 1; P.n_bnd = n_bnd;
+    P.tab = tab; P.ginfo = ginfo; P.gene_total = gtot; P.Wpad = Wpad; P.gene_flags = d_flags; P.verdict = d_verdict; P.unsorted = d_verdict + 3;
+    P.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0; P.tie_correct = (flags & ILLICO_FLAG_TIE_CORRECT) ? 1 : 0; P.alternative = alternative;
+    P.out_p = o.p; P.out_u = o.u; P.out_fc = o.fc; P.out_ld = o.ld; P.hist = hist;
+    P.chunk_p0 = c->d_csr_chunks; P.chunk_n = c->d_csr_chunks + n_chunks; P.chunk_slab = c->d_csr_chunks + 2 * n_chunks;
+    P.big_groups = c->d_csr_chunks + 3 * n_chunks; P.n_big = n_big; P.abl = c->csr_counts_abl;
+    {
+        ProfScope ps(c, KID_SPARSE_SEG);
+        const long long tot = (long long)n_rows * n_bnd;
+        hipLaunchKernelGGL((k_csr_row_bounds<IdxT>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_indices, d_indptr, (int)n_rows,
+                           (long long)n_cols, (long long)col_lb, (long long)col_ub, Wg, n_bnd, bounds);
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        ProfScope ps(c, KID_FUSED_REF);
+        auto kern = k_csr_hist<InT, IdxT>;
+        const size_t lds = csrh_lds_bytes(Wg);
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (n_chunks > 0) hipLaunchKernelGGL(kern, dim3(n_win, n_chunks), dim3(CSRH_NT), lds, c->stream, P); // the reference group (OVO), the big groups
+        if (!ovr) hipLaunchKernelGGL((k_csr_tables<false>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c->stream, (const u32 *)hist, (long long)Wpad, (int)W, (long long)c->h_counts[c->ref], 0, tab, ginfo, gtot);
+        HIPCHK(c, hipGetLastError());
+    }
+    const size_t lds = csrc_lds_bytes(Wg);
+    if (ovr) {
+        if ((rc = get_scratch(c, "csrc_dump", (size_t)G * n_win * CSRC_WPG * Wg * 4, &v))) return rc;
+        P.dump = (u32 *)v;
+        {
+            ProfScope ps(c, KID_CSR_COUNTS);
+            auto kern = k_csr_counts<InT, IdxT, true>;
+            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(n_win, G), dim3(CSRC_NT), lds, c->stream, P);
+            HIPCHK(c, hipGetLastError());
+        }
+        {
+            ProfScope ps(c, KID_FUSED_REF);
+            const int slices = std::max(1, std::min(G, (int)std::min<int64_t>(64, (1 << 20) / std::max<int64_t>(W, 1) + 1))); // ~a million threads
+            const int gps = (G + slices - 1) / slices;
+            hipLaunchKernelGGL(k_csr_colhist, dim3((unsigned)((W + 255) / 256), (unsigned)((G + gps - 1) / gps)), dim3(256), 0, c->stream, P, n_win, gps);
+            hipLaunchKernelGGL((k_csr_tables<true>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c->stream, (const u32 *)hist, (long long)Wpad, (int)W, (long long)n_rows, n_big, tab, ginfo, gtot);
+            HIPCHK(c, hipGetLastError());
+        }
+        ProfScope ps(c, KID_OVR_SCAN);
+        hipLaunchKernelGGL(k_csr_ovr_sweep, dim3(n_win, G), dim3(CSRC_NT), 0, c->stream, P);
+        if (n_big > 0) hipLaunchKernelGGL((k_csr_big_sweep<true>), dim3((unsigned)((W + 255) / 256), n_big), dim3(256), 0, c->stream, P);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        ProfScope ps(c, KID_CSR_COUNTS);
+        auto kern = k_csr_counts<InT, IdxT, false>;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_win, G), dim3(CSRC_NT), lds, c->stream, P);
+        if (n_big > 0) hipLaunchKernelGGL((k_csr_big_sweep<false>), dim3((unsigned)((W + 255) / 256), n_big), dim3(256), 0, c->stream, P);
+        HIPCHK(c, hipGetLastError());
+    }
+    return ILLICO_OK;
+}
+
+// sizes the group-major CSR pass holds (kernels_csr_counts.h)
+static bool csr_counts_route_fits(const illico_ctx *c, int flags, int64_t n_rows) {
+    if (c->no_csr_counts_path || c->hold_csr_counts || (flags & ILLICO_FLAG_LOG1P) || c->tap || c->no_counts_path) return false;
+    if (c->csr_n_big < 0 || n_rows >= (1ll << 30) || c->n_groups > 65535) return false;
+    if (c->ref >= 0 && (c->h_counts[c->ref] < 1 || c->h_counts[c->ref] >= 30000)) return false;
+    return true;
+}
+// what a call learns from the verdict words of the pass: true = the matrix was not for the route at all
+static bool csr_counts_verdict_bad(const u32 *vd) {
+    return (double)vd[0] > 0.02 * (double)vd[2] || (double)vd[1] > 0.005 * (double)vd[2] || vd[3] != 0u;
+}
+
 template <typename InT, typename IdxT, typename KeyT>
 int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indices, const void *indptr, int dtype,
                  int64_t n_rows, int64_t n_cols, int64_t col_lb, int64_t col_ub, int flags, int alternative,
-                 const OutPlanes &o, bool allow_dense_window, bool allow_transpose, bool indices_are_codes) {
+                 const OutPlanes &o, bool allow_dense_window, bool allow_transpose, bool indices_are_codes, bool allow_csr_counts) {
     // indices_are_codes: CSC whose `indices` hold the group code of each stored entry's cell (what the device CSR -> CSC
     // transposition writes: the per-entry lookup codes[row] is an uncoalesced gather the CSC kernels then skip)
     const int *d_codes = indices_are_codes ? nullptr : c->d_codes;
@@ -474,12 +584,43 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     // CSR, count-valued, not too sparse: dense windows + the fused single-pass kernels (below); the same question about the values
     const bool window_route = is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) &&
                               (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes;
+    // CSR, count-valued, small groups: the group-major single pass (kernels_csr_counts.h); the same question about the values
+    const bool csr_counts = is_csr && allow_csr_counts && W > 0 && csr_counts_route_fits(c, flags, n_rows);
     u32 h_sample[4] = {0, 0, 0, 0}; // non-integers, integers beyond the table, samples taken
     bool sampled = false;
     if ((flags & ILLICO_FLAG_DEFER) && in_dev && (flags & ILLICO_FLAG_OUTPUT_DEVICE) && !o.staged && counts_route && W > 0 &&
         !indices_are_codes && c->d_codes16 && !c->tap)
         return run_csc_counts_deferred<InT, IdxT>(c, data, indices, indptr, dtype, (int)(sizeof(IdxT) == 4 ? ILLICO_IDX_I32 : ILLICO_IDX_I64),
                                                   n_rows, n_cols, col_lb, col_ub, flags, alternative, o);
+
+    // the group-major CSR pass, deferred: device arrays, device planes -- enqueued as a whole, its flags + verdict travel to pinned memory
+    // behind an event (resolve_pending_csc)
+    if (csr_counts && (flags & ILLICO_FLAG_DEFER) && in_dev && (flags & ILLICO_FLAG_OUTPUT_DEVICE) && !o.staged) {
+        if ((rc = get_scratch(c, "csrc_flags", (size_t)(W + 4) * 4, &v))) return rc;
+        u32 *d_flags = (u32 *)v;
+        if ((rc = launch_csr_counts_route<InT, IdxT>(c, (const InT *)data, (const IdxT *)indices, (const IdxT *)indptr, n_rows, n_cols, col_lb, col_ub, flags,
+                                                     alternative, o, d_flags))) return rc;
+        const int slot = c->pend_next;
+        void *&pin = c->pend_pinned[slot];
+        if (c->pend_pinned_bytes[slot] < (size_t)(W + 4) * 4) {
+            if (pin) hipHostFree(pin);
+            pin = nullptr;
+            c->pend_pinned_bytes[slot] = 0;
+            HIPCHK(c, hipHostMalloc(&pin, (size_t)(W + 4) * 4 + 4096, hipHostMallocDefault));
+            c->pend_pinned_bytes[slot] = (size_t)(W + 4) * 4 + 4096;
+        }
+        if (!c->pend_event[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->pend_event[slot], hipEventDisableTiming));
+        HIPCHK(c, hipMemcpyAsync(pin, d_flags, (size_t)(W + 4) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->pend_event[slot], c->stream));
+        c->pend_next ^= 1;
+        PendingDense &q = c->pend;
+        q = PendingDense();
+        q.on = true; q.kind = 1; q.is_csr = true; q.sp_data = data; q.sp_indices = indices; q.sp_indptr = indptr;
+        q.idx_dtype = (int)(sizeof(IdxT) == 4 ? ILLICO_IDX_I32 : ILLICO_IDX_I64); q.n_cols = n_cols;
+        q.dtype = dtype; q.flags = flags & ~ILLICO_FLAG_DEFER; q.alternative = alternative; q.slot = slot; q.N = n_rows;
+        q.col_lb = col_lb; q.col_ub = col_ub; q.out_ld = o.ld; q.p = o.p; q.u = o.u; q.fc = o.fc;
+        return ILLICO_OK;
+    }
 
     // what the host needs of indptr: all of it for CSC (batch planning), its two ends for CSR (total stored entries)
     std::vector<IdxT> h_indptr;
@@ -536,22 +677,59 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
         c->h2d_input_bytes += (int64_t)(n_ptr * sizeof(IdxT) + (size_t)(k1 - k0) * (sizeof(InT) + sizeof(IdxT)));
     }
 
+    auto take_sample = [&]() -> int { // 64k evenly spaced stored values (device-resident arrays: taken with the indptr copy above)
+        if (sampled) return ILLICO_OK;
+        const int n_samples = (int)std::min<int64_t>(total_nnz, 1 << 16);
+        void *vv;
+        int rc2;
+        if ((rc2 = get_scratch(c, "flag", 16, &vv))) return rc2;
+        u32 *d_cnt = (u32 *)vv;
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
+        hipLaunchKernelGGL((k_sample_noncount<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, d_data, (long long)total_nnz,
+                           n_samples, FUSED_RT, d_cnt);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h_sample, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        h_sample[2] = (u32)n_samples;
+        sampled = true;
+        return ILLICO_OK;
+    };
+    // ---- CSR, count-valued, rows in order: the group-major single pass (kernels_csr_counts.h); ONE wait, for its flags + verdict ----
+    if (csr_counts && total_nnz > 0) {
+        if ((rc = get_scratch(c, "csrc_flags", (size_t)(W + 4) * 4, &v))) return rc;
+        u32 *d_flags = (u32 *)v;
+        if ((rc = launch_csr_counts_route<InT, IdxT>(c, d_data, d_indices, d_indptr, n_rows, n_cols, col_lb, col_ub, flags, alternative, o, d_flags))) return rc;
+        std::vector<u32> hf((size_t)W + 4);
+        HIPCHK(c, hipMemcpyAsync(hf.data(), d_flags, (size_t)(W + 4) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        int64_t n_flagged = 0;
+        for (int64_t j = 0; j < W; ++j) n_flagged += hf[j] ? 1 : 0;
+        if (!csr_counts_verdict_bad(hf.data() + W) && n_flagged * 16 > W) // many genes left the pass: all of the window by the other routes, once
+            return run_sparse_t<InT, IdxT, KeyT>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, col_lb, col_ub, flags, alternative, o, true, true,
+                                                 false, false);
+        if (!csr_counts_verdict_bad(hf.data() + W)) {
+            // runs of flagged genes (closer than 32 genes: one run; the genes in between are recomputed, identically)
+            for (int64_t j = 0; j < W;) {
+                if (!hf[j]) { ++j; continue; }
+                int64_t last = j;
+                for (int64_t e = j + 1; e < W && e - last <= 32; ++e) if (hf[e]) last = e;
+                OutPlanes o2 = o;
+                o2.p += j; o2.u += j; o2.fc += j;
+                if ((rc = run_sparse_t<InT, IdxT, KeyT>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, col_lb + j, col_lb + last + 1, flags,
+                                                        alternative, o2, false, true, false, false))) return rc;
+                j = last + 1;
+            }
+            return ILLICO_OK;
+        }
+        h_sample[0] = hf[W]; h_sample[1] = hf[W + 1]; h_sample[2] = hf[W + 2]; // (the same sample the dense-window route asks for)
+        sampled = true;
+    }
+
     // ---- CSR, count-valued, not too sparse: dense float32 windows + the fused single-pass kernels (k_csr_densify) ----
     const double density = (double)total_nnz / ((double)std::max<int64_t>(n_rows, 1) * (double)std::max<int64_t>(n_cols, 1));
     bool dense_window = window_route && density >= 0.015 && total_nnz > 0;
     if (dense_window) { // worth it only for count-valued data: look at 64k evenly spaced stored values first
-        if (!sampled) { // (device-resident arrays: taken with the indptr copy above)
-            const int n_samples = (int)std::min<int64_t>(total_nnz, 1 << 16);
-            if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
-            u32 *d_cnt = (u32 *)v;
-            HIPCHK(c, hipMemsetAsync(d_cnt, 0, 8, c->stream));
-            hipLaunchKernelGGL((k_sample_noncount<InT>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, d_data, (long long)total_nnz,
-                               n_samples, FUSED_RT, d_cnt);
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(h_sample, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            h_sample[2] = (u32)n_samples;
-        }
+        if ((rc = take_sample())) return rc;
         // the genes this route cannot take are redone over the column window that covers them, so it needs nearly all of
         // them to fit: no non-integers, few values beyond the table
         dense_window = (double)h_sample[0] <= 0.02 * (double)h_sample[2] && (double)h_sample[1] <= 0.005 * (double)h_sample[2];
@@ -594,7 +772,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
         OutPlanes o2 = o;
         o2.p += bad_lo - col_lb; o2.u += bad_lo - col_lb; o2.fc += bad_lo - col_lb;
         return run_sparse_t<InT, IdxT, KeyT>(c, is_csr, data, indices, indptr, dtype, n_rows, n_cols, bad_lo, bad_hi + 1, flags,
-                                             alternative, o2, false);
+                                             alternative, o2, false, true, false, false);
     }
 
     // ---- CSR, any values: transpose the column window into CSC on the device, then the CSC routes ----
@@ -677,7 +855,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
             OutPlanes o2 = o;
             o2.p += w0 - col_lb; o2.u += w0 - col_lb; o2.fc += w0 - col_lb;
             if ((rc = run_sparse_t<InT, int32_t, KeyT>(c, false, t_data, t_rows, col_ptr, dtype, n_rows, wn, 0, wn,
-                                                       flags | ILLICO_FLAG_INPUT_DEVICE, alternative, o2, false, false, true)))
+                                                       flags | ILLICO_FLAG_INPUT_DEVICE, alternative, o2, false, false, true, false)))
                 return rc;
             w0 += wn;
         }

@@ -22,20 +22,22 @@ def _run(engine, M, grpc, **kw):
     return engine.run_sparse(M.format, M.data, M.indices, M.indptr, M.shape, lb, ub, **kw)
 
 
-@pytest.fixture(params=["default", "two-kernel", "two-kernel-sort-only", "csr-regroup", "ovr-lds-sort"])
+@pytest.fixture(params=["default", "csr-window", "two-kernel", "two-kernel-sort-only", "csr-regroup", "ovr-lds-sort"])
 def route(request, engine):
     """Count-valued CSC genes with groups of at most 255 cells take the LDS-histogram kernel (OVO and OVR); otherwise
     CSC OVO has a single-kernel route (regroup + rank in LDS) with the two-kernel route (regroup into HBM, then
-    histogram / sort rank kernels) as fallback.  CSR first tries dense byte windows + the fused dense kernels
-    (count-valued data), otherwise it is transposed to CSC on the device and takes the CSC routes; the older CSR route
+    histogram / sort rank kernels) as fallback.  Count-valued CSR with groups of at most 255 cells takes the group-major single
+    pass (k_csr_counts); with that off ("csr-window") or larger groups, dense byte windows + the fused dense kernels; otherwise it is transposed to CSC on the device and takes the CSC routes; the older CSR route
     (regroup by (gene, group) with global atomics) is kept behind an option.  The params force each so that all are
     exercised on the same data.  CSC OVR with values the histogram kernel cannot take (and CSR OVR after the device
     transposition) ranks each gene's stored values inside LDS (k_csc_ovr_gene: value buckets, or a sort of the keys for
     tie-heavy columns); genes larger than its key buffer and the two-kernel params use the general route (regroup in
     HBM, segmented radix sort, sweeps)."""
     opts = {"no_csc_gene_path": 0, "no_dense_window_path": 0, "no_counts_path": 0, "no_csr_transpose_path": 0,
-            "no_csr_tile_gather": 0, "no_csc_counts_path": 0,
+            "no_csr_tile_gather": 0, "no_csc_counts_path": 0, "no_csr_counts_path": 0,
             "no_csc_regroup_lds": 0, "no_csc_ovr_gene_path": 0, "csc_ovr_sorted_form": 0, "no_ovo_ref_buckets": 0}
+    if request.param != "default":
+        opts.update(no_csr_counts_path=1)
     if request.param.startswith("two-kernel"):
         opts.update(no_csc_gene_path=1, no_dense_window_path=1, no_csc_counts_path=1, no_csc_ovr_gene_path=1)
     if request.param == "ovr-lds-sort":
@@ -226,6 +228,7 @@ def test_csr_dense_window_route(engine, test, dtype, f32_cells):
     M = sparse.csr_matrix(X.astype(dtype))
     want = oracle.run(X, g)
     engine.set_option("dense_window_f32", f32_cells)
+    engine.set_option("no_csr_counts_path", 1)
     engine.set_option("profile", 1)
     engine.profile_reset()
     try:
@@ -241,7 +244,56 @@ def test_csr_dense_window_route(engine, test, dtype, f32_cells):
         got = _run(engine, M, g, col_lb=100, col_ub=8290)
     finally:
         engine.set_option("gene_batch", 0)
+        engine.set_option("no_csr_counts_path", 0)
     assert_planes_match(got, oracle.run(X, g, col_lb=100, col_ub=8290), what=f"csr dense window batches {test}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("dtype,idx", [(np.float32, np.int32), (np.float64, np.int64), (np.int64, np.int32), (np.int32, np.int64)])
+def test_csr_counts_route(engine, test, dtype, idx):
+    """Count-valued CSR through the group-major single pass (k_csr_row_bounds, k_csr_hist, k_csr_tables, k_csr_counts): more genes
+    than one window of 2048, groups of 255 cells and of one cell, an empty row, explicit stored zeros, a 4-bit cell that overflows
+    (16 cells of one group with the value 9), and genes that must leave the route (a fractional value, a value of 64+, a negative);
+    column windows that start and end inside a gene window."""
+    rng = np.random.RandomState(503)
+    sizes = [255, 255, 120, 61, 33, 16, 2, 1, 700, 256]   # (two groups above 255 cells: chunked histograms + k_csr_big_sweep)
+    labels = np.concatenate([[f"s{i:04d}"] * sz for i, sz in enumerate(sizes)])
+    rng.shuffle(labels)
+    n, m = labels.size, 4300
+    X = (rng.poisson(rng.uniform(0.3, 14.0, size=m), size=(n, m)) * (rng.rand(n, m) < 0.15)).astype(np.float64)
+    X[11, :] = 0                                                                     # an empty row
+    X[labels == "s0002", 70] = np.where(rng.rand(120) < 0.5, 9, X[labels == "s0002", 70])   # ~60 cells of one group hold a 9
+    X[:, 2050] = np.where(rng.rand(n) < 0.05, rng.randint(64, 300, size=n), X[:, 2050])  # beyond the table
+    if dtype in (np.float32, np.float64):
+        X[:, 4111] = np.where(rng.rand(n) < 0.1, 0.5, X[:, 4111])                    # fractional
+    X[3, 17] = -2.0                                                                  # negative
+    X[:, 23] = 0.0                                                                   # an empty gene
+    M = sparse.csr_matrix(X.astype(dtype))
+    M.indices = M.indices.astype(idx)
+    M.indptr = M.indptr.astype(idx)
+    M.data[::97] = 0                                                                 # explicit stored zeros ...
+    Xd = M.toarray().astype(np.float64)                                              # ... are zeros
+    for ref in (["s0000", "s0004", "s0007", "s0008"] if test == "ovo" else [None]):
+        _, g = oracle.encode_and_count_groups(labels, ref)
+        engine.set_option("profile", 1)
+        engine.profile_reset()
+        try:
+            got = _run(engine, M, g)
+            prof = engine.profile_get()
+        finally:
+            engine.set_option("profile", 0)
+        assert "k_csr_counts" in prof, prof
+        assert_planes_match(got, oracle.run(Xd, g), what=f"csr counts {test} ref={ref}")
+        for lb, ub, kw in [(5, 4290, dict(alternative="less")), (2040, 2060, dict(use_continuity=False)), (100, 2148, dict(tie_correct=False, alternative="greater"))]:
+            got = _run(engine, M, g, col_lb=lb, col_ub=ub, **kw)
+            assert_planes_match(got, oracle.run(Xd, g, col_lb=lb, col_ub=ub, **kw), what=f"csr counts window {lb}:{ub} {test}")
+    # rows out of order: found on the device, every gene goes to the routes that do not need the order
+    for r in range(0, n, 7):
+        a, b = M.indptr[r], M.indptr[r + 1]
+        perm = rng.permutation(b - a)
+        M.indices[a:b] = M.indices[a:b][perm]
+        M.data[a:b] = M.data[a:b][perm]
+    assert_planes_match(_run(engine, M, g), oracle.run(Xd, g), what=f"csr counts {test}, rows out of order")
 
 
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
@@ -477,9 +529,10 @@ def test_sparse_type_extremes(engine, fmt, test, dtype, route):
     assert_planes_match(got, want, ref_row=g.encoded_ref_group if test == "ovo" else None, what=f"{fmt} {test} {np.dtype(dtype).name} {route}")
 
 
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
-def test_deferred_csc_calls_complete_their_leftover_genes(engine, test):
-    """ILLICO_FLAG_DEFER on device-resident CSC arrays: the count-valued pass is enqueued without a host wait; the genes it
+def test_deferred_csc_calls_complete_their_leftover_genes(engine, test, fmt):
+    """ILLICO_FLAG_DEFER on device-resident CSC arrays (and CSR arrays: the group-major pass, groups above 255 cells included): the count-valued pass is enqueued without a host wait; the genes it
     cannot take (values beyond the table, fractional values, 4-bit cells that overflow) are recomputed when the next call or
     synchronize() looks at their flags -- and a matrix that is no count matrix at all is sent on from the device-side sample."""
     import torch
@@ -497,7 +550,7 @@ def test_deferred_csc_calls_complete_their_leftover_genes(engine, test):
     dev = torch.device("cuda", engine.device)
 
     def up(M):
-        M = sparse.csc_matrix(M)
+        M = sparse.csc_matrix(M) if fmt == "csc" else sparse.csr_matrix(M)
         return tuple(torch.from_numpy(a).to(dev) for a in (M.data, M.indices, M.indptr)), M.shape
 
     (d, i, p), shape = up(X)
@@ -505,21 +558,21 @@ def test_deferred_csc_calls_complete_their_leftover_genes(engine, test):
     G = g.counts.size
     A = tuple(torch.full((G, 96), -7.0, dtype=torch.float64, device=dev) for _ in range(3))
     B = tuple(torch.full((G, 96), -7.0, dtype=torch.float64, device=dev) for _ in range(3))
-    engine.run_sparse("csc", d, i, p, shape, 0, 96, out=A, defer=True)
-    engine.run_sparse("csc", dc, ic, pc, shape, 0, 96, out=B, defer=True)   # other planes: enqueued before A is completed
-    engine.run_sparse("csc", d, i, p, shape, 0, 96, out=A, defer=True)      # the same planes again
+    engine.run_sparse(fmt, d, i, p, shape, 0, 96, out=A, defer=True)
+    engine.run_sparse(fmt, dc, ic, pc, shape, 0, 96, out=B, defer=True)   # other planes: enqueued before A is completed
+    engine.run_sparse(fmt, d, i, p, shape, 0, 96, out=A, defer=True)      # the same planes again
     engine.synchronize()
     ref_row = g.encoded_ref_group
-    assert_planes_match(tuple(t.cpu().numpy() for t in A), want, ref_row=ref_row, what=f"deferred csc {test}")
-    assert_planes_match(tuple(t.cpu().numpy() for t in B), want_c, ref_row=ref_row, what=f"deferred csc {test} continuous")
+    assert_planes_match(tuple(t.cpu().numpy() for t in A), want, ref_row=ref_row, what=f"deferred {fmt} {test}")
+    assert_planes_match(tuple(t.cpu().numpy() for t in B), want_c, ref_row=ref_row, what=f"deferred {fmt} {test} continuous")
     # a window, then a non-deferred call while one is pending
     C = tuple(torch.full((G, 96), -7.0, dtype=torch.float64, device=dev) for _ in range(3))
-    engine.run_sparse("csc", d, i, p, shape, 32, 80, out=tuple(t[:, 32:80] for t in C), defer=True)
-    got = engine.run_sparse("csc", d, i, p, shape, 0, 96)
-    assert_planes_match(got, want, ref_row=ref_row, what=f"csc {test} after a deferred call")
+    engine.run_sparse(fmt, d, i, p, shape, 32, 80, out=tuple(t[:, 32:80] for t in C), defer=True)
+    got = engine.run_sparse(fmt, d, i, p, shape, 0, 96)
+    assert_planes_match(got, want, ref_row=ref_row, what=f"{fmt} {test} after a deferred call")
     engine.synchronize()
     assert_planes_match(tuple(t[:, 32:80].cpu().numpy() for t in C), tuple(w[:, 32:80] for w in want), ref_row=ref_row,
-                        what=f"deferred csc window {test}")
+                        what=f"deferred {fmt} window {test}")
     assert all(float(t[:, :32].min()) == -7.0 and float(t[:, 80:].max()) == -7.0 for t in C)
 
 
