@@ -393,10 +393,11 @@ bool fused_path_allowed(const illico_ctx *c, int flags) {
 
 int launch_finalize(illico_ctx *c, const long long *s2u, const u64 *stie, const double *ssum, const double *gene_total,
                            int nb, int flags, int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld,
-                           int64_t col_off, const int *col_map, bool packed) {
+                           int64_t col_off, const int *col_map, bool packed, bool tie_f64) {
     FinalizeParams F;
     F.col_map = col_map;
     F.packed = packed ? 1 : 0;
+    F.tie_f64 = tie_f64 ? 1 : 0;
     F.in_2u = s2u; F.in_tie = stie; F.in_sum = ssum; F.gene_total = gene_total;
     F.counts = c->d_counts; F.G = (int)c->n_groups; F.ref = (int)c->ref; F.nb = nb; F.n_cells = c->n_cells;
     F.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;

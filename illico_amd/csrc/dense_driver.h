@@ -118,6 +118,7 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
     P.wide_bad = nullptr;
     P.hist_off = nullptr;
     P.hist_words = nullptr;
+    P.tie_mode = ovr ? (c->fused_tie_sparse ? 2 : 1) : 0; // (the reference's float64 tie accumulation: dense order, or a CSR window's sparse order)
     P.hist_full = c->ovr_full_dump ? 1 : 0;
     P.hist_total = (long long)c->hist_words;
     u32 *skipw = P.hist_all + (size_t)nb * RT; // (inside the 64 spare bytes of the allocation)

@@ -123,6 +123,7 @@ struct illico_ctx {
     int *d_csr_chunks = nullptr;
     int csr_n_chunks = 0, csr_n_big = 0; // csr_n_big < 0: more big groups than the route takes
     bool cur_sorted_known = false;       // the running call is on a bound CSR matrix whose rows were found in order when it was bound
+    bool fused_tie_sparse = false;       // the fused OVR kernels run on a window of CSR input: tie sums as the reference's SPARSE path forms them
     int csr_counts_abl = 0;              // timing experiments (CsrCountsParams::abl)
     bool hold_csr_counts = false;        // set while a deferred call's leftover genes are recomputed (they must not come back to the route)
     // options
@@ -251,7 +252,7 @@ bool counts_path_allowed(const illico_ctx *c, int flags);
 bool fused_path_allowed(const illico_ctx *c, int flags);
 int launch_finalize(illico_ctx *c, const long long *s2u, const u64 *stie, const double *ssum, const double *gene_total, int nb, int flags,
                     int alternative, double *out_p, double *out_u, double *out_fc, int64_t out_ld, int64_t col_off, const int *col_map = nullptr,
-                    bool packed = false);
+                    bool packed = false, bool tie_f64 = false);
 int launch_gene_totals(illico_ctx *c, const double *ssum, int G, int nb, double *gtot);
 void flagged_runs(const u32 *hf, int64_t wn, int64_t w0, std::vector<std::pair<int64_t, int64_t>> &runs);
 

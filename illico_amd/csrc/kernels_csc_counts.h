@@ -28,6 +28,7 @@
 #pragma once
 #include <type_traits>
 #include "common.h"
+#include "kernels_finalize.h"
 
 #define CSCC_NT 512
 #ifndef CSCC_UL
@@ -60,6 +61,7 @@ struct CscCountsParams {
     double *gene_total;                  // OVR: [nb] the column's value sum (what k_gene_totals would add up from out_sum), or nullptr
     int pack16;                          // statistics as 16 bytes per test: out_2u = value sum << 40 | 2U (40 bits; all ones: the OVO reference
                                          // row), out_tie; out_sum unused.  Host-checked: no group beyond 255 cells (sums < 2^24, 2U < 2^40)
+    int tie_f64;                         // OVR: out_tie = the bits of the float64 tie sum of the reference's sparse path (tie_f64_sparse)
     const u32 *verdict;                  // deferred calls: {non-integers, -, samples} of k_sample_noncount_cols, looked at on the device
                                          // (more than 2 % non-integers: not a count matrix, every gene is left to the general routes); or nullptr
 };
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(NTT, MIXED ? (NTT == 1024 ? 8 : 4) : 2) void k_csc_
             const u64 zB = (u64)(n_g - (long long)nnz_g);
             if (OVR) {
                 acc += zB * (zsel + 1ull);
-                emit(gg, 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)acc, T_sel + (zsel * zsel * zsel - zsel), (u64)vsum);
+                emit(gg, 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)acc, P.tie_f64 ? tie_f64_sparse(T_sel, (long long)zsel) : T_sel + (zsel * zsel * zsel - zsel), (u64)vsum);
             } else {
                 acc += zB * zsel;
                 const u64 t0 = zsel + zB;

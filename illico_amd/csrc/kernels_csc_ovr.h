@@ -25,6 +25,7 @@
 // rank inside its own part -- one workgroup per gene, its parts one after the other.  Dense continuous OVR at C4 shape: 68 ms (segmented radix sort of (key, group) pairs in HBM) -> see DESIGN.
 #pragma once
 #include "common.h"
+#include "kernels_finalize.h"
 #include "kernels_sparse.h"
 
 #define CSCO_NT 1024
@@ -54,6 +55,7 @@ struct CscOvrParams {
     u32 *fallback;                       // [nb] set to 1 for genes this kernel cannot take
     long long *out_2u;                   // [nb][G] 2 U (U of "the rest", dense_ovr.py:57-61)
     u64 *out_tie;                        // [nb][G] sum (t^3 - t), the same for every group of a gene
+    int tie_f64;                         // out_tie = the bits of the float64 tie sum of the reference's sparse path (tie_f64_sparse)
     // (per-group value sums are not formed here: they would be order-dependent float64 atomics.  The host launches
     //  k_csc_value_sums / k_group_sums_rows, kernels_sums.h, whose results do not depend on the order of arrival.)
 };
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         __syncthreads();
         u64 tie_total = 0;
         for (int w = 0; w < NW; ++w) tie_total += s_red[w];
-        tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
+        if (P.tie_f64) tie_total = tie_f64_sparse(tie_total, n0);
+        else tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
         for (int g = tid; g < G; g += NT) {
             const long long n_g = P.counts[g];
             const u64 a = acc[g];

@@ -49,7 +49,7 @@ struct CsrCountsParams {
     int bstep;                           // fine windows (Wf genes) per workgroup window
     int n_bnd;                           // boundaries (fine windows + 1)
     const u32 *tab;                      // [64][Wpad]: OVO (A << 15) | tA,  A = 2 zA + 2 cumA[c] + tA[c];  OVR A = 2 n0 + 2 cum[c] + t[c] + 1
-    const uint4 *ginfo;                  // [Wpad]: OVO {T_A lo, T_A hi, zA, value sum of the reference}; OVR {T lo, T hi, n0, -}
+    const uint4 *ginfo;                  // [Wpad]: OVO {T_A lo, T_A hi, zA, value sum of the reference}; OVR {T lo, T hi, n0, -}, T = the bits of the float64 tie sum
     const double *gene_total;            // [Wpad] OVR: the column's value sum; OVO: the reference group's mean (mu_ref)
     long long Wpad;
     u32 *gene_flags;                     // [W]
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_csr_tables(const u32 *__restrict__ hist
         sum += t * (u64)c;
     }
     if (OVR) {
-        T += z * z * z - z;
+        T = tie_f64_sparse(T, (long long)z); // the BITS of the float64 tie sum, as the reference's sparse OVR path forms it (kernels_finalize.h)
         gene_total[j] = (double)sum; // integer sums: exact whatever the order of addition
         ginfo[j] = make_uint4((u32)T, (u32)(T >> 32), (u32)z, 0u);
     } else {
@@ -407,7 +407,7 @@ __device__ __forceinline__ void csrc_sweep(const CsrCountsParams &P, int g, int 
                 tie_sum = T_sel + tie + (t0 * t0 * t0 - t0);
             }
             U = 0.5 * (double)two_u;
-            const double tie_d = P.tie_correct ? (double)tie_sum : 0.0;
+            const double tie_d = !P.tie_correct ? 0.0 : (OVR ? __longlong_as_double((long long)tie_sum) : (double)tie_sum);
             p = (P.abl & 8) ? tie_d : pval_device_pre(nnn, var0, n12, tie_d, U, mu, cc, P.alternative);
             // fold change, math.py:181-192 (integer value sums: exact)
             const double sum_g = (double)vsum;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void k_csr_big_sweep(CsrCountsParams P) {
     const double cc = P.use_continuity ? 0.5 : 0.0;
     const double mu = (double)(n_ref * n_tgt) / 2.0;
     const double U = 0.5 * (double)two_u;
-    const double p = pval_device(n_ref, n_tgt, n, P.tie_correct ? (double)tie_sum : 0.0, U, mu, cc, P.alternative);
+    const double p = pval_device(n_ref, n_tgt, n, !P.tie_correct ? 0.0 : (OVR ? __longlong_as_double((long long)tie_sum) : (double)tie_sum), U, mu, cc, P.alternative);
     const double sum_g = (double)vsum;
     const double mu_tgt = sum_g / (double)n_tgt;
     const double mu_ref = OVR ? (P.gene_total[jc] - sum_g) / (double)(P.n_cells - n_tgt) : P.gene_total[jc];

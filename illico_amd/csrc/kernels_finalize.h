@@ -18,12 +18,25 @@ struct FinalizeParams {
     double *out_p, *out_u, *out_fc; // [G][out_ld], column offset already applied
     long long out_ld;
     const int *col_map;       // optional: output column of batch gene j (relative to the offset); nullptr = j
+    int tie_f64;              // in_tie holds the BITS of a float64: the tie sum as the reference's sparse OVR path accumulates it
+                              // (tie_f64_sparse below), not an exact integer
     int packed;               // 16-byte statistics (k_csc_counts): in_2u = value sum << 40 | 2U (40 bits, all ones = the OVO reference row); no in_sum
 };
 
 // compute_pval with its per-(group) constants handed in -- nnn = (double)(n (n-1) (n+1)) (math.py:95), var0 = (double)(n_ref n_tgt
 // (n_ref + n_tgt + 1)) / 12.0 (:97, the part in front of "* tie_corr"), n12 = (double)(n_ref n_tgt) -- so that a kernel which computes
 // many genes of one group forms them once: the same operations on the same values, bit for bit
+// The reference forms the tie sum in a float64 accumulator.  Its dense paths add exact integers, block by block
+// (utils/ranking.py:30-47); its sparse OVR path adds the non-zero blocks first and then `n0**3 - n0` with n0 a float64
+// (ovr/sparse_ovr.py:49,83): beyond n0 ~ 2.1e5 zeros n0^3 leaves float64's 53 bits, the two differ in the last bits, and at
+// z ~ 36 those bits show in p at the 1e-12 level (tests/test_gpu_tail.py).  t_nonzero: the exact sum over the non-zero blocks.
+__device__ __forceinline__ u64 tie_f64_sparse(u64 t_nonzero, long long n_zeros) {
+    const double n0 = (double)n_zeros;
+    double t = (double)t_nonzero;
+    t += n0 * n0 * n0 - n0;
+    return (u64)__double_as_longlong(t);
+}
+
 __device__ __forceinline__ double pval_device_pre(double nnn, double var0, double n12, double tie_sum, double U, double mu, double cc, int alternative) {
     double tie_corr = 1.0 - tie_sum / nnn;                                         // math.py:95
     if (tie_corr > 1.0e-9) {                                                       // :96
@@ -99,7 +112,7 @@ static __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
             long long n_ref = ovr ? (total_cells - n_tgt) : n_refc;
             long long n = ovr ? total_cells : (n_ref + n_tgt);
             double U = 0.5 * (double)in2u[k];
-            double tie = P.tie_correct ? (double)intie[k] : 0.0;
+            double tie = !P.tie_correct ? 0.0 : (P.tie_f64 ? __longlong_as_double((long long)intie[k]) : (double)intie[k]);
             double mu = (double)(n_ref * n_tgt) / 2.0;
             double p;
             if (!ovr && g == P.ref) { p = 1.0; U = -1.0; }                         // sparse_ovo.py:140-143

@@ -37,7 +37,10 @@ struct FusedParams {
     const int *counts;        // [G]
     int G, ref;
     u32 *ref_cum;             // [tile][RT+1][64] cumulative counts, tile = 64 consecutive genes (the LDS image of k_ovo_fused)
-    u64 *ref_TA;              // [ncols] sum_v (tA^3 - tA)
+    u64 *ref_TA;              // [ncols] sum_v (tA^3 - tA); OVR with tie_mode != 0: the BITS of the float64 the reference's accumulator holds
+    int tie_mode;             // OVR: 1 = the reference's dense path (exact integers added block by block, ascending: utils/ranking.py:30-47),
+                              // 2 = its sparse path (non-zero blocks, then n0**3 - n0 in float64: ovr/sparse_ovr.py:49,83) -- what a CSR
+                              // window is held to.  The same value as the exact sum while n^3 fits 53 bits; beyond, the bits the reference has
     u64 *ref_sum;             // [ncols] sum of reference values
     u32 *hist_all;            // [ncols][RT] whole-column histogram (OVR; zeroed by the host)
     long long n_cells;
@@ -461,6 +464,14 @@ template <int RT, bool WIDE = false> __global__ void k_fused_tables_all(FusedPar
         ta += t * t * t - t;
         sum += t * (u64)c;
     }
+    if (P.ref < 0 && P.tie_mode) { // the float64 tie sum as the reference accumulates it
+        if (P.tie_mode == 2) ta = tie_f64_sparse(ta - ((u64)h[0] * h[0] * h[0] - (u64)h[0]), (long long)h[0]);
+        else {
+            double td = 0.0;
+            for (int c = 0; c < RT; ++c) { const u64 t = h[c]; td += (double)(t * t * t - t); }
+            ta = (u64)__double_as_longlong(td);
+        }
+    }
     P.ref_TA[gene] = ta;
     P.ref_sum[gene] = sum;
     if (P.ref >= 0) { // OVO (tables of the reference group, k_fused_ref_hist): the reference group's own row
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(FUSED_NT, WIDE ? (OVR ? 2 : 1) : ((OVR || CB == 8) 
             // 2*ranksum = S2 + n_tgt (2 rank = 2 #less + #equal + 1);  U = n_rest n_tgt + n_tgt(n_tgt+1)/2 - ranksum
             const long long two_u = 2ll * n_rest * n_tgt + n_tgt * (n_tgt + 1) - ((long long)S2 + n_tgt);
             Ustat = 0.5 * (double)two_u;
-            const double tie = P.tie_correct ? (double)T_A : 0.0;
+            const double tie = !P.tie_correct ? 0.0 : (P.tie_mode ? __longlong_as_double((long long)T_A) : (double)T_A);
             const double mu = (double)(n_rest * n_tgt) / 2.0;
             pv = pval_device(n_rest, n_tgt, P.n_cells, tie, Ustat, mu, cc, P.alternative);
             const double mu_ref = (ref_sum - (double)vsum) / (double)n_rest; // math.py:185-188
@@ -769,7 +780,7 @@ __global__ __launch_bounds__(FUSED_NT, NPL == 3 ? 3 : 2) void k_ovr_from_hists(F
     }
     const u64 T_A = P.ref_TA[gene];
     const double total = (double)P.ref_sum[gene], cc = P.use_continuity ? 0.5 : 0.0;
-    const double tie = P.tie_correct ? (double)T_A : 0.0;
+    const double tie = !P.tie_correct ? 0.0 : (P.tie_mode ? __longlong_as_double((long long)T_A) : (double)T_A);
     auto narrow = [&](int g) { return CB == 8 || P.counts[g] <= 255; }; // uniform
     auto hist_of = [&](int g, int bw) {
         const size_t base = CB ? ((size_t)blockIdx.x * P.G + g) * (BW8 * 64) : ((size_t)blockIdx.x * P.hist_total + P.hist_off[g]) * 64;

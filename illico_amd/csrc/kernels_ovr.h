@@ -13,6 +13,7 @@
 // block between the negative and the positive keys (sparse_ovr.py:70-83).
 #pragma once
 #include "common.h"
+#include "kernels_finalize.h"
 
 struct OvrParams {
     void *keys_a;             // [n_genes rows]  in: unsorted keys (destroyed)
@@ -32,6 +33,7 @@ struct OvrParams {
     u64 *acc_global;          // ACCG: per-gene accumulators [n_genes][3*G] in HBM (group counts beyond what LDS holds)
     long long *out_2u;        // [n_genes][G]
     u64 *out_tie;             // [n_genes][G]
+    int tie_f64;              // sparse OVR: out_tie = the bits of the float64 tie sum of the reference's sparse path (tie_f64_sparse)
     double *out_sum;          // [n_genes][G]
     // split form (MODE 1 / 2: the sort between them is rocPRIM's segmented radix sort)
     u32 *seg_begin, *seg_end; // [n_genes] element offsets of each gene's (key, code) pairs in the unsorted buffers
@@ -546,7 +548,8 @@ __global__ __launch_bounds__(NT) void k_ovr_gene(OvrParams P) {
         __syncthreads();
         u64 tie_total = 0;
         for (int w = 0; w < NW; ++w) tie_total += red[w];
-        tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
+        if (P.tie_f64) tie_total = tie_f64_sparse(tie_total, (long long)n0);
+        else tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
         const long long nneg = flag[2];
         for (int g = tid; g < G; g += NT) {
             long long n_g = P.counts[g];

@@ -71,7 +71,7 @@ int run_ovr_dense_batch(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, 
     P.code_by_pos = padded ? c->d_pk_code : c->d_code_by_pos; P.seg_ptr = nullptr; P.stride = stride; P.pos_ptr = c->d_posptr;
     P.counts = c->d_counts; P.G = (int)c->n_groups; P.n_genes = nb; P.dt = dtype;
     P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = N; P.scan_len = padded ? c->pk_len : 0; P.ref = -1; P.gene_flags = nullptr;
-    P.out_2u = s2u; P.out_tie = stie; P.out_sum = padded ? nullptr : ssum;
+    P.out_2u = s2u; P.out_tie = stie; P.out_sum = padded ? nullptr : ssum; P.tie_f64 = 0;
     if ((rc = launch_ovr_gene<KeyT, false>(c, P))) return rc;
     return launch_gene_totals(c, ssum, (int)c->n_groups, nb, gtot);
 }
@@ -204,7 +204,7 @@ int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_
         Q.code_by_pos = sparse ? nullptr : c->d_code_by_pos; Q.seg_ptr = P.seg_ptr; Q.stride = P.gene_stride;
         Q.pos_ptr = P.pos_ptr; Q.counts = P.counts; Q.G = P.G; Q.n_genes = P.n_genes; Q.dt = P.dt; Q.is_log1p = P.is_log1p;
         Q.n_cells = c->n_cells; Q.ref = P.ref; Q.gene_flags = flags;
-        Q.out_2u = P.out_2u; Q.out_tie = P.out_tie; Q.out_sum = P.out_sum;
+        Q.out_2u = P.out_2u; Q.out_tie = P.out_tie; Q.out_sum = P.out_sum; Q.tie_f64 = 0;
         return sparse ? launch_ovr_gene<KeyT, true, true>(c, Q) : launch_ovr_gene<KeyT, false, true>(c, Q);
     }
     int ref_cap = (int)std::max<int64_t>(max_ref_nnz, 1);

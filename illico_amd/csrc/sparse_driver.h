@@ -195,6 +195,7 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
             P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes16 = codes16; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref;
             P.n_cells = n_rows; P.fallback = fb; P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot;
             P.gene_total = ovr ? gtot : nullptr;
+            P.tie_f64 = ovr ? 1 : 0; // (the reference's sparse OVR arithmetic, kernels_finalize.h: tie_f64_sparse)
             P.verdict = nullptr;
             const bool pack16 = n_big == 0 && !w16; // 16-byte statistics while every ranked group has at most 255 cells
             P.pack16 = pack16 ? 1 : 0;
@@ -204,8 +205,8 @@ static int run_csc_counts_route(illico_ctx *c, const InT *d_data, const IdxT *d_
                 if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
                 else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds, w16))) return rc;
             }
-            if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0, pack16))) return rc; }
-            else if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb, nullptr, pack16))) return rc;
+            if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0, pack16, ovr))) return rc; }
+            else if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb, nullptr, pack16, ovr))) return rc;
             if (c->pinned_bytes < (size_t)nb * 4) {
                 if (c->pinned) hipHostFree(c->pinned);
                 c->pinned = nullptr; c->pinned_bytes = 0;
@@ -280,7 +281,7 @@ static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *
         CscCountsParams P;
         P.data = data; P.indices = indices; P.indptr = indptr; P.kshift = 0; P.col0 = col_lb + b0; P.gene_cols = nullptr; P.nb = nb;
         P.codes16 = c->d_codes16; P.counts = c->d_counts; P.G = G; P.ref = (int)c->ref; P.n_cells = n_rows; P.fallback = fb + b0;
-        P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot; P.gene_total = ovr ? gtot : nullptr; P.verdict = d_cnt;
+        P.out_2u = s2u; P.out_tie = stie; P.out_sum = ssum; P.big_slot = d_slot; P.gene_total = ovr ? gtot : nullptr; P.verdict = d_cnt; P.tie_f64 = ovr ? 1 : 0;
         const bool pack16 = n_big == 0 && !w16;
         P.pack16 = pack16 ? 1 : 0;
         P.G_total = G;
@@ -289,7 +290,7 @@ static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *
             if (mixed) { if ((rc = launch_csc_counts<InT, IdxT, true>(c, P, rt, n_big > 0, ovr, lds))) return rc; }
             else if ((rc = launch_csc_counts<InT, IdxT, false>(c, P, rt, n_big > 0, ovr, lds, w16))) return rc;
         }
-        if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0, nullptr, pack16))) return rc;
+        if ((rc = launch_finalize(c, s2u, stie, ssum, ovr ? gtot : nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, b0, nullptr, pack16, ovr))) return rc;
     }
     const int slot = c->pend_next;
     void *&pin = c->pend_pinned[slot];
@@ -415,7 +416,7 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
         P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.codes16 = d_codes ? c->d_codes16 : nullptr; P.counts = c->d_counts; P.G = G; P.dt = dtype;
         P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.key_cap = key_cap; P.lg_buckets = lg;
         P.force_sorted = c->csc_ovr_sorted_form ? 1 : 0; P.fallback = fb;
-        P.out_2u = s2u; P.out_tie = stie;
+        P.out_2u = s2u; P.out_tie = stie; P.tie_f64 = 1;
         {
             ProfScope ps(c, KID_CSC_OVR);
             hipLaunchKernelGGL(kern, dim3(nb), dim3(CSCO_NT), lds, c->stream, P);
@@ -423,8 +424,8 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
         }
         if ((rc = launch_csc_value_sums<InT, IdxT>(c, d_data, d_indices, d_indptr, kshift, cols[b0], d_cols ? d_cols + b0 : nullptr, d_codes, nb, dtype, flags, ssum))) return rc;
         if ((rc = launch_gene_totals(c, ssum, G, nb, gtot))) return rc;
-        if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0))) return rc; }
-        else if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb))) return rc;
+        if (d_cols) { if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, -col_lb, d_cols + b0, false, true))) return rc; }
+        else if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cols[b0] - col_lb, nullptr, false, true))) return rc;
         if (c->pinned_bytes < (size_t)nb * 4) {
             if (c->pinned) hipHostFree(c->pinned);
             c->pinned = nullptr; c->pinned_bytes = 0;
@@ -758,8 +759,11 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                                        (int)n_rows, (long long)w0, (int)wn, (float *)v, (long long)ldD);
                 HIPCHK(c, hipGetLastError());
             }
-            if (bytes) { if ((rc = run_fused_ovo<uint8_t>(c, v, ldD, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc; }
-            else if ((rc = run_fused_ovo<float>(c, v, ldD, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf))) return rc;
+            c->fused_tie_sparse = true; // (the window holds CSR input: the reference ranks it by its sparse path)
+            if (bytes) rc = run_fused_ovo<uint8_t>(c, v, ldD, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf);
+            else rc = run_fused_ovo<float>(c, v, ldD, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf);
+            c->fused_tie_sparse = false;
+            if (rc) return rc;
             for (int64_t j = 0; j < wn; ++j)
                 if (hf[j] == 1u || hf[j] == 3u) { // (2 = taken by the fused route's second, wider pass)
                     if (bad_lo < 0) bad_lo = w0 + j;
@@ -1060,11 +1064,11 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
             P.keys_a = Xs; P.keys_b = kb; P.vals_a = va; P.vals_b = vb; P.code_by_pos = nullptr; P.seg_ptr = seg;
             P.stride = 0; P.pos_ptr = nullptr; P.counts = c->d_counts; P.G = G; P.n_genes = nb; P.dt = dtype;
             P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.ref = -1; P.gene_flags = nullptr;
-            P.out_2u = s2u; P.out_tie = stie; P.out_sum = nullptr; // (the sort below permutes Xs: the sums come first)
+            P.out_2u = s2u; P.out_tie = stie; P.out_sum = nullptr; P.tie_f64 = 1; // (the sort below permutes Xs: the sums come first)
             if ((rc = launch_seg_value_sums<KeyT>(c, Xs, seg, nb, dtype, flags, ssum))) return rc;
             if ((rc = launch_ovr_gene<KeyT, true>(c, P))) return rc;
             if ((rc = launch_gene_totals(c, ssum, G, nb, gtot))) return rc;
-            if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, fin_off, d_cols))) return rc;
+            if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, fin_off, d_cols, false, true))) return rc;
         }
     }
     }
