@@ -1,6 +1,10 @@
 // Dense-input drivers, templated on the value type: instantiated in dense_<type>.hip.
 #pragma once
 #include "keyed_driver.h"
+#include "host_narrow.h"
+#ifndef ILLICO_DENSE_U8_UNIT // the fused kernels on byte windows are instantiated in dense_u8.hip only
+extern template int run_fused_ovo<uint8_t>(illico_ctx *, const void *, int64_t, int64_t, int, int, int, const OutPlanes &, int64_t, std::vector<u32> &, int, bool, int64_t, const u32 *);
+#endif
 
 // k_group_compact over one gene batch; pack = false: the padded dense layout (every key kept, sums only)
 template <typename InT, typename KeyT>
@@ -328,15 +332,19 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
 }
 // Of 64k evenly spaced cells of a HOST matrix window: is it count-valued at all?  (The fused route over a host matrix copies
 // the window up; on normalised data that copy would be made twice, once for nothing.)
-template <typename InT> static bool host_window_is_count_valued(const InT *X, int64_t ld, int64_t col_lb, int64_t N, int64_t W) {
+template <typename InT> static bool host_window_is_count_valued(const InT *X, int64_t ld, int64_t col_lb, int64_t N, int64_t W, bool *light_tails = nullptr) {
     const int64_t n_samples = std::min<int64_t>(N * W, 1 << 16);
-    int64_t bad = 0;
+    int64_t bad = 0, big = 0;
     for (int64_t i = 0; i < n_samples; ++i) {
         const int64_t k = (int64_t)((double)i * (double)(N * W) / (double)n_samples);
         const int64_t r = k / W, j = k - r * W;
         const InT v = X[r * ld + col_lb + j];
         if (!(v >= (InT)0 && v < (InT)(1 << 24) && (InT)(int)v == v)) ++bad;
+        else if (v >= (InT)255) ++big;
     }
+    // light tails: (nearly) no sampled cell of 255 or more -- the byte windows of host_windows_pipeline_narrow then hold (nearly) every
+    // gene; a heavy-tailed count matrix keeps the float32 windows, whose flagged genes are gathered on the device instead of going up again
+    if (light_tails) *light_tails = (double)(bad + big) * 2048.0 <= (double)n_samples;
     return (double)bad <= 0.02 * (double)n_samples;
 }
 // ---- host-resident dense input: a three-stage pipeline over column windows ----------------------------------------------
@@ -346,6 +354,7 @@ template <typename InT> static bool host_window_is_count_valued(const InT *X, in
 // stream runs the fused pass on window k - 1 -- all three at once, three slots deep.  Slot j serves the windows k = j mod 3: its
 // pinned half is free once its upload has completed, its device half once the pass over it has (events both ways).
 #define HS_THREADS 12
+#define HS_THREADS_NARROW 16 // (the byte pipeline: the fill -- 9.6 GB of host reads at C2 -- is what must keep up with a quarter-size upload)
 struct HostLeftovers { // the flagged genes' columns, gathered on the device while their window is still there
     void *xl = nullptr;    // [N][cap] values
     int64_t cap = 0, n = 0;
@@ -422,11 +431,17 @@ static int host_windows_pipeline(illico_ctx *c, const InT *X, int64_t ld, int64_
             const size_t piece = (size_t)wn * sizeof(InT);
             const auto t_a = std::chrono::steady_clock::now();
             std::vector<std::thread> pool;
-            for (int t = 1; t < T; ++t)
-                pool.emplace_back([=] {
-                    for (int64_t r = N * t / T; r < N * (t + 1) / T; ++r) memcpy(dst + (size_t)r * wn, X + (size_t)r * ld + w0, piece);
-                });
-            for (int64_t r = 0; r < N / T; ++r) memcpy(dst + (size_t)r * wn, X + (size_t)r * ld + w0, piece);
+            auto rows = [=](int64_t r0, int64_t r1) { // (the piece eight rows ahead is prefetched by hand: see host_windows_pipeline_narrow)
+                for (int64_t r = r0; r < r1; ++r) {
+                    if (r + 8 < r1) {
+                        const char *pf = (const char *)(X + (size_t)(r + 8) * ld + w0);
+                        for (size_t b = 0; b < piece; b += 64) __builtin_prefetch(pf + b, 0, 1);
+                    }
+                    memcpy(dst + (size_t)r * wn, X + (size_t)r * ld + w0, piece);
+                }
+            };
+            for (int t = 1; t < T; ++t) pool.emplace_back(rows, N * t / T, N * (t + 1) / T);
+            rows(0, N / T);
             for (auto &th : pool) th.join();
             t_fill += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
             hipError_t e = hipMemcpyAsync(dev[j], dst, piece * (size_t)N, hipMemcpyHostToDevice, hs->copy);
@@ -489,6 +504,125 @@ static int host_windows_pipeline(illico_ctx *c, const InT *X, int64_t ld, int64_
     hipStreamSynchronize(hs->copy);
     if (getenv("ILLICO_HS_DEBUG"))
         fprintf(stderr, "[illico] host windows: %lld x %lld genes, slot fill %.1f ms, consumer waited %.1f ms for uploads\n", (long long)n_win,
+                (long long)wmax, t_fill * 1e3, t_wait * 1e3);
+    return rc;
+}
+
+// ---- the same pipeline with BYTE windows (host_narrow.h): a count matrix in host memory goes up as a quarter of its float32 bytes ----
+// The threads that fill a pinned slot convert as they copy (cell = the value when it is an integer in [0, 255), else 255); the copy
+// stream moves N x wn bytes; the context's stream runs the fused kernels on the byte window -- k_ovo_fused<uint8_t> /
+// k_ovr_group_hists<uint8_t>, the forms count-valued CSR windows take, 64-value pass and 256-value second pass alike.  A gene they
+// flag (a 255 cell: a value of 255 or more, a fraction, a negative) comes back as a column run and goes up again, in its own type,
+// through the two-pass routes (run_dense_twopass on the host matrix): few genes on count data.  Windows are four times as wide as the
+// float32 pipeline's for the same pinned memory: each row piece is a longer contiguous read of the caller's matrix.
+template <typename InT>
+static int host_windows_pipeline_narrow(illico_ctx *c, const InT *X, int64_t ld, int64_t N, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                                        const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> &runs) {
+    int rc;
+    void *v;
+    int64_t wmax = std::max<int64_t>(64, (int64_t)(((size_t)256 << 20) / (size_t)N) & ~63ll);
+    wmax = std::min<int64_t>(wmax, std::max<int64_t>(64, (int64_t)((size_t)c->scratch_bytes / HS_SLOTS / (size_t)N) & ~63ll));
+    if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, std::max<int64_t>(64, (c->gene_batch + 63) & ~63ll));
+    const int64_t n_win = (col_ub - col_lb + wmax - 1) / wmax;
+    const size_t slot_bytes = (size_t)wmax * (size_t)N; // (wmax is a multiple of 64: every window's row pitch, its width rounded up to 64, fits)
+    HostStage *hs = host_stage_of(c);
+    if (!hs->copy) HIPCHK(c, hipStreamCreateWithFlags(&hs->copy, hipStreamNonBlocking));
+    for (int j = 0; j < HS_SLOTS; ++j) {
+        if (!hs->up[j]) HIPCHK(c, hipEventCreateWithFlags(&hs->up[j], hipEventDisableTiming));
+        if (!hs->done[j]) HIPCHK(c, hipEventCreateWithFlags(&hs->done[j], hipEventDisableTiming));
+    }
+    if (hs->pin_bytes < slot_bytes) {
+        for (int j = 0; j < HS_SLOTS; ++j) { if (hs->pin[j]) hipHostFree(hs->pin[j]); hs->pin[j] = nullptr; }
+        hs->pin_bytes = 0;
+        for (int j = 0; j < HS_SLOTS; ++j) HIPCHK(c, hipHostMalloc(&hs->pin[j], slot_bytes, hipHostMallocDefault));
+        hs->pin_bytes = slot_bytes;
+    }
+    uint8_t *dev[HS_SLOTS];
+    static const char *names[HS_SLOTS] = {"xin0", "xin1", "xin2"};
+    for (int j = 0; j < HS_SLOTS; ++j) {
+        if ((rc = get_scratch(c, names[j], slot_bytes, &v))) return rc;
+        dev[j] = (uint8_t *)v;
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t ready = 0, consumed = 0;
+    int err = 0;
+    double t_fill = 0.0, t_wait = 0.0;
+    const int device = c->device;
+    hipStream_t compute = c->stream;
+    std::thread producer([&] {
+        hipSetDevice(device);
+        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(HS_THREADS_NARROW, N / 4096 + 1));
+        for (int64_t k = 0; k < n_win; ++k) {
+            const int j = (int)(k % HS_SLOTS);
+            const int64_t w0 = col_lb + k * wmax, wn = std::min<int64_t>(wmax, col_ub - w0), pitch = (wn + 63) & ~63ll;
+            if (k >= HS_SLOTS) { // slot j still belongs to window k - HS_SLOTS until the pass over it is done
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return consumed > k - HS_SLOTS || err; });
+                if (err) return;
+                lk.unlock();
+                if (hipEventSynchronize(hs->done[j]) != hipSuccess) { std::lock_guard<std::mutex> g(mu); err = 1; cv.notify_all(); return; }
+            }
+            uint8_t *dst = (uint8_t *)hs->pin[j];
+            const auto t_a = std::chrono::steady_clock::now();
+            auto rows = [=](int64_t r0, int64_t r1) {
+                for (int64_t r = r0; r < r1; ++r) {
+                    // a row piece is a few KB, the next one a whole matrix row further on: the hardware prefetchers do not follow; ask for
+                    // the piece eight rows ahead by hand (a thread is otherwise held to its handful of outstanding cache misses)
+                    if (r + 8 < r1) {
+                        const char *pf = (const char *)(X + (size_t)(r + 8) * ld + w0);
+                        for (size_t b = 0; b < (size_t)wn * sizeof(InT); b += 64) __builtin_prefetch(pf + b, 0, 1);
+                    }
+                    narrow_cells<InT>(X + (size_t)r * ld + w0, dst + (size_t)r * pitch, wn);
+                    if (pitch > wn) memset(dst + (size_t)r * pitch + wn, 0, (size_t)(pitch - wn));
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < T; ++t) pool.emplace_back(rows, N * t / T, N * (t + 1) / T);
+            rows(0, N / T);
+            for (auto &th : pool) th.join();
+            t_fill += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
+            hipError_t e = hipMemcpyAsync(dev[j], dst, (size_t)pitch * (size_t)N, hipMemcpyHostToDevice, hs->copy);
+            if (e == hipSuccess) e = hipEventRecord(hs->up[j], hs->copy);
+            std::lock_guard<std::mutex> g(mu);
+            if (e != hipSuccess) err = 1;
+            ready = k + 1;
+            cv.notify_all();
+            if (err) return;
+        }
+    });
+    std::vector<u32> hf;
+    rc = ILLICO_OK;
+    for (int64_t k = 0; k < n_win && !rc; ++k) {
+        const int j = (int)(k % HS_SLOTS);
+        const int64_t w0 = col_lb + k * wmax, wn = std::min<int64_t>(wmax, col_ub - w0), pitch = (wn + 63) & ~63ll;
+        {
+            const auto t_a = std::chrono::steady_clock::now();
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return ready > k || err; });
+            t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
+            if (err) { rc = fail(c, ILLICO_ERR_HIP, "staging a host window failed"); break; }
+        }
+        if (hipStreamWaitEvent(compute, hs->up[j], 0) != hipSuccess) { rc = fail(c, ILLICO_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        rc = run_fused_ovo<uint8_t>(c, dev[j], pitch, 0, (int)wn, flags, alternative, o, w0 - col_lb, hf);
+        if (!rc) flagged_runs(hf.data(), wn, w0, runs); // these genes go up again in the matrix's own type (the two-pass routes)
+        if (!rc && hipEventRecord(hs->done[j], compute) != hipSuccess) rc = fail(c, ILLICO_ERR_HIP, "hipEventRecord failed");
+        c->h2d_input_bytes += (int64_t)((size_t)pitch * (size_t)N);
+        std::lock_guard<std::mutex> g(mu);
+        consumed = k + 1;
+        if (rc) err = 1;
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (rc) err = 1;
+        consumed = n_win + HS_SLOTS;
+        cv.notify_all();
+    }
+    producer.join();
+    hipStreamSynchronize(hs->copy);
+    if (getenv("ILLICO_HS_DEBUG"))
+        fprintf(stderr, "[illico] host byte windows: %lld x %lld genes, slot fill %.1f ms, consumer waited %.1f ms for uploads\n", (long long)n_win,
                 (long long)wmax, t_fill * 1e3, t_wait * 1e3);
     return rc;
 }
@@ -612,6 +746,11 @@ int run_dense_t(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, 
         }
         if ((rc = run_fused_ovo<InT>(c, X, ld, col_lb, (int)W, flags, alternative, o, 0, hf, -1, ovr, max_gather))) return rc;
         return run_leftovers<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, hf.data(), hf[W] != 0u);
+    } else if (bool light = false; !in_dev && try_fused && N > 0 && W > 0 && c->host_narrow >= 0 && c->max_nonref <= 65535 &&
+               (c->host_narrow > 0 || (host_window_is_count_valued<InT>((const InT *)X, ld, col_lb, N, W, &light) && light))) {
+        // host matrix of counts: byte windows ("host_narrow": 1 forces them, -1 forbids them)
+        if ((rc = host_windows_pipeline_narrow<InT>(c, (const InT *)X, ld, N, col_lb, col_ub, flags, alternative, o, runs))) return rc;
+        if (runs.empty()) return ILLICO_OK;
     } else if (!in_dev && try_fused && N > 0 && W > 0 && host_window_is_count_valued<InT>((const InT *)X, ld, col_lb, N, W)) {
         // host matrix: column windows travel through pinned staging slots (host_windows_pipeline below) and take the same fused pass
         HostLeftovers left;

@@ -153,6 +153,7 @@ struct illico_ctx {
     bool no_csr_tile_gather = false;    // 1: CSR -> CSC always by the scatter form (k_csr_block_scatter), as for unsorted rows
     bool no_csr_transpose_path = false; // 1: CSR is regrouped by (gene, group) with global atomics instead of being transposed to CSC
     bool dense_window_f32 = false;      // 1: CSR dense windows hold float32 cells instead of bytes
+    int host_narrow = 0;               // host-resident count matrices as byte windows: 0 = when a value sample says counts, 1 = always, -1 = never
     bool no_csr_counts_path = false;   // 1: count-valued CSR never takes the group-major single pass (k_csr_counts)
     bool no_dense_window_path = false; // 1: CSR never goes through dense float32 windows + the fused kernels
     int fused_groups_per_wg = 0; // 0 = auto

@@ -34,7 +34,7 @@ def _run(engine, X, grpc, **kw):
     return engine.run_dense(X, kw.pop("col_lb", 0), kw.pop("col_ub", X.shape[1]), **kw)
 
 
-@pytest.fixture(params=["fused+counts+sort", "fused-host+counts+sort", "packed", "counts+sort", "sort-only"])
+@pytest.fixture(params=["fused+counts+sort", "fused-host+counts+sort", "fused-host-narrow+counts+sort", "packed", "counts+sort", "sort-only"])
 def route(request, engine):
     """Dense OVO has four device routes per gene: the fused single-pass histogram kernel (integer values < 64; X
     device-resident, or a host matrix copied up in column windows), the packed route (group-wise packing + look-ups), and
@@ -46,7 +46,10 @@ def route(request, engine):
     engine.set_option("no_packed_dense", 1 if request.param in ("counts+sort", "sort-only") else 0)
     engine.set_option("no_counts_path", 1 if request.param == "sort-only" else 0)
     # fused OVR has a one-pass form (per-group histograms) and a two-pass form: the host-input param runs the latter
-    engine.set_option("no_ovr_one_pass", 1 if request.param.startswith("fused-host") else 0)
+    engine.set_option("no_ovr_one_pass", 1 if request.param.startswith("fused-host+") else 0)
+    # a host matrix goes up as float32 windows ("fused-host": the byte form forbidden) or as byte windows ("fused-host-narrow": forced,
+    # whatever the values: genes with a cell the bytes cannot hold come back and go up again in their own type)
+    engine.set_option("host_narrow", 1 if request.param.startswith("fused-host-narrow") else (-1 if request.param.startswith("fused-host+") else 0))
     # ... and is itself the fallback of the value-range parts route (k_ovr_partition + k_csc_ovr_gene), which the fused
     # params leave on
     engine.set_option("no_ovr_parts_path", 0 if request.param.startswith("fused") else 1)
@@ -59,6 +62,7 @@ def route(request, engine):
     engine.set_option("no_fused_path", 0)
     engine.set_option("no_ovr_one_pass", 0)
     engine.set_option("no_packed_dense", 0)
+    engine.set_option("host_narrow", 0)
     _DEVICE_INPUT = False
 
 
