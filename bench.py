@@ -96,6 +96,8 @@ def parse(argv=None):
     ap.add_argument("--c5-genes", type=int, default=30_000)
     ap.add_argument("--c5-groups", type=int, default=5_000)
     ap.add_argument("--c5-steps", type=int, default=3)
+    ap.add_argument("--no-single-call", action="store_true", help="skip the single_call measurement (one call, gathers of its own blocks only)")
+    ap.add_argument("--no-n1-reference", action="store_true", help="N > 1: do not let rank 0 compute the whole workload alone for speedup_vs_n1")
     ap.add_argument("--no-events", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-defer", action="store_true", help="dense passes wait for their route flags inside the call (no ILLICO_FLAG_DEFER)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU baseline run")
@@ -322,6 +324,25 @@ class Job:
             dt = float(t.item())
         return dt
 
+    def single_call(self, reps=5):
+        """ONE call, as a user of asymptotic_wilcoxon makes it (asymptotic_wilcoxon.py:213-241: its gene chunks one after the other):
+        this rank's genes in the blocks of `setup`, block b's gather under block b + 1's pass, the clock stopped when rank 0 holds every
+        plane (nothing of a NEXT call hides this call's last gather).  Median of `reps` calls, each the MAX over ranks; ms."""
+        runs = []
+        for _ in range(reps):
+            self.sync()
+            t0 = time.perf_counter()
+            self.step()
+            self.sync()
+            dt = time.perf_counter() - t0
+            if self.world > 1:
+                red_dev = self.device if self.args.backend == "nccl" else self.torch.device("cpu")
+                t = self.torch.tensor([dt], dtype=self.torch.float64, device=red_dev)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                dt = float(t.item())
+            runs.append(dt * 1e3)
+        return float(np.median(runs)), [round(r, 4) for r in runs]
+
     def host_columns(self, cols):
         """Dense float32 host copy of a few of this rank's genes (whatever the input format)."""
         torch = self.torch
@@ -403,6 +424,60 @@ def measure(job, steps, warmup, settle=5, events=True):
             "settle": settle}
 
 
+def single_call_of(torch, dist, eng, args, job, job_kw, n_blocks, tests, steady_ms, gather_alone_ms=None):
+    """The `single_call` object of a workload (see Job.single_call) and, at N > 1, its N = 1 reference: the SAME workload computed by
+    rank 0 alone in the same launch (the other ranks wait), so that the line carries its own speed-up.  Collective: every rank calls."""
+    world, rank = job.world, job.rank
+    job.sync()
+    job.setup(n_blocks if world > 1 else 1, gather=world > 1)  # (one GPU: nothing to overlap, the call is one pass over every column)
+    for _ in range(2):
+        job.step()
+    ms, runs = job.single_call()
+    out = {"blocks": len(job.blocks), "ms_single_call": round(ms, 4), "runs_ms": runs, "tests_per_s": round(tests / (ms * 1e-3), 1),
+           "steady_state_ms_per_step": round(steady_ms, 4),
+           "note": "one call: the rank's genes in `blocks` blocks, block b's gather under block b + 1's pass, clock stopped when rank 0 holds every "
+                   "plane (max over ranks, median of the runs); steady_state = steps back to back, step k's gather under step k + 1's pass"}
+    if world > 1:
+        bytes0 = 24 * job.G * (job.M_total - job.M)
+        if gather_alone_ms is None:  # one gather by itself (no pass under it)
+            from illico_amd.distributed import gather_block_async
+            job.sync()
+            t0 = time.perf_counter()
+            hs = [gather_block_async(st, job.recv_sets[0][b] if rank == 0 else None, rank, world) for b, st in enumerate(job.stage_sets[0])]
+            for h in hs:
+                h.wait()
+            torch.cuda.synchronize(); dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=job.device if args.backend == "nccl" else torch.device("cpu"))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gather_alone_ms = float(t.item()) * 1e3
+            out["ms_gather_alone"] = round(gather_alone_ms, 4)
+        if gather_alone_ms:
+            out["gather_into_rank0_GBs"] = round(bytes0 / (gather_alone_ms * 1e-3) / 1e9, 1)
+            out["gather_ceiling_note"] = ("24 bytes per test travel into rank 0: at the measured gather rate the planes alone take "
+                                          f"{bytes0 / 1e6:.0f} MB / rate; a call cannot be faster than its last block's gather")
+        n1 = None
+        if not args.no_n1_reference and args.scaling == "strong":
+            if rank == 0:
+                try:
+                    j1 = Job(torch, dist, eng, args, rank=0, world=1, scaling="strong", **job_kw)
+                    j1.setup(1, gather=False)
+                    for _ in range(3):
+                        j1.step()
+                    n1_ms, n1_runs = j1.single_call()
+                    n1 = {"ms_single_call": round(n1_ms, 4), "runs_ms": n1_runs, "genes": j1.M,
+                          "note": "the same workload on rank 0 alone in the same launch: one pass over every column (what a single GPU's call is)"}
+                    del j1
+                    torch.cuda.empty_cache()
+                    eng.set_groups(job.grpc)
+                except (MemoryError, RuntimeError) as e:
+                    n1 = {"skipped": f"{type(e).__name__}: {str(e)[:200]}"}
+            dist.barrier()
+        out["n1_reference"] = n1
+        if n1 and "ms_single_call" in n1:
+            out["speedup_vs_n1"] = round(n1["ms_single_call"] / ms, 3)
+    return out
+
+
 def roofline_of(job, m, steps, wl_key):
     dom, prof = m["dom"], m["prof"]
     if not dom or dom not in prof:
@@ -473,8 +548,9 @@ def main():
         eng.set_option(k, int(v))
 
     N, G = args.cells, args.groups
-    job = Job(torch, dist, eng, args, cells=N, genes_total=args.genes, groups=G, sparsity=args.sparsity, test=args.test, fmt=args.fmt,
-              values=args.values, mean_max=args.mean_max, seed=args.seed, rank=rank, world=world, device=device, scaling=args.scaling)
+    job_kw = dict(cells=N, genes_total=args.genes, groups=G, sparsity=args.sparsity, test=args.test, fmt=args.fmt, values=args.values,
+                  mean_max=args.mean_max, seed=args.seed, device=device)
+    job = Job(torch, dist, eng, args, rank=rank, world=world, scaling=args.scaling, **job_kw)
     M, M_total, ovr, sparse_fmt, nnz = job.M, job.M_total, job.ovr, job.sparse_fmt, job.nnz
     in_step = world > 1 and not args.no_gather_in_step
     job.setup(args.gather_batches, gather=in_step)
@@ -505,6 +581,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             gather_ms = max(0.0, float(t.item()) * 1e3 - ms_per_step)
     m["pass_ms"] = pass_only_ms
+    single = None
+    if not args.no_single_call:
+        single = single_call_of(torch, dist, eng, args, job, job_kw, max(args.gather_batches, 4), tests_per_step, ms_per_step)
 
     # what this box's HBM delivers to a plain streaming read (boxes of the pool differ by up to 15 %: 1.65 vs 1.90 ms for the
     # same C2 kernel): torch's sum over the resident input
@@ -632,6 +711,9 @@ def main():
                        "settle_steps": m["settle"],
                        "parallelism": f"gene-shard x{world}, planes gathered to rank 0" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "timing_scopes": scopes, "box_calibration": calib,
+            "single_call": single,
+            "steady_state": {"ms_per_step": round(ms_per_step, 4), "tests_per_s": round(value, 1),
+                             "note": "`value`: the timed steps back to back" + (", step k's gather under step k + 1's pass" if in_step else "")},
         }
         if world > 1:
             plane_bytes = 24 * G * M
@@ -678,6 +760,12 @@ def main():
                 t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if args.backend == "nccl" else torch.device("cpu"))
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 gather_alone_ms = float(t.item()) * 1e3
+            single5 = None
+            if not args.no_single_call:
+                c5_kw = dict(cells=args.c5_cells, genes_total=args.c5_genes, groups=args.c5_groups, sparsity=0.5, test="ovo", fmt="dense", values="counts",
+                             mean_max=15.0, seed=args.seed + 5, device=device)
+                single5 = single_call_of(torch, dist, eng, args, j5, c5_kw, max(args.gather_batches, 4), args.c5_groups * args.c5_genes, both_ms,
+                                         gather_alone_ms if world > 1 else None)
             if rank == 0:
                 tests5 = args.c5_groups * args.c5_genes
                 r5 = roofline_of(j5, m5, args.c5_steps, None)
@@ -687,7 +775,7 @@ def main():
                       "tests_per_s": round(tests5 / (both_ms * 1e-3), 1), "tests_per_s_pass_only": round(tests5 / (m5["ms_per_step"] * 1e-3), 1),
                       "bytes_into_rank0": 24 * args.c5_groups * (args.c5_genes - j5.M), "input_bytes_per_gpu": int(args.c5_cells) * j5.M * 4,
                       "roofline": None if r5 is None else {k: r5[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "pipeline_frac", "all_kernels_ms_per_step")},
-                      "parity": None if args.no_parity else j5.parity(8), "generate_s": round(t_gen, 1),
+                      "parity": None if args.no_parity else j5.parity(8), "generate_s": round(t_gen, 1), "single_call": single5,
                       "note": "tests_per_s = tests / (pass + gather), the gather of step k under the pass of step k + 1; at N = 1 there is no gather"}
         except (MemoryError, RuntimeError) as e:
             if rank == 0:

@@ -30,7 +30,7 @@ SYMBOLS = [
     "illico_last_error", "illico_ctx_synchronize", "illico_set_groups", "illico_run_dense", "illico_run_csc",
     "illico_run_csr", "illico_csr_indices_sorted", "illico_rank_statistics", "illico_profile_num_kernels", "illico_profile_kernel_name",
     "illico_profile_get", "illico_profile_reset", "illico_version", "illico_csr_bind", "illico_csc_bind", "illico_run_bound",
-    "illico_matrix_release", "illico_profile_input_bytes",
+    "illico_matrix_release", "illico_profile_input_bytes", "illico_planes_to_host",
 ]
 
 _lib = None
@@ -73,6 +73,7 @@ def load() -> ctypes.CDLL:
         lib.illico_run_bound.argtypes = [vp, vp, i64, i64, ci, ci, vp, vp, vp, i64]
         lib.illico_matrix_release.argtypes = [vp, vp]
         lib.illico_profile_input_bytes.argtypes = [vp, ctypes.POINTER(i64)]
+        lib.illico_planes_to_host.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64]
         for name in SYMBOLS:  # fail at load time, not at first use, if the library and the header have drifted
             getattr(lib, name)
         _lib = lib
@@ -344,6 +345,22 @@ class Engine:
         n = ctypes.c_int64(0)
         self._check(self.lib.illico_profile_input_bytes(self.h, ctypes.byref(n)))
         return int(n.value)
+
+    def planes_to_host(self, planes, out=None):
+        """A contiguous device tensor ``[3, n_groups, n_cols]`` of float64 planes -> a host ndarray of the same shape, through the
+        context's pinned double buffer (include/illico_hip.h: illico_planes_to_host): what the gathering rank of a multi-GPU call does
+        ONCE with everything it has received."""
+        if not (_is_torch_tensor(planes) and planes.is_cuda and planes.is_contiguous() and planes.dim() == 3 and planes.shape[0] == 3):
+            raise ValueError("planes_to_host wants a contiguous CUDA tensor of shape [3, n_groups, n_cols]")
+        _, G, W = (int(x) for x in planes.shape)
+        if out is None:
+            out = np.empty((3, G, W), dtype=np.float64)
+        self._bind_torch_stream(planes)
+        esz = planes.element_size()
+        base = planes.data_ptr()
+        self._check(self.lib.illico_planes_to_host(self.h, base, base + G * W * esz, base + 2 * G * W * esz, W,
+                                                   out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, out.strides[1] // 8))
+        return out
 
     def rank_statistics(self, X, col_lb, col_ub, *, is_log1p=False):
         """The ranking primitives before finalisation (include/illico_hip.h: illico_rank_statistics):

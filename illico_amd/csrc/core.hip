@@ -646,6 +646,23 @@ extern "C" int illico_run_dense(illico_ctx *c, const void *X, int dtype, int64_t
     return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
 }
 
+extern "C" int illico_planes_to_host(illico_ctx *c, const double *dev_p, const double *dev_u, const double *dev_fc, int64_t n_cols, double *out_p,
+                                     double *out_u, double *out_fc, int64_t out_ld) {
+    if (!c) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
+    if (!c->has_groups) return fail(c, ILLICO_ERR_NO_GROUPS, "illico_set_groups has not been called");
+    if (!dev_p || !dev_u || !dev_fc || !out_p || !out_u || !out_fc) return fail(c, ILLICO_ERR_ARG, "null plane");
+    if (n_cols < 0 || out_ld < n_cols) return fail(c, ILLICO_ERR_ARG, "out_ld smaller than n_cols");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = resolve_pending(c);
+    if (rc || n_cols == 0) return rc;
+    const OutPlanes o{const_cast<double *>(dev_p), const_cast<double *>(dev_u), const_cast<double *>(dev_fc), n_cols, true};
+    PlaneTouch touch;
+    { double *const dst[3] = {out_p, out_u, out_fc}; touch.start(dst, (size_t)c->n_groups, (size_t)n_cols * 8, (size_t)out_ld * 8); }
+    touch.join();
+    return end_outputs(c, o, n_cols, out_p, out_u, out_fc, out_ld);
+}
+
 extern "C" int illico_rank_statistics(illico_ctx *c, const void *X, int dtype, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t col_lb,
                                       int64_t col_ub, int flags, int64_t *out_two_u, uint64_t *out_tie_sum, double *out_value_sum) {
     if (!c) return ILLICO_ERR_ARG;

@@ -94,6 +94,40 @@ def gather_block_async(stage, recv_list, rank: int, world: int, dst: int = 0, gr
     return dist.gather(stage, gather_list=recv_list if rank == dst else None, dst=dst, group=group, async_op=True)
 
 
+def gather_block_p2p(stage, recv_bufs, rank: int, world: int, dst: int = 0, group=None):
+    """Start the gather of one block whose WIDTH DIFFERS per rank (no padding to the widest rank): every source rank sends its
+    ``stage`` (contiguous, [3, G, w_r]; nothing when w_r == 0), ``dst`` receives into ``recv_bufs[r]`` (one exactly-sized
+    contiguous tensor per source rank r != dst, None where w_r == 0).  One grouped batch of sends / receives per block: over RCCL
+    the 7 peers of an 8-GPU node push over 7 distinct xGMI links at once.  Returns the work handles."""
+    import torch.distributed as dist
+    if rank != dst and stage.numel() == 0:
+        return []
+    via_host = stage.is_cuda and dist.get_backend(group) == "gloo"  # test mode (no RCCL, e.g. several ranks sharing one GPU)
+    if rank == dst:
+        ops, hosts = [], []
+        for r in range(world):
+            if r == dst or recv_bufs[r] is None or recv_bufs[r].numel() == 0:
+                continue
+            buf = torch_empty_like_cpu(recv_bufs[r]) if via_host else recv_bufs[r]
+            hosts.append((recv_bufs[r], buf))
+            ops.append(dist.P2POp(dist.irecv, buf, r, group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        if via_host:
+            for w in works:
+                w.wait()
+            for dev_buf, host_buf in hosts:
+                dev_buf.copy_(host_buf)
+            return []
+        return works
+    src = stage.cpu() if via_host else stage
+    works = dist.batch_isend_irecv([dist.P2POp(dist.isend, src, dst, group)])
+    if via_host:
+        for w in works:
+            w.wait()
+        return []
+    return works
+
+
 class _DoneWork:
     def wait(self):
         return True
@@ -178,34 +212,46 @@ def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, referenc
         Xmine = column_loader(my_lb, my_ub) if my_ub > my_lb else None
         if Xmine is not None and int(Xmine.shape[1]) != my_ub - my_lb:
             raise ValueError(f"column_loader({my_lb}, {my_ub}) returned {Xmine.shape[1]} columns")
-    handles, stages, recvs = [], [], []
+    # Block b of rank r is exactly as wide as r's own b-th share (no padding to the widest rank: ranges balanced by stored entries differ
+    # in width).  Rank 0 lays everything it computes and receives out in ONE device tensor [3][G][n_genes] -- its own blocks are
+    # computed straight into it, a peer's block lands in an exactly-sized receive buffer and is copied into its column range on the
+    # device -- and brings that tensor to the host ONCE, through the engine's pinned double buffer.
+    widths_of = lambda r, b: (lambda se: se[1] - se[0])(shard_bounds(ranges[r][1] - ranges[r][0], n_blocks)[b])
+    handles, keep, placed = [], [], []
+    planes_dev = torch.empty((3, G, n_genes), dtype=torch.float64, device=dev) if rank == 0 else None
     for b in range(n_blocks):
         lb, ub = shard_bounds(my_ub - my_lb, n_blocks)[b]
-        widths = [shard_bounds(ru - rl, n_blocks)[b][1] - shard_bounds(ru - rl, n_blocks)[b][0] for rl, ru in ranges]
-        wmax = max(widths)
-        stage = torch.zeros((3, G, wmax), dtype=torch.float64, device=dev)
+        stage = torch.empty((3, G, ub - lb), dtype=torch.float64, device=dev)
         if ub > lb:
             if column_loader is not None:
                 p, u, fc = compute_planes(Xmine, grpc, lb, ub, **opts)
             else:
                 p, u, fc = compute_planes(X, grpc, my_lb + lb, my_lb + ub, **opts)
             for k, a in enumerate((p, u, fc)):
-                stage[k, :, : ub - lb] = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
-        recv = [torch.empty_like(stage) for _ in range(world)] if rank == 0 else None
-        handles.append(gather_block_async(stage, recv, rank, world, 0, group))
-        stages.append(stage)
-        recvs.append((recv, widths))
+                stage[k] = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+            if rank == 0:
+                planes_dev[:, :, my_lb + lb: my_lb + ub] = stage
+        recv = None
+        if rank == 0:
+            recv = [None] * world
+            for r in range(1, world):
+                w = widths_of(r, b)
+                if w > 0:
+                    recv[r] = torch.empty((3, G, w), dtype=torch.float64, device=dev)
+                    rl = ranges[r][0] + shard_bounds(ranges[r][1] - ranges[r][0], n_blocks)[b][0]
+                    placed.append((recv[r], rl, rl + w))
+        handles.extend(gather_block_p2p(stage, recv, rank, world, 0, group))
+        keep.append((stage, recv))
     for h in handles:
         h.wait()
     if rank != 0:
         return None
-    planes = np.empty((3, G, n_genes), dtype=np.float64)
-    for b, (recv, widths) in enumerate(recvs):
-        for r in range(world):
-            rl, ru = ranges[r]
-            bl, bu = shard_bounds(ru - rl, n_blocks)[b]
-            if bu > bl:
-                planes[:, :, rl + bl: rl + bu] = recv[r][:, :, : bu - bl].cpu().numpy()
+    for buf, cl, cu in placed:
+        planes_dev[:, :, cl:cu] = buf
+    if on_gpu:
+        planes = eng.planes_to_host(planes_dev)  # one device -> host copy of 24 bytes per test
+    else:
+        planes = planes_dev.numpy()
     cols = pd.Series(np.asarray(var_names), name="feature", dtype=str)
     rows = pd.Series(unique, name="pert", dtype=str)
     return pd.DataFrame(

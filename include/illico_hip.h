@@ -173,7 +173,15 @@ int illico_rank_statistics(illico_ctx *ctx, const void *X, int dtype, int64_t n_
  * Gene sharding is host-side: one context per GPU and process, each computing its own column range with the entry points
  * above (no input is exchanged); the one collective of the path -- the gather of the planes to rank 0 -- is issued by the
  * host over RCCL (illico_amd/distributed.py: torch.distributed.gather on device planes, backend "nccl").  The C-ABI has no
- * illico_gather entry: a binding that wants several GPUs brings its own process group, as the Python host does. */
+ * illico_gather entry: a binding that wants several GPUs brings its own process group, as the Python host does.
+ *
+ * What the C-ABI does offer the gathering rank: the way its planes reach host memory.  Three gathered device planes [n_groups][n_cols]
+ * (dense, row pitch n_cols) are copied into the caller's host planes (row pitch out_ld >= n_cols) through the context's two pinned
+ * buffers -- block i travels at the link's rate while block i - 1 is scattered by a few host threads -- i.e. the path the results of
+ * an ordinary call with host planes take (asymptotic_wilcoxon.py:242-244 copies each chunk's planes into `results`).  Needs groups
+ * (n_groups).  */
+int illico_planes_to_host(illico_ctx *ctx, const double *dev_p, const double *dev_u, const double *dev_fc, int64_t n_cols,
+                          double *out_p, double *out_u, double *out_fc, int64_t out_ld);
 
 /* ---- measurement hooks (bench.py roofline leg) ------------------------------------------- */
 int illico_profile_num_kernels(void);

@@ -59,8 +59,15 @@ def test_two_ranks_spawned_by_bench_itself_gloo_shared_device():
     assert two["value"] == pytest.approx(50 * 256 / (two["ms_per_step"] * 1e-3), rel=1e-3)
     assert two["pass_only"]["ms_per_step"] > 0 and two["pass_only"]["tests_per_s"] == pytest.approx(50 * 256 / (two["pass_only"]["ms_per_step"] * 1e-3), rel=1e-3)
     assert two["parity"]["statistic_mismatches"] == 0 and two["parity"]["p_value_max_rel_err"] <= 1e-12 and len(two["parity"]["genes_checked"]) == 16
+    # a single call: the gathers of its own blocks only, at least four blocks, its own N = 1 reference and speed-up in the same line
+    sc = two["single_call"]
+    assert sc["blocks"] >= 4 and sc["ms_single_call"] > 0 and len(sc["runs_ms"]) == 5 and sc["ms_gather_alone"] > 0 and sc["gather_into_rank0_GBs"] > 0
+    assert sc["n1_reference"]["genes"] == 256 and sc["n1_reference"]["ms_single_call"] > 0
+    assert sc["speedup_vs_n1"] == pytest.approx(sc["n1_reference"]["ms_single_call"] / sc["ms_single_call"], rel=1e-2)
+    assert two["steady_state"]["ms_per_step"] == two["ms_per_step"]
     # (c): configs[4] in the same line
     c5 = two["c5_strong"]
+    assert c5["single_call"]["blocks"] >= 4 and c5["single_call"]["speedup_vs_n1"] > 0 and c5["single_call"]["n1_reference"]["genes"] == 192
     assert c5["genes_total"] == 192 and c5["genes_per_gpu"] == 96 and c5["cells"] == 30000 and c5["groups"] == 40 and c5["scaling"] == "strong"
     assert c5["ms_pass"] > 0 and c5["ms_gather_alone"] > 0 and c5["ms_pass_plus_gather"] > 0 and c5["bytes_into_rank0"] == 24 * 40 * 96
     assert 0 < c5["roofline"]["frac"] < 1 and c5["parity"]["statistic_mismatches"] == 0
@@ -71,6 +78,7 @@ def test_two_ranks_spawned_by_bench_itself_gloo_shared_device():
     assert one["n_gpus"] == 1 and one["scaling"] == "strong" and one["roofline"]["kernel"] == two["roofline"]["kernel"]
     assert one["config"]["genes_total"] == 256 and "final_gather" not in one
     assert one["c5_strong"]["genes_per_gpu"] == 192 and one["c5_strong"]["bytes_into_rank0"] == 0 and one["c5_strong"]["ms_gather_alone"] == 0
+    assert one["single_call"]["blocks"] == 1 and one["single_call"]["ms_single_call"] > 0 and "speedup_vs_n1" not in one["single_call"]
     # weak scaling on request: every rank a full shard; the gather outside the step on request
     r2 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--scaling", "weak",
                          "--no-gather-in-step", "--no-c5", *common], capture_output=True, text=True, env=env, timeout=900)
