@@ -56,17 +56,18 @@ struct CscOvrParams {
     long long *out_2u;                   // [nb][G] 2 U (U of "the rest", dense_ovr.py:57-61)
     u64 *out_tie;                        // [nb][G] sum (t^3 - t), the same for every group of a gene
     int tie_f64;                         // out_tie = the bits of the float64 tie sum of the reference's sparse path (tie_f64_sparse)
+    u64 *acc_global;                     // ACCG: [nb][G] the accumulators in HBM (zeroed by the host), for more groups than LDS holds beside the keys
     // (per-group value sums are not formed here: they would be order-dependent float64 atomics.  The host launches
     //  k_csc_value_sums / k_group_sums_rows, kernels_sums.h, whose results do not depend on the order of arrival.)
 };
 
-__host__ __device__ static inline size_t csco_fixed_lds_bytes(int G, int lg_buckets, bool parts) {
-    // acc (packed rank sums / counts) | bucket table | reductions: a multiple of 16
+__host__ __device__ static inline size_t csco_fixed_lds_bytes(int G, int lg_buckets, bool parts, bool accg = false) {
+    // acc (packed rank sums / counts; none with ACCG: they live in HBM) | bucket table | reductions: a multiple of 16
     (void)parts;
-    return (size_t)((G + 1) & ~1) * 8 + ((size_t)2 << lg_buckets) + 256;
+    return (accg ? 0 : (size_t)((G + 1) & ~1) * 8) + ((size_t)2 << lg_buckets) + 256;
 }
-static inline int csco_key_cap(int G, int lg_buckets, size_t key_size, size_t lds_max, bool parts = false) {
-    const size_t fixed = csco_fixed_lds_bytes(G, lg_buckets, parts);
+static inline int csco_key_cap(int G, int lg_buckets, size_t key_size, size_t lds_max, bool parts = false, bool accg = false) {
+    const size_t fixed = csco_fixed_lds_bytes(G, lg_buckets, parts, accg);
     if (fixed + (size_t)CSCO_NT * 4 + 64 > lds_max) return 0; // the scan borrows NT words of the key buffer
     // bucket offsets are 16-bit; 4 slots stay free behind the keys (the bucket walk reads 4 keys at a time)
     return (int)std::min<size_t>((lds_max - fixed) / key_size - 4, 65535 - 4);
@@ -185,7 +186,9 @@ __device__ __forceinline__ void ovr_for_entries(const Src &src, long long k0, lo
     }
 }
 
-template <typename InT, typename IdxT, typename KeyT>
+// ACCG: the per-group accumulators in HBM (global atomics, read back at L2) instead of LDS: with thousands of groups acc[G] would
+// take the key buffer's place (6000 groups: 48 KB; the C3 gene's 30 000 keys then no longer fit and the gene fell to the HBM sort).
+template <typename InT, typename IdxT, typename KeyT, bool ACCG = false>
 __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     constexpr int NT = CSCO_NT, NW = NT / 64, CH = 64 * CSCO_K;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
@@ -193,14 +196,14 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     constexpr u64 CNT1 = 1ull << CSCO_CNT_SHIFT, R2MASK = CNT1 - 1ull;
     extern __shared__ __align__(16) unsigned char smem[];
     const int G = P.G, NBKT = 1 << P.lg_buckets;
-    const size_t accb = (size_t)((G + 1) & ~1) * 8;
-    u64 *acc = (u64 *)smem;                                   // [G]
+    const size_t accb = ACCG ? 0 : (size_t)((G + 1) & ~1) * 8;
+    u64 *acc_lds = (u64 *)smem;                               // [G] (none with ACCG)
     u32 *tab = (u32 *)(smem + accb);                          // [NBKT / 2] two 16-bit bucket counters / offsets per word
     u16 *tab16 = (u16 *)tab;
     u64 *s_red = (u64 *)(tab + NBKT / 2);                     // [NW]
     KeyT *s_k = (KeyT *)(s_red + NW);                         // [2] smallest / largest non-zero key
     u32 *s_misc = (u32 *)(s_red + NW + 2);                    // [0] stored zeros  [1] negatives  [2] largest bucket
-    KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G, P.lg_buckets, false));
+    KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G, P.lg_buckets, false, ACCG));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const IdxT *indptr = (const IdxT *)P.indptr;
@@ -220,7 +223,8 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         // ---- 0. key range of the bucket function, from every 8th row of NT entries.  Any monotone bucket function ranks
         // correctly (keys outside the sampled range are clamped into the first / last bucket); the range only balances
         // the buckets. ----
-        for (int g = tid; g < G; g += NT) acc[g] = 0ull;
+        u64 *acc = ACCG ? P.acc_global + (size_t)gene * G : acc_lds;
+        if (!ACCG) for (int g = tid; g < G; g += NT) acc[g] = 0ull;
         for (int b = tid; b < NBKT / 2; b += NT) tab[b] = 0u;
         if (tid == 0) { s_k[0] = MAXK; s_k[1] = (KeyT)0; s_misc[0] = 0u; s_misc[1] = 0u; s_misc[2] = 0u; }
         __syncthreads();
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         else tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
         for (int g = tid; g < G; g += NT) {
             const long long n_g = P.counts[g];
-            const u64 a = acc[g];
+            const u64 a = ACCG ? atomicAdd(&acc[g], 0ull) : acc[g]; // (HBM accumulators: read at L2, where the atomics landed)
             const long long z = n_g - (long long)(a >> CSCO_CNT_SHIFT);
             const u64 r2 = (a & R2MASK) + (u64)z * (u64)(2 * nneg + n0 + 1);
             P.out_2u[(size_t)gene * G + g] = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;
