@@ -101,7 +101,7 @@ int illico_ctx_create(int device_id, illico_ctx **out_ctx) {
 }
 
 static void free_groups(illico_ctx *c) {
-    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos, &c->d_pk_blk, &c->d_pk_code}) {
+    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos, &c->d_pk_blk, &c->d_pk_code, &c->d_pk_big}) {
         if (*p) hipFree(*p);
         *p = nullptr;
     }
@@ -321,6 +321,19 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
         c->pk_stride = pos + (ref >= 0 ? ((counts[ref] + 63) & ~63ll) : 0) + 64;
         HIPCHK(c, hipMalloc((void **)&c->d_pk_blk, packed.size() * sizeof(int)));
         HIPCHK(c, hipMemcpy(c->d_pk_blk, packed.data(), packed.size() * sizeof(int), hipMemcpyHostToDevice));
+        { // groups whose packed runs can exceed the 256 keys the packed rank kernel looks up at a time
+            std::vector<int> big;
+            for (int64_t g = 0; g < n_groups; ++g)
+                if (g != ref && counts[g] > 256) big.push_back((int)g);
+            c->pk_nbig = (int)big.size();
+            if (!big.empty()) {
+                std::vector<int> both(big);
+                both.resize(big.size() + (size_t)n_groups, -1);
+                for (size_t k = 0; k < big.size(); ++k) both[big.size() + (size_t)big[k]] = (int)k;
+                HIPCHK(c, hipMalloc((void **)&c->d_pk_big, both.size() * sizeof(int)));
+                HIPCHK(c, hipMemcpy(c->d_pk_big, both.data(), both.size() * sizeof(int), hipMemcpyHostToDevice));
+            }
+        }
         if (ref < 0) { // dense OVR walks the padded rows: group code per key slot
             std::vector<int> pc((size_t)c->pk_stride, 0);
             for (size_t b = 0; b < g0.size(); ++b) {

@@ -29,7 +29,7 @@ static int launch_group_compact(illico_ctx *c, GroupCompactParams Q, int nb, int
 
 template <typename InT, typename KeyT>
 static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0, int nb, int N, KeyT *Xt, int64_t stride, int dtype, int flags,
-                          long long *s2u, u64 *stie, double *ssum) {
+                          long long *s2u, u64 *stie, double *ssum, std::vector<int> *redo /* genes of the batch the route left (groups above 1024 cells) */) {
     const int G = (int)c->n_groups, ref = (int)c->ref;
     const int64_t n_ref = c->h_counts[ref];
     const int nseg = gcmp_ref_segments(n_ref);
@@ -51,12 +51,26 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.gofs = gofs; Q.blk_cnt = nullptr; Q.out_sum = ssum; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum;
         if ((rc = launch_group_compact<InT, KeyT>(c, Q, nb, flags, true))) return rc;
     }
+    BigRunFn<KeyT> *big_fn = nullptr;
+    if (c->pk_nbig > 0) { // runs of more than 256 non-zero keys are dealt into value buckets in place: the rank kernel walks them in pieces
+        if ((rc = get_scratch(c, "packed_big_fn", (size_t)nb * c->pk_nbig * sizeof(BigRunFn<KeyT>), &v))) return rc;
+        big_fn = (BigRunFn<KeyT> *)v;
+        ProfScope ps(c, KID_GROUP_COMPACT);
+        auto kern = k_bucket_big_runs<KeyT>;
+        const int cap = (int)std::min<int64_t>(srt_cap<KeyT>(), (c->max_nonref + 63) & ~63ll); // (a run holds at most its group's cells)
+        const size_t lds = srt_lds_bytes(sizeof(KeyT), cap);
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(c->pk_nbig, nb), dim3(SRT_NT), lds, c->stream, (void *)Xt, (long long)stride, (const u16 *)nnz, (const u32 *)gofs,
+                           (const int *)c->d_pk_big, c->pk_nbig, G, cap, big_fn, route);
+        HIPCHK(c, hipGetLastError());
+    }
     {
         OvoCompactParams C;
         C.Xs = Xt; C.gene_stride = stride; C.counts = c->d_counts; C.nnz = nnz; C.gofs = gofs; C.ref_out = c->pk_ref_out; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum;
         C.out_sum = ssum; C.G = G; C.ref = ref; C.n_genes = nb; C.nseg = nseg;
         packed_ref_sizing<KeyT>(n_ref, &C.ref_cap, &C.nbk_lg);
-        C.out_2u = s2u; C.out_tie = stie; C.route = route;
+        C.out_2u = s2u; C.out_tie = stie; C.route = route; C.big_sorted = c->pk_nbig > 0 ? 1 : 0;
+        C.big_fn = big_fn; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
         const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
         // large references: the bucket function follows the reference's distribution (a crowded stretch of values would otherwise
         // fill buckets beyond three keys and send whole table words to key-by-key walks); "packed_eq_buckets" = 0 / 1 forces
@@ -66,6 +80,15 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         ProfScope ps(c, KID_OVO_RANK_COMPACT);
         hipLaunchKernelGGL(kern, dim3(nb), dim3(OCR_NT), lds, c->stream, C);
         HIPCHK(c, hipGetLastError());
+    }
+    if (c->max_nonref > 1024) { // what the packed kernel leaves cannot go to k_ovo_rank (groups of at most 1024 keys): the caller sends those
+        // genes through the transposition + general sort route
+        std::vector<u32> hr((size_t)nb);
+        HIPCHK(c, hipMemcpyAsync(hr.data(), route, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int j = 0; j < nb; ++j)
+            if (hr[j]) redo->push_back(j);
+        return ILLICO_OK;
     }
     // the genes the packed kernel left (tie-heavy reference column, a group of more than 256 non-zeros): k_ovo_rank over the
     // packed layout; its workgroups return at once for every other gene
@@ -630,7 +653,7 @@ static int host_windows_pipeline_narrow(illico_ctx *c, const InT *X, int64_t ld,
 template <typename InT, typename KeyT>
 static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
                              int alternative, const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> runs, const int *col_map = nullptr,
-                             bool prefer_counts = false);
+                             bool prefer_counts = false, bool allow_packed = true);
 
 // The genes the fused passes of a DEVICE-resident window [col_lb, col_ub) left behind (hf[j] = 1 / 3).  Few and scattered (a count
 // matrix's highly expressed genes): gathered into a narrow matrix of their own and computed as ONE window whose results
@@ -773,7 +796,7 @@ template <typename InT, typename KeyT>
 // with per-gene histogram routes (k_ovo_counts / k_ovr_counts) first, the routes for continuous values only for what they leave.
 static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags,
                              int alternative, const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> runs, const int *col_map,
-                             bool prefer_counts) {
+                             bool prefer_counts, bool allow_packed) {
     const int G = (int)c->n_groups;
     const bool ovr = c->ref < 0;
     const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
@@ -781,7 +804,8 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
     // dense OVO: group-wise packing + look-ups (kernels_ovo_compact.h) whenever the sizes allow; it has no histogram side path
     // (count-valued genes reach this function only when the fused route is off, or as gathered leftovers: prefer_counts) and holds
     // ties exactly
-    const bool packed = !ovr && !prefer_counts && packed_route_fits<KeyT>(c);
+    const bool packed = !ovr && !prefer_counts && allow_packed && packed_route_fits<KeyT>(c);
+    std::vector<std::pair<int64_t, int64_t>> redo_runs; // genes the packed route left while groups above 1024 cells rule k_ovo_rank out
     // dense OVR: the transposition with the group sums folded in (k_group_compact keeping every key: padded dense layout)
     const bool padded = ovr && !prefer_counts && !c->no_packed_dense && c->pk_nblk > 0 && c->max_nonref <= 65535 && c->pk_stride < (1ll << 31);
     const bool ovr_counts = ovr && prefer_counts && N < (1ll << 31);
@@ -849,7 +873,12 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             src = xin; src_ld = nb; src_col0 = 0;
         }
         if (packed) {
-            if ((rc = run_ovo_packed<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, dtype, flags, s2u, stie, ssum))) return rc;
+            std::vector<int> redo;
+            if ((rc = run_ovo_packed<InT, KeyT>(c, src, src_ld, src_col0, nb, (int)N, Xt, stride, dtype, flags, s2u, stie, ssum, &redo))) return rc;
+            for (int j : redo) {
+                if (!redo_runs.empty() && redo_runs.back().second == b0 + j) redo_runs.back().second = b0 + j + 1;
+                else redo_runs.push_back({b0 + j, b0 + j + 1});
+            }
             if (c->tap) {
                 const size_t off = (size_t)(b0 - col_lb) * G, cnt = (size_t)nb * G;
                 HIPCHK(c, hipMemcpyAsync(c->tap->two_u + off, s2u, cnt * 8, hipMemcpyDeviceToHost, c->stream));
@@ -951,5 +980,7 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cmap ? 0 : b0 - col_lb, cmap ? cmap + (b0 - col_lb) : nullptr))) return rc;
         }
     }
+    if (!redo_runs.empty()) // (tie-heavy columns of a matrix with groups above 1024 cells: transposition + the general sort route)
+        return run_dense_twopass<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, redo_runs, col_map, prefer_counts, false);
     return ILLICO_OK;
 }

@@ -112,6 +112,9 @@ struct illico_ctx {
     int pk_nblk = 0, pk_ref_out = 0;
     int *d_pk_code = nullptr;     // padded dense layout (dense OVR): group code of every key slot (holes: 0, they hold zero keys)
     int64_t pk_stride = 0;        // keys per gene in the packed layout
+    int *d_pk_big = nullptr;      // [pk_nbig] the groups (never the reference) of more than 256 cells: their packed runs may need k_bucket_big_runs;
+                                  // then [G]: a group's place in that list, or -1
+    int pk_nbig = 0;
     int64_t pk_len = 0;           // ... of which the blocks take the first pk_len (the padded dense layout's row length)
     int *d_counts = nullptr;      // [G]
     int *d_code_by_pos = nullptr; // [N] group code at position p

@@ -306,6 +306,12 @@ struct OvoCompactParams {
     int nbk_lg;              // log2(value buckets), 14 .. 17
     long long *out_2u;       // [n_genes][G]
     u64 *out_tie;            // [n_genes][G]
+    int big_sorted;          // 1: the runs of more than 256 non-zero keys were dealt into value buckets (k_bucket_big_runs): they are walked in
+                             // pieces of at most 256 keys cut where the bucket number changes (equal keys never straddle two pieces, so the
+                             // pieces' terms add up); 0: a gene with such a group leaves the kernel
+    const void *big_fn;      // [n_genes][n_cand] BigRunFn<KeyT>: each such run's bucket function
+    const int *cand_of;      // [G] a group's place among the n_cand groups of more than 256 cells, or -1
+    int n_cand;
     u32 *route;              // [n_genes], zeroed by the host: set to 1 for the genes this kernel leaves to k_ovo_rank (packed
                              // mode): crowded value buckets (a tie-heavy column: it wants the sorted reference and the sort form
                              // of the group loop) or a group of more than 256 non-zeros.  For those the reference's segments are
@@ -510,6 +516,83 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
     TT_out = TT;
 }
 
+
+// ---- groups of more than 256 non-zero keys -----------------------------------------------------------------------------------
+// The rank kernel below looks a group's keys up 256 at a time, and what it has to know about a group beyond the look-ups -- which of
+// its keys repeat, how often -- it finds among those 256 keys.  A larger group (a cluster of thousands of cells: the common
+// non-perturbation use; the reference's cost per element does not depend on the group size, dense_ovo.py:118-132) is therefore dealt
+// into VALUE BUCKETS first, in place, one workgroup per (gene, group) run, through LDS: bucket = (key - kmin) >> shift over the run's
+// own key range, about four keys per bucket, one counting-sort pass (histogram, scan, scatter).  Equal keys share a bucket, buckets
+// come out in ascending order, and the rank kernel cuts its pieces where the bucket number changes (big_fn[gene][k] = {kmin, shift}
+// lets it recompute the number): no value straddles two pieces, so the pieces' terms simply add up.  No sort: inside a bucket the order
+// is arbitrary, which the piece-wise duplicate search does not mind.  Runs of at most 256 keys are left alone; a run longer than
+// the LDS buffer sets route[gene] = 2 (the gene takes the general sort route), as a bucket of more than 256 keys does in the rank kernel.
+#define SRT_NT 256
+#define SRT_LG_MAX 12 // at most 4096 buckets
+template <typename KeyT> __host__ __device__ constexpr int srt_cap() { return sizeof(KeyT) == 4 ? 32768 : 16384; } // at most 128 KB of keys in LDS
+// LDS for runs of at most `cap` keys (the host passes the largest candidate group's cell count, capped): keys + bucket counters
+static inline int srt_lg_of(int n) { int lg = 6; while (lg < SRT_LG_MAX && (4 << lg) < n) ++lg; return lg; }
+static inline size_t srt_lds_bytes(size_t key_size, int cap) { return (size_t)cap * key_size + ((size_t)4 << srt_lg_of(cap)) + 64; }
+template <typename KeyT> struct BigRunFn { KeyT kmin; int shift; };
+template <typename KeyT> __device__ __forceinline__ u32 big_bucket(const BigRunFn<KeyT> &f, KeyT k) { return (u32)((KeyT)(k - f.kmin) >> f.shift); }
+
+template <typename KeyT>
+__global__ __launch_bounds__(SRT_NT) void k_bucket_big_runs(void *Xs, long long gene_stride, const u16 *__restrict__ nnz, const u32 *__restrict__ gofs,
+                                                            const int *__restrict__ cand, int n_cand, int G, int cap /* LDS key slots */,
+                                                            BigRunFn<KeyT> *__restrict__ big_fn, u32 *__restrict__ route) {
+    extern __shared__ __align__(16) unsigned char srt_smem[];
+    constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
+    KeyT *K = (KeyT *)srt_smem;
+    u32 *cnt = (u32 *)(srt_smem + (size_t)cap * sizeof(KeyT)); // [buckets]
+    __shared__ KeyT s_min, s_max;
+    __shared__ u32 s_part[SRT_NT / 64];
+    const int gene = blockIdx.y, g = cand[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = (int)nnz[(size_t)gene * G + g];
+    if (n <= 64 * OCR_KMAX) return;
+    if (n > cap) { if (tid == 0) route[gene] = 2u; return; }
+    KeyT *run = (KeyT *)Xs + (long long)gene * gene_stride + gofs[(size_t)gene * G + g];
+    if (tid == 0) { s_min = MAXK; s_max = (KeyT)0; }
+    __syncthreads();
+    KeyT lo = MAXK, hi = (KeyT)0;
+    for (int i = tid; i < n; i += SRT_NT) { const KeyT k = run[i]; K[i] = k; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const KeyT a = __shfl_xor(lo, d), b = __shfl_xor(hi, d); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if (lane == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+    __syncthreads();
+    // about four keys per bucket
+    int lg = 6;
+    while (lg < SRT_LG_MAX && (4 << lg) < n) ++lg;
+    const int B = 1 << lg;
+    const KeyT range = (KeyT)(s_max - s_min);
+    const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
+    BigRunFn<KeyT> f;
+    f.kmin = s_min;
+    f.shift = bits > lg ? bits - lg : 0;
+    if (tid == 0) big_fn[(size_t)gene * n_cand + blockIdx.x] = f;
+    for (int b = tid; b < B; b += SRT_NT) cnt[b] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += SRT_NT) atomicAdd(&cnt[big_bucket(f, K[i])], 1u);
+    __syncthreads();
+    { // exclusive scan of the B counters (B <= 4096 = 8 per thread)
+        const int per = (B + SRT_NT - 1) / SRT_NT;
+        u32 loc[(1 << SRT_LG_MAX) / SRT_NT], sum = 0;
+#pragma unroll
+        for (int e = 0; e < (1 << SRT_LG_MAX) / SRT_NT; ++e) { const int b = tid * per + e; loc[e] = (e < per && b < B) ? cnt[b] : 0u; sum += loc[e]; }
+        const u32 inc = (u32)wave_incl_scan_add((int)sum);
+        if (lane == 63) s_part[wave] = inc;
+        __syncthreads();
+        u32 base = inc - sum;
+        for (int w = 0; w < wave; ++w) base += s_part[w];
+#pragma unroll
+        for (int e = 0; e < (1 << SRT_LG_MAX) / SRT_NT; ++e) { const int b = tid * per + e; if (e < per && b < B) { cnt[b] = base; base += loc[e]; } }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += SRT_NT) {
+        const KeyT k = K[i];
+        run[atomicAdd(&cnt[big_bucket(f, k)], 1u)] = k;
+    }
+}
+
 template <typename KeyT, bool EQ>
 __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -657,7 +740,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         if (lane == 0) { s_scan[wave] = tot; if (ftot) atomicAdd(&s_cnt[4], ftot); }
         if (lane == 63 && fmax) atomicMax(&s_cnt[2], fmax);
         __syncthreads();
-        if (nA > (u32)P.ref_cap || s_cnt[2] > OCR_MAX_WORD || s_cnt[4] * 2u > nA || s_cnt[3] > 64u * OCR_KMAX) { // uniform: this gene goes to k_ovo_rank
+        if (nA > (u32)P.ref_cap || s_cnt[2] > OCR_MAX_WORD || s_cnt[4] * 2u > nA || (s_cnt[3] > 64u * OCR_KMAX && !P.big_sorted)) { // uniform: this gene goes to k_ovo_rank
             u32 dst = P.nseg ? (u32)seg_nnz[0] : 0u;
             for (int sg = 1; sg < P.nseg; ++sg) { // move the reference's segments together (a segment holds at most NT / 2 keys)
                 const u32 c = (u32)seg_nnz[sg];
@@ -722,6 +805,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         int nB_n = 0;
         auto fetch = [&](int j) {
             nB_n = j < 64 ? (int)__builtin_amdgcn_readlane((int)my_n, j) : 0;
+            if (nB_n > 64 * KMAX) nB_n = 0; // (big_sorted: such a group is walked piece by piece below)
             const KeyT *seg = Xg + __builtin_amdgcn_readlane(my_pos, j & 63);
 #pragma unroll
             for (int r = 0; r < KMAX; ++r)
@@ -760,7 +844,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
             }
             rS2.push(S2, j, lane);
         }
-        if (gl < G) { // lane j now holds the totals of group g0 + j
+        if (gl < G && my_n <= 64u * KMAX) { // lane j now holds the totals of group g0 + j
             const size_t o = (size_t)gene * G + gl;
             if (gl == ref) {
                 P.out_2u[o] = -2;
@@ -772,6 +856,59 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
                 const u64 t0 = (u64)aZ + zc;
                 P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
                 P.out_tie[o] = T_A + 3ull * tt_out + (t0 * t0 * t0 - t0);
+            }
+        }
+    }
+    // ---- groups of more than 256 non-zero keys (dealt into value buckets by k_bucket_big_runs): one wavefront each, in pieces of at most
+    // 256 keys cut at bucket boundaries -- every piece is a group of its own to ocr_group, and S2, the tie term and the negatives add up ----
+    if (P.big_sorted && s_cnt[3] > 64u * KMAX) {
+        for (int gb = wave; gb < G; gb += NW) { // (uniform per wavefront; few groups are big)
+            if (gb == ref) continue;
+            const int n = (int)nnz[gb];
+            if (n <= 64 * KMAX) continue;
+            const KeyT *seg = Xg + P.gofs[(size_t)gene * G + gb];
+            const BigRunFn<KeyT> fn = ((const BigRunFn<KeyT> *)P.big_fn)[(size_t)gene * P.n_cand + P.cand_of[gb]];
+            u64 s2_acc = 0, tt_acc = 0; // per-lane partial sums
+            u32 neg_acc = 0;            // (uniform)
+            bool bad = false;
+            for (int s0 = 0; s0 < n && !bad;) {
+                const int win = min(64 * KMAX, n - s0);
+                KeyT cur[KMAX];
+#pragma unroll
+                for (int r = 0; r < KMAX; ++r) cur[r] = (r * 64 + lane < win) ? seg[s0 + r * 64 + lane] : ZEROK;
+                int nB = win;
+                if (s0 + win < n) { // does the window's last bucket go on beyond it?  then the piece ends where that bucket starts
+                    const u32 bn = big_bucket(fn, seg[s0 + win]); // (uniform address)
+                    int same = 0;
+#pragma unroll
+                    for (int r = 0; r < KMAX; ++r) same += (int)__popcll(__ballot(r * 64 + lane < win && big_bucket(fn, cur[r]) == bn));
+                    nB = win - same;
+                }
+                if (nB == 0) { bad = true; break; } // a bucket of more than 256 keys: a tie-heavy column, not for this kernel
+#pragma unroll
+                for (int r = 0; r < KMAX; ++r) cur[r] = (r * 64 + lane < nB) ? cur[r] : ZEROK;
+                u32 less = 0, eqs = 0, negs = 0;
+                u64 TT = 0;
+                if (nB <= 64) ocr_group<KeyT, 1>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else if (nB <= 128) ocr_group<KeyT, 2>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else if (nB <= 192) ocr_group<KeyT, 3>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else ocr_group<KeyT, 4>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                s2_acc += 2ull * less + eqs;
+                tt_acc += TT;
+                neg_acc += negs;
+                s0 += nB;
+            }
+            if (bad) { if (lane == 0) P.route[gene] = 2u; continue; }
+            s2_acc = wave_sum<u64>(s2_acc);
+            tt_acc = wave_sum<u64>(tt_acc);
+            if (lane == 0) {
+                const size_t o = (size_t)gene * G + gb;
+                const long long n_g = P.counts[gb];
+                const u64 zc = (u64)(n_g - (long long)n);
+                const u64 S2 = s2_acc + 2ull * aZ * (u64)((u32)n - neg_acc) + zc * (2ull * nneg + aZ);
+                const u64 t0 = (u64)aZ + zc;
+                P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
+                P.out_tie[o] = T_A + 3ull * tt_acc + (t0 * t0 * t0 - t0);
             }
         }
     }

@@ -40,11 +40,13 @@ template <typename KeyT> static void packed_ref_sizing(int64_t n_ref, int *cap, 
     *cap = (int)std::min<int64_t>(n_ref, (int64_t)((kMaxLds - fixed) / sizeof(KeyT)) - 8);
 }
 // Sizes the route holds: reference of at most 65535 cells whose keys fit k_ovo_rank's LDS (it takes the tie-heavy genes and those
-// whose non-zeros exceed the packed kernel's key slots), other groups of at most 1024 cells (k_ovo_rank's register form).
+// whose non-zeros exceed the packed kernel's key slots), other groups of at most 65535 cells.
 template <typename KeyT> static bool packed_route_fits(const illico_ctx *c) {
     if (c->ref < 0 || c->no_packed_dense) return false;
     const int64_t n_ref = c->h_counts[c->ref];
-    return n_ref >= 1 && n_ref <= 65535 && c->max_nonref <= 1024 && ovo_sort_route_fits<KeyT>(n_ref, c->max_nonref);
+    // (groups above 1024 cells: their runs are sorted and walked in pieces, k_sort_big_runs; the genes the packed kernel leaves then
+    //  take the general sort route instead of k_ovo_rank)
+    return n_ref >= 1 && n_ref <= 65535 && c->max_nonref <= 65535 && ovo_sort_route_fits<KeyT>(n_ref, std::min<int64_t>(c->max_nonref, 1024));
 }
 
 constexpr int kOvrThreads = 256; // several small workgroups per CU overlap each other's barriers (1024 measured the same)

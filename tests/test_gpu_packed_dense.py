@@ -254,3 +254,37 @@ def test_padded_ovr_route_windows_unaligned_rows_and_log1p(engine, lb, ub):
     _check_ovr(engine, Xd, labels, what=f"ovr device window {lb}:{ub}", lb=lb, ub=ub)
     # expm1 is evaluated in float32 (utils/math.py:212): device and libm expm1f may differ by an f32 ulp
     _check_ovr(engine, np.log1p(X), labels, what="ovr log1p", fc_rtol=1e-6, lb=lb, ub=ub, is_log1p=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_groups_of_thousands_of_cells_are_walked_in_sorted_pieces(engine, dtype):
+    """Dense continuous OVO with groups above 1024 cells (clusters: the common non-perturbation use): each such group's packed run is
+    sorted in LDS (k_sort_big_runs) and looked up in pieces of at most 256 keys cut at run boundaries.  Values rounded to three
+    decimals put many duplicates inside a group -- across piece borders too --; a gene that holds one value in 400 cells of a big
+    group (a run longer than a piece), a count-valued (tie-heavy) gene and a group too large for the LDS sort buffer all leave the
+    route for the general one.  Statistics against the oracle and, bit for bit, against the transposition + sort route."""
+    import torch
+    rng = np.random.RandomState(2024)
+    sizes = [3000, 2600, 1500, 1025, 700, 300, 257, 40, 1]   # group 0: the reference
+    labels = np.concatenate([["non-targeting"] * sizes[0]] + [[f"c{i:02d}"] * sz for i, sz in enumerate(sizes[1:])])
+    rng.shuffle(labels)
+    n, m = labels.size, 48
+    X = np.where(rng.rand(n, m) < 0.55, np.round(np.log1p(rng.poisson(4.0, size=(n, m)) * rng.uniform(0.5, 1.5, size=(n, m))), 3), 0.0)
+    X[:, 3] = np.where(rng.rand(n) < 0.6, np.round(rng.rand(n) * 3, 1), 0.0)                       # ~30 distinct values: long runs everywhere
+    X[labels == "c00", 7] = np.where(rng.rand(2600) < 0.2, 1.234, X[labels == "c00", 7])           # one value ~500 times in a big group
+    X[:, 11] = rng.poisson(2.0, size=n) * (rng.rand(n) < 0.5)                                       # counts: tie-heavy reference column
+    X[:, 12] = -X[:, 12]                                                                            # negatives
+    X[:, 13] = 0.0                                                                                  # an empty gene
+    X = X.astype(dtype)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    want = oracle.run(X.astype(np.float64) if dtype == np.float64 else X, g)
+    Xd = torch.from_numpy(X).cuda()
+    (p_new, s_new, prof_new), (p_old, s_old, prof_old) = _both_routes(engine, Xd, g)
+    assert "k_group_compact" in prof_new and "k_ovo_rank_compact" in prof_new, prof_new
+    assert "k_ovr_gene" in prof_new, prof_new                                                       # ... and the genes that left took the general route
+    np.testing.assert_array_equal(s_new[0], s_old[0], err_msg="2U")
+    np.testing.assert_array_equal(s_new[1], s_old[1], err_msg="tie sums")
+    assert_planes_match(p_new, want, ref_row=g.encoded_ref_group, what=f"big groups, packed {np.dtype(dtype).name}")
+    assert_planes_match(p_old, want, ref_row=g.encoded_ref_group, what=f"big groups, general {np.dtype(dtype).name}")
+    got = engine.run_dense(X, 5, 40)                                                                # host input, a column window
+    assert_planes_match(got, oracle.run(X, g, col_lb=5, col_ub=40), ref_row=g.encoded_ref_group, what="big groups, host window")
