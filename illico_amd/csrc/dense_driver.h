@@ -70,7 +70,7 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         C.out_sum = ssum; C.G = G; C.ref = ref; C.n_genes = nb; C.nseg = nseg;
         packed_ref_sizing<KeyT>(n_ref, &C.ref_cap, &C.nbk_lg);
         C.out_2u = s2u; C.out_tie = stie; C.route = route; C.big_sorted = c->pk_nbig > 0 ? 1 : 0;
-        C.big_fn = big_fn; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
+        C.ref_by_gofs = 0; C.gene_flags = nullptr; C.big_fn = big_fn; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
         const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
         // large references: the bucket function follows the reference's distribution (a crowded stretch of values would otherwise
         // fill buckets beyond three keys and send whole table words to key-by-key walks); "packed_eq_buckets" = 0 / 1 forces

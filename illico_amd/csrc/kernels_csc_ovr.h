@@ -57,17 +57,19 @@ struct CscOvrParams {
     u64 *out_tie;                        // [nb][G] sum (t^3 - t), the same for every group of a gene
     int tie_f64;                         // out_tie = the bits of the float64 tie sum of the reference's sparse path (tie_f64_sparse)
     u64 *acc_global;                     // ACCG: [nb][G] the accumulators in HBM (zeroed by the host), for more groups than LDS holds beside the keys
+    int g_lds;                           // ACCG: the groups [0, g_lds) keep theirs in LDS all the same (what is left beside the keys)
     // (per-group value sums are not formed here: they would be order-dependent float64 atomics.  The host launches
     //  k_csc_value_sums / k_group_sums_rows, kernels_sums.h, whose results do not depend on the order of arrival.)
 };
 
 __host__ __device__ static inline size_t csco_fixed_lds_bytes(int G, int lg_buckets, bool parts, bool accg = false) {
-    // acc (packed rank sums / counts; none with ACCG: they live in HBM) | bucket table | reductions: a multiple of 16
-    (void)parts;
-    return (accg ? 0 : (size_t)((G + 1) & ~1) * 8) + ((size_t)2 << lg_buckets) + 256;
+    // acc (packed rank sums / counts; with ACCG: G = the groups that keep theirs in LDS, the others live in HBM) | bucket table |
+    // reductions: a multiple of 16
+    (void)parts; (void)accg;
+    return (size_t)((G + 1) & ~1) * 8 + ((size_t)2 << lg_buckets) + 256;
 }
 static inline int csco_key_cap(int G, int lg_buckets, size_t key_size, size_t lds_max, bool parts = false, bool accg = false) {
-    const size_t fixed = csco_fixed_lds_bytes(G, lg_buckets, parts, accg);
+    const size_t fixed = csco_fixed_lds_bytes(accg ? 0 : G, lg_buckets, parts, accg);
     if (fixed + (size_t)CSCO_NT * 4 + 64 > lds_max) return 0; // the scan borrows NT words of the key buffer
     // bucket offsets are 16-bit; 4 slots stay free behind the keys (the bucket walk reads 4 keys at a time)
     return (int)std::min<size_t>((lds_max - fixed) / key_size - 4, 65535 - 4);
@@ -196,14 +198,15 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     constexpr u64 CNT1 = 1ull << CSCO_CNT_SHIFT, R2MASK = CNT1 - 1ull;
     extern __shared__ __align__(16) unsigned char smem[];
     const int G = P.G, NBKT = 1 << P.lg_buckets;
-    const size_t accb = ACCG ? 0 : (size_t)((G + 1) & ~1) * 8;
-    u64 *acc_lds = (u64 *)smem;                               // [G] (none with ACCG)
+    const int G_lds = ACCG ? P.g_lds : G;                    // groups whose accumulators are in LDS
+    const size_t accb = (size_t)((G_lds + 1) & ~1) * 8;
+    u64 *acc_lds = (u64 *)smem;                               // [G_lds]
     u32 *tab = (u32 *)(smem + accb);                          // [NBKT / 2] two 16-bit bucket counters / offsets per word
     u16 *tab16 = (u16 *)tab;
     u64 *s_red = (u64 *)(tab + NBKT / 2);                     // [NW]
     KeyT *s_k = (KeyT *)(s_red + NW);                         // [2] smallest / largest non-zero key
     u32 *s_misc = (u32 *)(s_red + NW + 2);                    // [0] stored zeros  [1] negatives  [2] largest bucket
-    KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G, P.lg_buckets, false, ACCG));
+    KeyT *A = (KeyT *)(smem + csco_fixed_lds_bytes(G_lds, P.lg_buckets, false, ACCG));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const IdxT *indptr = (const IdxT *)P.indptr;
@@ -223,8 +226,12 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         // ---- 0. key range of the bucket function, from every 8th row of NT entries.  Any monotone bucket function ranks
         // correctly (keys outside the sampled range are clamped into the first / last bucket); the range only balances
         // the buckets. ----
-        u64 *acc = ACCG ? P.acc_global + (size_t)gene * G : acc_lds;
-        if (!ACCG) for (int g = tid; g < G; g += NT) acc[g] = 0ull;
+        u64 *acc_hbm = ACCG ? P.acc_global + (size_t)gene * G : nullptr;
+        auto acc_add = [&](int g, u64 x) { // one atomic per entry: LDS for the groups that fit there, HBM (L2) for the others
+            if (!ACCG || g < G_lds) atomicAdd(&acc_lds[g], x);
+            else atomicAdd(&acc_hbm[g], x);
+        };
+        for (int g = tid; g < G_lds; g += NT) acc_lds[g] = 0ull;
         for (int b = tid; b < NBKT / 2; b += NT) tab[b] = 0u;
         if (tid == 0) { s_k[0] = MAXK; s_k[1] = (KeyT)0; s_misc[0] = 0u; s_misc[1] = 0u; s_misc[2] = 0u; }
         __syncthreads();
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                         eq += (b0 == q ? 1u : 0u) + (b1 == q ? 1u : 0u) + (b2 == q ? 1u : 0u) + (b3 == q ? 1u : 0u);
                     }
                     if (q == MAXK) eq = (hi - lo) - less; // the largest key also matches the pad slots
-                    atomicAdd(&acc[cd], ((q > ZEROK) ? c_pos : c_neg) + (u64)(2u * (lo + less) + eq));
+                    acc_add(cd, ((q > ZEROK) ? c_pos : c_neg) + (u64)(2u * (lo + less) + eq));
                     tie32 += eq * eq - 1u;
                 }
             });
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
                     u32 e = s + 1;
                     if (e < un && A[e] == q) e = upper_bound_pow2(A, un, top, q);
                     const u64 add = (u64)s + (u64)e + 1ull + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull);
-                    atomicAdd(&acc[cd], add + CNT1);
+                    acc_add(cd, add + CNT1);
                 }
             });
         }
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
         else tie_total += (u64)n0 * (u64)n0 * (u64)n0 - (u64)n0;
         for (int g = tid; g < G; g += NT) {
             const long long n_g = P.counts[g];
-            const u64 a = ACCG ? atomicAdd(&acc[g], 0ull) : acc[g]; // (HBM accumulators: read at L2, where the atomics landed)
+            const u64 a = (ACCG && g >= G_lds) ? atomicAdd(&acc_hbm[g], 0ull) : acc_lds[g]; // (HBM accumulators: read at L2, where the atomics landed)
             const long long z = n_g - (long long)(a >> CSCO_CNT_SHIFT);
             const u64 r2 = (a & R2MASK) + (u64)z * (u64)(2 * nneg + n0 + 1);
             P.out_2u[(size_t)gene * G + g] = 2ll * (P.n_cells - n_g) * n_g + n_g * (n_g + 1) - (long long)r2;

@@ -309,6 +309,9 @@ struct OvoCompactParams {
     int big_sorted;          // 1: the runs of more than 256 non-zero keys were dealt into value buckets (k_bucket_big_runs): they are walked in
                              // pieces of at most 256 keys cut where the bucket number changes (equal keys never straddle two pieces, so the
                              // pieces' terms add up); 0: a gene with such a group leaves the kernel
+    int ref_by_gofs;         // 1 (sparse input, regrouped by k_csc_regroup / k_csc_segment): the reference's keys are ONE run at gofs[gene][ref]
+                             // (seg_nnz: [n_genes] its length, nseg = 1; no seg_sum: value sums are formed elsewhere); gene_stride = 0
+    const u32 *gene_flags;   // optional [n_genes]: a gene whose word is 0 is somebody else's (count-valued: the histogram kernel's)
     const void *big_fn;      // [n_genes][n_cand] BigRunFn<KeyT>: each such run's bucket function
     const int *cand_of;      // [G] a group's place among the n_cand groups of more than 256 cells, or -1
     int n_cand;
@@ -593,6 +596,19 @@ __global__ __launch_bounds__(SRT_NT) void k_bucket_big_runs(void *Xs, long long 
     }
 }
 
+// sparse input regrouped into Xs + seg ([n_genes][G + 1] offsets of the (gene, group) runs): the same runs in the packed layout's terms
+static __global__ __launch_bounds__(256) void k_seg_to_packed(const u32 *__restrict__ seg, int G, int nb, int ref, u16 *__restrict__ nnz, u32 *__restrict__ gofs,
+                                                             u16 *__restrict__ ref_nnz, u32 *__restrict__ route) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nb * G) return;
+    const int gene = (int)(i / G), g = (int)(i - (long long)gene * G);
+    const u32 a = seg[(size_t)gene * (G + 1) + g], n = seg[(size_t)gene * (G + 1) + g + 1] - a;
+    if (n > 65535u) route[gene] = 2u; // (16-bit run lengths: the gene takes the general sort route)
+    nnz[i] = (u16)(n > 65535u ? 65535u : n);
+    gofs[i] = a;
+    if (g == ref) ref_nnz[gene] = (u16)(n > 65535u ? 65535u : n);
+}
+
 template <typename KeyT, bool EQ>
 __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -615,11 +631,12 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene = blockIdx.x;
+    if (P.gene_flags && P.gene_flags[gene] == 0u) return; // (uniform)
     const int G = P.G, ref = P.ref;
     const int n_ref = P.counts[ref];
     u16 *nnz = P.nnz + (size_t)gene * G;
     KeyT *Xg = (KeyT *)P.Xs + (long long)gene * P.gene_stride;
-    KeyT *src = Xg + P.ref_out;
+    KeyT *src = P.ref_by_gofs ? Xg + P.gofs[(size_t)gene * G + ref] : Xg + P.ref_out;
     const u16 *seg_nnz = P.seg_nnz + (size_t)gene * P.nseg;
     // the reference's non-zero keys lie in nseg packed segments: wavefront w walks segments w, w + NW, ...
     auto for_ref = [&](auto f) {
@@ -664,7 +681,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         for (int gq = tid; gq < G; gq += NT) gmax = max(gmax, gq == ref ? 0u : (u32)nnz[gq]);
         gmax = (u32)wave_incl_scan_max((int)gmax);
         if (lane == 63 && gmax) atomicMax(&s_cnt[3], gmax);
-        if (tid == NT - 1) { // the reference's value sum: its segments' sums in order
+        if (tid == NT - 1 && P.seg_sum) { // the reference's value sum: its segments' sums in order
             double t = 0.0;
             for (int sg = 0; sg < P.nseg; ++sg) t += P.seg_sum[(size_t)gene * P.nseg + sg];
             P.out_sum[(size_t)gene * G + ref] = t;
@@ -750,7 +767,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
                 if ((u32)tid < c) src[dst + tid] = k;
                 dst += c;
             }
-            if (tid == 0) { nnz[ref] = (u16)nA; P.gofs[(size_t)gene * G + ref] = (u32)P.ref_out; P.route[gene] = 1u; }
+            if (tid == 0) { nnz[ref] = (u16)nA; if (!P.ref_by_gofs) P.gofs[(size_t)gene * G + ref] = (u32)P.ref_out; P.route[gene] = 1u; }
             return;
         }
         u32 base = 0;

@@ -71,7 +71,8 @@ template <typename KeyT>
 int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, int dtype, int flags, long long *s2u, u64 *stie, double *ssum,
                         double *gtot, bool *done, bool padded = false, const OvrPackedInput *packed = nullptr);
 template <typename KeyT>
-int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz, const u32 *flags, const OvoGlobalBufs *gb, bool sparse);
+int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz, const u32 *flags, const OvoGlobalBufs *gb, bool sparse,
+               const u32 *only = nullptr);
 
 #define ILLICO_KEYED_INSTANCES(X, KeyT)                                                                                                  \
     X template int launch_seg_value_sums<KeyT>(illico_ctx *, const KeyT *, const u32 *, int, int, int, double *);                            \
@@ -82,7 +83,7 @@ int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_
     X template int launch_ovr_gene<KeyT, false, true>(illico_ctx *, OvrParams);                                                             \
     X template int run_ovr_dense_batch<KeyT>(illico_ctx *, KeyT *, int64_t, int, int, int, int, long long *, u64 *, double *, double *, bool); \
     X template int run_ovr_dense_parts<KeyT>(illico_ctx *, KeyT *, int64_t, int, int, int, int, long long *, u64 *, double *, double *, bool *, bool, const OvrPackedInput *); \
-    X template int launch_ovo<KeyT>(illico_ctx *, OvoParams, int64_t, int64_t, const u32 *, const OvoGlobalBufs *, bool);
+    X template int launch_ovo<KeyT>(illico_ctx *, OvoParams, int64_t, int64_t, const u32 *, const OvoGlobalBufs *, bool, const u32 *);
 #ifndef ILLICO_KEYED_IMPL
 ILLICO_KEYED_INSTANCES(extern, u32)
 ILLICO_KEYED_INSTANCES(extern, u64)

@@ -190,7 +190,9 @@ static int launch_ovo_t(illico_ctx *c, const OvoParams &P, size_t lds, const u32
 // OVO mode), which has no size limit.
 template <typename KeyT>
 int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_nnz, const u32 *flags,
-               const OvoGlobalBufs *gb, bool sparse) {
+               const OvoGlobalBufs *gb, bool sparse, const u32 *only) {
+    // only (non-null; flags null): the genes with a non-zero word alone (what the packed rank kernel left)
+    if (only) P.only = only;
     if (flags) { // (the ingest kernels flagged with the same limit: ovo_counts_limit)
         ProfScope ps(c, KID_OVO_COUNTS);
         if (ovo_counts_limit(c) == COUNTS_R8) hipLaunchKernelGGL((k_ovo_counts<KeyT, COUNTS_R8, 8>), dim3(P.n_genes), dim3(COUNTS_NT), 0, c->stream, P, flags);
@@ -203,7 +205,7 @@ int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_
         Q.keys_a = (void *)P.Xs; Q.keys_b = gb->kb; Q.vals_a = gb->va; Q.vals_b = gb->vb;
         Q.code_by_pos = sparse ? nullptr : c->d_code_by_pos; Q.seg_ptr = P.seg_ptr; Q.stride = P.gene_stride;
         Q.pos_ptr = P.pos_ptr; Q.counts = P.counts; Q.G = P.G; Q.n_genes = P.n_genes; Q.dt = P.dt; Q.is_log1p = P.is_log1p;
-        Q.n_cells = c->n_cells; Q.ref = P.ref; Q.gene_flags = flags;
+        Q.n_cells = c->n_cells; Q.ref = P.ref; Q.gene_flags = only ? only : flags;
         Q.out_2u = P.out_2u; Q.out_tie = P.out_tie; Q.out_sum = P.out_sum; Q.tie_f64 = 0;
         return sparse ? launch_ovr_gene<KeyT, true, true>(c, Q) : launch_ovr_gene<KeyT, false, true>(c, Q);
     }

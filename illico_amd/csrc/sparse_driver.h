@@ -390,11 +390,18 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
     int key_cap = csco_key_cap(G, lg, sizeof(KeyT), kMaxLds);
     // thousands of groups: acc[G] takes the key buffer's place -- the accumulators then live in HBM (global atomics) and the keys keep LDS
     bool accg = false;
+    int g_lds = G; // groups whose accumulators stay in LDS
     if (key_cap < max_nnz) {
         int lg2 = 14;
         if (csco_key_cap(G, lg2, sizeof(KeyT), kMaxLds, false, true) < max_nnz) lg2 = 13;
         const int cap2 = csco_key_cap(G, lg2, sizeof(KeyT), kMaxLds, false, true);
-        if (cap2 > key_cap) { accg = true; lg = lg2; key_cap = cap2; }
+        if (cap2 > key_cap) {
+            accg = true; lg = lg2;
+            // what the largest gene's keys leave of LDS holds the accumulators of the first groups; the others' live in HBM
+            const size_t need = csco_fixed_lds_bytes(0, lg, false) + ((size_t)std::min<int64_t>(max_nnz, cap2) + 8) * sizeof(KeyT);
+            g_lds = need < kMaxLds ? (int)std::min<size_t>((size_t)G, ((kMaxLds - need) / 8) & ~(size_t)1) : 0;
+            key_cap = (int)std::min<size_t>((kMaxLds - csco_fixed_lds_bytes(g_lds, lg, false)) / sizeof(KeyT) - 4, 65535 - 4);
+        }
     }
     if (key_cap <= 0) return ILLICO_OK;
     int rc;
@@ -402,7 +409,7 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
     const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
     const int *d_cols = nullptr;
     if (!contiguous && (rc = upload_cols(c, cols, &d_cols))) return rc;
-    const size_t lds = csco_fixed_lds_bytes(G, lg, false, accg) + (size_t)(key_cap + 4) * sizeof(KeyT);
+    const size_t lds = csco_fixed_lds_bytes(g_lds, lg, false, accg) + (size_t)(key_cap + 4) * sizeof(KeyT);
     const int64_t n = (int64_t)cols.size();
     const int64_t nb_max = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)((size_t)(4ll << 30) / ((size_t)G * 24 + 16))));
     if ((rc = get_scratch(c, "stats", (size_t)nb_max * G * 24 + (size_t)nb_max * 8, &v))) return rc;
@@ -429,7 +436,7 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
         P.gene_cols = d_cols ? d_cols + b0 : nullptr; P.nb = nb; P.codes = d_codes; P.codes16 = d_codes ? c->d_codes16 : nullptr; P.counts = c->d_counts; P.G = G; P.dt = dtype;
         P.is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0; P.n_cells = n_rows; P.key_cap = key_cap; P.lg_buckets = lg;
         P.force_sorted = c->csc_ovr_sorted_form ? 1 : 0; P.fallback = fb;
-        P.out_2u = s2u; P.out_tie = stie; P.tie_f64 = 1; P.acc_global = acc_g;
+        P.out_2u = s2u; P.out_tie = stie; P.tie_f64 = 1; P.acc_global = acc_g; P.g_lds = g_lds;
         if (accg) HIPCHK(c, hipMemsetAsync(acc_g, 0, (size_t)nb * G * 8, c->stream));
         {
             ProfScope ps(c, KID_CSC_OVR);
@@ -552,6 +559,14 @@ static int launch_csr_counts_route(illico_ctx *c, const InT *d_data, const IdxT 
         HIPCHK(c, hipGetLastError());
     }
     return ILLICO_OK;
+}
+
+// Sparse OVO with groups whose (gene, group) runs outgrow what k_csc_gene / k_ovo_rank take quickly (clusters of hundreds or
+// thousands of cells): regroup, then the packed rank kernel of the dense route (kernels_ovo_compact.h) on the regrouped runs
+static bool sparse_packed_rank_fits(const illico_ctx *c) {
+    if (c->ref < 0 || c->no_packed_dense || c->max_nonref <= 256 || c->max_nonref > 65535) return false;
+    const int64_t n_ref = c->h_counts[c->ref];
+    return n_ref >= 1 && n_ref <= 65535;
 }
 
 // sizes the group-major CSR pass holds (kernels_csr_counts.h)
@@ -927,7 +942,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
             if (cols.empty()) return ILLICO_OK;
         }
     }
-    if (!is_csr && !ovr && !c->no_csc_gene_path) {
+    if (!is_csr && !ovr && !c->no_csc_gene_path && !sparse_packed_rank_fits(c)) { // (runs of more than 128 keys leave k_csc_gene, runs of 32 .. 128 are slow in it)
         if ((rc = run_csc_gene_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, d_codes, dtype, col_lb, flags, alternative, o, cols)))
             return rc;
         if (cols.empty()) return ILLICO_OK;
@@ -1074,6 +1089,50 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
             // short runs of a sparse layout cheap for any key type); the histogram route is kept for the sizes it
             // alone can take without the global-sort fallback.
             const u32 *route_flags = need_glob ? gflags : nullptr;
+            if (sparse_packed_rank_fits(c) && ovo_sort_route_fits<KeyT>(std::min<int64_t>(c->h_counts[c->ref], b.max_gene), 1024)) {
+                // groups of hundreds / thousands of cells: the regrouped runs in the packed layout's terms, runs above 256 keys dealt into
+                // value buckets, then k_ovo_rank_compact (look-ups in the bucketed reference, pieces of 256 keys); what it leaves -- tie-heavy
+                // reference runs -- and the count-valued genes (gflags == 0: k_ovo_counts) go on to launch_ovo
+                if ((rc = get_scratch(c, "sp_pk_nnz", (size_t)nb * G * 2 + (size_t)nb * 2 + 64, &v))) return rc;
+                u16 *pk_nnz = (u16 *)v, *ref_nnz = pk_nnz + (((size_t)nb * G + 7) & ~(size_t)7);
+                if ((rc = get_scratch(c, "sp_pk_gofs", (size_t)nb * G * 4 + (size_t)nb * 4, &v))) return rc;
+                u32 *pk_gofs = (u32 *)v, *route = pk_gofs + (size_t)nb * G;
+                HIPCHK(c, hipMemsetAsync(route, 0, (size_t)nb * 4, c->stream));
+                BigRunFn<KeyT> *big_fn = nullptr;
+                {
+                    ProfScope ps(c, KID_GROUP_COMPACT);
+                    hipLaunchKernelGGL(k_seg_to_packed, dim3((unsigned)(((size_t)nb * G + 255) / 256)), dim3(256), 0, c->stream, (const u32 *)seg, G, nb, (int)c->ref,
+                                       pk_nnz, pk_gofs, ref_nnz, route);
+                    if (c->pk_nbig > 0) {
+                        if ((rc = get_scratch(c, "packed_big_fn", (size_t)nb * c->pk_nbig * sizeof(BigRunFn<KeyT>), &v))) return rc;
+                        big_fn = (BigRunFn<KeyT> *)v;
+                        auto kern = k_bucket_big_runs<KeyT>;
+                        const int cap = (int)std::min<int64_t>(srt_cap<KeyT>(), (std::min<int64_t>(c->max_nonref, b.max_gene) + 63) & ~63ll);
+                        const size_t lds = srt_lds_bytes(sizeof(KeyT), cap);
+                        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        hipLaunchKernelGGL(kern, dim3(c->pk_nbig, nb), dim3(SRT_NT), lds, c->stream, (void *)Xs, 0ll, (const u16 *)pk_nnz, (const u32 *)pk_gofs,
+                                           (const int *)c->d_pk_big, c->pk_nbig, G, cap, big_fn, route);
+                    }
+                    HIPCHK(c, hipGetLastError());
+                }
+                {
+                    OvoCompactParams C;
+                    memset(&C, 0, sizeof C);
+                    C.Xs = Xs; C.gene_stride = 0; C.counts = c->d_counts; C.nnz = pk_nnz; C.gofs = pk_gofs; C.ref_out = 0; C.seg_nnz = ref_nnz; C.seg_sum = nullptr;
+                    C.out_sum = nullptr; C.G = G; C.ref = (int)c->ref; C.n_genes = nb; C.nseg = 1;
+                    packed_ref_sizing<KeyT>(std::min<int64_t>(c->h_counts[c->ref], std::max<int64_t>(b.max_gene, 1)), &C.ref_cap, &C.nbk_lg);
+                    C.out_2u = s2u; C.out_tie = stie; C.route = route; C.big_sorted = c->pk_nbig > 0 ? 1 : 0; C.ref_by_gofs = 1; C.gene_flags = route_flags;
+                    C.big_fn = big_fn; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
+                    const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
+                    const bool eq = c->packed_eq_buckets >= 0 ? c->packed_eq_buckets != 0 : c->h_counts[c->ref] > 16384;
+                    auto kern = eq ? k_ovo_rank_compact<KeyT, true> : k_ovo_rank_compact<KeyT, false>;
+                    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    ProfScope ps(c, KID_OVO_RANK_COMPACT);
+                    hipLaunchKernelGGL(kern, dim3(nb), dim3(OCR_NT), lds, c->stream, C);
+                    HIPCHK(c, hipGetLastError());
+                }
+                if ((rc = launch_ovo<KeyT>(c, P, ref_cap_b, grp_cap_b, route_flags, &gb, true, route))) return rc;
+            } else
             if ((rc = launch_ovo<KeyT>(c, P, ref_cap_b, grp_cap_b, route_flags, &gb, true))) return rc;
             if ((rc = launch_finalize(c, s2u, stie, ssum, nullptr, nb, flags, alternative, o.p, o.u, o.fc, o.ld, fin_off, d_cols))) return rc;
         } else {

@@ -1,0 +1,119 @@
+"""The shape sweep as a test: unusual group counts / group sizes / densities / value kinds, each (i) exact against the oracle on four
+genes and (ii) within 4x of the time its algorithmic bytes take at the rate of the dense continuous OVO pass at C2
+grouping, measured in the same session -- the sweeps of tools/shape_sweep*.sh found cliffs of 10 - 100x (groups above 1024 cells on
+continuous data, thousands of groups on continuous sparse data, CSC counts with groups above 255 cells); none may come back.
+
+300 000 cells x 2048 genes (a quarter of C2's genes: times scale with the genes, the rate does not); input and planes resident in HBM.
+"""
+import time
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import assert_planes_match
+
+pytestmark = pytest.mark.gpu
+
+N, M = 300_000, 2048
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    from bench import compress, group_container, make_labels, make_matrix
+    from illico_amd._lib import Engine
+    dev = torch.device("cuda", 0)
+    eng = Engine(0)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    cache = {}
+
+    def data(values, sparsity, fmt):
+        key = (values, sparsity, fmt)
+        if key not in cache:
+            cache.clear()   # one matrix at a time
+            torch.cuda.empty_cache()
+            X = make_matrix(torch, N, M, sparsity, 0, dev, values=values)
+            cache[key] = (X if fmt == "dense" else compress(torch, X, fmt), X[:, ::M // 4][:, :4].contiguous().cpu().numpy(), int((X != 0).sum()))
+        return cache[key]
+
+    def run(values, sparsity, fmt, G, ovr):
+        """(ms per pass, algorithmic bytes, planes of genes 0, M/4, 2M/4, 3M/4, their oracle planes)."""
+        Xd, Xs, nnz = data(values, sparsity, fmt)
+        codes = make_labels(N, G, 0)
+        grpc = group_container(codes, G, ovr)
+        eng.set_groups(grpc)
+        out = tuple(torch.empty((G, M), dtype=torch.float64, device=dev) for _ in range(3))
+
+        def step():
+            if fmt == "dense":
+                eng.run_dense(Xd, 0, M, out=out, defer=True)
+            else:
+                eng.run_sparse(fmt, Xd[0], Xd[1], Xd[2], (N, M), 0, M, out=out, defer=True)
+            eng.synchronize()
+            torch.cuda.synchronize()
+
+        step()
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            step()
+            best = min(best, (time.perf_counter() - t0) * 1e3)
+        alg = (N * M * 4 if fmt == "dense" else nnz * 8 + 4 * ((M if fmt == "csc" else N) + 1)) + 4 * N + 24 * G * M
+        cols = list(range(0, M, M // 4))[:4]
+        got = tuple(t[:, cols].cpu().numpy() for t in out)
+        want = oracle.run(Xs, grpc, batch_size=1, n_threads=4)
+        return best, alg, got, want, grpc
+
+    yield {"run": run, "eng": eng}
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def base_rate(ctx):
+    """bytes per ms of the dense continuous OVO pass at C2 grouping (2000 groups of ~145 cells): the yardstick of the sweep."""
+    ms, alg, got, want, grpc = ctx["run"]("continuous", 0.5, "dense", 2000, False)
+    assert_planes_match(got, want, ref_row=grpc.encoded_ref_group, what="yardstick")
+    return alg / ms
+
+
+SHAPES = [
+    # values,      sparsity, format,  groups, test
+    ("continuous", 0.5, "dense", 10, "ovo"),      # 9 clusters of 32 000 cells: big runs in value buckets, pieces of 256 keys
+    ("continuous", 0.5, "dense", 50, "ovo"),      # 153 ms at the start of round 4
+    ("continuous", 0.5, "dense", 300, "ovo"),
+    ("continuous", 0.5, "dense", 10000, "ovo"),
+    ("continuous", 0.5, "dense", 50, "ovr"),
+    ("continuous", 0.5, "dense", 2000, "ovr"),
+    ("continuous", 0.5, "dense", 10000, "ovr"),
+    ("counts", 0.5, "dense", 50, "ovo"),
+    ("counts", 0.5, "dense", 300, "ovr"),
+    ("counts", 0.5, "dense", 10000, "ovo"),
+    ("counts", 0.5, "dense", 10000, "ovr"),
+    ("nb", 0.5, "dense", 2000, "ovo"),            # heavy-tailed counts
+    ("counts", 0.9, "csc", 300, "ovo"),           # groups above 255 cells: 16-bit cells
+    ("counts", 0.9, "csc", 5000, "ovr"),          # windows of groups over the LDS histograms
+    ("counts", 0.9, "csc", 10000, "ovo"),
+    ("counts", 0.5, "csc", 2000, "ovo"),          # half of the entries stored: 4-bit cells overflow
+    ("continuous", 0.9, "csc", 50, "ovo"),        # clusters of thousands of cells on sparse input: 21 ms at the start of round 4
+    ("continuous", 0.9, "csc", 300, "ovo"),
+    ("continuous", 0.9, "csc", 50, "ovr"),
+    ("continuous", 0.9, "csc", 6000, "ovo"),      # 15.6 ms at full size at the start of round 4
+    ("continuous", 0.9, "csc", 6000, "ovr"),      # 44 ms
+    ("continuous", 0.9, "csc", 10000, "ovr"),     # 100 ms
+    ("counts", 0.9, "csr", 2000, "ovo"),          # the group-major single pass
+    ("counts", 0.9, "csr", 2000, "ovr"),
+    ("counts", 0.9, "csr", 300, "ovo"),           # more big groups than it takes: byte windows
+    ("counts", 0.5, "csr", 2000, "ovo"),
+    ("continuous", 0.9, "csr", 2000, "ovo"),
+    ("nb", 0.9, "csr", 2000, "ovo"),
+]
+
+
+@pytest.mark.parametrize("values,sparsity,fmt,G,test", SHAPES)
+def test_no_shape_falls_off_a_cliff(ctx, base_rate, values, sparsity, fmt, G, test):
+    ms, alg, got, want, grpc = ctx["run"](values, sparsity, fmt, G, test == "ovr")
+    assert_planes_match(got, want, ref_row=grpc.encoded_ref_group if test == "ovo" else None, what=f"{values} {fmt} G={G} {test}")
+    budget = 4.0 * alg / base_rate + 0.3   # (+ 0.3 ms: launch sequences and host waits do not shrink with the gene count)
+    print(f"{values} s={sparsity} {fmt} G={G} {test}: {ms:.2f} ms, budget {budget:.2f} ms")
+    assert ms <= budget, f"{values} s={sparsity} {fmt} G={G} {test}: {ms:.2f} ms for {alg / 1e9:.2f} GB, budget {budget:.2f} ms"

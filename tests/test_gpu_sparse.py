@@ -722,3 +722,43 @@ def test_csc_counts_with_a_reference_of_tens_of_thousands_of_cells(engine):
     engine.profile(False)
     assert "k_csc_counts" in prof and "k_csc_gene" not in prof, prof
     assert_planes_match(got, want, ref_row=g.encoded_ref_group, what="csc counts, large reference")
+
+
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sparse_ovo_with_groups_of_thousands_of_cells_takes_the_packed_rank_kernel(engine, fmt, dtype):
+    """Continuous sparse OVO with cluster-sized groups: the regrouped (gene, group) runs go to the dense route's packed rank kernel
+    (runs above 256 keys dealt into value buckets and walked in pieces); a count-valued gene takes the histogram kernel, a gene whose
+    reference run is tie-heavy and one with a value repeated 500 times in one group the general routes.  Against the oracle."""
+    rng = np.random.RandomState(4242)
+    sizes = [2500, 4000, 1800, 1100, 600, 300, 257, 33, 1]   # group 0: the reference
+    labels = np.concatenate([["non-targeting"] * sizes[0]] + [[f"c{i:02d}"] * sz for i, sz in enumerate(sizes[1:])])
+    rng.shuffle(labels)
+    n, m = labels.size, 40
+    X = np.where(rng.rand(n, m) < 0.3, np.round(np.log1p(rng.poisson(4.0, size=(n, m)) * rng.uniform(0.5, 1.5, size=(n, m))), 3), 0.0)
+    X[:, 3] = np.where(rng.rand(n) < 0.4, np.round(rng.rand(n) * 3, 1) + 0.1, 0.0)                 # ~30 distinct values
+    X[labels == "c00", 7] = np.where(rng.rand(4000) < 0.15, 1.234, X[labels == "c00", 7])          # one value ~600 times in a big group
+    X[:, 11] = rng.poisson(2.0, size=n) * (rng.rand(n) < 0.3)                                      # counts
+    X[:, 13] = 0.0                                                                                 # an empty gene
+    X = X.astype(dtype)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    want = oracle.run(X.astype(np.float64) if dtype == np.float64 else X, g)
+    M = (sparse.csc_matrix if fmt == "csc" else sparse.csr_matrix)(X)
+    engine.set_option("profile", 1)
+    engine.profile_reset()
+    try:
+        got = _run(engine, M, g)
+        prof = engine.profile_get()
+    finally:
+        engine.set_option("profile", 0)
+    assert "k_ovo_rank_compact" in prof, prof
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"sparse OVO, big groups {fmt} {np.dtype(dtype).name}")
+    got = _run(engine, M, g, col_lb=2, col_ub=30, alternative="less")
+    assert_planes_match(got, oracle.run(X, g, col_lb=2, col_ub=30, alternative="less"), ref_row=g.encoded_ref_group, what="sparse OVO, big groups, window")
+    engine.set_option("no_packed_dense", 1)   # ... and the routes it replaces give the same planes
+    try:
+        old = _run(engine, M, g)
+    finally:
+        engine.set_option("no_packed_dense", 0)
+    for a, b in zip(_run(engine, M, g), old):
+        np.testing.assert_array_equal(a, b)
