@@ -263,10 +263,13 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
     if (tot != n_cells || indptr[n_groups] != n_cells) return fail(c, ILLICO_ERR_ARG, "counts do not sum to n_cells");
     {   // n (n-1) (n+1) and the t^3 tie terms are 64-bit integer products, as in the reference (utils/math.py:95,
         // ranking.py:107): they hold up to n = 2^21 - 1 cells per test (n = n_ref + n_tgt for OVO, every cell for OVR).
-        // Beyond that the reference's int64 wraps silently; this build refuses instead of returning wrapped values.
+        // Beyond that the reference's int64 wraps silently.  OVO: refused.  OVR: the groups are accepted -- SPARSE input then takes the
+        // routes whose arithmetic holds (float64 zero block and variance terms, kernels_finalize.h: tie_f64_sparse / pval_nnn) and returns
+        // what the reference's formulas give WITHOUT the wrap; dense input is refused at the call (illico_run_dense).
         const int64_t n_test = ref < 0 ? n_cells : counts[ref] + max_nonref;
-        if (n_test > 2097151)
+        if (n_test > 2097151 && ref >= 0)
             return fail(c, ILLICO_ERR_UNSUPPORTED, "%lld cells in one test: n(n-1)(n+1) and the tie sums overflow 64-bit integers beyond 2097151 cells (the reference's int64 arithmetic wraps there, utils/math.py:95)", (long long)n_test);
+        c->big_n = n_test > 2097151;
     }
     posptr[n_groups] = (int)n_cells;
     for (int64_t i = 0; i < n_cells; ++i) {
@@ -631,6 +634,7 @@ extern "C" int illico_run_dense(illico_ctx *c, const void *X, int dtype, int64_t
     if (!X) return fail(c, ILLICO_ERR_ARG, "null X");
     if (ld < n_cols) return fail(c, ILLICO_ERR_ARG, "ld smaller than n_cols");
     if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    if (c->big_n) return fail(c, ILLICO_ERR_UNSUPPORTED, "%lld cells in one test: the dense routes' 64-bit tie sums hold up to 2097151 cells (the reference's int64 arithmetic wraps there, utils/math.py:95); sparse input is taken", (long long)c->n_cells);
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t W = col_ub - col_lb;
     // A deferred call still in flight: when this call is deferred too and writes other planes, its fused pass is enqueued
@@ -687,6 +691,7 @@ extern "C" int illico_rank_statistics(illico_ctx *c, const void *X, int dtype, i
     if (dtype < 0 || dtype > 3) return fail(c, ILLICO_ERR_DTYPE, "unsupported dtype code %d", dtype);
     HIPCHK(c, hipSetDevice(c->device));
     if ((rc = resolve_pending(c))) return rc;
+    if (c->big_n) return fail(c, ILLICO_ERR_UNSUPPORTED, "%lld cells in one test: dense input holds up to 2097151", (long long)c->n_cells);
     if (col_ub == col_lb) return ILLICO_OK;
     illico_ctx::StatsTap tap{(long long *)out_two_u, (u64 *)out_tie_sum, out_value_sum};
     c->tap = &tap;

@@ -105,6 +105,7 @@ struct illico_ctx {
     int64_t n_cells = 0, n_groups = 0, ref = -1;
     std::vector<int> h_counts;
     int64_t max_nonref = 0;
+    bool big_n = false;           // OVR over more than 2^21 - 1 cells: sparse input only, on the routes whose arithmetic does not wrap
     int *d_codes = nullptr;       // [N] group code of each cell
     int *d_perm = nullptr;        // [N] cell index at group-contiguous position p
     int *d_posptr = nullptr;      // [G+1]

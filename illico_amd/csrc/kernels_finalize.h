@@ -58,10 +58,20 @@ __device__ __forceinline__ double pval_device_pre(double nnn, double var0, doubl
     }
     return 1.0;                                                                    // :117-118
 }
+// n (n - 1) (n + 1) and n_ref n_tgt (n_ref + n_tgt + 1) as float64.  Up to 2^21 - 1 cells the int64 products of the reference
+// (utils/math.py:95,97) are exact and converted once -- bit for bit the reference.  Beyond, its int64 WRAPS (the reference is wrong
+// there); here the last factor is multiplied in float64 instead: n (n - 1) and n_ref n_tgt are still exact integers below 2^53 / 2^62,
+// so the result is the correctly rounded product.  (Sparse OVR only: illico_set_groups refuses larger dense / OVO problems.)
+__device__ __forceinline__ double pval_nnn(long long n) {
+    return n < 2097152ll ? (double)(n * (n - 1) * (n + 1)) : (double)(n * (n - 1)) * (double)(n + 1);
+}
+__device__ __forceinline__ double pval_var0(long long n_ref, long long n_tgt) {
+    const long long n1 = n_ref + n_tgt + 1;
+    return (n1 <= 2097152ll ? (double)(n_ref * n_tgt * n1) : (double)(n_ref * n_tgt) * (double)n1) / 12.0;
+}
 __device__ __forceinline__ double pval_device(long long n_ref, long long n_tgt, long long n, double tie_sum, double U,
                                               double mu, double cc, int alternative) {
-    return pval_device_pre((double)(n * (n - 1) * (n + 1)), (double)(n_ref * n_tgt * (n_ref + n_tgt + 1)) / 12.0, (double)(n_ref * n_tgt), tie_sum, U, mu, cc,
-                           alternative);
+    return pval_device_pre(pval_nnn(n), pval_var0(n_ref, n_tgt), (double)(n_ref * n_tgt), tie_sum, U, mu, cc, alternative);
 }
 
 // 32 genes x 32 groups per block; stats are read coalesced along groups, results written coalesced

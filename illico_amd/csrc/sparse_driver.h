@@ -571,7 +571,7 @@ static bool sparse_packed_rank_fits(const illico_ctx *c) {
 
 // sizes the group-major CSR pass holds (kernels_csr_counts.h)
 static bool csr_counts_route_fits(const illico_ctx *c, int flags, int64_t n_rows) {
-    if (c->no_csr_counts_path || c->hold_csr_counts || (flags & ILLICO_FLAG_LOG1P) || c->tap || c->no_counts_path) return false;
+    if (c->no_csr_counts_path || c->hold_csr_counts || (flags & ILLICO_FLAG_LOG1P) || c->tap || c->no_counts_path || c->big_n) return false;
     if (c->csr_n_big < 0 || n_rows >= (1ll << 30) || c->n_groups > 65535) return false;
     if (c->ref >= 0 && (c->h_counts[c->ref] < 1 || c->h_counts[c->ref] >= 30000)) return false;
     return true;
@@ -609,10 +609,11 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     const int n_windows = (G + cscc_group_window(G, w16_needed) - 1) / std::max(1, cscc_group_window(G, w16_needed));
     const bool cells_fit = (!w16_needed || (max_ranked <= 65535 && !c->no_csc_counts_wide)) && n_windows <= 8 &&
                            (n_windows == 1 || (!c->no_csc_counts_windows && c->d_codes16 && !indices_are_codes));
-    const bool counts_route = !is_csr && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && cells_fit && n_rows < (1ll << 30) &&
+    // (big_n -- OVR over more than 2^21 - 1 cells --: the table kernels' t^3 terms could wrap; the sort-based routes hold)
+    const bool counts_route = !is_csr && !c->big_n && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && cells_fit && n_rows < (1ll << 30) &&
                               (ovr || c->h_counts[c->ref] < (1ll << 30));
     // CSR, count-valued, not too sparse: dense windows + the fused single-pass kernels (below); the same question about the values
-    const bool window_route = is_csr && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) &&
+    const bool window_route = is_csr && !c->big_n && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) &&
                               (size_t)n_rows * 4 * 64 <= (size_t)c->scratch_bytes;
     // CSR, count-valued, small groups: the group-major single pass (kernels_csr_counts.h); the same question about the values
     const bool csr_counts = is_csr && allow_csr_counts && W > 0 && csr_counts_route_fits(c, flags, n_rows);

@@ -142,17 +142,65 @@ def test_every_group_size_through_the_chunk_cascade(engine, ref):
     _check(engine, X, labels, ref, "chunk cascade")
 
 
-def test_more_cells_per_test_than_the_64bit_products_hold_is_refused(engine):
+def test_more_cells_per_test_than_the_64bit_products_hold(engine):
     """n (n-1)(n+1) and the t^3 tie terms are 64-bit integer products (utils/math.py:95): beyond 2^21 - 1 cells in one test the
-    reference's int64 wraps silently; illico_set_groups refuses instead (OVR: every cell is in every test; OVO: n_ref + n_tgt)."""
+    reference's int64 wraps silently.  OVO (n_ref + n_tgt cells per test) is refused by illico_set_groups; OVR is refused for DENSE input
+    at the call and taken for SPARSE input (below: test_sparse_ovr_over_three_million_cells)."""
     n = (1 << 21) + 5
     labels = np.array(["a", "b", "c"])[np.arange(n) % 3]
     _, g_ovr = oracle.encode_and_count_groups(labels, None)
-    with pytest.raises(NotImplementedError, match="overflow 64-bit"):
-        engine.set_groups(g_ovr)
+    engine.set_groups(g_ovr)
+    with pytest.raises(NotImplementedError, match="2097151"):
+        engine.run_dense(np.zeros((n, 2), dtype=np.float32), 0, 2)
     _, g_ovo = oracle.encode_and_count_groups(labels, "a")     # 0.7M + 0.7M cells per test: fine
     engine.set_groups(g_ovo)
     big = np.where(np.arange(n) < n - 10, "a", "b")             # reference of 2^21 - 5 cells + a group of 10: 2^21 + 5 per test
     _, g_big = oracle.encode_and_count_groups(big, "a")
     with pytest.raises(NotImplementedError, match="overflow 64-bit"):
         engine.set_groups(g_big)
+
+
+@pytest.mark.parametrize("fmt", ["csc", "csr"])
+def test_sparse_ovr_over_three_million_cells(engine, fmt):
+    """Atlas-scale OVR on sparse input: 3 000 000 cells in every test.  The reference cannot be the yardstick here -- its int64
+    n (n-1)(n+1) wraps (utils/math.py:95) --, so the expected planes are built from scipy's ranks with Python integers (exact tie sums
+    and products) and the reference's own float64 formulas (utils/math.py:95-104, sparse_ovr.py:49,83): U exact, p at 1e-12."""
+    import math
+    from scipy import sparse, stats
+    rng = np.random.RandomState(99)
+    n, m = 3_000_000, 3
+    codes = rng.randint(0, 4, size=n)
+    codes[:37] = 4                                             # a small group that sits on top: a tiny p-value
+    labels = np.array([f"g{c}" for c in codes])
+    X = np.zeros((n, m), dtype=np.float32)
+    for j in range(m):
+        nz = rng.rand(n) < 0.05
+        v = np.round(np.exp(rng.randn(n) * 0.7) + 0.05, 2) if j < 2 else 1.0 + rng.poisson(2.0, size=n)
+        X[:, j] = np.where(nz, v, 0)
+    X[:37, :] = 50.0 + rng.rand(37, m).round(2)
+    _, g = oracle.encode_and_count_groups(labels, None)
+    M = (sparse.csc_matrix if fmt == "csc" else sparse.csr_matrix)(X)
+    engine.set_groups(g)
+    got = engine.run_sparse(fmt, M.data, M.indices, M.indptr, M.shape, 0, m)
+    G = g.counts.size
+    for j in range(m):
+        col = X[:, j].astype(np.float64)
+        ranks = stats.rankdata(col)
+        vals, cnt = np.unique(col[col != 0], return_counts=True)
+        n0 = float(n - int(cnt.sum()))
+        tie = float(sum(int(t) ** 3 - int(t) for t in cnt))    # the non-zero blocks: exact
+        tie += n0 * n0 * n0 - n0                                # sparse_ovr.py:83, n0 a float64 (:49)
+        nnn = float(n * (n - 1) * (n + 1))                      # Python integers: no wrap
+        for k in range(G):
+            n_t = int(g.counts[k]); n_r = n - n_t
+            R = float(ranks[g.encoded_groups == k].sum())
+            U = n_r * n_t + n_t * (n_t + 1) / 2 - R
+            assert got[1][k, j] == U, (fmt, j, k)
+            tie_corr = 1.0 - tie / nnn
+            sigma = math.sqrt(float(n_r * n_t * (n_r + n_t + 1)) / 12.0 * tie_corr)
+            mu = n_r * n_t / 2.0
+            Um = min(U, n_r * n_t - U)
+            d = Um - mu
+            z = (abs(d) + (1.0 if d > 0 else (-1.0 if d < 0 else 0.0)) * 0.5) / sigma
+            p = math.erfc(z / math.sqrt(2.0))
+            assert got[0][k, j] == pytest.approx(p, rel=1e-12, abs=0), (fmt, j, k, got[0][k, j], p)
