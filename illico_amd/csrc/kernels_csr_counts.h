@@ -152,11 +152,10 @@ __device__ __forceinline__ long long csrc_uniform(long long x) { // a wavefront-
 // the value 0, which no entry has), so that the sweep can tell a 4-bit cell that overflowed: a carry only loses entries, the gene's
 // 4-bit cells then add up to fewer than were counted.  Else 8-bit cells for every value.  An entry outside the window it was found in
 // means the row's columns are not in order: *unsorted.
-template <typename InT, typename IdxT, bool MIXED>
+template <typename InT, typename IdxT, bool MIXED, int U = CSRC_U>
 __device__ __forceinline__ void csrc_entries(const InT *__restrict__ data, const IdxT *__restrict__ indices, int n_rows_wg, const long long *row_k,
                                              const u32 *row_n, int wave, int NW, int lane, long long cbase, int wcols, int Wg, u32 *h,
                                              u32 *__restrict__ gene_flags /* of the window's first gene */, u32 *__restrict__ unsorted) {
-    constexpr int U = CSRC_U;
     IdxT ni[U];
     InT nv[U];
     long long nk = 0;
@@ -224,10 +223,76 @@ __device__ __forceinline__ void csrc_entries(const InT *__restrict__ data, const
             if (nn) load(nk, 0, nn, ni, nv); else zero(ni, nv);
         }
         put(ci, cv);
-        for (u32 j0 = 64 * U; j0 < cn; j0 += 64 * U) { // (a stretch of more than 256 entries: the rest, round by round)
+        for (u32 j0 = 64 * U; j0 < cn; j0 += 64 * U) { // (a stretch of more than 64 U entries: the rest, round by round)
             load(ck, j0, cn, ci, cv);
             put(ci, cv);
         }
+    }
+}
+
+// The same loop for NARROW column windows (the reference's driver asks for 256 genes at a time: a row's stretch is a few dozen entries).
+// One 64-entry chunk per row, R rows of the wavefront's list in flight at once (and the next R requested meanwhile) instead of R chunks
+// of one row: the same number of requests in flight, no request wasted on entries that are not there.
+template <typename InT, typename IdxT, bool MIXED, int R = CSRC_U>
+__device__ __forceinline__ void csrc_entries_narrow(const InT *__restrict__ data, const IdxT *__restrict__ indices, int n_rows_wg, const long long *row_k,
+                                                    const u32 *row_n, int wave, int NW, int lane, long long cbase, int wcols, int Wg, u32 *h,
+                                                    u32 *__restrict__ gene_flags, u32 *__restrict__ unsorted) {
+    IdxT ni[R];
+    InT nv[R];
+    long long nk[R];
+    u32 nn[R];
+    auto load1 = [&](long long k0, u32 j0, u32 n, IdxT &di, InT &dv) { // one chunk of a stretch; n > j0
+        const u32 left = n - j0, ec = min((u32)lane, left - 1u);
+        di = (indices + k0 + j0)[ec];
+        const InT v = (data + k0 + j0)[ec];
+        dv = (u32)lane < left ? v : (InT)0;
+    };
+    auto put1 = [&](IdxT ci, InT cv) {
+        const int c = csrc_code(cv);
+        const long long col64 = (long long)ci - cbase;
+        const int col = (int)col64;
+        const bool inr = sizeof(IdxT) == 4 ? (u32)col < (u32)wcols : (unsigned long long)col64 < (unsigned long long)wcols;
+        if (c > 0 && inr) {
+            if (MIXED) {
+                const u32 q = (u32)c + min((u32)c, 8u);
+                atomicAdd(&h[__umul24(q >> 3, (u32)Wg) + (u32)col], 1u << ((q & 7u) * 4u));
+                if (c >= 8) atomicAdd(&h[col], 1u);
+            } else atomicAdd(&h[__umul24((u32)c >> 2, (u32)Wg) + (u32)col], 1u << (((u32)c & 3u) * 8u));
+        } else if (c != 0) {
+            if (!inr) *unsorted = 1u;
+            else gene_flags[col64] = 1u;
+        }
+    };
+    auto fetch = [&](int row0) { // the stretches of rows row0, row0 + NW, ... (R of them)
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int r = row0 + u * NW;
+            nk[u] = 0; nn[u] = 0; ni[u] = (IdxT)0; nv[u] = (InT)0;
+            if (r < n_rows_wg) { // (uniform)
+                nk[u] = csrc_uniform(row_k[r]);
+                nn[u] = (u32)__builtin_amdgcn_readfirstlane((int)row_n[r]);
+                if (nn[u]) load1(nk[u], 0, nn[u], ni[u], nv[u]);
+            }
+        }
+    };
+    fetch(wave);
+    for (int row0 = wave; row0 < n_rows_wg; row0 += NW * R) {
+        IdxT ci[R];
+        InT cv[R];
+        long long ck[R];
+        u32 cn[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) { ci[u] = ni[u]; cv[u] = nv[u]; ck[u] = nk[u]; cn[u] = nn[u]; }
+        if (row0 + NW * R < n_rows_wg) fetch(row0 + NW * R);
+#pragma unroll
+        for (int u = 0; u < R; ++u) put1(ci[u], cv[u]);
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+            for (u32 j0 = 64; j0 < cn[u]; j0 += 64) { // (a stretch of more than 64 entries: rare here)
+                IdxT xi; InT xv;
+                load1(ck[u], j0, cn[u], xi, xv);
+                put1(xi, xv);
+            }
     }
 }
 
@@ -451,9 +516,13 @@ __global__ __launch_bounds__(CSRC_NT, 4) void k_csr_counts(CsrCountsParams P) {
         uint4 *h4 = (uint4 *)csrc_h;
         for (int i = tid; i < (Wg * CSRC_WPG) >> 2; i += CSRC_NT) h4[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
-        if (!(P.abl & 1))
-        csrc_entries<InT, IdxT, true>((const InT *)P.data, (const IdxT *)P.indices, n_g, row_k, row_n, wave, CSRC_NT / 64, lane,
-                                      P.col_lb + (long long)w * Wg, wcols, Wg, csrc_h, P.gene_flags + (size_t)w * Wg, P.unsorted);
+        if (P.abl & 1) {}
+        else if (Wg > 640) // (uniform) a row's stretch of ~2000 genes: four chunks of 64 entries requested together
+            csrc_entries<InT, IdxT, true, CSRC_U>((const InT *)P.data, (const IdxT *)P.indices, n_g, row_k, row_n, wave, CSRC_NT / 64, lane,
+                                                  P.col_lb + (long long)w * Wg, wcols, Wg, csrc_h, P.gene_flags + (size_t)w * Wg, P.unsorted);
+        else // a narrow column window (the reference's driver asks for 256 genes at a time): stretches of a few dozen entries, one chunk
+            csrc_entries_narrow<InT, IdxT, true>((const InT *)P.data, (const IdxT *)P.indices, n_g, row_k, row_n, wave, CSRC_NT / 64, lane,
+                                                 P.col_lb + (long long)w * Wg, wcols, Wg, csrc_h, P.gene_flags + (size_t)w * Wg, P.unsorted);
         __syncthreads();
     }
     if (P.abl & 2) return;
