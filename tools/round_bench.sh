@@ -21,6 +21,9 @@ b c3_cont_ovo --workload c3 --values continuous --no-c5 --steps 10
 b c3_cont_ovr --workload c3 --values continuous --test ovr --no-c5 --steps 10
 b c3_csr --workload c3 --format csr --no-c5 --steps 10
 b c3_csr_ovr --workload c3 --format csr --test ovr --no-c5 --steps 10
+b c2_cont_g50 --workload c2 --values continuous --groups 50 --no-c5 --steps 5
+b c3_cont_g300 --workload c3 --values continuous --groups 300 --no-c5 --steps 5
+b c3_cont_ovr_g6000 --workload c3 --values continuous --test ovr --groups 6000 --no-c5 --steps 5
 p() { name=$1; shift; bash tools/profile_bench.sh ${T}_$name "$@" > $O/prof_$name.log 2>&1; echo "profile $name rc=$?"; }
 p c2 --workload c2
 p c3 --workload c3
@@ -31,3 +34,7 @@ p c2_nb --workload c2 --values nb
 p c2_cont_ovr --workload c2 --values continuous --test ovr
 p c3_cont_ovr --workload c3 --values continuous --test ovr
 p c2_nb_ovr --workload c2 --values nb --test ovr
+p c3_csr --workload c3 --format csr
+p c3_csr_ovr --workload c3 --format csr --test ovr
+p c2_cont_ovo --workload c2 --values continuous
+p c3_cont_ovo --workload c3 --values continuous
