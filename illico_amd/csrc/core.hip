@@ -109,6 +109,8 @@ static void free_groups(illico_ctx *c) {
     c->d_codes16 = nullptr;
     if (c->d_hist_off) hipFree(c->d_hist_off);
     c->d_hist_off = nullptr;
+    if (c->d_gconst) hipFree(c->d_gconst);
+    c->d_gconst = nullptr;
     if (c->d_csr_chunks) hipFree(c->d_csr_chunks);
     c->d_csr_chunks = nullptr;
     c->csr_n_chunks = c->csr_n_big = 0;
@@ -294,6 +296,15 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
         (rc = up(&c->d_counts, cnt)) || (rc = up(&c->d_code_by_pos, cbp)))
         return rc;
     {
+        std::vector<GroupConst> gc(n_groups);
+        for (int64_t g = 0; g < n_groups; ++g) {
+            const long long n_tgt = cnt[g], n_ref = ref >= 0 ? (long long)cnt[ref] : (long long)n_cells - n_tgt;
+            gc[g] = group_const(n_ref, n_tgt, ref >= 0 ? n_ref + n_tgt : (long long)n_cells);
+        }
+        HIPCHK(c, hipMalloc((void **)&c->d_gconst, gc.size() * sizeof(GroupConst)));
+        HIPCHK(c, hipMemcpy(c->d_gconst, gc.data(), gc.size() * sizeof(GroupConst), hipMemcpyHostToDevice));
+    }
+    {
         std::vector<u32> ho(n_groups + 1, 0u);
         for (int64_t g = 0; g < n_groups; ++g) ho[g + 1] = ho[g] + (counts[g] <= 255 ? 16u : 32u);
         HIPCHK(c, hipMalloc((void **)&c->d_hist_off, ho.size() * sizeof(u32)));
@@ -416,7 +427,7 @@ int launch_finalize(illico_ctx *c, const long long *s2u, const u64 *stie, const 
     F.packed = packed ? 1 : 0;
     F.tie_f64 = tie_f64 ? 1 : 0;
     F.in_2u = s2u; F.in_tie = stie; F.in_sum = ssum; F.gene_total = gene_total;
-    F.counts = c->d_counts; F.G = (int)c->n_groups; F.ref = (int)c->ref; F.nb = nb; F.n_cells = c->n_cells;
+    F.counts = c->d_counts; F.gconst = c->d_gconst; F.G = (int)c->n_groups; F.ref = (int)c->ref; F.nb = nb; F.n_cells = c->n_cells;
     F.use_continuity = (flags & ILLICO_FLAG_CONTINUITY) ? 1 : 0;
     F.tie_correct = (flags & ILLICO_FLAG_TIE_CORRECT) ? 1 : 0;
     F.alternative = alternative;

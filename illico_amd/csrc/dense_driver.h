@@ -117,6 +117,15 @@ static int launch_transpose(illico_ctx *c, const void *X, int64_t ld, int64_t co
 }
 
 
+static int ensure_pinned(illico_ctx *c, size_t bytes) {
+    if (c->pinned_bytes >= bytes) return ILLICO_OK;
+    if (c->pinned) hipHostFree(c->pinned);
+    c->pinned = nullptr;
+    c->pinned_bytes = 0;
+    HIPCHK(c, hipHostMalloc(&c->pinned, bytes + 4096, hipHostMallocDefault));
+    c->pinned_bytes = bytes + 4096;
+    return ILLICO_OK;
+}
 // Fused single-pass route over genes [b0, b0+nb): writes final planes for every gene it can take and sets
 // h_flags[j] != 0 for the others (1 / 3: left to the two-pass routes; 2: done by the 256-value stage).  h_flags[nb] (also word nb of
 // the deferred call's pinned flags) != 0: the 256-value stage was left to the host (k_wide_decide; only with max_gather > 0).
@@ -133,7 +142,7 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
     size_t bytes = nb64 * (RT + 1) * 4 + (size_t)nb * 8 * 2 + (size_t)nb * 4 + (size_t)nb * RT * 4 + 64;
     if ((rc = get_scratch(c, "fused_tables", bytes, &v))) return rc;
     FusedParams P;
-    P.X = X; P.ld = ld; P.col0 = b0; P.ncols = nb; P.perm = c->d_perm; P.pos_ptr = c->d_posptr; P.counts = c->d_counts;
+    P.X = X; P.ld = ld; P.col0 = b0; P.ncols = nb; P.perm = c->d_perm; P.pos_ptr = c->d_posptr; P.counts = c->d_counts; P.gconst = c->d_gconst;
     P.G = (int)c->n_groups; P.ref = (int)c->ref;
     P.ref_TA = (u64 *)v;
     P.ref_sum = P.ref_TA + nb;
@@ -340,13 +349,7 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
         HIPCHK(c, hipEventRecord(c->pend_event[defer_slot], c->stream));
         return ILLICO_OK;
     }
-    if (c->pinned_bytes < (size_t)nb * 4 + 4) {
-        if (c->pinned) hipHostFree(c->pinned);
-        c->pinned = nullptr;
-        c->pinned_bytes = 0;
-        HIPCHK(c, hipHostMalloc(&c->pinned, (size_t)nb * 4 + 4096, hipHostMallocDefault));
-        c->pinned_bytes = (size_t)nb * 4 + 4096;
-    }
+    if ((rc = ensure_pinned(c, (size_t)nb * 4 + 4))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->pinned, P.gene_flags, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync((u32 *)c->pinned + nb, skipw, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -655,6 +658,51 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
                              int alternative, const OutPlanes &o, std::vector<std::pair<int64_t, int64_t>> runs, const int *col_map = nullptr,
                              bool prefer_counts = false, bool allow_packed = true);
 
+template <typename InT, typename KeyT>
+int run_leftovers(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                  const OutPlanes &o, const u32 *hf, bool wide_skipped, const int *outer);
+
+// A narrow device matrix xl [N][n_pad] of n flagged genes (gathered by run_leftovers) computed as one window: init[j] = 1: the 256-value stage first (wide_skipped: it was left to us), 3: not worth it;
+// dst[j]: gene j's column of the caller's planes.
+template <typename InT, typename KeyT>
+static int leftovers_on_narrow(illico_ctx *c, InT *xl, int dtype, int64_t N, int64_t n, int64_t n_pad, int flags, int alternative, const OutPlanes &o,
+                               const std::vector<u32> &init, const std::vector<int> &dst, bool wide_skipped, bool is_outer) {
+    const int G = (int)c->n_groups;
+    int rc;
+    void *v;
+    if ((rc = get_scratch(c, is_outer ? "xleft2_cols" : "xleft_cols", (size_t)n * 8, &v))) return rc;
+    int *d_dst = (int *)v;
+    u32 *d_flags2 = (u32 *)(d_dst + n);
+    HIPCHK(c, hipMemcpyAsync(d_dst, dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // (the host list may go out of scope)
+    const int lflags = (flags | ILLICO_FLAG_INPUT_DEVICE) & ~ILLICO_FLAG_DEFER;
+    if (wide_skipped) {
+        std::vector<u32> hf2;
+        bool any = false;
+        for (int64_t j = 0; j < n; ++j) any = any || init[j] == 1u;
+        if (any) {
+            if ((rc = get_scratch(c, "wide_tmp", (size_t)3 * G * (size_t)n_pad * 8, &v))) return rc;
+            double *tp = (double *)v;
+            const OutPlanes ot{tp, tp + (size_t)G * n_pad, tp + (size_t)2 * G * n_pad, n_pad, false};
+            if ((rc = run_fused_ovo<InT>(c, xl, n_pad, 0, (int)n, lflags, alternative, ot, 0, hf2, -1, false, 0, init.data()))) return rc;
+            HIPCHK(c, hipMemcpyAsync(d_flags2, hf2.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            {
+                ProfScope ps(c, KID_GATHER_COLS);
+                const dim3 grid((unsigned)((n + 255) / 256), (unsigned)std::min(G, 1024));
+                hipLaunchKernelGGL(k_scatter_planes, grid, dim3(256), 0, c->stream, (const double *)ot.p, (const double *)ot.u, (const double *)ot.fc, (long long)n_pad,
+                                   (const int *)d_dst, (const u32 *)d_flags2, 2u, (int)n, G, o.p, o.u, o.fc, (long long)o.ld);
+                HIPCHK(c, hipGetLastError());
+            }
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::vector<u32> hf3((size_t)n);
+            for (int64_t j = 0; j < n; ++j) hf3[j] = hf2[j] == 2u ? 0u : 1u;
+            return run_leftovers<InT, KeyT>(c, xl, dtype, N, n_pad, 0, n, lflags, alternative, o, hf3.data(), false, dst.data());
+        }
+    }
+    std::vector<std::pair<int64_t, int64_t>> runs{{0, n}};
+    return run_dense_twopass<InT, KeyT>(c, xl, dtype, N, n_pad, 0, n, lflags, alternative, o, runs, d_dst, true);
+}
+
 // The genes the fused passes of a DEVICE-resident window [col_lb, col_ub) left behind (hf[j] = 1 / 3).  Few and scattered (a count
 // matrix's highly expressed genes): gathered into a narrow matrix of their own and computed as ONE window whose results
 // k_finalize scatters back through a column map (kernels_leftover.h).  Many (normalised data: every gene): the column runs, as before.
@@ -696,44 +744,19 @@ int run_leftovers(illico_ctx *c, const void *X, int dtype, int64_t N, int64_t ld
     }
     if ((rc = get_scratch(c, outer ? "xleft2" : "xleft", (size_t)N * (size_t)n_pad * sizeof(InT), &v))) return rc;
     InT *xl = (InT *)v;
-    if ((rc = get_scratch(c, outer ? "xleft2_cols" : "xleft_cols", (size_t)n * 12, &v))) return rc;
-    int *d_src = (int *)v, *d_dst = d_src + n;
-    u32 *d_flags2 = (u32 *)(d_dst + n);
+    if ((rc = get_scratch(c, outer ? "xleft2_src" : "xleft_src", (size_t)n * 4, &v))) return rc;
+    int *d_src = (int *)v;
     HIPCHK(c, hipMemcpyAsync(d_src, src.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_dst, dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, KID_GATHER_COLS);
         hipLaunchKernelGGL((k_gather_columns<InT>), dim3((unsigned)((N + 63) / 64)), dim3(256), 0, c->stream, (const InT *)X, (long long)ld, (int)N,
                            (const int *)d_src, (int)n, (int)n_pad, xl, (long long)n_pad, 0ll);
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream)); // (the host lists go out of scope)
-    const int lflags = (flags | ILLICO_FLAG_INPUT_DEVICE) & ~ILLICO_FLAG_DEFER;
-    if (wide_skipped) {
-        std::vector<u32> init((size_t)n), hf2;
-        bool any = false;
-        for (int64_t j = 0; j < n; ++j) { init[j] = hf[src[j] - col_lb] == 1u ? 1u : 3u; any = any || init[j] == 1u; }
-        if (any) {
-            if ((rc = get_scratch(c, "wide_tmp", (size_t)3 * G * (size_t)n_pad * 8, &v))) return rc;
-            double *tp = (double *)v;
-            const OutPlanes ot{tp, tp + (size_t)G * n_pad, tp + (size_t)2 * G * n_pad, n_pad, false};
-            if ((rc = run_fused_ovo<InT>(c, xl, n_pad, 0, (int)n, lflags, alternative, ot, 0, hf2, -1, false, 0, init.data()))) return rc;
-            HIPCHK(c, hipMemcpyAsync(d_flags2, hf2.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-            {
-                ProfScope ps(c, KID_GATHER_COLS);
-                const dim3 grid((unsigned)((n + 255) / 256), (unsigned)std::min(G, 1024));
-                hipLaunchKernelGGL(k_scatter_planes, grid, dim3(256), 0, c->stream, (const double *)ot.p, (const double *)ot.u, (const double *)ot.fc, (long long)n_pad,
-                                   (const int *)d_dst, (const u32 *)d_flags2, 2u, (int)n, G, o.p, o.u, o.fc, (long long)o.ld);
-                HIPCHK(c, hipGetLastError());
-            }
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            std::vector<u32> hf3((size_t)n);
-            for (int64_t j = 0; j < n; ++j) hf3[j] = hf2[j] == 2u ? 0u : 1u;
-            return run_leftovers<InT, KeyT>(c, xl, dtype, N, n_pad, 0, n, lflags, alternative, o, hf3.data(), false, dst.data());
-        }
-    }
-    std::vector<std::pair<int64_t, int64_t>> runs{{0, n}};
-    return run_dense_twopass<InT, KeyT>(c, xl, dtype, N, n_pad, 0, n, lflags, alternative, o, runs, d_dst, true);
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // (the host list goes out of scope)
+    std::vector<u32> init((size_t)n);
+    for (int64_t j = 0; j < n; ++j) init[j] = hf[src[j] - col_lb] == 1u ? 1u : 3u;
+    return leftovers_on_narrow<InT, KeyT>(c, xl, dtype, N, n, n_pad, flags, alternative, o, init, dst, wide_skipped, outer != nullptr);
 }
 
 template <typename InT, typename KeyT>

@@ -118,6 +118,7 @@ struct illico_ctx {
     int pk_nbig = 0;
     int64_t pk_len = 0;           // ... of which the blocks take the first pk_len (the padded dense layout's row length)
     int *d_counts = nullptr;      // [G]
+    GroupConst *d_gconst = nullptr; // [G] per-group constants of the p-value / fold change for this ref (kernels_finalize.h)
     int *d_code_by_pos = nullptr; // [N] group code at position p
     u32 *d_hist_off = nullptr;    // [G+1] OVR one-pass histograms: words per lane before group g (16 per group of <= 255 cells, else 32)
     size_t hist_words = 0;        // d_hist_off[G]

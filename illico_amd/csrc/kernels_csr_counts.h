@@ -395,9 +395,8 @@ __device__ __forceinline__ void csrc_sweep(const CsrCountsParams &P, int g, int 
     const long long n_ref = OVR ? (P.n_cells - n_tgt) : n_refc;
     const long long n = OVR ? P.n_cells : (n_ref + n_tgt);
     // what compute_pval forms from the group's sizes alone, once per workgroup (pval_device_pre)
-    const double mu = (double)(n_ref * n_tgt) / 2.0, n12 = (double)(n_ref * n_tgt);
-    const double nnn = (double)(n * (n - 1) * (n + 1)), var0 = (double)(n_ref * n_tgt * (n_ref + n_tgt + 1)) / 12.0;
-    const double d_tgt = (double)n_tgt, d_rest = (double)(P.n_cells - n_tgt);
+    const GroupConst gc = group_const(n_ref, n_tgt, n);
+    const double mu = gc.mu, n12 = gc.n12, nnn = gc.nnn, var0 = gc.var0;
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     for (int j0 = 0; j0 < wcols; j0 += CSRC_NT) { // (uniform trip count: the word skips below are wavefront-wide votes)
         const int j = j0 + tid;
@@ -476,9 +475,11 @@ __device__ __forceinline__ void csrc_sweep(const CsrCountsParams &P, int g, int 
             p = (P.abl & 8) ? tie_d : pval_device_pre(nnn, var0, n12, tie_d, U, mu, cc, P.alternative);
             // fold change, math.py:181-192 (integer value sums: exact)
             const double sum_g = (double)vsum;
-            const double mu_tgt = sum_g / d_tgt;
-            const double mu_ref = OVR ? (gt - sum_g) / d_rest : gt;
-            fc = (mu_ref == 0.0) ? inf : mu_tgt / mu_ref;
+            if (OVR) fc = fold_change_device(sum_g, gt - sum_g, gc);
+            else { // (gt: the reference group's mean, formed once per gene by k_csr_tables)
+                const double mu_tgt = sum_g / gc.d_tgt;
+                fc = (gt == 0.0) ? inf : mu_tgt / gt;
+            }
         }
         if (live) {
             const size_t o = (size_t)g * P.out_ld + jc;
@@ -618,13 +619,13 @@ __global__ __launch_bounds__(256) void k_csr_big_sweep(CsrCountsParams P) {
         tie_sum = T_sel + tie + (t0 * t0 * t0 - t0);
     }
     const double cc = P.use_continuity ? 0.5 : 0.0;
-    const double mu = (double)(n_ref * n_tgt) / 2.0;
+    const GroupConst gc = group_const(n_ref, n_tgt, n);
     const double U = 0.5 * (double)two_u;
-    const double p = pval_device(n_ref, n_tgt, n, !P.tie_correct ? 0.0 : (OVR ? __longlong_as_double((long long)tie_sum) : (double)tie_sum), U, mu, cc, P.alternative);
-    const double sum_g = (double)vsum;
-    const double mu_tgt = sum_g / (double)n_tgt;
-    const double mu_ref = OVR ? (P.gene_total[jc] - sum_g) / (double)(P.n_cells - n_tgt) : P.gene_total[jc];
-    const double fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+    const double p = pval_device_pre(gc.nnn, gc.var0, gc.n12, !P.tie_correct ? 0.0 : (OVR ? __longlong_as_double((long long)tie_sum) : (double)tie_sum), U, gc.mu, cc, P.alternative);
+    const double sum_g = (double)vsum, gt = P.gene_total[jc];
+    double fc;
+    if (OVR) fc = fold_change_device(sum_g, gt - sum_g, gc);
+    else fc = (gt == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : (sum_g / gc.d_tgt) / gt;
     const size_t o = (size_t)g * P.out_ld + jc;
     P.out_p[o] = p;
     P.out_u[o] = U;

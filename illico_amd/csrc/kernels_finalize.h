@@ -6,12 +6,14 @@
 #pragma once
 #include "common.h"
 
+struct GroupConst;
 struct FinalizeParams {
     const long long *in_2u;   // [nb][G]  2*U
     const u64 *in_tie;        // [nb][G]  tie sum
     const double *in_sum;     // [nb][G]  per-group sum of (expm1'd) values
     const double *gene_total; // [nb] sum over groups, OVR only (utils/math.py:185)
     const int *counts;        // [G]
+    const GroupConst *gconst; // [G] (declared below) for this call's test: OVO against ref, or OVR
     int G, ref, nb;           // ref == -1 => OVR
     long long n_cells;
     int use_continuity, tie_correct, alternative;
@@ -62,16 +64,39 @@ __device__ __forceinline__ double pval_device_pre(double nnn, double var0, doubl
 // (utils/math.py:95,97) are exact and converted once -- bit for bit the reference.  Beyond, its int64 WRAPS (the reference is wrong
 // there); here the last factor is multiplied in float64 instead: n (n - 1) and n_ref n_tgt are still exact integers below 2^53 / 2^62,
 // so the result is the correctly rounded product.  (Sparse OVR only: illico_set_groups refuses larger dense / OVO problems.)
-__device__ __forceinline__ double pval_nnn(long long n) {
+__host__ __device__ inline double pval_nnn(long long n) {
     return n < 2097152ll ? (double)(n * (n - 1) * (n + 1)) : (double)(n * (n - 1)) * (double)(n + 1);
 }
-__device__ __forceinline__ double pval_var0(long long n_ref, long long n_tgt) {
+__host__ __device__ inline double pval_var0(long long n_ref, long long n_tgt) {
     const long long n1 = n_ref + n_tgt + 1;
     return (n1 <= 2097152ll ? (double)(n_ref * n_tgt * n1) : (double)(n_ref * n_tgt) * (double)n1) / 12.0;
 }
 __device__ __forceinline__ double pval_device(long long n_ref, long long n_tgt, long long n, double tie_sum, double U,
                                               double mu, double cc, int alternative) {
     return pval_device_pre(pval_nnn(n), pval_var0(n_ref, n_tgt), (double)(n_ref * n_tgt), tie_sum, U, mu, cc, alternative);
+}
+
+// What compute_pval and fold_change_from_summed_expr form from a group's SIZES alone (math.py:95,97,100 and :186-188): formed once
+// per illico_set_groups (for the context's test: OVO against the reference group, or OVR) instead of once per test -- the same
+// operations on the same values, bit for bit.  (The two group means of the fold change stay true divisions: taking them by
+// reciprocals of the sizes saves two of the three divisions per test -- k_finalize 0.188 -> 0.161 ms at C3, nothing at C2 / C4 -- but
+// moves the fold change by a unit in the last place, and tests/test_gpu_determinism.py holds it to the reference's bits:
+// profiles/NOTES_r04.md.)
+struct GroupConst { double d_tgt, d_ref, var0, n12, nnn, mu; };
+__host__ __device__ inline GroupConst group_const(long long n_ref, long long n_tgt, long long n) {
+    GroupConst c;
+    c.d_tgt = (double)n_tgt;
+    c.d_ref = (double)n_ref;
+    c.var0 = pval_var0(n_ref, n_tgt);
+    c.n12 = (double)(n_ref * n_tgt);
+    c.nnn = pval_nnn(n);
+    c.mu = (double)(n_ref * n_tgt) / 2.0;
+    return c;
+}
+// math.py:181-192; ref_part: the reference group's value sum (OVO) / the column total minus the group's (OVR)
+__device__ __forceinline__ double fold_change_device(double sum_g, double ref_part, const GroupConst &c) {
+    const double mu_tgt = sum_g / c.d_tgt, mu_ref = ref_part / c.d_ref;
+    return (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
 }
 
 // 32 genes x 32 groups per block; stats are read coalesced along groups, results written coalesced
@@ -82,13 +107,19 @@ static __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     const int gene0 = blockIdx.x * 32, grp0 = blockIdx.y * 32;
     const bool ovr = P.ref < 0;
     const double cc = P.use_continuity ? 0.5 : 0.0;
-    long long total_cells = P.n_cells;
     // every load of this thread's four (gene, group) pairs is requested before any of the arithmetic: the kernel moves 48 bytes
     // per test and does not compute much -- what it must not do is wait for memory four times in a row
     const int g = grp0 + tx;
     const bool gok = g < P.G;
-    const long long n_tgt = gok ? P.counts[g] : 1;
-    const long long n_refc = ovr ? 0 : (long long)P.counts[P.ref];
+    const GroupConst gc = P.gconst[gok ? g : 0]; // this thread's four tests are four genes of ONE group
+    // OVO: the reference group's mean is a gene's, not a test's (math.py:183): 32 divisions per block instead of 1024
+    __shared__ double s_mref[32];
+    if (!ovr && threadIdx.x < 32) {
+        const int gene = gene0 + (int)threadIdx.x;
+        double rs = 1.0;
+        if (gene < P.nb) rs = P.packed ? (double)((u64)P.in_2u[(size_t)gene * P.G + P.ref] >> 40) : P.in_sum[(size_t)gene * P.G + P.ref];
+        s_mref[threadIdx.x] = rs / (double)P.counts[P.ref];
+    }
     long long in2u[4];
     u64 intie[4];
     double insum[4], inref[4];
@@ -101,10 +132,10 @@ static __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
         intie[k] = (ok && P.tie_correct) ? P.in_tie[o] : 0ull;
         if (P.packed) { // (uniform)
             insum[k] = 0.0;
-            inref[k] = !ok ? 1.0 : (ovr ? P.gene_total[gene] : (double)((u64)P.in_2u[(size_t)gene * P.G + P.ref] >> 40));
+            inref[k] = (ok && ovr) ? P.gene_total[gene] : 1.0;
         } else {
             insum[k] = ok ? P.in_sum[o] : 0.0;
-            inref[k] = !ok ? 1.0 : (ovr ? P.gene_total[gene] : P.in_sum[(size_t)gene * P.G + P.ref]);
+            inref[k] = (ok && ovr) ? P.gene_total[gene] : 1.0;
         }
     }
     if (P.packed) {
@@ -115,25 +146,23 @@ static __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
             in2u[k] = lo == 0xFFFFFFFFFFull ? -2ll : (long long)lo;
         }
     }
+    __syncthreads(); // s_mref
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int gy = ty + 8 * k, gene = gene0 + gy;
         if (gene < P.nb && gok) {
-            long long n_ref = ovr ? (total_cells - n_tgt) : n_refc;
-            long long n = ovr ? total_cells : (n_ref + n_tgt);
             double U = 0.5 * (double)in2u[k];
             double tie = !P.tie_correct ? 0.0 : (P.tie_f64 ? __longlong_as_double((long long)intie[k]) : (double)intie[k]);
-            double mu = (double)(n_ref * n_tgt) / 2.0;
             double p;
             if (!ovr && g == P.ref) { p = 1.0; U = -1.0; }                         // sparse_ovo.py:140-143
-            else p = pval_device(n_ref, n_tgt, n, tie, U, mu, cc, P.alternative);
-            // fold change, math.py:181-192
-            double sum_g = insum[k];
-            double mu_tgt = sum_g / (double)n_tgt;
-            double mu_ref;
-            if (ovr) mu_ref = (inref[k] - sum_g) / (double)(total_cells - n_tgt);
-            else mu_ref = inref[k] / (double)n_refc;
-            double fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+            else p = pval_device_pre(gc.nnn, gc.var0, gc.n12, tie, U, gc.mu, cc, P.alternative);
+            const double sum_g = insum[k];
+            double fc;
+            if (ovr) fc = fold_change_device(sum_g, inref[k] - sum_g, gc);
+            else {
+                const double mu_ref = s_mref[gy];
+                fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : (sum_g / gc.d_tgt) / mu_ref;
+            }
             tp[gy][tx] = p;
             tu[gy][tx] = U;
             tf[gy][tx] = fc;

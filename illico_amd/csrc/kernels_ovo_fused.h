@@ -35,6 +35,7 @@ struct FusedParams {
     const int *perm;          // [N] GroupContainer.indices
     const int *pos_ptr;       // [G+1]
     const int *counts;        // [G]
+    const GroupConst *gconst; // [G] what compute_pval forms from the group sizes alone (kernels_finalize.h)
     int G, ref;
     u32 *ref_cum;             // [tile][RT+1][64] cumulative counts, tile = 64 consecutive genes (the LDS image of k_ovo_fused)
     u64 *ref_TA;              // [ncols] sum_v (tA^3 - tA); OVR with tie_mode != 0: the BITS of the float64 the reference's accumulator holds
@@ -541,6 +542,7 @@ __global__ __launch_bounds__(FUSED_NT, WIDE ? (OVR ? 2 : 1) : ((OVR || CB == 8) 
     cell_t *cb = (cell_t *)cbw + lane;
     const long long n_ref = OVR ? 0 : P.counts[OVR ? 0 : P.ref];
     const double cc = P.use_continuity ? 0.5 : 0.0;
+    const double mu_ref_ovo = OVR ? 0.0 : ref_sum / (double)n_ref; // (math.py:183: the reference group's mean is this lane's gene's, not a test's)
 
     const int gbeg = gchunk * P.groups_per_wg, gend = min(gbeg + P.groups_per_wg, P.G);
 
@@ -548,26 +550,22 @@ __global__ __launch_bounds__(FUSED_NT, WIDE ? (OVR ? 2 : 1) : ((OVR || CB == 8) 
     auto emit = [&](int g, long long n_tgt, u64 S2, u64 TT, u32 vsum) {
         if (!act) return;
         double pv, Ustat, fc;
-        const double mu_tgt = (double)vsum / (double)n_tgt;
+        const GroupConst gc = P.gconst[g]; // (uniform address: one scalar load per group)
         if (OVR) { // dense_ovr.py:57-75: the "reference" of group g is every other cell
             const long long n_rest = P.n_cells - n_tgt;
             // 2*ranksum = S2 + n_tgt (2 rank = 2 #less + #equal + 1);  U = n_rest n_tgt + n_tgt(n_tgt+1)/2 - ranksum
             const long long two_u = 2ll * n_rest * n_tgt + n_tgt * (n_tgt + 1) - ((long long)S2 + n_tgt);
             Ustat = 0.5 * (double)two_u;
             const double tie = !P.tie_correct ? 0.0 : (P.tie_mode ? __longlong_as_double((long long)T_A) : (double)T_A);
-            const double mu = (double)(n_rest * n_tgt) / 2.0;
-            pv = pval_device(n_rest, n_tgt, P.n_cells, tie, Ustat, mu, cc, P.alternative);
-            const double mu_ref = (ref_sum - (double)vsum) / (double)n_rest; // math.py:185-188
-            fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+            pv = pval_device_pre(gc.nnn, gc.var0, gc.n12, tie, Ustat, gc.mu, cc, P.alternative);
+            fc = fold_change_device((double)vsum, ref_sum - (double)vsum, gc); // math.py:185-188
         } else {
             const u64 tie_i = T_A + 3ull * TT;
             const long long two_u = 2ll * n_ref * n_tgt - (long long)S2;
             Ustat = 0.5 * (double)two_u;
             const double tie = P.tie_correct ? (double)tie_i : 0.0;
-            const double mu = (double)(n_ref * n_tgt) / 2.0;
-            pv = pval_device(n_ref, n_tgt, n_ref + n_tgt, tie, Ustat, mu, cc, P.alternative);
-            const double mu_ref = ref_sum / (double)n_ref;
-            fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+            pv = pval_device_pre(gc.nnn, gc.var0, gc.n12, tie, Ustat, gc.mu, cc, P.alternative);
+            fc = (mu_ref_ovo == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : ((double)vsum / gc.d_tgt) / mu_ref_ovo;
         }
         const size_t o = (size_t)g * P.out_ld + gene;
         P.out_p[o] = pv;
@@ -851,11 +849,9 @@ __global__ __launch_bounds__(FUSED_NT, NPL == 3 ? 3 : 2) void k_ovr_from_hists(F
         const long long n_rest = P.n_cells - n_tgt;
         const long long two_u = 2ll * n_rest * n_tgt + n_tgt * (n_tgt + 1) - ((long long)R2 + n_tgt);
         const double Ustat = 0.5 * (double)two_u;
-        const double mu = (double)(n_rest * n_tgt) / 2.0;
-        const double pv = pval_device(n_rest, n_tgt, P.n_cells, tie, Ustat, mu, cc, P.alternative);
-        const double mu_tgt = (double)vsum / (double)n_tgt;
-        const double mu_ref = (total - (double)vsum) / (double)n_rest; // math.py:185-188
-        const double fc = (mu_ref == 0.0) ? __longlong_as_double(0x7FF0000000000000ll) : mu_tgt / mu_ref;
+        const GroupConst gc = P.gconst[g]; // (uniform address)
+        const double pv = pval_device_pre(gc.nnn, gc.var0, gc.n12, tie, Ustat, gc.mu, cc, P.alternative);
+        const double fc = fold_change_device((double)vsum, total - (double)vsum, gc); // math.py:185-188
         const size_t o = (size_t)g * P.out_ld + gene;
         P.out_p[o] = pv;
         P.out_u[o] = Ustat;
