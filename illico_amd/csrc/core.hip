@@ -132,6 +132,7 @@ int illico_ctx_destroy(illico_ctx *c) {
     }
     free_groups(c);
     free_host_stage(c);
+    for (auto &a : c->ahead) if (a.planes) hipFree(a.planes);
     for (illico_matrix *m : c->bound) {
         if (m->owns) { hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr); }
         delete m;
@@ -169,6 +170,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_fused_wide")) c->no_fused_wide = value != 0;
     else if (!strcmp(key, "no_leftover_gather")) c->no_leftover_gather = value != 0;
     else if (!strcmp(key, "no_wide_gather")) c->no_wide_gather = value != 0;
+    else if (!strcmp(key, "bound_ahead_genes")) c->bound_ahead_genes = value < 0 ? 0 : value;
     else if (!strcmp(key, "no_csc_counts_windows")) c->no_csc_counts_windows = value != 0;
     else if (!strcmp(key, "no_csc_counts_wide")) c->no_csc_counts_wide = value != 0;
     else if (!strcmp(key, "ovr_full_dump")) c->ovr_full_dump = value != 0;
@@ -395,6 +397,7 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
     c->ref = ref;
     c->max_nonref = max_nonref;
     c->has_groups = true;
+    ++c->groups_gen;
     return ILLICO_OK;
 }
 
@@ -914,6 +917,58 @@ extern "C" int illico_csc_bind(illico_ctx *c, const void *data, int dtype, const
                                int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out) {
     return sparse_bind(c, false, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, flags, out);
 }
+// "bound_ahead_genes" = A: genes [col_lb, col_ub), fewer than A, of a bound CSR matrix.  The aligned window of A genes that holds them
+// (or the A genes from col_lb on, when they straddle a boundary) is computed ONCE into planes of the context's own -- two such windows
+// are kept, the older one is replaced -- and every call for genes inside it is a copy of its slice: 32 calls of 256 genes at C3 shape
+// cost 7.2 ms as 32 passes over the rows, 1.3 ms this way.  A window belongs to (matrix, groups, flags, alternative).
+static int run_bound_ahead(illico_ctx *c, const illico_matrix *m, int64_t col_lb, int64_t col_ub, int flags, int alternative,
+                           double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
+    const int64_t A = c->bound_ahead_genes, W = col_ub - col_lb;
+    const size_t G = (size_t)c->n_groups;
+    const int kflags = flags & (ILLICO_FLAG_LOG1P | ILLICO_FLAG_CONTINUITY | ILLICO_FLAG_TIE_CORRECT);
+    int rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    illico_ctx::AheadWindow *w = nullptr;
+    for (auto &a : c->ahead)
+        if (a.m == m && a.gen == c->groups_gen && a.flags == kflags && a.alternative == alternative && a.lb <= col_lb && col_ub <= a.ub) w = &a;
+    if (!w) {
+        w = c->ahead[0].stamp <= c->ahead[1].stamp ? &c->ahead[0] : &c->ahead[1];
+        for (auto &a : c->ahead) if (!a.m) w = &a; // (a free one first)
+        int64_t lb = (col_lb / A) * A, ub = std::min(lb + A, m->n_cols);
+        if (col_ub > ub) { lb = col_lb; ub = std::min(lb + A, m->n_cols); }
+        const size_t need = 3 * G * (size_t)(ub - lb) * sizeof(double);
+        w->m = nullptr;
+        if (w->cap < need) {
+            if (w->planes) hipFree(w->planes);
+            w->planes = nullptr; w->cap = 0;
+            HIPCHK(c, hipMalloc((void **)&w->planes, need));
+            w->cap = need;
+        }
+        const size_t plane = G * (size_t)(ub - lb);
+        if ((rc = run_sparse(c, true, m->d_data, m->dtype, m->d_indices, m->d_indptr, m->idx_dtype, m->n_rows, m->n_cols, lb, ub,
+                             kflags | ILLICO_FLAG_INPUT_DEVICE | ILLICO_FLAG_OUTPUT_DEVICE, alternative, w->planes, w->planes + plane, w->planes + 2 * plane, ub - lb)))
+            return rc;
+        w->m = m; w->gen = c->groups_gen; w->flags = kflags; w->alternative = alternative; w->lb = lb; w->ub = ub;
+    } else { // (a deferred call of another kind may still be in flight: completed first, as every entry point does)
+        PendingDense prev = c->pend;
+        c->pend.on = false;
+        if ((rc = resolve_pending(c, prev))) return rc;
+    }
+    w->stamp = ++c->ahead_clock;
+    OutPlanes o;
+    if ((rc = begin_outputs(c, flags, W, out_p, out_u, out_fc, out_ld, &o))) return rc;
+    const int64_t cw = w->ub - w->lb;
+    const size_t plane = G * (size_t)cw;
+    double *const dst[3] = {o.p, o.u, o.fc};
+    for (int k = 0; k < 3; ++k)
+        HIPCHK(c, hipMemcpy2DAsync(dst[k], (size_t)o.ld * 8, w->planes + (size_t)k * plane + (col_lb - w->lb), (size_t)cw * 8, (size_t)W * 8, G, hipMemcpyDeviceToDevice, c->stream));
+    if (!o.staged) {
+        if (!(flags & ILLICO_FLAG_DEFER)) HIPCHK(c, hipStreamSynchronize(c->stream));
+        return ILLICO_OK;
+    }
+    return end_outputs(c, o, W, out_p, out_u, out_fc, out_ld);
+}
+
 extern "C" int illico_run_bound(illico_ctx *c, const illico_matrix *m, int64_t col_lb, int64_t col_ub, int flags, int alternative,
                                 double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
     if (!c || !m) return ILLICO_ERR_ARG;
@@ -926,8 +981,14 @@ extern "C" int illico_run_bound(illico_ctx *c, const illico_matrix *m, int64_t c
     const bool hold0 = c->hold_csr_counts;
     c->cur_sorted_known = m->is_csr && m->sorted == 1;
     if (m->is_csr && m->sorted == 0) c->hold_csr_counts = true;
-    const int rc = run_sparse(c, m->is_csr, m->d_data, m->dtype, m->d_indices, m->d_indptr, m->idx_dtype, m->n_rows, m->n_cols, col_lb, col_ub,
-                              (flags & keep) | ILLICO_FLAG_INPUT_DEVICE, alternative, out_p, out_u, out_fc, out_ld);
+    int rc;
+    const int64_t A = c->bound_ahead_genes;
+    if (A > 0 && m->is_csr && !c->tap && c->has_groups && col_lb >= 0 && col_lb < col_ub && col_ub <= m->n_cols && col_ub - col_lb < A && col_ub - col_lb < m->n_cols &&
+        out_p && out_u && out_fc && out_ld >= col_ub - col_lb)
+        rc = run_bound_ahead(c, m, col_lb, col_ub, flags & keep, alternative, out_p, out_u, out_fc, out_ld);
+    else
+        rc = run_sparse(c, m->is_csr, m->d_data, m->dtype, m->d_indices, m->d_indptr, m->idx_dtype, m->n_rows, m->n_cols, col_lb, col_ub,
+                        (flags & keep) | ILLICO_FLAG_INPUT_DEVICE, alternative, out_p, out_u, out_fc, out_ld);
     c->cur_sorted_known = false;
     c->hold_csr_counts = hold0;
     return rc;
@@ -941,6 +1002,7 @@ extern "C" int illico_matrix_release(illico_ctx *c, illico_matrix *m) {
     int rc = resolve_pending(c); // a deferred call may still read the arrays
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->bound.erase(it);
+    for (auto &a : c->ahead) if (a.m == m) a.m = nullptr;
     if (m->owns) { hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr); }
     delete m;
     return rc;

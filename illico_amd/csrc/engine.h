@@ -177,6 +177,20 @@ struct illico_ctx {
     size_t pinned_bytes = 0;
     int64_t h2d_input_bytes = 0;  // matrix bytes copied host -> device (illico_profile_input_bytes)
     std::vector<illico_matrix *> bound; // matrices bound to this context and not yet released
+    // "bound_ahead_genes" > 0: a call for FEWER genes of a bound CSR matrix computes the aligned window of that many genes around them
+    // into planes of the context's own and hands out slices -- the reference's driver asks for ~256 genes at a time
+    // (asymptotic_wilcoxon.py:213-241), and a CSR call walks every row whatever the width of its window (core.hip: run_bound_ahead)
+    int64_t bound_ahead_genes = 0;
+    uint64_t groups_gen = 0;      // counts illico_set_groups calls (the windows below belong to one set of groups)
+    struct AheadWindow {
+        const illico_matrix *m = nullptr;
+        uint64_t gen = 0, stamp = 0;
+        int flags = 0, alternative = 0;
+        int64_t lb = 0, ub = 0;
+        double *planes = nullptr;   // device, [3][G][ub - lb]
+        size_t cap = 0;             // bytes
+    } ahead[2];
+    uint64_t ahead_clock = 0;
     struct HostStage *host_stage = nullptr; // pinned slots / copy stream of the host-window pipeline (dense driver)
     std::vector<ProfEvent> events;
     std::vector<hipEvent_t> event_pool;

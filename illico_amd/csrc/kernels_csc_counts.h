@@ -59,8 +59,8 @@ struct CscCountsParams {
     u64 *out_tie;
     double *out_sum;
     double *gene_total;                  // OVR: [nb] the column's value sum (what k_gene_totals would add up from out_sum), or nullptr
-    int pack16;                          // statistics as 16 bytes per test: out_2u = value sum << 40 | 2U (40 bits; all ones: the OVO reference
-                                         // row), out_tie; out_sum unused.  Host-checked: no group beyond 255 cells (sums < 2^24, 2U < 2^40)
+    int pack16;                          // statistics as 16 bytes per test: out_2u = value sum << 40 | 2U (40 bits, two's complement: -2 = the OVO
+                                         // reference row), out_tie; out_sum unused.  Host-checked: no group beyond 255 cells (sums < 2^24, 2U < 2^39)
     int tie_f64;                         // OVR: out_tie = the bits of the float64 tie sum of the reference's sparse path (tie_f64_sparse)
     const u32 *verdict;                  // deferred calls: {non-integers, -, samples} of k_sample_noncount_cols, looked at on the device
                                          // (more than 2 % non-integers: not a count matrix, every gene is left to the general routes); or nullptr

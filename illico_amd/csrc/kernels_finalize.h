@@ -22,7 +22,7 @@ struct FinalizeParams {
     const int *col_map;       // optional: output column of batch gene j (relative to the offset); nullptr = j
     int tie_f64;              // in_tie holds the BITS of a float64: the tie sum as the reference's sparse OVR path accumulates it
                               // (tie_f64_sparse below), not an exact integer
-    int packed;               // 16-byte statistics (k_csc_counts): in_2u = value sum << 40 | 2U (40 bits, all ones = the OVO reference row); no in_sum
+    int packed;               // 16-byte statistics (k_csc_counts): in_2u = value sum << 40 | 2U (40 bits, two's complement: -2 = the OVO reference row); no in_sum
 };
 
 // compute_pval with its per-(group) constants handed in -- nnn = (double)(n (n-1) (n+1)) (math.py:95), var0 = (double)(n_ref n_tgt
@@ -143,7 +143,7 @@ static __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
         for (int k = 0; k < 4; ++k) {
             const u64 w = (u64)in2u[k], lo = w & 0xFFFFFFFFFFull;
             insum[k] = (double)(w >> 40);
-            in2u[k] = lo == 0xFFFFFFFFFFull ? -2ll : (long long)lo;
+            in2u[k] = (long long)(lo << 24) >> 24; // the 40-bit field sign-extended: 2U of a ranked group is below 2^39, the OVO reference row carries -2
         }
     }
     __syncthreads(); // s_mref

@@ -611,6 +611,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                            (n_windows == 1 || (!c->no_csc_counts_windows && c->d_codes16 && !indices_are_codes));
     // (big_n -- OVR over more than 2^21 - 1 cells --: the table kernels' t^3 terms could wrap; the sort-based routes hold)
     const bool counts_route = !is_csr && !c->big_n && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && cells_fit && n_rows < (1ll << 30) &&
+                              (uint64_t)n_rows * std::max(sizeof(InT), sizeof(IdxT)) < (1ull << 32) && // (k_csc_counts forms the byte offsets of a column's entries in 32 bits)
                               (ovr || c->h_counts[c->ref] < (1ll << 30));
     // CSR, count-valued, not too sparse: dense windows + the fused single-pass kernels (below); the same question about the values
     const bool window_route = is_csr && !c->big_n && allow_dense_window && !c->no_dense_window_path && fused_path_allowed(c, flags) &&

@@ -11,6 +11,8 @@ kernels is the stored entry, illico/ovo/sparse_ovo.py:163-210).
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 
 
@@ -185,6 +187,21 @@ def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, referenc
     if len(ranges) != world or ranges[0][0] != 0 or ranges[-1][1] != n_genes:
         raise ValueError("gene ranges do not cover the genes")
     unique, grpc = encode_and_count_groups(labels, reference)
+    index_box: list = []
+    index_thread = None
+    if rank == 0:  # the result's row index does not depend on the statistics: built while the ranks compute (as in asymptotic_wilcoxon)
+        from illico_amd.asymptotic_wilcoxon import _product_index
+        cols = pd.Series(np.asarray(var_names), name="feature", dtype=str)
+        rows = pd.Series(unique, name="pert", dtype=str)
+
+        def build_index():
+            try:
+                index_box.append(_product_index(rows, cols))
+            except BaseException as e:  # re-raised below
+                index_box.append(e)
+
+        index_thread = threading.Thread(target=build_index, name="illico-index", daemon=True)
+        index_thread.start()
     G = int(grpc.counts.size)
     opts = dict(is_log1p=is_log1p, use_continuity=use_continuity, tie_correct=tie_correct, alternative=alternative)
 
@@ -252,8 +269,9 @@ def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, referenc
         planes = eng.planes_to_host(planes_dev)  # one device -> host copy of 24 bytes per test
     else:
         planes = planes_dev.numpy()
-    cols = pd.Series(np.asarray(var_names), name="feature", dtype=str)
-    rows = pd.Series(unique, name="pert", dtype=str)
+    index_thread.join()
+    if isinstance(index_box[0], BaseException):
+        raise index_box[0]
     return pd.DataFrame(
         {"p_value": planes[0].reshape(-1), "statistic": planes[1].reshape(-1), "fold_change": planes[2].reshape(-1)},
-        index=pd.MultiIndex.from_product([rows, cols], names=["pert", "feature"]), copy=False)
+        index=index_box[0], copy=False)

@@ -762,3 +762,67 @@ def test_sparse_ovo_with_groups_of_thousands_of_cells_takes_the_packed_rank_kern
         engine.set_option("no_packed_dense", 0)
     for a, b in zip(_run(engine, M, g), old):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_bound_csr_chunk_calls_are_served_from_windows_computed_ahead(engine, test, where):
+    """`bound_ahead_genes`: the reference's driver asks a dispatcher for ~256 genes at a time (asymptotic_wilcoxon.py:213-241), and a CSR
+    call walks every row whatever its width.  With the option set, a narrow call on a bound CSR matrix computes the aligned window
+    around it once and later calls are slices of it: chunks in a scrambled order, a chunk that straddles two windows, the last
+    (short) window, other flags (their own windows), new groups (the windows are dropped), against the oracle every time."""
+    import torch
+    rng = np.random.RandomState(811)
+    n, m = 3000, 1500
+    X = (rng.poisson(rng.uniform(0.3, 9.0, size=m), size=(n, m)) * (rng.rand(n, m) < 0.2)).astype(np.float32)
+    labels = make_labels(rng, n, 12, n_ref=200)
+    M = sparse.csr_matrix(X)
+    dev = torch.device("cuda", engine.device)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    engine.set_groups(g)
+    bm = engine.bind_sparse("csr", M.data, M.indices, M.indptr, M.shape)
+    G = g.counts.size
+
+    def chunked(bounds, **kw):
+        if where == "host":
+            out = tuple(np.full((G, m), -7.0) for _ in range(3))
+            for lb, ub in bounds:
+                got = bm.run(lb, ub, **kw)
+                for k in range(3):
+                    out[k][:, lb:ub] = got[k]
+            return out
+        out = tuple(torch.full((G, m), -7.0, dtype=torch.float64, device=dev) for _ in range(3))
+        for lb, ub in bounds:
+            bm.run(lb, ub, out=tuple(t[:, lb:ub] for t in out), **kw)
+        engine.synchronize()
+        return tuple(t.cpu().numpy() for t in out)
+
+    engine.set_option("bound_ahead_genes", 512)
+    try:
+        bounds = [(lb, min(lb + 100, m)) for lb in range(0, m, 100)]     # 100-gene chunks: some straddle a 512 boundary
+        engine.set_option("profile", 1)
+        engine.profile_reset()
+        got = chunked(bounds)
+        prof = engine.profile_get()
+        engine.set_option("profile", 0)
+        assert_planes_match(got, oracle.run(X, g), ref_row=g.encoded_ref_group, what=f"ahead {test} {where}")
+        assert prof["k_csr_counts"]["launches"] <= 2 * 3, prof["k_csr_counts"]   # three windows were computed ([0, 512), [500, 1012), [1000, 1500)), not 15 chunks
+        got = chunked([bounds[i] for i in rng.permutation(len(bounds))])
+        assert_planes_match(got, oracle.run(X, g), ref_row=g.encoded_ref_group, what=f"ahead {test} {where}, scrambled order")
+        kw = dict(alternative="less", use_continuity=False)
+        got = chunked(bounds, **kw)
+        assert_planes_match(got, oracle.run(X, g, **kw), ref_row=g.encoded_ref_group, what=f"ahead {test} {where} other flags")
+        # new groups: a window computed for the old ones must not be handed out
+        labels2 = make_labels(rng, n, 7, n_ref=300)
+        _, g2 = oracle.encode_and_count_groups(labels2, "non-targeting" if test == "ovo" else None)
+        engine.set_groups(g2)
+        G = g2.counts.size
+        got = chunked(bounds)
+        assert_planes_match(got, oracle.run(X, g2), ref_row=g2.encoded_ref_group, what=f"ahead {test} {where} new groups")
+        # a call at least as wide as the window goes straight through
+        got = bm.run(0, m)
+        assert_planes_match(got, oracle.run(X, g2), ref_row=g2.encoded_ref_group, what=f"ahead {test} {where} whole")
+    finally:
+        engine.set_option("profile", 0)
+        engine.set_option("bound_ahead_genes", 0)
+        bm.release()
