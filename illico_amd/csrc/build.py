@@ -33,6 +33,7 @@ def _flags() -> list[str]:
     flags = list(CFLAGS)
     if _dev():  # development: float32 / int32-index kernels only
         flags.append("-DILLICO_DEV_F32_ONLY")
+    flags += os.environ.get("ILLICO_EXTRA_CFLAGS", "").split()  # kernel experiments (-DTRG_WIN=16 ...): the stamp records them
     return flags
 
 

@@ -90,7 +90,9 @@ __global__ void k_csr_density_verdict(const IdxT *__restrict__ indptr, long long
 // lines per boundary where a plain binary search over a row of 800 entries touches six.
 template <typename IdxT>
 __global__ __launch_bounds__(256) void k_csr_row_bounds(const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr, int n_rows, long long n_cols,
-                                                       long long col_lb, long long col_ub, int Wf, int n_bnd, u32 *__restrict__ bounds) {
+                                                       long long col_lb, long long col_ub, int Wf, int n_bnd, u32 *__restrict__ bounds,
+                                                       const u32 *__restrict__ verdict = nullptr) {
+    if (csrc_verdict_bad(verdict)) return; // (not a matrix for the route: 0.09 ms of searches at C3 shape that nobody would read)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)n_rows * n_bnd) return;
     const int b = (int)(i / n_rows), r = (int)(i - (long long)b * n_rows);
@@ -350,7 +352,9 @@ __global__ __launch_bounds__(CSRH_NT) void k_csr_hist(CsrCountsParams P) {
 template <bool OVR>
 __global__ __launch_bounds__(256) void k_csr_tables(const u32 *__restrict__ hist, long long Wpad, int W, long long n_sel /* reference cells (OVO) / all cells (OVR) */,
                                                    int n_add /* OVR: slabs 1 .. n_add (the big groups) belong to the column as well */,
-                                                   u32 *__restrict__ tab, uint4 *__restrict__ ginfo, double *__restrict__ gene_total) {
+                                                   u32 *__restrict__ tab, uint4 *__restrict__ ginfo, double *__restrict__ gene_total,
+                                                   const u32 *__restrict__ verdict = nullptr) {
+    if (csrc_verdict_bad(verdict)) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= W) return;
     auto cell = [&](int c) {

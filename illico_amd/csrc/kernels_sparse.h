@@ -270,22 +270,31 @@ __global__ void k_sample_noncount_cols(const InT *__restrict__ data, const IdxT 
 // with their rows grouped by block (ascending) but unordered inside a block; the CSC kernels do not need row order.
 // Device counterpart of csr_get_contig_cols_into_csc (utils/sparse/csr.py:19-100).
 #define TR_NT 256
+#define TRC_NT 1024 // the counting pass: a row block is one workgroup, and there are only n_rows / 512 of them -- 16 wavefronts each
 template <typename IdxT>
-__global__ __launch_bounds__(TR_NT) void k_csr_block_count(const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr, int n_rows,
+__global__ __launch_bounds__(TRC_NT) void k_csr_block_count(const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr, int n_rows,
                                                           int RB, long long c0, int W, u32 *__restrict__ counts) {
     extern __shared__ u32 tr_cnt[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < W; i += TR_NT) tr_cnt[i] = 0;
+    for (int i = tid; i < W; i += TRC_NT) tr_cnt[i] = 0;
     __syncthreads();
     const int r0 = blockIdx.x * RB, r1 = min(r0 + RB, n_rows);
     const long long k0 = (long long)indptr[r0], k1 = (long long)indptr[r1];
-    for (long long k = k0 + tid; k < k1; k += TR_NT) {
-        const long long col = (long long)indices[k] - c0;
-        if (col >= 0 && col < W) atomicAdd(&tr_cnt[col], 1u);
+    // eight requests in flight per thread (one at a time, this pass ran at 1.2 TB/s: 0.77 ms at C3 shape for 0.9 GB of column indices)
+    for (long long kb = k0; kb < k1; kb += TRC_NT * 8) {
+        long long col[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long k = kb + u * TRC_NT + tid;
+            col[u] = k < k1 ? (long long)indices[k] - c0 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (col[u] >= 0 && col[u] < W) atomicAdd(&tr_cnt[col[u]], 1u);
     }
     __syncthreads();
     u32 *dst = counts + (size_t)blockIdx.x * W;
-    for (int i = tid; i < W; i += TR_NT) dst[i] = tr_cnt[i];
+    for (int i = tid; i < W; i += TRC_NT) dst[i] = tr_cnt[i];
 }
 // per column: exclusive scan of the block counts (in place) and the column's total
 static __global__ void k_col_block_scan(u32 *__restrict__ counts, int n_blocks, int W, u32 *__restrict__ col_total) {
@@ -338,11 +347,14 @@ __global__ __launch_bounds__(TR_NT) void k_csr_block_scatter(const InT *__restri
 // k_csr_block_scatter above sends each entry straight to its final position instead: 8000 open write streams per
 // workgroup, far more than L2 can merge (17 ms at C3 shape).
 #define TRG_COLS 64
-#define TRG_RPT 2
-#define TRG_WIN 8 // entries of a row held in registers (16 measured no better: 146 VGPRs)
+#define TRG_RPT 1
+#define TRG_NT 512 // one row per thread, 512 rows per block (two rows per thread and 256 threads: half the wavefronts for the same LDS)
+#ifndef TRG_WIN
+#define TRG_WIN 16 // entries of a row held in registers: 8 / 16 / 32 -> 2.19 / 1.96 / 3.39 ms at C3 shape (32: 168 registers); requesting the
+#endif              // next refill ahead of time changes nothing (8: 2.22, 16: 1.97): the pass is not waiting for its refills
 template <typename T, int N> struct __attribute__((packed, aligned(4))) PackedRun { T v[N]; }; // 4-byte aligned multi-dword load
 template <typename InT, typename IdxT>
-__global__ __launch_bounds__(TR_NT) void k_csr_tile_gather(const InT *__restrict__ data, const IdxT *__restrict__ indices,
+__global__ __launch_bounds__(TRG_NT) void k_csr_tile_gather(const InT *__restrict__ data, const IdxT *__restrict__ indices,
                                                           const IdxT *__restrict__ indptr, int n_rows, int RB, long long c0, int W,
                                                           const u32 *__restrict__ offsets, const u32 *__restrict__ col_total,
                                                           const u32 *__restrict__ col_ptr, int cap, const int *__restrict__ row_codes,
@@ -363,9 +375,30 @@ __global__ __launch_bounds__(TR_NT) void k_csr_tile_gather(const InT *__restrict
     long long knext[RPT], kend[RPT];
     int wcol[RPT][WN], wp[RPT], wn[RPT], tag[RPT]; // tag: what is stored for the row -- its group code, or the row index
     InT wval[RPT][WN];
+    auto refill = [&](int j) { // the next WN entries of row j become its window; false: the row is finished
+        const long long k = knext[j], left = kend[j] - k;
+        if (left <= 0) return false;
+        if (left >= WN) {
+            const PackedRun<IdxT, WN> pi = *(const PackedRun<IdxT, WN> *)(indices + k);
+            const PackedRun<InT, WN> pv = *(const PackedRun<InT, WN> *)(data + k);
+#pragma unroll
+            for (int i = 0; i < WN; ++i) { wcol[j][i] = (int)((long long)pi.v[i] - c0); wval[j][i] = pv.v[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < WN; ++i) {
+                const bool ok = i < left;
+                wcol[j][i] = ok ? (int)((long long)indices[k + i] - c0) : 0x7FFFFFFF;
+                wval[j][i] = ok ? data[k + i] : (InT)0;
+            }
+        }
+        wp[j] = 0;
+        wn[j] = (int)(left < WN ? left : WN);
+        knext[j] = k + wn[j];
+        return true;
+    };
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
-        const int r = r0 + j * TR_NT + tid;
+        const int r = r0 + j * TRG_NT + tid;
         knext[j] = kend[j] = 0;
         wp[j] = wn[j] = 0;
         tag[j] = r;
@@ -402,7 +435,7 @@ __global__ __launch_bounds__(TR_NT) void k_csr_tile_gather(const InT *__restrict
         }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            const int r = r0 + j * TR_NT + tid;
+            const int r = r0 + j * TRG_NT + tid;
             bool more = true;
             while (more) {
 #pragma unroll
@@ -417,32 +450,11 @@ __global__ __launch_bounds__(TR_NT) void k_csr_tile_gather(const InT *__restrict
                             wp[j] = i + 1;
                         } else more = false;
                     }
-                if (more) { // window consumed: refill, or the row is finished
-                    const long long k = knext[j], left = kend[j] - k;
-                    if (left <= 0) more = false;
-                    else {
-                        if (left >= WN) {
-                            const PackedRun<IdxT, WN> pi = *(const PackedRun<IdxT, WN> *)(indices + k);
-                            const PackedRun<InT, WN> pv = *(const PackedRun<InT, WN> *)(data + k);
-#pragma unroll
-                            for (int i = 0; i < WN; ++i) { wcol[j][i] = (int)((long long)pi.v[i] - c0); wval[j][i] = pv.v[i]; }
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < WN; ++i) {
-                                const bool ok = i < left;
-                                wcol[j][i] = ok ? (int)((long long)indices[k + i] - c0) : 0x7FFFFFFF;
-                                wval[j][i] = ok ? data[k + i] : (InT)0;
-                            }
-                        }
-                        wp[j] = 0;
-                        wn[j] = (int)(left < WN ? left : WN);
-                        knext[j] = k + wn[j];
-                    }
-                }
+                if (more) more = refill(j); // window consumed: the next entries, or the row is finished
             }
         }
         __syncthreads();
-        for (u32 i = tid; i < total; i += TR_NT) {
+        for (u32 i = tid; i < total; i += TRG_NT) {
             const u32 dst = gbase[scol[i]] + i;
             out_data[dst] = sval[i];
             out_rows[dst] = srow[i];
@@ -532,9 +544,30 @@ __global__ void k_csr_sorted_check(const IdxT *__restrict__ indices, const IdxT 
     const int lane = threadIdx.x & 63;
     const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (int row = wave_global; row < n_rows; row += n_waves) {
-        long long s = (long long)indptr[row], e = (long long)indptr[row + 1];
-        for (long long k = s + 1 + lane; k < e; k += 64)
-            if (indices[k] < indices[k - 1]) *bad = 1;
+    // four rows of a wavefront in flight at once (a row holds a few hundred entries: one row at a time, most of the pass is waiting)
+    for (int row0 = wave_global * 4; row0 < n_rows; row0 += n_waves * 4) {
+        long long s[4], e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = min(row0 + j, n_rows - 1);
+            s[j] = (long long)indptr[row];
+            e[j] = row0 + j < n_rows ? (long long)indptr[row + 1] : s[j];
+        }
+        long long span = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) span = max(span, e[j] - s[j]);
+        bool out_of_order = false;
+        for (long long i = 1 + lane; i < span; i += 64) { // (uniform trip count)
+            IdxT a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = s[j] + i < e[j];
+                a[j] = ok ? indices[s[j] + i] : (IdxT)0;
+                b[j] = ok ? indices[s[j] + i - 1] : (IdxT)0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out_of_order |= a[j] < b[j];
+        }
+        if (out_of_order) *bad = 1;
     }
 }

@@ -515,7 +515,7 @@ static int launch_csr_counts_route(illico_ctx *c, const InT *d_data, const IdxT 
         ProfScope ps(c, KID_SPARSE_SEG);
         const long long tot = (long long)n_rows * n_bnd;
         hipLaunchKernelGGL((k_csr_row_bounds<IdxT>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, d_indices, d_indptr, (int)n_rows,
-                           (long long)n_cols, (long long)col_lb, (long long)col_ub, Wg, n_bnd, bounds);
+                           (long long)n_cols, (long long)col_lb, (long long)col_ub, Wg, n_bnd, bounds, (const u32 *)d_verdict);
         HIPCHK(c, hipGetLastError());
     }
     {
@@ -524,7 +524,7 @@ static int launch_csr_counts_route(illico_ctx *c, const InT *d_data, const IdxT 
         const size_t lds = csrh_lds_bytes(Wg);
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (n_chunks > 0) hipLaunchKernelGGL(kern, dim3(n_win, n_chunks), dim3(CSRH_NT), lds, c->stream, P); // the reference group (OVO), the big groups
-        if (!ovr) hipLaunchKernelGGL((k_csr_tables<false>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c->stream, (const u32 *)hist, (long long)Wpad, (int)W, (long long)c->h_counts[c->ref], 0, tab, ginfo, gtot);
+        if (!ovr) hipLaunchKernelGGL((k_csr_tables<false>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c->stream, (const u32 *)hist, (long long)Wpad, (int)W, (long long)c->h_counts[c->ref], 0, tab, ginfo, gtot, (const u32 *)d_verdict);
         HIPCHK(c, hipGetLastError());
     }
     const size_t lds = csrc_lds_bytes(Wg);
@@ -543,7 +543,7 @@ static int launch_csr_counts_route(illico_ctx *c, const InT *d_data, const IdxT 
             const int slices = std::max(1, std::min(G, (int)std::min<int64_t>(64, (1 << 20) / std::max<int64_t>(W, 1) + 1))); // ~a million threads
             const int gps = (G + slices - 1) / slices;
             hipLaunchKernelGGL(k_csr_colhist, dim3((unsigned)((W + 255) / 256), (unsigned)((G + gps - 1) / gps)), dim3(256), 0, c->stream, P, n_win, gps);
-            hipLaunchKernelGGL((k_csr_tables<true>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c->stream, (const u32 *)hist, (long long)Wpad, (int)W, (long long)n_rows, n_big, tab, ginfo, gtot);
+            hipLaunchKernelGGL((k_csr_tables<true>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c->stream, (const u32 *)hist, (long long)Wpad, (int)W, (long long)n_rows, n_big, tab, ginfo, gtot, (const u32 *)d_verdict);
             HIPCHK(c, hipGetLastError());
         }
         ProfScope ps(c, KID_OVR_SCAN);
@@ -813,8 +813,8 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     // ---- CSR, any values: transpose the column window into CSC on the device, then the CSC routes ----
     if (is_csr && allow_transpose && !c->no_csr_transpose_path && n_rows < (1ll << 31)) {
         // sorted column indices (the reference's contract) allow the gather form of pass 2
-        int sorted = 0;
-        if (!c->no_csr_tile_gather) {
+        int sorted = (c->cur_sorted_known && !c->no_csr_tile_gather) ? 1 : 0; // (a bound matrix: looked at when it was bound)
+        if (!sorted && !c->no_csr_tile_gather) {
             if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
             int *d_bad = (int *)v;
             HIPCHK(c, hipMemsetAsync(d_bad, 0, 8, c->stream));
@@ -830,7 +830,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
         int RB = 256;
         if (sorted) { // expected entries per (row block, 64-column tile) <= cap / 2
             const double per_row = std::max(density * TRG_COLS, 1e-9);
-            RB = TR_NT * TRG_RPT;
+            RB = TRG_NT * TRG_RPT;
             while (RB > 64 && RB * per_row > cap / 2) RB >>= 1;
         }
         const int n_blocks = (int)((n_rows + RB - 1) / RB);
@@ -847,7 +847,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                 HIPCHK(c, hipMemsetAsync(col_total + wn, 0, 4, c->stream));
                 HIPCHK(c, hipMemsetAsync(d_over, 0, 4, c->stream));
                 HIPCHK(c, hipFuncSetAttribute((const void *)k_csr_block_count<IdxT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wn * 4)));
-                hipLaunchKernelGGL((k_csr_block_count<IdxT>), dim3(n_blocks), dim3(TR_NT), (size_t)wn * 4, c->stream, d_indices, d_indptr,
+                hipLaunchKernelGGL((k_csr_block_count<IdxT>), dim3(n_blocks), dim3(TRC_NT), (size_t)wn * 4, c->stream, d_indices, d_indptr,
                                    (int)n_rows, RB, (long long)w0, (int)wn, counts);
                 hipLaunchKernelGGL(k_col_block_scan, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, c->stream, counts, n_blocks, (int)wn, col_total);
                 hipLaunchKernelGGL(k_gene_base_scan, dim3(1), dim3(1024), 0, c->stream, (const u32 *)col_total, (int)wn + 1, col_ptr);
@@ -871,7 +871,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                 ProfScope ps(c, KID_SPARSE_SEG);
                 const size_t lds = (size_t)cap * (sizeof(InT) + 4 + 1);
                 HIPCHK(c, hipFuncSetAttribute((const void *)k_csr_tile_gather<InT, IdxT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((k_csr_tile_gather<InT, IdxT>), dim3(n_blocks), dim3(TR_NT), lds, c->stream,
+                hipLaunchKernelGGL((k_csr_tile_gather<InT, IdxT>), dim3(n_blocks), dim3(TRG_NT), lds, c->stream,
                                    d_data, d_indices, d_indptr, (int)n_rows, RB, (long long)w0, (int)wn, (const u32 *)counts, (const u32 *)col_total,
                                    (const u32 *)col_ptr, cap, (const int *)c->d_codes, t_data, t_rows, d_over);
                 HIPCHK(c, hipGetLastError());
