@@ -485,6 +485,11 @@ template <> __device__ __forceinline__ uint8_t dens_cell<uint8_t, double>(double
 template <> __device__ __forceinline__ uint8_t dens_cell<uint8_t, int32_t>(int32_t v) { return (v >= 0 && v < 255) ? (uint8_t)v : (uint8_t)255; }
 template <> __device__ __forceinline__ uint8_t dens_cell<uint8_t, int64_t>(int64_t v) { return (v >= 0 && v < 255) ? (uint8_t)v : (uint8_t)255; }
 
+// (the window in the matrix's own type, for the dense routes that take any values: run_sparse_t's dense-ish continuous CSR branch)
+template <> __device__ __forceinline__ double dens_cell<double, double>(double v) { return v; }
+template <> __device__ __forceinline__ int32_t dens_cell<int32_t, int32_t>(int32_t v) { return v; }
+template <> __device__ __forceinline__ int64_t dens_cell<int64_t, int64_t>(int64_t v) { return v; }
+
 template <typename InT, typename IdxT, typename OutT>
 __global__ __launch_bounds__(DENS_NT) void k_csr_densify(const InT *__restrict__ data, const IdxT *__restrict__ indices,
                                                          const IdxT *__restrict__ indptr, int n_rows, long long c0, int W,
@@ -535,6 +540,79 @@ __global__ __launch_bounds__(DENS_NT) void k_csr_densify(const InT *__restrict__
             __syncthreads();
         }
         s = sn; e = en;
+    }
+}
+
+// CSC columns [c0, c0 + W) -> a dense row-major window D[n_rows][ldD] in the matrix's own type (run_sparse_t: CSC windows whose columns
+// are longer than the per-gene LDS kernels hold take the dense routes).  The columns' row indices must ascend (checked by the caller:
+// k_csr_sorted_check over the CSC arrays).  Workgroup = (64 columns, CDN_SUP row chunks of CDN_RC rows): a lane finds its column's first
+// entry of the stretch once (binary search), then the columns' cursors walk on chunk by chunk -- a chunk's entries are scattered into an
+// LDS tile [row][column] (one pad word per row: a column's rows fall into different banks) and the tile leaves as full 64-cell rows.
+#define CDN_NT 256
+#define CDN_SUP 8
+template <typename InT, typename IdxT, int RC>
+__global__ __launch_bounds__(CDN_NT) void k_csc_densify(const InT *__restrict__ data, const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr,
+                                                       long long kshift, long long c0, int W, int n_rows, InT *__restrict__ D, long long ldD) {
+    __shared__ InT tile[RC][65];
+    __shared__ long long cur[64], kend[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = blockIdx.x * 64;
+    const long long row_first = (long long)blockIdx.y * (RC * CDN_SUP);
+    if (tid < 64) {
+        long long a = 0, e = 0;
+        if (cb + tid < W) {
+            a = (long long)indptr[c0 + cb + tid] - kshift;
+            e = (long long)indptr[c0 + cb + tid + 1] - kshift;
+            long long lo = a, hi = e;
+            while (lo < hi) { const long long m = (lo + hi) >> 1; if ((long long)indices[m] < row_first) lo = m + 1; else hi = m; }
+            a = lo;
+        }
+        cur[tid] = a;
+        kend[tid] = e;
+    }
+    for (int ch = 0; ch < CDN_SUP; ++ch) {
+        const long long r0 = row_first + (long long)ch * RC, r1 = min(r0 + RC, (long long)n_rows);
+        if (r0 >= n_rows) break; // (uniform)
+        for (int i = tid; i < RC * 65; i += CDN_NT) (&tile[0][0])[i] = (InT)0;
+        __syncthreads();
+        // a wavefront takes four columns at a time, 128 entries of each per step: their entries of this chunk are the next ones behind
+        // the cursors (eight index requests in flight, then the values of those that belong to the chunk)
+        for (int jb = wave * 16; jb < wave * 16 + 16; jb += 4) {
+            long long k[4], e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { k[q] = cur[jb + q]; e[q] = kend[jb + q]; }
+            bool more = true;
+            while (more) { // (uniform per wavefront)
+                long long row[4][2];
+                InT val[4][2]; // (requested with the rows, not behind the test that needs the row: eight round trips in a row otherwise -- 9 ms)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const long long kk = k[q] + h * 64 + lane;
+                        row[q][h] = kk < e[q] ? (long long)indices[kk] : (long long)0x7FFFFFFFFFFFll;
+                        val[q][h] = kk < e[q] ? data[kk] : (InT)0;
+                    }
+                more = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int n_in = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const bool in = row[q][h] < r1;
+                        if (in) tile[row[q][h] - r0][jb + q] = val[q][h];
+                        n_in += (int)__popcll(__ballot(in));
+                    }
+                    k[q] += n_in;
+                    more = more || n_in == 128;
+                }
+            }
+            if (lane < 4) cur[jb + lane] = lane == 0 ? k[0] : lane == 1 ? k[1] : lane == 2 ? k[2] : k[3];
+        }
+        __syncthreads();
+        for (int r = wave; r < (int)(r1 - r0); r += CDN_NT / 64)
+            if (cb + lane < (int)ldD) D[(size_t)(r0 + r) * ldD + cb + lane] = tile[r][lane];
+        __syncthreads();
     }
 }
 

@@ -810,6 +810,35 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                                              alternative, o2, false, true, false, false);
     }
 
+    // ---- CSR, any values, columns longer than the per-gene LDS kernels hold (a "sparse" matrix a fifth or more of whose cells are
+    // stored): a dense window in the matrix's own type + the dense routes.  The per-gene kernels behind the transposition keep a
+    // gene's keys in LDS (~36 000 of them); longer columns fall to the general sort routes one by one -- C3 shape with 30 % of the cells
+    // stored and continuous values: 76 ms (OVR) / 37 ms (OVO) that way, against 12.6 ms for the same values handed over dense.
+    // OVR: the reference accumulates a sparse column's tie sum in float64 (sparse_ovr.py:49,83), the dense routes in exact integers;
+    // from a tenth of the cells stored on the two agree to 2e-13 of p at |z| = 37 (kernels_finalize.h: tie_f64_sparse), below that the
+    // window stays with the sparse routes.
+    if (is_csr && allow_dense_window && allow_transpose && !c->no_csr_densify_any && !c->tap && !c->big_n && n_rows < (1ll << 31) &&
+        density * (double)n_rows > 32768.0 && (c->ref >= 0 || density >= 0.1) && (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
+        int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * sizeof(InT))) & ~63ll;
+        wmax = std::min<int64_t>(wmax, (1ll << 29));
+        if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, (c->gene_batch + 63) & ~63ll);
+        for (int64_t w0 = col_lb; w0 < col_ub; w0 += wmax) {
+            const int64_t wn = std::min<int64_t>(wmax, col_ub - w0), ldD = (wn + 63) & ~63ll;
+            if ((rc = get_scratch(c, "dense_window", (size_t)n_rows * ldD * sizeof(InT), &v))) return rc;
+            {
+                ProfScope ps(c, KID_DENSIFY);
+                const dim3 grid((unsigned)std::min<int64_t>(n_rows, 1 << 16));
+                hipLaunchKernelGGL((k_csr_densify<InT, IdxT, InT>), grid, dim3(DENS_NT), 0, c->stream, d_data, d_indices, d_indptr,
+                                   (int)n_rows, (long long)w0, (int)wn, (InT *)v, (long long)ldD);
+                HIPCHK(c, hipGetLastError());
+            }
+            OutPlanes o2 = o;
+            o2.p += w0 - col_lb; o2.u += w0 - col_lb; o2.fc += w0 - col_lb;
+            if ((rc = run_dense_t<InT, KeyT>(c, v, dtype, n_rows, ldD, 0, wn, (flags | ILLICO_FLAG_INPUT_DEVICE) & ~ILLICO_FLAG_DEFER, alternative, o2))) return rc;
+        }
+        return ILLICO_OK;
+    }
+
     // ---- CSR, any values: transpose the column window into CSC on the device, then the CSC routes ----
     if (is_csr && allow_transpose && !c->no_csr_transpose_path && n_rows < (1ll << 31)) {
         // sorted column indices (the reference's contract) allow the gather form of pass 2
@@ -942,6 +971,44 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
         if (counts) {
             if ((rc = run_csc_counts_route<InT, IdxT>(c, d_data, d_indices, d_indptr, kshift, d_codes, n_rows, col_lb, flags, alternative, o, cols))) return rc;
             if (cols.empty()) return ILLICO_OK;
+        }
+    }
+    // ---- CSC, any values, columns longer than the per-gene LDS kernels hold: a dense window in the matrix's own type + the dense routes
+    // (as for CSR above; the columns' row indices must ascend: asked on the device) ----
+    if (!is_csr && !indices_are_codes && allow_dense_window && !c->no_csr_densify_any && !c->tap && !c->big_n && n_rows < (1ll << 31) &&
+        (int64_t)cols.size() == W && W > 0 && (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) / (double)W > 32768.0 &&
+        (c->ref >= 0 || (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) >= 0.1 * (double)W * (double)n_rows) &&
+        (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
+        if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
+        int *d_bad = (int *)v;
+        HIPCHK(c, hipMemsetAsync(d_bad, 0, 8, c->stream));
+        // (the check walks "rows" = the window's columns: indptr from col_lb on, entries relative to kshift)
+        hipLaunchKernelGGL((k_csr_sorted_check<IdxT>), dim3((unsigned)std::min<int64_t>((W + 3) / 4 + 1, 8192)), dim3(256), 0, c->stream,
+                           d_indices - kshift, d_indptr + col_lb, (int)W, d_bad);
+        HIPCHK(c, hipGetLastError());
+        int bad = 0;
+        HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!bad) {
+            int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * sizeof(InT))) & ~63ll;
+            wmax = std::min<int64_t>(wmax, (1ll << 29));
+            if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, (c->gene_batch + 63) & ~63ll);
+            constexpr int RC = sizeof(InT) == 4 ? 128 : 64; // (33 KB tiles: four workgroups per CU)
+            for (int64_t w0 = col_lb; w0 < col_ub; w0 += wmax) {
+                const int64_t wn = std::min<int64_t>(wmax, col_ub - w0), ldD = (wn + 63) & ~63ll;
+                if ((rc = get_scratch(c, "dense_window", (size_t)n_rows * ldD * sizeof(InT), &v))) return rc;
+                {
+                    ProfScope ps(c, KID_DENSIFY);
+                    const dim3 grid((unsigned)(ldD / 64), (unsigned)((n_rows + RC * CDN_SUP - 1) / (RC * CDN_SUP)));
+                    hipLaunchKernelGGL((k_csc_densify<InT, IdxT, RC>), grid, dim3(CDN_NT), 0, c->stream, d_data, d_indices, d_indptr, (long long)kshift,
+                                       (long long)w0, (int)wn, (int)n_rows, (InT *)v, (long long)ldD);
+                    HIPCHK(c, hipGetLastError());
+                }
+                OutPlanes o2 = o;
+                o2.p += w0 - col_lb; o2.u += w0 - col_lb; o2.fc += w0 - col_lb;
+                if ((rc = run_dense_t<InT, KeyT>(c, v, dtype, n_rows, ldD, 0, wn, (flags | ILLICO_FLAG_INPUT_DEVICE) & ~ILLICO_FLAG_DEFER, alternative, o2))) return rc;
+            }
+            return ILLICO_OK;
         }
     }
     if (!is_csr && !ovr && !c->no_csc_gene_path && !sparse_packed_rank_fits(c)) { // (runs of more than 128 keys leave k_csc_gene, runs of 32 .. 128 are slow in it)

@@ -1,40 +1,49 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): tools/round_bench.sh <round tag, e.g. r03>
+# Usage (on the GPU box, from the repo root): tools/round_bench.sh <round tag, e.g. r03> [part: b1 b2 b3 p1 p2 p3 chunks; default all]
+# (a gpurun call lasts 20 minutes at most: the whole script does not fit one)
 # The bench lines and rocprofv3 summaries a round commits under profiles/: every line into gpurun_out/<tag>_bench_*.json,
 # every profile into gpurun_out/<tag>_<workload>/ (tools/profile_bench.sh).  Prints a progress line per step.
 set -u
 T=$1
+PART=${2:-all}
+want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
 O=gpurun_out
 mkdir -p $O
 b() { name=$1; shift; python3 bench.py "$@" > $O/${T}_bench_$name.json 2> $O/${T}_bench_$name.err; echo "bench $name rc=$?"; }
-b c2 
-b c3 --workload c3 --no-c5
-b c3_ovr --workload c3 --test ovr --no-c5
-b c4 --workload c4 --no-c5
-b c5shard --workload c5shard --no-c5
-b c5_one_gpu --workload c5 --no-c5 --steps 5 --warmup 1
-b c2_nb --workload c2 --values nb --no-c5
-b c2_nb_ovr --workload c2 --values nb --test ovr --no-c5
-b c2_cont_ovo --workload c2 --values continuous --no-c5 --steps 10
-b c2_cont_ovr --workload c2 --values continuous --test ovr --no-c5 --steps 10
-b c3_cont_ovo --workload c3 --values continuous --no-c5 --steps 10
-b c3_cont_ovr --workload c3 --values continuous --test ovr --no-c5 --steps 10
-b c3_csr --workload c3 --format csr --no-c5 --steps 10
-b c3_csr_ovr --workload c3 --format csr --test ovr --no-c5 --steps 10
-b c2_cont_g50 --workload c2 --values continuous --groups 50 --no-c5 --steps 5
-b c3_cont_g300 --workload c3 --values continuous --groups 300 --no-c5 --steps 5
-b c3_cont_ovr_g6000 --workload c3 --values continuous --test ovr --groups 6000 --no-c5 --steps 5
+want b1 && b c2 
+want b1 && b c3 --workload c3 --no-c5
+want b1 && b c3_ovr --workload c3 --test ovr --no-c5
+want b1 && b c4 --workload c4 --no-c5
+want b1 && b c5shard --workload c5shard --no-c5
+want b1 && b c5_one_gpu --workload c5 --no-c5 --steps 5 --warmup 1
+want b1 && b c2_nb --workload c2 --values nb --no-c5
+want b2 && b c2_nb_ovr --workload c2 --values nb --test ovr --no-c5
+want b2 && b c2_cont_ovo --workload c2 --values continuous --no-c5 --steps 10
+want b2 && b c2_cont_ovr --workload c2 --values continuous --test ovr --no-c5 --steps 10
+want b2 && b c3_cont_ovo --workload c3 --values continuous --no-c5 --steps 10
+want b2 && b c3_cont_ovr --workload c3 --values continuous --test ovr --no-c5 --steps 10
+want b2 && b c3_csr --workload c3 --format csr --no-c5 --steps 10
+want b2 && b c3_csr_ovr --workload c3 --format csr --test ovr --no-c5 --steps 10
+want b3 && b c3_csr_cont_ovo --workload c3 --format csr --values continuous --no-c5 --steps 10
+want b3 && b c3_csr_cont_ovr --workload c3 --format csr --values continuous --test ovr --no-c5 --steps 10
+want b3 && b c2_cont_g50 --workload c2 --values continuous --groups 50 --no-c5 --steps 5
+want b3 && b c3_cont_g300 --workload c3 --values continuous --groups 300 --no-c5 --steps 5
+want b3 && b c3_cont_ovr_g6000 --workload c3 --values continuous --test ovr --groups 6000 --no-c5 --steps 5
 p() { name=$1; shift; bash tools/profile_bench.sh ${T}_$name "$@" > $O/prof_$name.log 2>&1; echo "profile $name rc=$?"; }
-p c2 --workload c2
-p c3 --workload c3
-p c3_ovr --workload c3 --test ovr
-p c4 --workload c4
-p c5shard --workload c5shard
-p c2_nb --workload c2 --values nb
-p c2_cont_ovr --workload c2 --values continuous --test ovr
-p c3_cont_ovr --workload c3 --values continuous --test ovr
-p c2_nb_ovr --workload c2 --values nb --test ovr
-p c3_csr --workload c3 --format csr
-p c3_csr_ovr --workload c3 --format csr --test ovr
-p c2_cont_ovo --workload c2 --values continuous
-p c3_cont_ovo --workload c3 --values continuous
+want p1 && p c2 --workload c2
+want p1 && p c3 --workload c3
+want p1 && p c3_ovr --workload c3 --test ovr
+want p1 && p c4 --workload c4
+want p1 && p c5shard --workload c5shard
+want p2 && p c2_nb --workload c2 --values nb
+want p2 && p c2_cont_ovr --workload c2 --values continuous --test ovr
+want p2 && p c3_cont_ovr --workload c3 --values continuous --test ovr
+want p2 && p c2_nb_ovr --workload c2 --values nb --test ovr
+want p2 && p c3_csr --workload c3 --format csr
+want p3 && p c3_csr_ovr --workload c3 --format csr --test ovr
+want p3 && p c2_cont_ovo --workload c2 --values continuous
+want p3 && p c3_csr_cont_ovr --workload c3 --format csr --values continuous --test ovr
+want p3 && p c3_cont_ovo --workload c3 --values continuous
+# the reference driver's chunking on a bound CSR matrix, with and without the windows computed ahead
+want chunks && { for a in 0 2048; do for t in ovo ovr; do python3 tools/bench_bound_chunks.py --ahead $a --test $t; done; done > $O/${T}_bound_chunks.txt 2>&1; echo "bound chunks rc=$?"; }
+exit 0
