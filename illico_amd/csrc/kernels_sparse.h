@@ -575,36 +575,30 @@ __global__ __launch_bounds__(CDN_NT) void k_csc_densify(const InT *__restrict__ 
         if (r0 >= n_rows) break; // (uniform)
         for (int i = tid; i < RC * 65; i += CDN_NT) (&tile[0][0])[i] = (InT)0;
         __syncthreads();
-        // a wavefront takes four columns at a time, 128 entries of each per step: their entries of this chunk are the next ones behind
-        // the cursors (eight index requests in flight, then the values of those that belong to the chunk)
+        // a wavefront takes four columns at a time, 64 entries of each per step: their entries of this chunk are the next ones behind
+        // the cursors (rows and values of the four requested together; 128 per step read the arrays 3.4 times over at 30 % stored)
         for (int jb = wave * 16; jb < wave * 16 + 16; jb += 4) {
             long long k[4], e[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { k[q] = cur[jb + q]; e[q] = kend[jb + q]; }
             bool more = true;
             while (more) { // (uniform per wavefront)
-                long long row[4][2];
-                InT val[4][2]; // (requested with the rows, not behind the test that needs the row: eight round trips in a row otherwise -- 9 ms)
+                long long row[4];
+                InT val[4]; // (requested with the rows, not behind the test that needs the row: a round trip per column otherwise)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const long long kk = k[q] + h * 64 + lane;
-                        row[q][h] = kk < e[q] ? (long long)indices[kk] : (long long)0x7FFFFFFFFFFFll;
-                        val[q][h] = kk < e[q] ? data[kk] : (InT)0;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const long long kk = k[q] + lane;
+                    row[q] = kk < e[q] ? (long long)indices[kk] : (long long)0x7FFFFFFFFFFFll;
+                    val[q] = kk < e[q] ? data[kk] : (InT)0;
+                }
                 more = false;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    int n_in = 0;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const bool in = row[q][h] < r1;
-                        if (in) tile[row[q][h] - r0][jb + q] = val[q][h];
-                        n_in += (int)__popcll(__ballot(in));
-                    }
+                    const bool in = row[q] < r1;
+                    if (in) tile[row[q] - r0][jb + q] = val[q];
+                    const int n_in = (int)__popcll(__ballot(in));
                     k[q] += n_in;
-                    more = more || n_in == 128;
+                    more = more || n_in == 64;
                 }
             }
             if (lane < 4) cur[jb + lane] = lane == 0 ? k[0] : lane == 1 ? k[1] : lane == 2 ? k[2] : k[3];
@@ -613,6 +607,28 @@ __global__ __launch_bounds__(CDN_NT) void k_csc_densify(const InT *__restrict__ 
         for (int r = wave; r < (int)(r1 - r0); r += CDN_NT / 64)
             if (cb + lane < (int)ldD) D[(size_t)(r0 + r) * ldD + cb + lane] = tile[r][lane];
         __syncthreads();
+    }
+}
+
+// The same question for FEW, LONG parcels (the columns of a CSC window with tens of thousands of stored entries each, where a wavefront
+// per parcel leaves most of the chip idle): the stored entries [k0, k1) as one flat run -- order[0] += the positions whose index is
+// smaller than the one before it, order[1] += the parcels (after the first) that start with such a step.  In order <=> the two agree.
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_flat_descents(const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr, int n_parcels, long long kshift,
+                                                       u32 *__restrict__ order) {
+    const long long k0 = (long long)indptr[0] - kshift, k1 = (long long)indptr[n_parcels] - kshift;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    u32 d = 0, r = 0;
+    for (long long k = k0 + 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x; k < k1; k += stride) d += indices[k] < indices[k - 1] ? 1u : 0u;
+    for (long long j = 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n_parcels; j += stride) {
+        const long long s = (long long)indptr[j] - kshift, e = (long long)indptr[j + 1] - kshift;
+        if (s < e && s > k0 && indices[s] < indices[s - 1]) ++r;
+    }
+    d = (u32)wave_sum((int)d);
+    r = (u32)wave_sum((int)r);
+    if ((threadIdx.x & 63) == 0) {
+        if (d) atomicAdd(&order[0], d);
+        if (r) atomicAdd(&order[1], r);
     }
 }
 

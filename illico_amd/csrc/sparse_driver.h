@@ -982,14 +982,13 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
         if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
         int *d_bad = (int *)v;
         HIPCHK(c, hipMemsetAsync(d_bad, 0, 8, c->stream));
-        // (the check walks "rows" = the window's columns: indptr from col_lb on, entries relative to kshift)
-        hipLaunchKernelGGL((k_csr_sorted_check<IdxT>), dim3((unsigned)std::min<int64_t>((W + 3) / 4 + 1, 8192)), dim3(256), 0, c->stream,
-                           d_indices - kshift, d_indptr + col_lb, (int)W, d_bad);
+        // (few, long parcels: the window's entries as one flat run, kernels_sparse.h)
+        hipLaunchKernelGGL((k_flat_descents<IdxT>), dim3(4096), dim3(256), 0, c->stream, d_indices, d_indptr + col_lb, (int)W, (long long)kshift, (u32 *)d_bad);
         HIPCHK(c, hipGetLastError());
-        int bad = 0;
-        HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+        u32 h_order[2] = {0u, 0u};
+        HIPCHK(c, hipMemcpyAsync(h_order, d_bad, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (!bad) {
+        if (h_order[0] == h_order[1]) {
             int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * sizeof(InT))) & ~63ll;
             wmax = std::min<int64_t>(wmax, (1ll << 29));
             if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, (c->gene_batch + 63) & ~63ll);
