@@ -108,7 +108,11 @@ __global__ __launch_bounds__(COUNTS_NT, CB == 8 ? 3 : 4) void k_ovo_counts(OvoPa
         // ---- groups: one wavefront each; lane = cell.  Per cell with value c (a = cntA[c], o = earlier cells of
         // the group with the same value, from a fetch-and-add on the wavefront's counter table; zeros are ranked by
         // ballot instead of 64 same-address atomics):  S2 += cum[c] + cum[c+1],  TT += t (t+1), t = a + o.
-        for (int g0 = wave * 64; g0 < G; g0 += NW * 64) {
+        // (gridDim.y > 1: a gene's groups are dealt to that many workgroups, each with the reference tables of its own -- a few hundred genes
+        //  are one workgroup per CU or less, and a workgroup walks 250 groups per wavefront one after the other)
+        const int g_chunk = (((G + (int)gridDim.y - 1) / (int)gridDim.y) + 63) & ~63;
+        const int g_lo = (int)blockIdx.y * g_chunk, g_hi = min(G, g_lo + g_chunk);
+        for (int g0 = g_lo + wave * 64; g0 < g_hi; g0 += NW * 64) {
             TrReduce<u64> rS2, rTie, rSum;
             // next group's first 256 keys are fetched while the current group is processed
             KeyT nxt[4];

@@ -195,8 +195,10 @@ int launch_ovo(illico_ctx *c, OvoParams P, int64_t max_ref_nnz, int64_t max_grp_
     if (only) P.only = only;
     if (flags) { // (the ingest kernels flagged with the same limit: ovo_counts_limit)
         ProfScope ps(c, KID_OVO_COUNTS);
-        if (ovo_counts_limit(c) == COUNTS_R8) hipLaunchKernelGGL((k_ovo_counts<KeyT, COUNTS_R8, 8>), dim3(P.n_genes), dim3(COUNTS_NT), 0, c->stream, P, flags);
-        else hipLaunchKernelGGL((k_ovo_counts<KeyT, COUNTS_R, 16>), dim3(P.n_genes), dim3(COUNTS_NT), 0, c->stream, P, flags);
+        // few genes (the leftovers of a count matrix): a gene's groups over several workgroups, 512 groups (eight wavefronts x 64) each at least
+        const int splits = std::max(1, std::min({(1024 + P.n_genes - 1) / std::max(P.n_genes, 1), (P.G + 511) / 512, 16}));
+        if (ovo_counts_limit(c) == COUNTS_R8) hipLaunchKernelGGL((k_ovo_counts<KeyT, COUNTS_R8, 8>), dim3(P.n_genes, splits), dim3(COUNTS_NT), 0, c->stream, P, flags);
+        else hipLaunchKernelGGL((k_ovo_counts<KeyT, COUNTS_R, 16>), dim3(P.n_genes, splits), dim3(COUNTS_NT), 0, c->stream, P, flags);
         HIPCHK(c, hipGetLastError());
     }
     if (!ovo_sort_route_fits<KeyT>(max_ref_nnz, max_grp_nnz)) {
