@@ -575,33 +575,38 @@ __global__ __launch_bounds__(CDN_NT) void k_csc_densify(const InT *__restrict__ 
         if (r0 >= n_rows) break; // (uniform)
         for (int i = tid; i < RC * 65; i += CDN_NT) (&tile[0][0])[i] = (InT)0;
         __syncthreads();
-        // a wavefront takes four columns at a time, 64 entries of each per step: their entries of this chunk are the next ones behind
-        // the cursors (rows and values of the four requested together; 128 per step read the arrays 3.4 times over at 30 % stored)
-        for (int jb = wave * 16; jb < wave * 16 + 16; jb += 4) {
-            long long k[4], e[4];
+        // a wavefront takes its sixteen columns at once, 64 entries of each per step: their entries of this chunk are the next ones behind
+        // the cursors (rows and values of all of them requested together; 128 per step read the arrays 3.4 times over at 30 % stored)
+        constexpr int CQ = 16;
+        for (int jb = wave * 16; jb < wave * 16 + 16; jb += CQ) {
+            long long k[CQ], e[CQ];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { k[q] = cur[jb + q]; e[q] = kend[jb + q]; }
+            for (int q = 0; q < CQ; ++q) { k[q] = cur[jb + q]; e[q] = kend[jb + q]; }
             bool more = true;
             while (more) { // (uniform per wavefront)
-                long long row[4];
-                InT val[4]; // (requested with the rows, not behind the test that needs the row: a round trip per column otherwise)
+                IdxT row[CQ];
+                bool have[CQ];
+                InT val[CQ]; // (requested with the rows, not behind the test that needs the row: a round trip per column otherwise)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < CQ; ++q) {
                     const long long kk = k[q] + lane;
-                    row[q] = kk < e[q] ? (long long)indices[kk] : (long long)0x7FFFFFFFFFFFll;
-                    val[q] = kk < e[q] ? data[kk] : (InT)0;
+                    have[q] = kk < e[q];
+                    row[q] = have[q] ? indices[kk] : (IdxT)0;
+                    val[q] = have[q] ? data[kk] : (InT)0;
                 }
                 more = false;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool in = row[q] < r1;
-                    if (in) tile[row[q] - r0][jb + q] = val[q];
+                for (int q = 0; q < CQ; ++q) {
+                    const bool in = have[q] && (long long)row[q] < r1;
+                    if (in) tile[(long long)row[q] - r0][jb + q] = val[q];
                     const int n_in = (int)__popcll(__ballot(in));
                     k[q] += n_in;
                     more = more || n_in == 64;
                 }
             }
-            if (lane < 4) cur[jb + lane] = lane == 0 ? k[0] : lane == 1 ? k[1] : lane == 2 ? k[2] : k[3];
+#pragma unroll
+            for (int q = 0; q < CQ; ++q)
+                if (lane == q) cur[jb + q] = k[q];
         }
         __syncthreads();
         for (int r = wave; r < (int)(r1 - r0); r += CDN_NT / 64)

@@ -108,7 +108,7 @@ SHAPES = [
     ("continuous", 0.9, "csr", 2000, "ovo"),
     ("nb", 0.9, "csr", 2000, "ovo"),
     ("continuous", 0.7, "csr", 2000, "ovr"),      # columns of 90 000 stored entries: 76 ms at full size before the dense-window branch
-    ("continuous", 0.7, "csc", 2000, "ovr"),      # 76 ms (k_csc_densify: the dense window costs a CSC matrix twice what it costs a CSR one)
+    ("continuous", 0.7, "csc", 2000, "ovr"),      # 76 ms
 ]
 
 
