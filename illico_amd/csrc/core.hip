@@ -918,10 +918,22 @@ extern "C" int illico_csc_bind(illico_ctx *c, const void *data, int dtype, const
                                int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out) {
     return sparse_bind(c, false, data, dtype, indices, indptr, idx_dtype, n_rows, n_cols, flags, out);
 }
+// columns [0, W) of three [G][src_ld] planes that lie `plane` doubles apart -> three planes of pitch dst_ld (run_bound_ahead: a chunk's slice of a window)
+static __global__ __launch_bounds__(256) void k_copy_plane_slices(const double *__restrict__ src, long long plane, long long src_ld, double *__restrict__ d0,
+                                                                  double *__restrict__ d1, double *__restrict__ d2, long long dst_ld, int W, int G) {
+    for (int g = blockIdx.x; g < G; g += gridDim.x)
+        for (int j = threadIdx.x; j < W; j += 256) {
+            const size_t i = (size_t)g * src_ld + j, o = (size_t)g * dst_ld + j;
+            d0[o] = src[i];
+            d1[o] = src[plane + i];
+            d2[o] = src[2 * plane + i];
+        }
+}
+
 // "bound_ahead_genes" = A: genes [col_lb, col_ub), fewer than A, of a bound CSR matrix.  The aligned window of A genes that holds them
 // (or the A genes from col_lb on, when they straddle a boundary) is computed ONCE into planes of the context's own -- two such windows
 // are kept, the older one is replaced -- and every call for genes inside it is a copy of its slice: 32 calls of 256 genes at C3 shape
-// cost 7.2 ms as 32 passes over the rows, 1.3 ms this way.  A window belongs to (matrix, groups, flags, alternative).
+// cost 7.2 ms as 32 passes over the rows, 2.3 ms this way.  A window belongs to (matrix, groups, flags, alternative).
 static int run_bound_ahead(illico_ctx *c, const illico_matrix *m, int64_t col_lb, int64_t col_ub, int flags, int alternative,
                            double *out_p, double *out_u, double *out_fc, int64_t out_ld) {
     const int64_t A = c->bound_ahead_genes, W = col_ub - col_lb;
@@ -961,8 +973,10 @@ static int run_bound_ahead(illico_ctx *c, const illico_matrix *m, int64_t col_lb
     const int64_t cw = w->ub - w->lb;
     const size_t plane = G * (size_t)cw;
     double *const dst[3] = {o.p, o.u, o.fc};
-    for (int k = 0; k < 3; ++k)
-        HIPCHK(c, hipMemcpy2DAsync(dst[k], (size_t)o.ld * 8, w->planes + (size_t)k * plane + (col_lb - w->lb), (size_t)cw * 8, (size_t)W * 8, G, hipMemcpyDeviceToDevice, c->stream));
+    // one launch for the three slices (three strided copies cost three launches per chunk: 1 ms of the 32 chunks' 2.5)
+    hipLaunchKernelGGL(k_copy_plane_slices, dim3((unsigned)std::min<size_t>(G, 65535)), dim3(256), 0, c->stream, (const double *)(w->planes + (col_lb - w->lb)), (long long)plane,
+                       (long long)cw, dst[0], dst[1], dst[2], (long long)o.ld, (int)W, (int)G);
+    HIPCHK(c, hipGetLastError());
     if (!o.staged) {
         if (!(flags & ILLICO_FLAG_DEFER)) HIPCHK(c, hipStreamSynchronize(c->stream));
         return ILLICO_OK;
