@@ -617,17 +617,18 @@ __global__ __launch_bounds__(CDN_NT) void k_csc_densify(const InT *__restrict__ 
 
 // The same question for FEW, LONG parcels (the columns of a CSC window with tens of thousands of stored entries each, where a wavefront
 // per parcel leaves most of the chip idle): the stored entries [k0, k1) as one flat run -- order[0] += the positions whose index is
-// smaller than the one before it, order[1] += the parcels (after the first) that start with such a step.  In order <=> the two agree.
+// not larger than the one before it, order[1] += the parcels (after the first) that start with such a step.  In order <=> the two agree.
 template <typename IdxT>
 __global__ __launch_bounds__(256) void k_flat_descents(const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr, int n_parcels, long long kshift,
                                                        u32 *__restrict__ order) {
     const long long k0 = (long long)indptr[0] - kshift, k1 = (long long)indptr[n_parcels] - kshift;
     const long long stride = (long long)gridDim.x * blockDim.x;
     u32 d = 0, r = 0;
-    for (long long k = k0 + 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x; k < k1; k += stride) d += indices[k] < indices[k - 1] ? 1u : 0u;
+    // (<=: an index stored twice in a parcel counts as out of order too -- a dense window would keep one of the two entries)
+    for (long long k = k0 + 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x; k < k1; k += stride) d += indices[k] <= indices[k - 1] ? 1u : 0u;
     for (long long j = 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n_parcels; j += stride) {
         const long long s = (long long)indptr[j] - kshift, e = (long long)indptr[j + 1] - kshift;
-        if (s < e && s > k0 && indices[s] < indices[s - 1]) ++r;
+        if (s < e && s > k0 && indices[s] <= indices[s - 1]) ++r;
     }
     d = (u32)wave_sum((int)d);
     r = (u32)wave_sum((int)r);
