@@ -30,7 +30,14 @@ __global__ __launch_bounds__(256) void k_gather_columns(const InT *__restrict__ 
         const int j = j0 + (int)threadIdx.x;
         const long long col = j < n ? (long long)cols[j] : -1;
         if (j < n_pad)
-            for (int r = r0; r < r1; ++r) dst[(size_t)r * dst_ld + dst_col0 + j] = col >= 0 ? src[(size_t)r * ld + col] : (InT)0;
+            for (int r = r0; r < r1; r += 8) { // eight rows' requests in flight per thread (one at a time the pass ran on latency)
+                InT v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (col >= 0 && r + u < r1) ? src[(size_t)(r + u) * ld + col] : (InT)0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r + u < r1) dst[(size_t)(r + u) * dst_ld + dst_col0 + j] = v[u];
+            }
     }
 }
 
