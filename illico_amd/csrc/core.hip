@@ -417,10 +417,12 @@ int ovo_counts_limit(const illico_ctx *c) { return c->max_nonref <= 255 ? COUNTS
 bool counts_path_allowed(const illico_ctx *c, int flags) {
     return !(flags & ILLICO_FLAG_LOG1P) && c->ref >= 0 && c->max_nonref <= 65535 && !c->no_counts_path;
 }
-// fused single-pass routes (OVO and OVR): integer value sums (no expm1), 16-bit running multiplicities (OVO),
+// fused single-pass routes (OVO and OVR): integer value sums (no expm1), 16-bit running multiplicities (OVO) / histogram cells (OVR in one pass),
 // 32-bit chunk partial sums (n_cells < 2^25)
 bool fused_path_allowed(const illico_ctx *c, int flags) {
-    return !(flags & ILLICO_FLAG_LOG1P) && c->max_nonref <= 65535 && c->n_cells < (1ll << 25) && !c->no_counts_path && !c->no_fused_path;
+    // (OVO: 16-bit running multiplicities per group.  OVR keeps no per-group state in its two-pass form -- a control group of 70 000 cells
+    //  among 2 000 000 sent the whole matrix to the general sort route: 115 ms for 9.6 GB -- only its one-pass form counts in 16-bit cells)
+    return !(flags & ILLICO_FLAG_LOG1P) && (c->ref < 0 || c->max_nonref <= 65535) && c->n_cells < (1ll << 25) && !c->no_counts_path && !c->no_fused_path;
 }
 
 int launch_finalize(illico_ctx *c, const long long *s2u, const u64 *stie, const double *ssum, const double *gene_total,

@@ -260,7 +260,7 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
         // the histogram bytes of all the small ones
         const int cbits = c->max_nonref <= 255 ? 8 : 0;
         const size_t hist_bytes = cbits ? (size_t)c->n_groups * tiles * (RT * cbits / 32) * 64 * 4 : (size_t)c->hist_words * tiles * 64 * 4;
-        if (!c->no_ovr_one_pass && hist_bytes <= (size_t)c->scratch_bytes) {
+        if (!c->no_ovr_one_pass && c->max_nonref <= 65535 && hist_bytes <= (size_t)c->scratch_bytes) { // (16-bit cells: no group beyond 65535 cells)
             if ((rc = get_scratch(c, "group_hist", hist_bytes, &v))) return rc;
             P.group_hist = (u32 *)v;
             if ((rc = get_scratch(c, "group_hist_words", (size_t)c->n_groups * tiles, &v))) return rc;

@@ -480,3 +480,30 @@ def test_scattered_big_count_genes_are_gathered_and_take_the_histogram_routes(en
             engine.set_option(option, 0)
         for a, b in zip(got, again):
             np.testing.assert_array_equal(a, b, err_msg=option)
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_dense_ovr_counts_with_a_group_of_more_than_65535_cells(engine, where):
+    """OVR on a count matrix whose control group holds 70 000 cells (an atlas of two million cells has one): the one-pass form of the
+    fused OVR route counts in 16-bit cells per group, the two-pass form keeps no per-group state -- it must take over, not the general
+    sort route (115 ms instead of 5 at 2 000 000 x 1200).  Genes beyond the tables ride along."""
+    import torch
+    rng = np.random.RandomState(123)
+    n, m = 90_000, 130
+    labels = np.array(["ctrl"] * 70_000 + [f"p{i % 40:02d}" for i in range(n - 70_000)])
+    rng.shuffle(labels)
+    X = rng.poisson(rng.uniform(0.2, 12.0, size=m), size=(n, m)).astype(np.float32)
+    X[rng.rand(n, m) < 0.4] = 0
+    X[:, 7] = rng.poisson(90.0, size=n)        # beyond the 64-value table
+    X[:, 11] = rng.poisson(400.0, size=n)      # beyond the 256-value table
+    _, g = oracle.encode_and_count_groups(labels, None)
+    assert g.counts.max() == 70_000
+    want = oracle.run(X, g)
+    engine.set_groups(g)
+    engine.profile(True)
+    engine.profile_reset()
+    got = engine.run_dense(torch.from_numpy(X).to(torch.device("cuda", engine.device)) if where == "device" else X, 0, m)
+    prof = engine.profile_get()
+    engine.profile(False)
+    assert "k_ovr_fused" in prof, prof
+    assert_planes_match(got, want, what=f"ovr, a group of 70 000 cells, {where}")
