@@ -81,8 +81,8 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         hipLaunchKernelGGL(kern, dim3(nb), dim3(OCR_NT), lds, c->stream, C);
         HIPCHK(c, hipGetLastError());
     }
-    if (c->max_nonref > 1024) { // what the packed kernel leaves cannot go to k_ovo_rank (groups of at most 1024 keys): the caller sends those
-        // genes through the transposition + general sort route
+    if (!packed_leftovers_fit_sort_route<KeyT>(c)) { // what the packed kernel leaves cannot go to k_ovo_rank (groups of at most 1024 keys, a
+        // reference that fits its LDS): the caller sends those genes through the transposition + general sort route
         std::vector<u32> hr((size_t)nb);
         HIPCHK(c, hipMemcpyAsync(hr.data(), route, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -39,14 +39,19 @@ template <typename KeyT> static void packed_ref_sizing(int64_t n_ref, int *cap, 
     const size_t fixed = ocr_lds_bytes(0, 16, sizeof(KeyT));
     *cap = (int)std::min<int64_t>(n_ref, (int64_t)((kMaxLds - fixed) / sizeof(KeyT)) - 8);
 }
-// Sizes the route holds: reference of at most 65535 cells whose keys fit k_ovo_rank's LDS (it takes the tie-heavy genes and those
-// whose non-zeros exceed the packed kernel's key slots), other groups of at most 65535 cells.
+// Sizes the route holds: ranked groups of at most 65535 cells (16-bit counts per (gene, group)).  The reference may be of any size: it
+// is packed in 512-row segments, the rank kernel keeps as many of its NON-ZERO keys as LDS holds (packed_ref_sizing) and leaves a gene
+// with more -- like the tie-heavy ones -- to k_ovo_rank, or, when that kernel's LDS does not hold the reference either (or groups exceed
+// 1024 cells), to the general sort route (run_ovo_packed: redo).  (Until sweep 10 the route asked for a reference of at most 65535
+// cells: the control group of a two-million-cell atlas -- 66 667 cells -- sent every gene to the radix sort in HBM, 287 ms for 9.6 GB.)
 template <typename KeyT> static bool packed_route_fits(const illico_ctx *c) {
     if (c->ref < 0 || c->no_packed_dense) return false;
     const int64_t n_ref = c->h_counts[c->ref];
-    // (groups above 1024 cells: their runs are sorted and walked in pieces, k_sort_big_runs; the genes the packed kernel leaves then
-    //  take the general sort route instead of k_ovo_rank)
-    return n_ref >= 1 && n_ref <= 65535 && c->max_nonref <= 65535 && ovo_sort_route_fits<KeyT>(n_ref, std::min<int64_t>(c->max_nonref, 1024));
+    return n_ref >= 1 && n_ref < (1ll << 24) && c->max_nonref <= 65535;
+}
+// ... and whether what the packed kernel leaves can go to k_ovo_rank over the same layout
+template <typename KeyT> static bool packed_leftovers_fit_sort_route(const illico_ctx *c) {
+    return c->max_nonref <= 1024 && ovo_sort_route_fits<KeyT>(c->h_counts[c->ref], c->max_nonref);
 }
 
 constexpr int kOvrThreads = 256; // several small workgroups per CU overlap each other's barriers (1024 measured the same)

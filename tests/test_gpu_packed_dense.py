@@ -181,7 +181,9 @@ def test_packed_route_reference_larger_than_its_key_slots(engine):
     _check(engine, X[perm], labels[perm], what="large reference")
 
 
-def test_reference_beyond_16_bit_positions_takes_the_other_route(engine):
+def test_reference_beyond_65535_cells_keeps_the_packed_route(engine):
+    """(Until round 4's tenth sweep such a reference sent every gene to the general sort route: the route asked for a reference k_ovo_rank's
+    LDS holds, which only its leftover genes need.)  Host-resident input; 30 % of the cells stored: 20 000 reference keys per gene."""
     rng = np.random.RandomState(16)
     n = 70000
     labels = np.array(["non-targeting"] * 66000 + [f"pert_{i % 20}" for i in range(n - 66000)])
@@ -195,7 +197,7 @@ def test_reference_beyond_16_bit_positions_takes_the_other_route(engine):
         prof = engine.profile_get()
     finally:
         engine.set_option("profile", 0)
-    assert "k_group_compact" not in prof, prof
+    assert "k_ovo_rank_compact" in prof, prof
     assert_planes_match(got, oracle.run(X.astype(np.float64), g), ref_row=g.encoded_ref_group, what="large reference")
 
 
@@ -288,3 +290,27 @@ def test_groups_of_thousands_of_cells_are_walked_in_sorted_pieces(engine, dtype)
     assert_planes_match(p_old, want, ref_row=g.encoded_ref_group, what=f"big groups, general {np.dtype(dtype).name}")
     got = engine.run_dense(X, 5, 40)                                                                # host input, a column window
     assert_planes_match(got, oracle.run(X, g, col_lb=5, col_ub=40), ref_row=g.encoded_ref_group, what="big groups, host window")
+
+
+@pytest.mark.parametrize("density", [0.08, 0.6])
+def test_dense_ovo_continuous_with_a_reference_of_more_than_65535_cells(engine, density):
+    """The control group of an atlas: 70 000 reference cells, continuous values.  The packed rank kernel keeps as many of the reference's
+    NON-ZERO keys as LDS holds: at 8 % density (log-normalised counts) every gene fits and takes it; at 60 % none does and every gene
+    goes on to the general sort route -- both against the oracle.  (The route used to be closed to references above 65535 cells.)"""
+    import torch
+    rng = np.random.RandomState(321)
+    n, m = 84_000, 70
+    labels = np.array(["non-targeting"] * 70_000 + [f"p{i % 30:02d}" for i in range(n - 70_000)])
+    rng.shuffle(labels)
+    X = (np.exp(rng.normal(0.0, 1.0, size=(n, m))) * (rng.rand(n, m) < density)).astype(np.float32)
+    X[:, 3] = 0
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    want = oracle.run(X.astype(np.float64), g)
+    engine.set_groups(g)
+    engine.profile(True)
+    engine.profile_reset()
+    got = engine.run_dense(torch.from_numpy(X).to(torch.device("cuda", engine.device)), 0, m)
+    prof = engine.profile_get()
+    engine.profile(False)
+    assert "k_ovo_rank_compact" in prof, prof
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"ovo continuous, reference of 70 000 cells, density {density}")
