@@ -830,7 +830,8 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
     const bool packed = !ovr && !prefer_counts && allow_packed && packed_route_fits<KeyT>(c);
     std::vector<std::pair<int64_t, int64_t>> redo_runs; // genes the packed route left while groups above 1024 cells rule k_ovo_rank out
     // dense OVR: the transposition with the group sums folded in (k_group_compact keeping every key: padded dense layout)
-    const bool padded = ovr && !prefer_counts && !c->no_packed_dense && c->pk_nblk > 0 && c->max_nonref <= 65535 && c->pk_stride < (1ll << 31);
+    // (any group sizes: only the PACKED rows below count a (gene, group)'s non-zeros in 16 bits)
+    const bool padded = ovr && !prefer_counts && !c->no_packed_dense && c->pk_nblk > 0 && c->pk_stride < (1ll << 31);
     const bool ovr_counts = ovr && prefer_counts && N < (1ll << 31);
     const int64_t stride = (packed || padded) ? c->pk_stride : ((N + 63) & ~63ll);
     int rc;
@@ -914,7 +915,7 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             continue;
         }
         OvrPackedInput pki;
-        const bool ovr_packed = padded && !c->no_ovr_packed_partition && !c->no_ovr_parts_path && G <= 65535;
+        const bool ovr_packed = padded && !c->no_ovr_packed_partition && !c->no_ovr_parts_path && G <= 65535 && c->max_nonref <= 65535;
         if (padded) {
             GroupCompactParams Q;
             memset(&Q, 0, sizeof Q);
