@@ -422,7 +422,8 @@ bool counts_path_allowed(const illico_ctx *c, int flags) {
 bool fused_path_allowed(const illico_ctx *c, int flags) {
     // (OVO: 16-bit running multiplicities per group.  OVR keeps no per-group state in its two-pass form -- a control group of 70 000 cells
     //  among 2 000 000 sent the whole matrix to the general sort route: 115 ms for 9.6 GB -- only its one-pass form counts in 16-bit cells)
-    return !(flags & ILLICO_FLAG_LOG1P) && (c->ref < 0 || c->max_nonref <= 65535) && c->n_cells < (1ll << 25) && !c->no_counts_path && !c->no_fused_path;
+    //  OVO with ranked groups above 65 535 cells -- cluster against cluster -- runs the same kernel with 32-bit multiplicities: 158 -> see NOTES_r04)
+    return !(flags & ILLICO_FLAG_LOG1P) && c->n_cells < (1ll << 25) && !c->no_counts_path && !c->no_fused_path;
 }
 
 int launch_finalize(illico_ctx *c, const long long *s2u, const u64 *stie, const double *ssum, const double *gene_total,

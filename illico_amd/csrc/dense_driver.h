@@ -219,7 +219,13 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
             ProfScope ps(c, KID_OVO_FUSED);
             if (c->max_nonref <= 255) // 8-bit running multiplicities: 34 KB of LDS per workgroup instead of 50 KB
                 hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 8>), main_grid, dim3(FUSED_NT), lds8, c->stream, P);
-            else hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16>), main_grid, dim3(FUSED_NT), lds16, c->stream, P);
+            else if (c->max_nonref <= 65535) hipLaunchKernelGGL((k_ovo_fused<InT, RT, false, 16>), main_grid, dim3(FUSED_NT), lds16, c->stream, P);
+            else { // clusters of more than 65535 cells: 32-bit multiplicities (82 KB: one workgroup per CU)
+                auto kern = k_ovo_fused<InT, RT, false, 32>;
+                const size_t lds32 = fused_main_lds_bytes<RT, false, 32>();
+                HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+                hipLaunchKernelGGL(kern, main_grid, dim3(FUSED_NT), lds32, c->stream, P);
+            }
             HIPCHK(c, hipGetLastError());
         }
         // Second pass, 256-value tables, over the tiles that hold genes the first pass flagged (counts of 64 .. 255: highly

@@ -103,6 +103,7 @@ typedef const __attribute__((address_space(4))) int *const_int_p;
 template <int CB> struct CntCell;
 template <> struct CntCell<8> { typedef unsigned char type; };
 template <> struct CntCell<16> { typedef unsigned short type; };
+template <> struct CntCell<32> { typedef unsigned int type; };   // groups above 65535 cells (clusters of an atlas): 82 KB of LDS, one workgroup per CU
 // UU rows of the wavefront's 64-gene tile, requested back to back: v[u] = X[row_u][gene0 + lane], row_u = perm[p + u].
 // p, p1 are wave-uniform.  PRED: positions at or past p1 (the group's end) re-read the group's last row -- a cache hit,
 // no HBM traffic -- and are masked out by the consumer.

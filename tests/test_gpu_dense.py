@@ -507,3 +507,29 @@ def test_dense_ovr_counts_with_a_group_of_more_than_65535_cells(engine, where):
     engine.profile(False)
     assert "k_ovr_fused" in prof, prof
     assert_planes_match(got, want, what=f"ovr, a group of 70 000 cells, {where}")
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_dense_ovo_counts_with_a_ranked_group_of_more_than_65535_cells(engine, where):
+    """Cluster against cluster: a ranked group of 70 000 cells.  The fused OVO pass keeps a running multiplicity per (group, value) -- 8 or
+    16 bits -- and was closed to such groups (every gene then took the radix sort in HBM: 158 ms at one million cells x 2400 genes); with
+    32-bit cells it takes them.  A gene beyond the tables goes its own way."""
+    import torch
+    rng = np.random.RandomState(77)
+    n, m = 90_000, 130
+    labels = np.array(["ref"] * 6_000 + ["big"] * 70_000 + [f"p{i % 20:02d}" for i in range(n - 76_000)])
+    rng.shuffle(labels)
+    X = rng.poisson(rng.uniform(0.2, 12.0, size=m), size=(n, m)).astype(np.float32)
+    X[rng.rand(n, m) < 0.4] = 0
+    X[:, 5] = 3.0                               # one value: a tie block of 70 000
+    X[:, 7] = rng.poisson(90.0, size=n)         # beyond the 64-value table
+    _, g = oracle.encode_and_count_groups(labels, "ref")
+    want = oracle.run(X, g)
+    engine.set_groups(g)
+    engine.profile(True)
+    engine.profile_reset()
+    got = engine.run_dense(torch.from_numpy(X).to(torch.device("cuda", engine.device)) if where == "device" else X, 0, m)
+    prof = engine.profile_get()
+    engine.profile(False)
+    assert "k_ovo_fused" in prof, prof
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"ovo, a ranked group of 70 000 cells, {where}")
