@@ -252,7 +252,7 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
             if (PACK && lane < GPW && geneW < P.ncols) {
                 if (seg >= 0) P.seg_nnz[(size_t)geneW * P.nseg + seg] = (u16)cntv;
                 else {
-                    P.nnz[(size_t)geneW * P.G + cg] = (u16)(cntv - gstartv);
+                    P.nnz[(size_t)geneW * P.G + cg] = (u16)min(cntv - gstartv, 65535); // (saturating: a run of 65535 keys or more is beyond k_bucket_big_runs' slots, which sends the gene to the general route)
                     P.gofs[(size_t)geneW * P.G + cg] = (u32)(out0 + gstartv);
                 }
             }
@@ -632,6 +632,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene = blockIdx.x;
     if (P.gene_flags && P.gene_flags[gene] == 0u) return; // (uniform)
+    if (P.big_sorted && P.route[gene] == 2u) return;      // (uniform) k_bucket_big_runs met a run beyond its slots: the general route's gene
     const int G = P.G, ref = P.ref;
     const int n_ref = P.counts[ref];
     u16 *nnz = P.nnz + (size_t)gene * G;

@@ -39,7 +39,7 @@ template <typename KeyT> static void packed_ref_sizing(int64_t n_ref, int *cap, 
     const size_t fixed = ocr_lds_bytes(0, 16, sizeof(KeyT));
     *cap = (int)std::min<int64_t>(n_ref, (int64_t)((kMaxLds - fixed) / sizeof(KeyT)) - 8);
 }
-// Sizes the route holds: ranked groups of at most 65535 cells (16-bit counts per (gene, group)).  The reference may be of any size: it
+// Sizes the route holds.  The reference may be of any size: it
 // is packed in 512-row segments, the rank kernel keeps as many of its NON-ZERO keys as LDS holds (packed_ref_sizing) and leaves a gene
 // with more -- like the tie-heavy ones -- to k_ovo_rank, or, when that kernel's LDS does not hold the reference either (or groups exceed
 // 1024 cells), to the general sort route (run_ovo_packed: redo).  (Until sweep 10 the route asked for a reference of at most 65535
@@ -47,7 +47,9 @@ template <typename KeyT> static void packed_ref_sizing(int64_t n_ref, int *cap, 
 template <typename KeyT> static bool packed_route_fits(const illico_ctx *c) {
     if (c->ref < 0 || c->no_packed_dense) return false;
     const int64_t n_ref = c->h_counts[c->ref];
-    return n_ref >= 1 && n_ref < (1ll << 24) && c->max_nonref <= 65535;
+    // (ranked groups of any size: a (gene, group) run's 16-bit count saturates, and a run beyond k_bucket_big_runs' LDS slots -- 16 384 or
+    //  32 768 keys -- sends its gene to the general route; a cluster of 100 000 cells a tenth of whose values are stored stays here)
+    return n_ref >= 1 && n_ref < (1ll << 24) && c->max_nonref < (1ll << 24);
 }
 // ... and whether what the packed kernel leaves can go to k_ovo_rank over the same layout
 template <typename KeyT> static bool packed_leftovers_fit_sort_route(const illico_ctx *c) {

@@ -314,3 +314,27 @@ def test_dense_ovo_continuous_with_a_reference_of_more_than_65535_cells(engine, 
     engine.profile(False)
     assert "k_ovo_rank_compact" in prof, prof
     assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"ovo continuous, reference of 70 000 cells, density {density}")
+
+
+def test_dense_ovo_continuous_with_a_ranked_group_of_more_than_65535_cells(engine):
+    """Cluster against cluster on continuous values: a ranked group of 70 000 cells.  A tenth of the values stored: the group's run of 7000
+    keys per gene is dealt into value buckets and ranked piece by piece (packed rank kernel); a gene stored in full -- a run of 70 000 keys,
+    beyond the 16-bit run length and the bucket kernel's slots -- is flagged there and redone by the general route."""
+    import torch
+    rng = np.random.RandomState(654)
+    n, m = 88_000, 66
+    labels = np.array(["ref"] * 5_000 + ["big"] * 70_000 + [f"p{i % 25:02d}" for i in range(n - 75_000)])
+    rng.shuffle(labels)
+    X = (np.exp(rng.normal(0.0, 1.0, size=(n, m))) * (rng.rand(n, m) < 0.1)).astype(np.float32)
+    X[:, 4] = np.exp(rng.normal(0.0, 1.0, size=n)).astype(np.float32)      # stored in full
+    X[:, 9] = np.round(X[:, 9], 1)                                          # ties
+    _, g = oracle.encode_and_count_groups(labels, "ref")
+    want = oracle.run(X.astype(np.float64), g)
+    engine.set_groups(g)
+    engine.profile(True)
+    engine.profile_reset()
+    got = engine.run_dense(torch.from_numpy(X).to(torch.device("cuda", engine.device)), 0, m)
+    prof = engine.profile_get()
+    engine.profile(False)
+    assert "k_ovo_rank_compact" in prof, prof
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what="ovo continuous, a ranked group of 70 000 cells")
