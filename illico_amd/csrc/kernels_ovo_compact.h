@@ -677,7 +677,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
             atomicMax(&s_kr[1], tmax);
             if (ng) atomicAdd(&s_cnt[0], ng);
         }
-        if (tid < P.nseg) atomicAdd(&s_cnt[1], (u32)seg_nnz[tid]); // nseg <= 128 (reference of at most 65535 cells)
+        for (int sg = tid; sg < P.nseg; sg += NT) atomicAdd(&s_cnt[1], (u32)seg_nnz[sg]); // (a reference of any size: nseg = n_ref / 512)
         u32 gmax = 0;
         for (int gq = tid; gq < G; gq += NT) gmax = max(gmax, gq == ref ? 0u : (u32)nnz[gq]);
         gmax = (u32)wave_incl_scan_max((int)gmax);

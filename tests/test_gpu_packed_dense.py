@@ -338,3 +338,25 @@ def test_dense_ovo_continuous_with_a_ranked_group_of_more_than_65535_cells(engin
     engine.profile(False)
     assert "k_ovo_rank_compact" in prof, prof
     assert_planes_match(got, want, ref_row=g.encoded_ref_group, what="ovo continuous, a ranked group of 70 000 cells")
+
+
+def test_dense_ovo_continuous_with_a_reference_of_600000_cells(engine):
+    """More than 1024 reference segments of 512 rows (the rank kernel counts the reference's non-zeros segment by segment: once one thread
+    per segment, with 1024 threads)."""
+    import torch
+    rng = np.random.RandomState(987)
+    n, m = 700_000, 24
+    labels = np.array(["ref"] * 600_000 + [f"p{i % 20:02d}" for i in range(n - 600_000)])
+    rng.shuffle(labels)
+    X = (np.exp(rng.normal(0.0, 1.0, size=(n, m))) * (rng.rand(n, m) < 0.02)).astype(np.float32)
+    X[:, 2] = np.round(X[:, 2], 1)
+    _, g = oracle.encode_and_count_groups(labels, "ref")
+    want = oracle.run(X.astype(np.float64), g)
+    engine.set_groups(g)
+    engine.profile(True)
+    engine.profile_reset()
+    got = engine.run_dense(torch.from_numpy(X).to(torch.device("cuda", engine.device)), 0, m)
+    prof = engine.profile_get()
+    engine.profile(False)
+    assert "k_ovo_rank_compact" in prof, prof
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what="ovo continuous, reference of 600 000 cells")
