@@ -410,6 +410,13 @@ __global__ __launch_bounds__(FUSED_NT) void k_fused_hist_all(FusedParams P) {
         }
         __syncthreads();
         if (s_skip) return;
+    } else { // every gene of the tile already flagged (the row probe on continuous data: all of them): nothing to count
+        if (wave == 0) {
+            const bool all = __all(!act || P.gene_flags[gene] != 0u);
+            if (lane == 0) s_skip = all ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_skip) return;
     }
     for (int i = tid; i < 64 * STR; i += FUSED_NT) h[i] = 0;
     if (tid < 64) s_bad[tid] = 0;
