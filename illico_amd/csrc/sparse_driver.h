@@ -812,14 +812,14 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
 
     // ---- CSR, any values, columns longer than the per-gene LDS kernels hold (a "sparse" matrix a fifth or more of whose cells are
     // stored): a dense window in the matrix's own type + the dense routes.  The per-gene kernels behind the transposition keep a
-    // gene's keys in LDS (~36 000 of them); longer columns fall to the general sort routes one by one -- C3 shape with 30 % of the cells
+    // gene's keys in LDS (~36 000 four-byte keys, half as many eight-byte ones: the bound below); longer columns fall to the general sort routes one by one -- C3 shape with 30 % of the cells
     // stored and continuous values: 76 ms (OVR) / 37 ms (OVO) that way, against 12.6 ms for the same values handed over dense.
     // OVR: the reference accumulates a sparse column's tie sum in float64 (sparse_ovr.py:49,83), the dense routes in exact integers;
     // what separates them is the rounding of n0^3 (n0 zeros), 1.1e-16 of it, which reaches p as z^2 (1 - d)^3 / (6 d) x 1.1e-16 at a
     // fraction d of cells stored: 6e-13 at |z| = 37 (p ~ 1e-300) for d = 0.04, the bound used here; below that the window stays with
     // the sparse routes (kernels_finalize.h: tie_f64_sparse).
     if (is_csr && allow_dense_window && allow_transpose && !c->no_csr_densify_any && !c->tap && !c->big_n && n_rows < (1ll << 31) &&
-        density * (double)n_rows > 32768.0 && (c->ref >= 0 || density >= 0.04) && (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
+        density * (double)n_rows > 32768.0 * 4.0 / (double)sizeof(KeyT) && (c->ref >= 0 || density >= 0.04) && (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
         int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * sizeof(InT))) & ~63ll;
         wmax = std::min<int64_t>(wmax, (1ll << 29));
         if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, (c->gene_batch + 63) & ~63ll);
@@ -977,7 +977,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     // ---- CSC, any values, columns longer than the per-gene LDS kernels hold: a dense window in the matrix's own type + the dense routes
     // (as for CSR above; the columns' row indices must ascend: asked on the device) ----
     if (!is_csr && !indices_are_codes && allow_dense_window && !c->no_csr_densify_any && !c->tap && !c->big_n && n_rows < (1ll << 31) &&
-        (int64_t)cols.size() == W && W > 0 && (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) / (double)W > 32768.0 &&
+        (int64_t)cols.size() == W && W > 0 && (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) / (double)W > 32768.0 * 4.0 / (double)sizeof(KeyT) &&
         (c->ref >= 0 || (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) >= 0.04 * (double)W * (double)n_rows) &&
         (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
         if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
