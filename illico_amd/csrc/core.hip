@@ -191,6 +191,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_csr_tile_gather")) c->no_csr_tile_gather = value != 0;
     else if (!strcmp(key, "no_csr_transpose_path")) c->no_csr_transpose_path = value != 0;
     else if (!strcmp(key, "no_csr_densify_any")) c->no_csr_densify_any = value != 0;
+    else if (!strcmp(key, "no_f64_narrowing")) c->no_f64_narrowing = value != 0;
     else if (!strcmp(key, "dense_window_f32")) c->dense_window_f32 = value != 0;
     else if (!strcmp(key, "host_narrow")) c->host_narrow = value > 0 ? 1 : (value < 0 ? -1 : 0);
     else if (!strcmp(key, "no_csr_counts_path")) c->no_csr_counts_path = value != 0;

@@ -157,6 +157,7 @@ struct illico_ctx {
     bool no_csc_counts_mixed = false;  // 1: k_csc_counts with 8-bit cells for every value only (the form 4-bit overflows fall back to)
     bool no_ovr_one_pass = false;      // 1: dense OVR reads X twice (column histogram, then rank sums) instead of once
     bool no_csr_tile_gather = false;    // 1: CSR -> CSC always by the scatter form (k_csr_block_scatter), as for unsorted rows
+    bool no_f64_narrowing = false;      // 1: float64 sparse values that are all float32 values stay with the float64 kernels (A/B)
     bool no_csr_densify_any = false;    // 1: CSR windows with long columns of any values are never handed to the dense routes (A/B)
     bool no_csr_transpose_path = false; // 1: CSR is regrouped by (gene, group) with global atomics instead of being transposed to CSC
     bool dense_window_f32 = false;      // 1: CSR dense windows hold float32 cells instead of bytes

@@ -638,6 +638,20 @@ __global__ __launch_bounds__(256) void k_flat_descents(const IdxT *__restrict__ 
     }
 }
 
+// float64 values that are all float32 values (a float32 matrix widened somewhere on its way): *inexact != 0 if one is not.  Such a matrix
+// ranks, sums and divides to the same bits through the float32 kernels -- whose per-gene LDS buffers hold twice the keys.
+static __global__ __launch_bounds__(256) void k_f64_is_f32(const double *__restrict__ v, long long n, u32 *__restrict__ inexact) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double x = v[i];
+        bad |= !((double)(float)x == x); // (NaN: not taken)
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *inexact = 1u;
+}
+static __global__ __launch_bounds__(256) void k_f64_to_f32(const double *__restrict__ v, long long n, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = (float)v[i];
+}
+
 // replaces check_indices_sorted_per_parcel (utils/ranking.py:245-273) for device-resident CSR
 template <typename IdxT>
 __global__ void k_csr_sorted_check(const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr, int n_rows, int *__restrict__ bad) {

@@ -99,7 +99,8 @@ int illico_ctx_set_stream(illico_ctx *ctx, void *hip_stream);
  * "no_dense_window_path" (CSR through dense windows; "dense_window_f32" = 1: float32 cells instead of bytes), "no_csr_transpose_path" / "no_csr_tile_gather"
  * (CSR -> CSC transposition on the device / its gather form for sorted rows), "no_csr_counts_path" (count-valued CSR by the byte windows
  * instead of the group-major pass), "no_csr_densify_any" (sparse windows with columns of more than 32 768 stored entries stay with the
- * sparse routes instead of being written out dense).
+ * sparse routes instead of being written out dense), "no_f64_narrowing" (float64 sparse values that are all float32 values stay with the
+ * float64 kernels).
  * Not route switches: "host_narrow" (-1 automatic / 1 / 0: host-resident count matrices go up as bytes), "bound_ahead_genes" (0 = off:
  * a call for fewer genes of a bound CSR matrix computes the aligned window of that many genes around them once and later calls inside
  * the window are slices of it -- for bindings that keep the reference's 256-gene chunk loop).

@@ -911,3 +911,39 @@ def test_csc_with_long_columns_of_any_values_takes_the_dense_routes(engine, test
         engine.set_option("profile", 0)
     assert "k_densify" not in prof, prof
     assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"dense-ish csc {test}, a column out of order")
+
+
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+def test_float64_sparse_values_that_are_float32_values_take_the_float32_kernels(engine, fmt, test):
+    """A float32 matrix widened to float64 on its way (device-resident arrays): every stored value is a float32 value, so the float32
+    kernels -- whose per-gene LDS buffers hold twice the keys -- give the same bits: same planes as with `no_f64_narrowing`, and the
+    oracle's.  A matrix with ONE value that float32 cannot hold stays with the float64 kernels (same planes again)."""
+    import torch
+    rng = np.random.RandomState(2024)
+    n, m = 30_000, 150
+    X = (np.exp(rng.normal(0.0, 1.0, size=(n, m))).astype(np.float32) * (rng.rand(n, m) < 0.1)).astype(np.float64)
+    labels = make_labels(rng, n, 40, n_ref=1500)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    dev = torch.device("cuda", engine.device)
+    engine.set_groups(g)
+
+    def run(Xh):
+        M = (sparse.csr_matrix if fmt == "csr" else sparse.csc_matrix)(Xh)
+        d, i, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (M.data, M.indices, M.indptr))
+        return engine.run_sparse(fmt, d, i, p, M.shape, 0, m)
+
+    want = oracle.run(X, g)
+    got = run(X)
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"f64 holding f32 values {fmt} {test}")
+    engine.set_option("no_f64_narrowing", 1)
+    try:
+        wide = run(X)
+    finally:
+        engine.set_option("no_f64_narrowing", 0)
+    for a, b in zip(got, wide):
+        np.testing.assert_array_equal(a, b)
+    X2 = X.copy()
+    r, c = np.argwhere(X2 != 0)[123]
+    X2[r, c] = 1.0 + 2.0 ** -40                     # not a float32 value
+    assert_planes_match(run(X2), oracle.run(X2, g), ref_row=g.encoded_ref_group, what=f"f64 with one wide value {fmt} {test}")
