@@ -92,6 +92,11 @@ def parse(argv=None):
     ap.add_argument("--no-scopes", action="store_true", help="skip timing scopes (ii) and (iii)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the c5_strong object (BASELINE configs[4] in the same launch)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the objects c3 / c3_csr / c4 / c2_continuous_ovr (the other single-GPU BASELINE "
+                    "configs and one continuous line, measured in the same launch at N = 1)")
+    ap.add_argument("--extras-steps", type=int, default=10)
+    ap.add_argument("--extras-cpu-seconds", type=float, default=2.0, help="target wall time of each CPU baseline run of the extra configs")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="value type of the matrix handed to the engine (the workloads are float32: SURVEY.md 8d)")
     ap.add_argument("--c5-cells", type=int, default=1_000_000)
     ap.add_argument("--c5-genes", type=int, default=30_000)
     ap.add_argument("--c5-groups", type=int, default=5_000)
@@ -215,7 +220,7 @@ class Job:
     """One workload on this rank's GPU: data, engine calls, the gather; `measure` times it."""
 
     def __init__(self, torch, dist, eng, args, *, cells, genes_total, groups, sparsity, test, fmt, values, mean_max, seed,
-                 rank, world, device, scaling):
+                 rank, world, device, scaling, dtype="f32"):
         from illico_amd.distributed import rank_gene_range
         self.torch, self.dist, self.eng, self.args = torch, dist, eng, args
         self.rank, self.world, self.device = rank, world, device
@@ -240,14 +245,21 @@ class Job:
             self.nnz = int(self.csx[0].numel())
             self.X = None
             torch.cuda.empty_cache()
+        self.esize = 4
+        if dtype == "f64":  # the same values, widened (what a float32 matrix looks like after a float64 normalisation step upstream)
+            self.esize = 8
+            if self.sparse_fmt:
+                self.csx = (self.csx[0].double(), self.csx[1], self.csx[2])
+            else:
+                self.X = self.X.double()
         torch.cuda.synchronize()
         eng.set_groups(self.grpc)
 
     def alg_bytes(self):
         """input once + 4 B per cell of codes + three f64 planes (this rank's share)."""
         if self.sparse_fmt:
-            return self.nnz * 8 + ((self.M if self.sparse_fmt == "csc" else self.N) + 1) * 4 + 4 * self.N + 24 * self.G * self.M
-        return self.N * self.M * 4 + 4 * self.N + 24 * self.G * self.M
+            return self.nnz * (self.esize + 4) + ((self.M if self.sparse_fmt == "csc" else self.N) + 1) * 4 + 4 * self.N + 24 * self.G * self.M
+        return self.N * self.M * self.esize + 4 * self.N + 24 * self.G * self.M
 
     def setup(self, n_blocks, gather):
         from illico_amd.distributed import rank_gene_range, shard_bounds
@@ -348,7 +360,7 @@ class Job:
         torch = self.torch
         if not self.sparse_fmt:
             return self.X[:, cols].contiguous().cpu().numpy()
-        out = np.zeros((self.N, len(cols)), dtype=np.float32)
+        out = np.zeros((self.N, len(cols)), dtype=np.float32 if self.esize == 4 else np.float64)
         data, indices, indptr = self.csx
         if self.sparse_fmt == "csc":
             ip = indptr.cpu().numpy()
@@ -508,6 +520,95 @@ def roofline_of(job, m, steps, wl_key):
             "pipeline_note": "this rank's algorithmic bytes over its pass time (the gather excluded)"}
 
 
+def cpu_baseline_of(job, seconds):
+    """The oracle (C restatement of illico's algorithm, oracle/, -O3 -march=native, OpenMP over gene chunks, threads pinned one per
+    physical core) on a bounded sample of `job`'s workload -- all physical cores, and the reference's headline 8 threads -- each run
+    sized to ~`seconds` of wall time.  Test infrastructure timed as a reported baseline: nothing of it is in the product path."""
+    import oracle
+    from scipy import sparse as sp
+    oracle.use_native(True)
+    n_phys = oracle.pin_threads(True)
+    N, M, G, sparse_fmt = job.N, job.M, job.G, job.sparse_fmt
+    M_s = M if not sparse_fmt else int(job.X_sample.shape[1])
+
+    def sample(ns):
+        if sparse_fmt:  # the same stored entries in the same format, from the dense copy of the first genes
+            Xs = job.X_sample[:, :ns].contiguous().cpu().numpy()
+            return sp.csc_matrix(Xs) if sparse_fmt == "csc" else sp.csr_matrix(Xs)
+        return job.X[:, :ns].contiguous().cpu().numpy()
+
+    def timed(n_threads, batch):
+        """Probe with one batch per thread, then a run sized to ~`seconds`; returns (tests/s, genes, wall)."""
+        ns = min(M_s, n_threads * batch)
+        Xs = sample(ns)
+        t1 = time.perf_counter()
+        oracle.run(Xs, job.grpc, batch_size=batch, n_threads=n_threads)
+        el = time.perf_counter() - t1
+        ns2 = int(min(M_s, (G * ns / el) * seconds / G))
+        ns2 = max(n_threads * batch, (ns2 // (n_threads * batch)) * (n_threads * batch))
+        if ns2 > ns:
+            ns = min(ns2, M_s)
+            Xs = sample(ns)
+            t1 = time.perf_counter()
+            oracle.run(Xs, job.grpc, batch_size=batch, n_threads=n_threads)
+            el = time.perf_counter() - t1
+        return G * ns / el, ns, el
+
+    # all physical cores: chunks wide enough that the row gathers use whole cache lines, narrow enough to keep every
+    # core busy within the sample; 8 threads: the reference's 256-gene chunks (README.md:124 benchmarks)
+    b_all = int(max(8, min(256, M_s // max(n_phys, 1))))
+    v_all, ns_all, el_all = timed(n_phys, b_all)
+    v_8, ns_8, el_8 = timed(min(8, n_phys), int(min(256, max(8, M_s // 8))))
+    oracle.pin_threads(False)
+    oracle.use_native(False)
+    what = (f"same {N}x{M}x{G} {job.test.upper()} {job.fmt} workload; oracle/ (C restatement of illico's algorithm), -O3 -march=native, "
+            "OpenMP over gene chunks, threads pinned one per physical core")
+    return {"value": round(v_all, 1), "unit": "tests/s", "cores": n_phys, "kind": "port",
+            "sample": f"first {ns_all} genes in chunks of {b_all}, {el_all:.1f}s wall; {what}",
+            "at_8_threads": {"value": round(v_8, 1), "cores": min(8, n_phys), "sample": f"first {ns_8} genes, {el_8:.1f}s wall",
+                             "note": "the reference's headline setting (README.md:4: 8 threads)"},
+            "logical_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
+
+
+# the other single-GPU BASELINE configs and one continuous line, at the headline's shape, measured in the SAME launch (N = 1): the
+# reference's own benchmark matrix is dense + CSR x OVO + OVR (tests/test_asymptotic_wilcoxon.py:276-340)
+EXTRAS = {
+    "c3": dict(fmt="csc", test="ovo", sparsity=0.9, values="counts", workload="c3", label="BASELINE configs[2]: the headline's shape as CSC, 90 % zeros, OVO"),
+    "c3_csr": dict(fmt="csr", test="ovo", sparsity=0.9, values="counts", workload="c3", label="configs[2]'s matrix as CSR (AnnData's default container), OVO"),
+    "c4": dict(fmt="dense", test="ovr", sparsity=0.5, values="counts", workload="c4", label="BASELINE configs[3]: the headline's matrix, one-versus-rest"),
+    "c2_continuous_ovr": dict(fmt="dense", test="ovr", sparsity=0.5, values="continuous", workload="c2",
+                              label="the headline's shape with log-normalised values (SURVEY.md 8d's secondary stress), one-versus-rest"),
+}
+
+
+def extra_config(torch, dist, eng, args, device, tag):
+    """One more workload of the headline's shape in this launch: ms_per_step, roofline (dominant kernel timed live), parity, cpu_baseline."""
+    e = EXTRAS[tag]
+    t0 = time.perf_counter()
+    job = Job(torch, dist, eng, args, cells=args.cells, genes_total=args.genes, groups=args.groups, sparsity=e["sparsity"], test=e["test"], fmt=e["fmt"],
+              values=e["values"], mean_max=15.0, seed=args.seed, rank=0, world=1, device=device, scaling="strong")
+    t_gen = time.perf_counter() - t0
+    job.setup(1, gather=False)
+    m = measure(job, args.extras_steps, 1, settle=3)
+    m["pass_ms"] = m["ms_per_step"]
+    wl_key = {"workload": e["workload"], "cells": job.N, "genes_per_gpu": job.M, "groups": job.G, "test": e["test"], "format": e["fmt"],
+              "values": e["values"], "sparsity": e["sparsity"]}
+    r = roofline_of(job, m, args.extras_steps, wl_key)
+    keep = ("kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "algorithmic_bytes_per_launch",
+            "pipeline_frac", "all_kernels_ms_per_step")
+    out = {"workload": f"{e['fmt']} {job.N}x{job.M}x{job.G} {e['test'].upper()}" + ("" if e["values"] == "counts" else f" [{e['values']} values]"),
+           "what": e["label"], "format": e["fmt"], "test": e["test"], "values": e["values"], "sparsity": e["sparsity"], "nnz": job.nnz,
+           "steps": args.extras_steps, "ms_per_step": round(m["ms_per_step"], 4),
+           "tests_per_s": round(job.G * job.M / (m["ms_per_step"] * 1e-3), 1),
+           "roofline": None if r is None else dict({"bound": "hbm"}, **{k: r[k] for k in keep}),
+           "parity": None if args.no_parity else job.parity(16),
+           "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_of(job, args.extras_cpu_seconds),
+           "generate_s": round(t_gen, 1)}
+    del job
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -549,7 +650,7 @@ def main():
 
     N, G = args.cells, args.groups
     job_kw = dict(cells=N, genes_total=args.genes, groups=G, sparsity=args.sparsity, test=args.test, fmt=args.fmt, values=args.values,
-                  mean_max=args.mean_max, seed=args.seed, device=device)
+                  mean_max=args.mean_max, seed=args.seed, device=device, dtype=args.dtype)
     job = Job(torch, dist, eng, args, rank=rank, world=world, scaling=args.scaling, **job_kw)
     M, M_total, ovr, sparse_fmt, nnz = job.M, job.M_total, job.ovr, job.sparse_fmt, job.nnz
     in_step = world > 1 and not args.no_gather_in_step
@@ -604,6 +705,8 @@ def main():
                   "values": args.values, "sparsity": args.sparsity}
         if args.mean_max != 15.0:
             wl_key["mean_max"] = args.mean_max
+        if args.dtype != "f32":
+            wl_key["dtype"] = args.dtype
         roofline = roofline_of(job, m, args.steps, wl_key)
 
         # ---- parity of what was just timed: 16 genes of the final step's planes against the oracle ----
@@ -612,48 +715,7 @@ def main():
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample, threads pinned ----
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # contract: rank 0 at N = 1 only
-            import oracle
-            oracle.use_native(True)
-            n_phys = oracle.pin_threads(True)
-            from scipy import sparse as sp
-            M_s = M if not sparse_fmt else int(job.X_sample.shape[1])
-
-            def sample(ns):
-                if sparse_fmt:  # the same stored entries in the same format, from the dense copy of the first genes
-                    Xs = job.X_sample[:, :ns].contiguous().cpu().numpy()
-                    return sp.csc_matrix(Xs) if sparse_fmt == "csc" else sp.csr_matrix(Xs)
-                return job.X[:, :ns].contiguous().cpu().numpy()
-
-            def timed(n_threads, batch, seconds):
-                """Probe with one batch per thread, then a run sized to ~`seconds`; returns (tests/s, genes, wall)."""
-                ns = min(M_s, n_threads * batch)
-                Xs = sample(ns)
-                t1 = time.perf_counter()
-                oracle.run(Xs, job.grpc, batch_size=batch, n_threads=n_threads)
-                el = time.perf_counter() - t1
-                ns2 = int(min(M_s, (G * ns / el) * seconds / G))
-                ns2 = max(n_threads * batch, (ns2 // (n_threads * batch)) * (n_threads * batch))
-                if ns2 > ns:
-                    ns = min(ns2, M_s)
-                    Xs = sample(ns)
-                    t1 = time.perf_counter()
-                    oracle.run(Xs, job.grpc, batch_size=batch, n_threads=n_threads)
-                    el = time.perf_counter() - t1
-                return G * ns / el, ns, el
-
-            # all physical cores: chunks wide enough that the row gathers use whole cache lines, narrow enough to keep every
-            # core busy within the sample; 8 threads: the reference's 256-gene chunks (README.md:124 benchmarks)
-            b_all = int(max(8, min(256, M_s // max(n_phys, 1))))
-            v_all, ns_all, el_all = timed(n_phys, b_all, args.cpu_seconds)
-            v_8, ns_8, el_8 = timed(min(8, n_phys), int(min(256, max(8, M_s // 8))), args.cpu_seconds)
-            oracle.pin_threads(False)
-            oracle.use_native(False)
-            what = f"same {N}x{M}x{G} {args.test.upper()} {args.fmt} workload; oracle/ (C restatement of illico's algorithm), -O3 -march=native, OpenMP over gene chunks, threads pinned one per physical core"
-            cpu = {"value": round(v_all, 1), "unit": "tests/s", "cores": n_phys, "kind": "port",
-                   "sample": f"first {ns_all} genes in chunks of {b_all}, {el_all:.1f}s wall; {what}",
-                   "at_8_threads": {"value": round(v_8, 1), "cores": min(8, n_phys), "sample": f"first {ns_8} genes, {el_8:.1f}s wall",
-                                    "note": "the reference's headline setting (README.md:4: 8 threads)"},
-                   "logical_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
+            cpu = cpu_baseline_of(job, args.cpu_seconds)
 
         # ---- timing scopes (ii) engine + transfers and (iii) the drop-in call, SURVEY.md 8d ----
         scopes = {"engine_ms": round(ms_per_step, 4), "first_call_ms": round(m["first_call_ms"], 3),
@@ -704,7 +766,7 @@ def main():
         result = {
             "metric": "(group x gene) tests/sec", "value": round(value, 1), "unit": "tests/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["label"].format(N=N, M=M_total, G=G) + ("" if args.values == "counts" else f" [{args.values} values]"),
                        "workload_id": args.workload, "cells": N, "genes_per_gpu": M, "genes_total": M_total, "groups": G, "format": args.fmt,
                        "test": args.test, "sparsity": args.sparsity, "values": args.values, "gene_mean_max": args.mean_max, "nnz_per_gpu": nnz,
@@ -730,10 +792,19 @@ def main():
                                           "one_pass_plus_gather_ms": round(ms_per_step + gather_ms, 3),
                                           "tests_per_s_pass_plus_gather": round(tests_per_step / ((ms_per_step + gather_ms) * 1e-3), 1)}
 
+    del job
+    torch.cuda.empty_cache()
+
+    # ---- the other single-GPU BASELINE configs (and one continuous line) in the same launch ----
+    if world == 1 and not args.no_extras:
+        for tag in EXTRAS:
+            try:
+                result[tag] = extra_config(torch, dist, eng, args, device, tag)
+            except (MemoryError, RuntimeError) as e:
+                result[tag] = {"skipped": f"{type(e).__name__}: {str(e)[:300]}"}
+
     # ---- BASELINE configs[4] in the same launch: 1M x 30k x 5k dense OVO, genes split over the ranks ----
     if not args.no_c5:
-        del job
-        torch.cuda.empty_cache()
         c5 = None
         try:
             t_gen = time.perf_counter()

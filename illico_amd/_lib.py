@@ -30,7 +30,7 @@ SYMBOLS = [
     "illico_last_error", "illico_ctx_synchronize", "illico_set_groups", "illico_run_dense", "illico_run_csc",
     "illico_run_csr", "illico_csr_indices_sorted", "illico_rank_statistics", "illico_profile_num_kernels", "illico_profile_kernel_name",
     "illico_profile_get", "illico_profile_reset", "illico_version", "illico_csr_bind", "illico_csc_bind", "illico_run_bound",
-    "illico_matrix_release", "illico_profile_input_bytes", "illico_planes_to_host",
+    "illico_matrix_release", "illico_matrix_touch", "illico_profile_input_bytes", "illico_planes_to_host",
 ]
 
 _lib = None
@@ -72,6 +72,7 @@ def load() -> ctypes.CDLL:
             f.argtypes = [vp, vp, ci, vp, vp, ci, i64, i64, ci, ctypes.POINTER(vp)]
         lib.illico_run_bound.argtypes = [vp, vp, i64, i64, ci, ci, vp, vp, vp, i64]
         lib.illico_matrix_release.argtypes = [vp, vp]
+        lib.illico_matrix_touch.argtypes = [vp, vp]
         lib.illico_profile_input_bytes.argtypes = [vp, ctypes.POINTER(i64)]
         lib.illico_planes_to_host.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64]
         for name in SYMBOLS:  # fail at load time, not at first use, if the library and the header have drifted
@@ -353,8 +354,16 @@ class Engine:
         if not (_is_torch_tensor(planes) and planes.is_cuda and planes.is_contiguous() and planes.dim() == 3 and planes.shape[0] == 3):
             raise ValueError("planes_to_host wants a contiguous CUDA tensor of shape [3, n_groups, n_cols]")
         _, G, W = (int(x) for x in planes.shape)
+        import torch
+        if planes.dtype != torch.float64:
+            raise ValueError(f"planes_to_host wants float64 planes, got {planes.dtype}")
+        if G != getattr(self, "n_groups", -1):  # the library copies n_groups rows per plane: the groups last set on this engine
+            raise ValueError(f"planes hold {G} groups, the engine's groups are {getattr(self, 'n_groups', None)} (set_groups first)")
         if out is None:
             out = np.empty((3, G, W), dtype=np.float64)
+        elif not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (3, G, W) and out.strides[2] == 8
+                  and out.strides[1] % 8 == 0 and out.strides[1] >= 8 * W and out.flags.writeable):
+            raise ValueError("out must be a writeable float64 ndarray [3, n_groups, n_cols] whose rows are contiguous")
         self._bind_torch_stream(planes)
         esz = planes.element_size()
         base = planes.data_ptr()
@@ -441,6 +450,10 @@ class BoundMatrix:
         eng._bind_torch_stream(*planes)
         eng._check(eng.lib.illico_run_bound(eng.h, self.h, col_lb, col_ub, flags, alt, ptrs[0], ptrs[1], ptrs[2], out_ld))
         return planes
+
+    def touch(self):
+        """Adopted device arrays were rewritten in place: forget what the context remembers about them (include/illico_hip.h)."""
+        self.engine._check(self.engine.lib.illico_matrix_touch(self.engine.h, self.h))
 
     def release(self):
         if self.h is not None and self.h.value and getattr(self.engine, "h", None) is not None and self.engine.h.value:

@@ -64,7 +64,11 @@ def needs_build() -> bool:
     tag = " ".join(_flags())
     if not SO.exists() or not STAMP.exists() or STAMP.read_text() != tag + " | " + " ".join(_units()):
         return True
-    return any(_unit_stale(u, tag) for u in _units())
+    if any(_unit_stale(u, tag) for u in _units()):
+        return True
+    # objects newer than the library: every unit compiled but the link failed or was interrupted -- the library on disk is the OLD one
+    t = SO.stat().st_mtime
+    return any((OBJ / f"{u}.o").stat().st_mtime > t for u in _units())
 
 
 def _compile(unit: str, hipcc: str, flags: list[str], verbose: bool) -> tuple[str, int, str]:
@@ -94,6 +98,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     bad = [(u, out) for u, rc, out in results if rc != 0]
     if bad:
         raise RuntimeError("hipcc failed:\n" + "\n".join(f"--- {u} ---\n{out}" for u, out in bad))
+    STAMP.unlink(missing_ok=True)  # (written again only after a successful link)
     cmd = [hipcc, *LDFLAGS, "-o", str(SO), *[str(OBJ / f"{u}.o") for u in units]]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -748,8 +748,12 @@ int run_sparse_inner(illico_ctx *c, bool is_csr, const void *data, int dtype, co
 static int resolve_pending_csc(illico_ctx *c, const PendingDense &q) {
     const u32 *hf = (const u32 *)c->pend_pinned[q.slot];
     const int64_t W = q.col_ub - q.col_lb;
+    // what is known about the rows' order belongs to the matrix of the call that is running: while a PENDING call's columns are recomputed
+    // it is that call's knowledge that holds (another bound matrix may be the running one: illico_run_bound sets the flag before it gets here)
+    struct Sorted { illico_ctx *c; bool was; Sorted(illico_ctx *c_, bool now) : c(c_), was(c_->cur_sorted_known) { c->cur_sorted_known = now; }
+                    ~Sorted() { c->cur_sorted_known = was; } } sorted_scope(c, q.is_csr && q.sorted_known);
     if (q.is_csr) { // the group-major CSR pass: flags + 4 verdict words; its leftovers must not come back to it
-        struct Hold { illico_ctx *c; Hold(illico_ctx *c_) : c(c_) { c->hold_csr_counts = true; } ~Hold() { c->hold_csr_counts = false; } } hold(c);
+        struct Hold { illico_ctx *c; bool was; Hold(illico_ctx *c_) : c(c_), was(c_->hold_csr_counts) { c->hold_csr_counts = true; } ~Hold() { c->hold_csr_counts = was; } } hold(c);
         const u32 *vd = hf + W;
         int64_t n_flagged = 0;
         for (int64_t j = 0; j < W; ++j) n_flagged += hf[j] ? 1 : 0;
@@ -853,6 +857,24 @@ extern "C" int illico_run_csr(illico_ctx *c, const void *data, int dtype, const 
 }
 
 // ---- bound matrices -------------------------------------------------------------------------
+// the rows' order of a bound CSR matrix, looked at once: the group-major CSR pass of every later call relies on it
+static void look_at_row_order(illico_ctx *c, illico_matrix *m) {
+    m->sorted = -1;
+    if (!m->is_csr || m->n_rows >= (1ll << 31)) return;
+    void *v;
+    int bad = 0;
+    if (get_scratch(c, "flag", 16, &v) == ILLICO_OK && hipMemsetAsync(v, 0, 4, c->stream) == hipSuccess) {
+        const unsigned grid = (unsigned)std::min<int64_t>((m->n_rows + 3) / 4 + 1, 8192);
+        if (m->idx_dtype == ILLICO_IDX_I32)
+            hipLaunchKernelGGL((k_csr_sorted_check<int32_t>), dim3(grid), dim3(256), 0, c->stream, (const int32_t *)m->d_indices, (const int32_t *)m->d_indptr, (int)m->n_rows, (int *)v);
+        else
+            hipLaunchKernelGGL((k_csr_sorted_check<int64_t>), dim3(grid), dim3(256), 0, c->stream, (const int64_t *)m->d_indices, (const int64_t *)m->d_indptr, (int)m->n_rows, (int *)v);
+        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, v, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+            hipStreamSynchronize(c->stream) == hipSuccess)
+            m->sorted = bad ? 0 : 1;
+    }
+}
+
 static int sparse_bind(illico_ctx *c, bool is_csr, const void *data, int dtype, const void *indices, const void *indptr, int idx_dtype,
                        int64_t n_rows, int64_t n_cols, int flags, illico_matrix **out) {
     if (!c || !out) return ILLICO_ERR_ARG;
@@ -895,20 +917,7 @@ static int sparse_bind(illico_ctx *c, bool is_csr, const void *data, int dtype, 
         }
         c->h2d_input_bytes += (int64_t)((size_t)nnz * (vsz + isz) + (size_t)n_ptr * isz);
     }
-    if (is_csr && n_rows < (1ll << 31)) { // the rows' order, once: the group-major CSR pass of every later call relies on it
-        void *v;
-        int bad = 0;
-        if (get_scratch(c, "flag", 16, &v) == ILLICO_OK && hipMemsetAsync(v, 0, 4, c->stream) == hipSuccess) {
-            const unsigned grid = (unsigned)std::min<int64_t>((n_rows + 3) / 4 + 1, 8192);
-            if (idx_dtype == ILLICO_IDX_I32)
-                hipLaunchKernelGGL((k_csr_sorted_check<int32_t>), dim3(grid), dim3(256), 0, c->stream, (const int32_t *)m->d_indices, (const int32_t *)m->d_indptr, (int)n_rows, (int *)v);
-            else
-                hipLaunchKernelGGL((k_csr_sorted_check<int64_t>), dim3(grid), dim3(256), 0, c->stream, (const int64_t *)m->d_indices, (const int64_t *)m->d_indptr, (int)n_rows, (int *)v);
-            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad, v, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-                hipStreamSynchronize(c->stream) == hipSuccess)
-                m->sorted = bad ? 0 : 1;
-        }
-    }
+    look_at_row_order(c, m);
     c->bound.push_back(m);
     *out = m;
     return ILLICO_OK;
@@ -1024,6 +1033,18 @@ extern "C" int illico_matrix_release(illico_ctx *c, illico_matrix *m) {
     for (auto &a : c->ahead) if (a.m == m) a.m = nullptr;
     if (m->owns) { hipFree(m->d_data); hipFree(m->d_indices); hipFree(m->d_indptr); }
     delete m;
+    return rc;
+}
+
+extern "C" int illico_matrix_touch(illico_ctx *c, illico_matrix *m) {
+    if (!c || !m) return ILLICO_ERR_ARG;
+    CTX_LOCK(c);
+    if (m->owner != c || std::find(c->bound.begin(), c->bound.end(), m) == c->bound.end())
+        return fail(c, ILLICO_ERR_ARG, "the matrix handle does not belong to this context (or was released)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = resolve_pending(c); // (a deferred call on the arrays as they were completes first)
+    for (auto &a : c->ahead) if (a.m == m) a.m = nullptr;
+    look_at_row_order(c, m);
     return rc;
 }
 

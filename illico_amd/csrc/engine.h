@@ -74,6 +74,7 @@ struct PendingDense {
     const void *X = nullptr;
     int dtype = 0, flags = 0, alternative = 0, slot = 0;
     bool is_csr = false;          // kind 1: the arrays are CSR (the group-major count pass, kernels_csr_counts.h)
+    bool sorted_known = false;    // kind 1, CSR: the matrix was bound and its rows found in order (illico_ctx::cur_sorted_known when the call was made)
     int64_t N = 0, ld = 0, col_lb = 0, col_ub = 0, out_ld = 0;
     double *p = nullptr, *u = nullptr, *fc = nullptr;
 };

@@ -648,6 +648,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
         PendingDense &q = c->pend;
         q = PendingDense();
         q.on = true; q.kind = 1; q.is_csr = true; q.sp_data = data; q.sp_indices = indices; q.sp_indptr = indptr;
+        q.sorted_known = c->cur_sorted_known;
         q.idx_dtype = (int)(sizeof(IdxT) == 4 ? ILLICO_IDX_I32 : ILLICO_IDX_I64); q.n_cols = n_cols;
         q.dtype = dtype; q.flags = flags & ~ILLICO_FLAG_DEFER; q.alternative = alternative; q.slot = slot; q.N = n_rows;
         q.col_lb = col_lb; q.col_ub = col_ub; q.out_ld = o.ld; q.p = o.p; q.u = o.u; q.fc = o.fc;
@@ -813,7 +814,8 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     // ---- float64 values that are float32 values throughout (device-resident input, nothing count-valued took it above): the float32
     // kernels give the same bits and hold twice the keys per gene in LDS (C3 shape as CSR, continuous: 14 - 17 ms in float64, 6 in float32) ----
     if constexpr (std::is_same<InT, double>::value) {
-        if (is_csr && in_dev && allow_dense_window && allow_transpose && allow_csr_counts && !indices_are_codes && !c->no_f64_narrowing && !c->tap && total_nnz > 0) {
+        if (is_csr && in_dev && allow_dense_window && allow_transpose && allow_csr_counts && !indices_are_codes && !c->no_f64_narrowing && !c->tap && total_nnz > 0 &&
+            !(flags & ILLICO_FLAG_LOG1P)) { // (is_log1p: the float32 kernels form expm1 in float32, the float64 ones and the reference -- utils/sparse/csr.py:282 -- in float64)
             const long long k0 = 0, k1 = (long long)total_nnz;
             if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
             u32 *d_inexact = (u32 *)v;
@@ -1000,7 +1002,8 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     }
     // ---- CSC in float64 whose stored values are float32 values throughout: as for CSR above, behind the histogram route ----
     if constexpr (std::is_same<InT, double>::value) {
-        if (!is_csr && in_dev && allow_dense_window && !indices_are_codes && !c->no_f64_narrowing && !c->tap && (int64_t)cols.size() == W && W > 0) {
+        if (!is_csr && in_dev && allow_dense_window && !indices_are_codes && !c->no_f64_narrowing && !c->tap && (int64_t)cols.size() == W && W > 0 &&
+            !(flags & ILLICO_FLAG_LOG1P)) { // (utils/sparse/csc.py:207: expm1 of float64 data)
             const long long k0 = (long long)h_indptr[col_lb], k1 = (long long)h_indptr[col_ub];
             if (k1 > k0) {
                 if ((rc = get_scratch(c, "flag", 16, &v))) return rc;

@@ -156,6 +156,12 @@ int illico_csc_bind(illico_ctx *ctx, const void *data, int dtype, const void *in
 int illico_run_bound(illico_ctx *ctx, const illico_matrix *matrix, int64_t col_lb, int64_t col_ub, int flags, int alternative,
                      double *out_p, double *out_u, double *out_fc, int64_t out_ld);
 int illico_matrix_release(illico_ctx *ctx, illico_matrix *matrix);
+/* Adopted device arrays (ILLICO_FLAG_INPUT_DEVICE) stay the caller's: they must not change while a call on them is in flight, and what
+ * the context remembers about a bound matrix -- whether its CSR rows are in order (looked at once, at bind time) and, with the option
+ * "bound_ahead_genes", result windows computed ahead of the chunk calls -- describes the arrays as they were.  A caller that rewrites
+ * adopted arrays in place (normalise, log1p_) calls illico_matrix_touch afterwards: windows of the matrix are dropped, the row order is
+ * looked at again.  (Uploaded matrices are the library's own copy and never need it.) */
+int illico_matrix_touch(illico_ctx *ctx, illico_matrix *matrix);
 
 /* replaces check_indices_sorted_per_parcel (utils/ranking.py:245-273); *out_sorted = 1/0. */
 int illico_csr_indices_sorted(illico_ctx *ctx, const void *indices, const void *indptr, int idx_dtype,

@@ -79,6 +79,26 @@ def test_two_ranks_spawned_by_bench_itself_gloo_shared_device():
     assert one["config"]["genes_total"] == 256 and "final_gather" not in one
     assert one["c5_strong"]["genes_per_gpu"] == 192 and one["c5_strong"]["bytes_into_rank0"] == 0 and one["c5_strong"]["ms_gather_alone"] == 0
     assert one["single_call"]["blocks"] == 1 and one["single_call"]["ms_single_call"] > 0 and "speedup_vs_n1" not in one["single_call"]
+    # the other single-GPU BASELINE configs and one continuous line ride in the same (N = 1) line, at the headline's shape
+    assert all(k not in two for k in ("c3", "c3_csr", "c4", "c2_continuous_ovr"))
+    for tag, fmt, test, values in (("c3", "csc", "ovo", "counts"), ("c3_csr", "csr", "ovo", "counts"), ("c4", "dense", "ovr", "counts"),
+                                   ("c2_continuous_ovr", "dense", "ovr", "continuous")):
+        x = one[tag]
+        assert (x["format"], x["test"], x["values"]) == (fmt, test, values), x
+        assert x["ms_per_step"] > 0 and x["tests_per_s"] == pytest.approx(50 * 256 / (x["ms_per_step"] * 1e-3), rel=1e-3)
+        rf = x["roofline"]
+        assert rf["bound"] == "hbm" and rf["kernel"] and 0 < rf["frac"] < 1 and 0 < rf["pipeline_frac"] < 1 and "traffic" in rf and rf["avg_launch_ms"] > 0
+        assert x["parity"]["statistic_mismatches"] == 0 and x["parity"]["p_value_max_rel_err"] <= 1e-12 and x["parity"]["fold_change_max_rel_err"] <= 1e-12
+        assert x["cpu_baseline"] is None   # (--no-cpu-baseline in `common`)
+    # ... with their CPU baselines when the headline has one
+    r3 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--cells", "20000", "--genes", "256", "--groups", "50",
+                         "--no-scopes", "--no-c5", "--no-single-call", "--cpu-seconds", "0.3", "--extras-cpu-seconds", "0.2", "--extras-steps", "2"],
+                        capture_output=True, text=True, env=env, timeout=900)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    ex = json.loads([l for l in r3.stdout.splitlines() if l.startswith("{")][0])
+    for tag in ("c3", "c3_csr", "c4", "c2_continuous_ovr"):
+        cb = ex[tag]["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["at_8_threads"]["value"] > 0 and "sample" in cb
     # weak scaling on request: every rank a full shard; the gather outside the step on request
     r2 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--scaling", "weak",
                          "--no-gather-in-step", "--no-c5", *common], capture_output=True, text=True, env=env, timeout=900)

@@ -834,6 +834,47 @@ def test_bound_csr_chunk_calls_are_served_from_windows_computed_ahead(engine, te
         bm.release()
 
 
+def test_adopted_arrays_rewritten_in_place_are_looked_at_again_after_touch(engine):
+    """`illico_matrix_touch` (include/illico_hip.h): a bound matrix that ADOPTED device arrays remembers windows computed ahead and
+    the rows' order; the caller rewrites the values in place (a normalisation) and reverses every row's entries (rows no longer in
+    order), touches the handle, and gets the new matrix's results -- not slices of the old windows, not a pass that trusts the old order."""
+    import torch
+    rng = np.random.RandomState(4)
+    n, m = 2500, 700
+    X = (rng.poisson(rng.uniform(0.3, 9.0, size=m), size=(n, m)) * (rng.rand(n, m) < 0.2)).astype(np.float32)
+    labels = make_labels(rng, n, 9, n_ref=200)
+    M = sparse.csr_matrix(X)
+    dev = torch.device("cuda", engine.device)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    engine.set_groups(g)
+    d, i, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (M.data, M.indices, M.indptr))
+    bm = engine.bind_sparse("csr", d, i, p, M.shape)
+    engine.set_option("bound_ahead_genes", 512)
+    try:
+        got = bm.run(100, 200)
+        assert_planes_match(got, tuple(a[:, 100:200] for a in oracle.run(X, g)), ref_row=g.encoded_ref_group, what="adopted, first")
+        # in place: other values, and every row's entries in descending column order
+        X2 = X.copy()
+        X2[X2 > 0] += 3.0
+        M2 = sparse.csr_matrix(X2)
+        data2, idx2 = M2.data.copy(), M2.indices.copy()
+        for r in range(n):
+            a, b = M2.indptr[r], M2.indptr[r + 1]
+            data2[a:b] = data2[a:b][::-1]
+            idx2[a:b] = idx2[a:b][::-1]
+        d.copy_(torch.from_numpy(data2).to(dev))
+        i.copy_(torch.from_numpy(idx2).to(dev))
+        bm.touch()
+        want = oracle.run(X2, g)
+        got = bm.run(100, 200)
+        assert_planes_match(got, tuple(a[:, 100:200] for a in want), ref_row=g.encoded_ref_group, what="adopted, rewritten, chunk")
+        got = bm.run(0, m)
+        assert_planes_match(got, want, ref_row=g.encoded_ref_group, what="adopted, rewritten, whole")
+    finally:
+        engine.set_option("bound_ahead_genes", 0)
+        bm.release()
+
+
 @pytest.mark.parametrize("test", ["ovo", "ovr"])
 @pytest.mark.parametrize("dtype,idx", [(np.float32, np.int32), (np.float64, np.int64)])
 def test_csr_with_long_columns_of_any_values_takes_the_dense_routes(engine, test, dtype, idx):
@@ -947,3 +988,30 @@ def test_float64_sparse_values_that_are_float32_values_take_the_float32_kernels(
     r, c = np.argwhere(X2 != 0)[123]
     X2[r, c] = 1.0 + 2.0 ** -40                     # not a float32 value
     assert_planes_match(run(X2), oracle.run(X2, g), ref_row=g.encoded_ref_group, what=f"f64 with one wide value {fmt} {test}")
+
+
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_float64_sparse_values_with_is_log1p_keep_the_float64_kernels(engine, fmt):
+    """is_log1p: the reference forms expm1 of the float64 data in float64 (utils/sparse/csr.py:282, csc.py:207), the float32 kernels
+    in float32 -- a fold change 1e-7 apart.  So a float64 matrix that holds float32 values is NOT narrowed when is_log1p is set:
+    the planes are the oracle's at rtol 1e-12 and bit for bit those of `no_f64_narrowing`."""
+    import torch
+    rng = np.random.RandomState(7)
+    n, m = 20_000, 96
+    X = (np.log1p(np.exp(rng.normal(0.0, 1.0, size=(n, m)))).astype(np.float32) * (rng.rand(n, m) < 0.1)).astype(np.float64)
+    labels = make_labels(rng, n, 30, n_ref=1000)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    dev = torch.device("cuda", engine.device)
+    engine.set_groups(g)
+    M = (sparse.csr_matrix if fmt == "csr" else sparse.csc_matrix)(X)
+    d, i, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (M.data, M.indices, M.indptr))
+    want = oracle.run(M, g, is_log1p=True)
+    got = engine.run_sparse(fmt, d, i, p, M.shape, 0, m, is_log1p=True)
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"f64 holding f32 values, is_log1p, {fmt}")
+    engine.set_option("no_f64_narrowing", 1)
+    try:
+        wide = engine.run_sparse(fmt, d, i, p, M.shape, 0, m, is_log1p=True)
+    finally:
+        engine.set_option("no_f64_narrowing", 0)
+    for a, b in zip(got, wide):
+        np.testing.assert_array_equal(a, b)

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 for L in "${LIBS[@]}"; do
   cp $L $SO
   rm -rf gpurun_out/kt_ab
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_ab -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-scopes --no-parity --no-c5 --no-single-call "$@" > gpurun_out/kt_ab.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_ab -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-scopes --no-parity --no-c5 --no-extras --no-single-call "$@" > gpurun_out/kt_ab.log 2>&1
   f=$(find gpurun_out/kt_ab -name "*kernel_stats.csv" | head -1)
   python3 - "$f" "$PFX" "$L" <<'PY'
 import csv, sys

@@ -11,24 +11,24 @@ O=gpurun_out
 mkdir -p $O
 b() { name=$1; shift; python3 bench.py "$@" > $O/${T}_bench_$name.json 2> $O/${T}_bench_$name.err; echo "bench $name rc=$?"; }
 want b1 && b c2 
-want b1 && b c3 --workload c3 --no-c5
-want b1 && b c3_ovr --workload c3 --test ovr --no-c5
-want b1 && b c4 --workload c4 --no-c5
-want b1 && b c5shard --workload c5shard --no-c5
-want b1 && b c5_one_gpu --workload c5 --no-c5 --steps 5 --warmup 1
-want b1 && b c2_nb --workload c2 --values nb --no-c5
-want b2 && b c2_nb_ovr --workload c2 --values nb --test ovr --no-c5
-want b2 && b c2_cont_ovo --workload c2 --values continuous --no-c5 --steps 10
-want b2 && b c2_cont_ovr --workload c2 --values continuous --test ovr --no-c5 --steps 10
-want b2 && b c3_cont_ovo --workload c3 --values continuous --no-c5 --steps 10
-want b2 && b c3_cont_ovr --workload c3 --values continuous --test ovr --no-c5 --steps 10
-want b2 && b c3_csr --workload c3 --format csr --no-c5 --steps 10
-want b2 && b c3_csr_ovr --workload c3 --format csr --test ovr --no-c5 --steps 10
-want b3 && b c3_csr_cont_ovo --workload c3 --format csr --values continuous --no-c5 --steps 10
-want b3 && b c3_csr_cont_ovr --workload c3 --format csr --values continuous --test ovr --no-c5 --steps 10
-want b3 && b c2_cont_g50 --workload c2 --values continuous --groups 50 --no-c5 --steps 5
-want b3 && b c3_cont_g300 --workload c3 --values continuous --groups 300 --no-c5 --steps 5
-want b3 && b c3_cont_ovr_g6000 --workload c3 --values continuous --test ovr --groups 6000 --no-c5 --steps 5
+want b1 && b c3 --workload c3 --no-c5 --no-extras
+want b1 && b c3_ovr --workload c3 --test ovr --no-c5 --no-extras
+want b1 && b c4 --workload c4 --no-c5 --no-extras
+want b1 && b c5shard --workload c5shard --no-c5 --no-extras
+want b1 && b c5_one_gpu --workload c5 --no-c5 --no-extras --steps 5 --warmup 1
+want b1 && b c2_nb --workload c2 --values nb --no-c5 --no-extras
+want b2 && b c2_nb_ovr --workload c2 --values nb --test ovr --no-c5 --no-extras
+want b2 && b c2_cont_ovo --workload c2 --values continuous --no-c5 --no-extras --steps 10
+want b2 && b c2_cont_ovr --workload c2 --values continuous --test ovr --no-c5 --no-extras --steps 10
+want b2 && b c3_cont_ovo --workload c3 --values continuous --no-c5 --no-extras --steps 10
+want b2 && b c3_cont_ovr --workload c3 --values continuous --test ovr --no-c5 --no-extras --steps 10
+want b2 && b c3_csr --workload c3 --format csr --no-c5 --no-extras --steps 10
+want b2 && b c3_csr_ovr --workload c3 --format csr --test ovr --no-c5 --no-extras --steps 10
+want b3 && b c3_csr_cont_ovo --workload c3 --format csr --values continuous --no-c5 --no-extras --steps 10
+want b3 && b c3_csr_cont_ovr --workload c3 --format csr --values continuous --test ovr --no-c5 --no-extras --steps 10
+want b3 && b c2_cont_g50 --workload c2 --values continuous --groups 50 --no-c5 --no-extras --steps 5
+want b3 && b c3_cont_g300 --workload c3 --values continuous --groups 300 --no-c5 --no-extras --steps 5
+want b3 && b c3_cont_ovr_g6000 --workload c3 --values continuous --test ovr --groups 6000 --no-c5 --no-extras --steps 5
 p() { name=$1; shift; bash tools/profile_bench.sh ${T}_$name "$@" > $O/prof_$name.log 2>&1; echo "profile $name rc=$?"; }
 want p1 && p c2 --workload c2
 want p1 && p c3 --workload c3
