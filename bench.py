@@ -96,7 +96,9 @@ def parse(argv=None):
                     "configs and one continuous line, measured in the same launch at N = 1)")
     ap.add_argument("--extras-steps", type=int, default=10)
     ap.add_argument("--extras-cpu-seconds", type=float, default=2.0, help="target wall time of each CPU baseline run of the extra configs")
-    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="value type of the matrix handed to the engine (the workloads are float32: SURVEY.md 8d)")
+    ap.add_argument("--dtype", choices=["f32", "f64", "f64w"], default="f32",
+                    help="value type of the matrix handed to the engine (the workloads are float32: SURVEY.md 8d).  f64: genuine doubles (every non-zero "
+                         "value times 1 + 2^-30: no float32 holds it); f64w: the float32 values widened (what the engine may narrow again)")
     ap.add_argument("--c5-cells", type=int, default=1_000_000)
     ap.add_argument("--c5-genes", type=int, default=30_000)
     ap.add_argument("--c5-groups", type=int, default=5_000)
@@ -246,12 +248,14 @@ class Job:
             self.X = None
             torch.cuda.empty_cache()
         self.esize = 4
-        if dtype == "f64":  # the same values, widened (what a float32 matrix looks like after a float64 normalisation step upstream)
+        if dtype in ("f64", "f64w"):  # f64w: the same values, widened (a float32 matrix after a float64 step upstream); f64: no longer float32 values
             self.esize = 8
+            scale = 1.0 + 2.0 ** -30 if dtype == "f64" else 1.0
             if self.sparse_fmt:
-                self.csx = (self.csx[0].double(), self.csx[1], self.csx[2])
+                self.csx = (self.csx[0].double() * scale, self.csx[1], self.csx[2])
+                self.X_sample = self.X_sample.double() * scale
             else:
-                self.X = self.X.double()
+                self.X = self.X.double() * scale
         torch.cuda.synchronize()
         eng.set_groups(self.grpc)
 
@@ -487,6 +491,41 @@ def single_call_of(torch, dist, eng, args, job, job_kw, n_blocks, tests, steady_
         out["n1_reference"] = n1
         if n1 and "ms_single_call" in n1:
             out["speedup_vs_n1"] = round(n1["ms_single_call"] / ms, 3)
+    # ---- the drop-in scope of the same call: the planes on the HOST.  Every rank's engine writes host planes that are its own column
+    # range of ONE shared [3][G][M] result (illico_amd.distributed.SharedHostPlanes: what asymptotic_wilcoxon_sharded's default tail
+    # does) -- N PCIe links side by side, nothing over xGMI -- the clock stopped when every rank's planes have landed.
+    try:
+        from illico_amd.distributed import SharedHostPlanes, shard_bounds
+        shared = SharedHostPlanes(job.G, job.M_total, group=None)
+        nb = max(1, n_blocks)
+
+        def to_host_once():
+            job.sync()
+            t0 = time.perf_counter()
+            for lb, ub in shard_bounds(job.M, nb):
+                if ub > lb:
+                    job.run_block(lb, ub, shared.columns(job.g_lb + lb, job.g_lb + ub), defer=False)
+            job.eng.synchronize()
+            shared.barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=job.device if args.backend == "nccl" else torch.device("cpu"))
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt * 1e3
+
+        first = to_host_once()          # (the mapping's pages are touched here)
+        runs = [to_host_once() for _ in range(3)]
+        med = float(np.median(runs))
+        out["ms_to_host"] = round(med, 3)
+        out["to_host"] = {"runs_ms": [round(r, 3) for r in runs], "first_ms_fresh_mapping": round(first, 3), "blocks_per_rank": nb,
+                          "bytes_to_host_per_rank": 24 * job.G * job.M, "bytes_to_host_total": 24 * job.G * job.M_total,
+                          "aggregate_GBs": round(24 * job.G * job.M_total / (med * 1e-3) / 1e9, 1),
+                          "note": "one call, planes on the host: each rank's engine writes its own column range of one shared host result over its "
+                                  "own PCIe link (no gather); max over ranks, median of 3"}
+        del shared
+    except (OSError, MemoryError, RuntimeError) as e:
+        out["to_host"] = {"skipped": f"{type(e).__name__}: {str(e)[:200]}"}
     return out
 
 

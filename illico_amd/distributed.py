@@ -5,13 +5,23 @@ illico/asymptotic_wilcoxon.py:213-241), so rank r of R computes a contiguous gen
 exchange; the only collective is the gather of the three float64 result planes to rank 0, issued per
 gene block so that it overlaps the next block's compute.
 
+Two tails for the drop-in call (whose consumer is a host DataFrame): the default brings every rank's planes to the host over that
+rank's OWN PCIe link, straight into its column range of ONE [3][G][M] result in POSIX shared memory (`SharedHostPlanes`) -- the
+reference's workers write their slices of one host result the same way, illico/asymptotic_wilcoxon.py:236-244; 8 links x ~55 GB/s
+instead of 7 peers' planes over xGMI into rank 0 and then 3.6 GB (configs[4]) through rank 0's one link.  The device tail (RCCL p2p
+gather into one device tensor on rank 0) stays for consumers that want the planes on a GPU.  `asymptotic_wilcoxon_threads` is the
+single-process form (one host thread + one context per device, no process group at all: SURVEY.md 8e allows either).
+
 Ranges are balanced by gene COUNT for dense input and by STORED ENTRIES for sparse input (SURVEY.md 8e:
 "for sparse inputs balance by nnz rather than gene count"; the unit of work of the reference's sparse
 kernels is the stored entry, illico/ovo/sparse_ovo.py:163-210).
 """
 from __future__ import annotations
 
+import mmap
+import os
 import threading
+import uuid
 
 import numpy as np
 
@@ -130,6 +140,66 @@ def gather_block_p2p(stage, recv_bufs, rank: int, world: int, dst: int = 0, grou
     return works
 
 
+class SharedHostPlanes:
+    """ONE float64 [3][n_groups][n_genes] host result that every rank of the node maps (POSIX shared memory: a file under /dev/shm,
+    i.e. what shm_open makes; unlinked as soon as every rank has mapped it, so nothing outlives the processes).  Rank `dst` creates it
+    and broadcasts its name; every rank writes its own column range; after `barrier()` rank `dst` reads all of it.  ``array`` is backed
+    by the mapping and keeps it alive: the DataFrame built over it (copy=False) needs no further bookkeeping.  Collective: every rank
+    of `group` constructs it.  Without a process group (world 1) it is an anonymous mapping."""
+
+    def __init__(self, n_groups: int, n_genes: int, group=None, dst: int = 0, directory: str | None = None):
+        import torch.distributed as dist
+        self.shape = (3, int(n_groups), int(n_genes))
+        nbytes = max(8, 3 * int(n_groups) * int(n_genes) * 8)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        if self.world == 1:
+            self._mm = mmap.mmap(-1, nbytes)
+        else:
+            directory = directory or ("/dev/shm" if os.path.isdir("/dev/shm") else None)
+            box = [None]
+            fd, err = -1, None
+            if self.rank == dst:
+                try:
+                    if directory is None:
+                        raise OSError("no /dev/shm on this host")
+                    path = os.path.join(directory, f"illico_planes_{os.getpid()}_{uuid.uuid4().hex}")
+                    fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                    os.ftruncate(fd, nbytes)
+                    box[0] = path
+                except OSError as e:  # every rank learns of it (no rank may be left waiting in a collective)
+                    err, box[0] = e, f"!{e}"
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+            path = box[0]
+            if path.startswith("!"):
+                raise OSError(f"shared host planes: rank {dst} could not create the mapping: {path[1:]}") from err
+            try:
+                if self.rank != dst:
+                    fd = os.open(path, os.O_RDWR)
+                self._mm = mmap.mmap(fd, nbytes)
+            finally:
+                if fd >= 0:
+                    os.close(fd)
+                dist.barrier(group=group)      # every rank holds its mapping: the name can go
+                if self.rank == dst:
+                    try:
+                        os.unlink(path)
+                    except OSError:
+                        pass
+        self.array = np.frombuffer(self._mm, dtype=np.float64, count=3 * self.shape[1] * self.shape[2]).reshape(self.shape)
+
+    def columns(self, lb: int, ub: int):
+        """The three [G, ub - lb] windows of this rank's column range (row pitch = n_genes doubles: what `out_ld` of the C-ABI is for)."""
+        return tuple(self.array[k][:, lb:ub] for k in range(3))
+
+    def barrier(self):
+        """Every rank's stores are in the mapping (a rank's engine call returns when its planes have landed)."""
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.group)
+
+
 class _DoneWork:
     def wait(self):
         return True
@@ -143,7 +213,7 @@ def torch_empty_like_cpu(t):
 def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, reference=None, *, alternative="two-sided",
                                 use_continuity=True, tie_correct=True, layer=None, n_blocks: int = 4, group=None,
                                 compute_planes=None, column_loader=None, n_genes=None, var_names=None, groups=None,
-                                gene_weights=None):
+                                gene_weights=None, tail: str = "host"):
     """Gene-sharded drop-in: rank 0 returns the DataFrame, the others None.
 
     Two ways to hand over the data:
@@ -155,6 +225,11 @@ def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, referenc
       rank 0, ``var_names``: a rank then never holds another rank's genes -- at BASELINE configs[4] the whole matrix is
       120 GB, a rank's shard 15 GB.  ``adata`` may be None.  ``gene_weights`` (one number per gene, e.g. stored entries,
       identical on every rank) balances the ranges; without it they are balanced by gene count.
+
+    ``tail="host"`` (default): the result is ONE [3][G][M] array in shared host memory; every rank's engine writes its planes into
+    its own column range of it over its own PCIe link (`SharedHostPlanes`; no data-path collective at all, like the reference's
+    workers, asymptotic_wilcoxon.py:236-244).  ``tail="device"``: the planes are gathered over RCCL (exact-width p2p) into one device
+    tensor on rank 0 and leave through one D2H -- for when rank 0's GPU is where they are wanted; 24 B per test into ONE link.
 
     ``compute_planes(X, grpc, lb, ub, **opts) -> (p, u, fc)`` defaults to the HIP engine of this rank's GPU
     (planes stay on the device until gathered over RCCL); tests inject a CPU function to cover the sharding
@@ -214,12 +289,13 @@ def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, referenc
         eng.set_groups(grpc)
         dev = torch.device("cuda", eng.device)
 
-        def compute_planes(Xb, grpc, lb, ub, **o):  # noqa: F811
+        def compute_planes(Xb, grpc, lb, ub, out=None, **o):  # noqa: F811
             h = data_handler_registry.get(Xb)
             fmt = h.kernel_data_format()
+            kw = dict(device_out=True) if out is None else dict(out=out)   # (out: host windows of the shared result)
             if fmt == KernelDataFormat.DENSE:
-                return eng.run_dense(Xb, lb, ub, device_out=True, **o)
-            return eng.run_sparse(fmt.value, Xb.data, Xb.indices, Xb.indptr, Xb.shape, lb, ub, device_out=True, **o)
+                return eng.run_dense(Xb, lb, ub, **kw, **o)
+            return eng.run_sparse(fmt.value, Xb.data, Xb.indices, Xb.indptr, Xb.shape, lb, ub, **kw, **o)
     else:
         dev = torch.device("cpu")
 
@@ -229,6 +305,36 @@ def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, referenc
         Xmine = column_loader(my_lb, my_ub) if my_ub > my_lb else None
         if Xmine is not None and int(Xmine.shape[1]) != my_ub - my_lb:
             raise ValueError(f"column_loader({my_lb}, {my_ub}) returned {Xmine.shape[1]} columns")
+    if tail not in ("host", "device"):
+        raise ValueError(f"tail must be 'host' or 'device', got {tail!r}")
+    if tail == "host":
+        # ---- every rank writes its own column range of one shared host result; nothing travels between GPUs ----
+        shared = SharedHostPlanes(G, n_genes, group=group)
+        try:
+            for b in range(n_blocks if on_gpu else 1):  # (blocks: the engine's D2H of block b runs under the pass of block b + 1 inside the call)
+                lb, ub = shard_bounds(my_ub - my_lb, n_blocks if on_gpu else 1)[b]
+                if ub <= lb:
+                    continue
+                out = shared.columns(my_lb + lb, my_lb + ub)
+                Xb, l0, u0 = (Xmine, lb, ub) if column_loader is not None else (X, my_lb + lb, my_lb + ub)
+                if on_gpu:
+                    compute_planes(Xb, grpc, l0, u0, out=out, **opts)
+                else:  # an injected (CPU) function returns its planes
+                    for dst_k, a in zip(out, compute_planes(Xb, grpc, l0, u0, **opts)):
+                        dst_k[...] = a.numpy() if isinstance(a, torch.Tensor) else a
+        finally:
+            shared.barrier()  # (also on an error of this rank: the others must not wait for ever)
+        if rank != 0:
+            return None
+        planes = shared.array
+        index_thread.join()
+        if isinstance(index_box[0], BaseException):
+            raise index_box[0]
+        return pd.DataFrame(
+            {"p_value": planes[0].reshape(-1), "statistic": planes[1].reshape(-1), "fold_change": planes[2].reshape(-1)},
+            index=index_box[0], copy=False)
+
+    # ---- tail == "device" ----
     # Block b of rank r is exactly as wide as r's own b-th share (no padding to the widest rank: ranges balanced by stored entries differ
     # in width).  Rank 0 lays everything it computes and receives out in ONE device tensor [3][G][n_genes] -- its own blocks are
     # computed straight into it, a peer's block lands in an exactly-sized receive buffer and is copied into its column range on the
@@ -275,3 +381,73 @@ def asymptotic_wilcoxon_sharded(adata, is_log1p: bool, group_keys: str, referenc
     return pd.DataFrame(
         {"p_value": planes[0].reshape(-1), "statistic": planes[1].reshape(-1), "fold_change": planes[2].reshape(-1)},
         index=index_box[0], copy=False)
+
+
+def asymptotic_wilcoxon_threads(adata, is_log1p: bool, group_keys: str, reference=None, *, devices=None, alternative="two-sided",
+                                use_continuity=True, tie_correct=True, layer=None, gene_weights=None, compute_planes=None):
+    """The single-process multi-GPU form ("one process driving 8 devices with host threads"): one host thread and one
+    engine context per entry of ``devices`` (default: every visible GPU; an id may repeat -- two contexts on one GPU), each computing one
+    contiguous gene range of the HOST matrix ``adata.X`` straight into its column range of one [3][G][M] host result.  No process
+    group, no collective: ctypes releases the GIL inside the engine calls, the reference's own model ("threads, never processes",
+    README.md:6; asymptotic_wilcoxon.py:236-244).  Returns the reference's DataFrame.
+
+    ``compute_planes(X, grpc, lb, ub, out, device_index, **opts)`` replaces the engine (tests)."""
+    import pandas as pd
+
+    from illico_amd.asymptotic_wilcoxon import _product_index
+    from illico_amd.utils.groups import encode_and_count_groups
+    from illico_amd.utils.registry import KernelDataFormat, data_handler_registry
+
+    X = adata.layers[layer] if layer is not None else adata.X
+    if alternative not in ("two-sided", "less", "greater"):
+        raise ValueError(f"Unsupported alternative hypothesis: {alternative}")
+    handler = data_handler_registry.get(X)  # KeyError for an unsupported container, like the reference (registry.py:58)
+    fmt = handler.kernel_data_format()
+    if devices is None:
+        import torch
+        devices = list(range(torch.cuda.device_count()))
+    devices = list(devices)
+    if not devices:
+        raise RuntimeError("asymptotic_wilcoxon_threads: no GPU visible and no devices given (there is no CPU fallback)")
+    world = len(devices)
+    n_genes = int(X.shape[1])
+    unique, grpc = encode_and_count_groups(adata.obs[group_keys], reference)
+    G = int(grpc.counts.size)
+    ranges = balanced_gene_ranges(gene_weights, world) if gene_weights is not None else gene_ranges_for(X, world)
+    planes = np.empty((3, G, n_genes), dtype=np.float64)
+    opts = dict(is_log1p=is_log1p, use_continuity=use_continuity, tie_correct=tie_correct, alternative=alternative)
+    errors: list = [None] * world
+
+    def work(i):
+        lb, ub = ranges[i]
+        if ub <= lb:
+            return
+        out = tuple(planes[k][:, lb:ub] for k in range(3))
+        try:
+            if compute_planes is not None:
+                compute_planes(X, grpc, lb, ub, out, i, **opts)
+                return
+            from illico_amd._lib import Engine
+            eng = Engine(devices[i])  # a context of this thread's own (a context is single-threaded, include/illico_hip.h)
+            try:
+                eng.set_groups(grpc)
+                if fmt == KernelDataFormat.DENSE:
+                    eng.run_dense(X, lb, ub, out=out, **opts)
+                else:
+                    eng.run_sparse(fmt.value, X.data, X.indices, X.indptr, X.shape, lb, ub, out=out, **opts)
+            finally:
+                eng.close()
+        except BaseException as e:  # re-raised on the caller's thread
+            errors[i] = e
+
+    threads = [threading.Thread(target=work, args=(i,), name=f"illico-dev{devices[i]}-{i}") for i in range(world)]
+    for t in threads:
+        t.start()
+    index = _product_index(pd.Series(unique, name="pert", dtype=str), pd.Series(np.asarray(adata.var_names), name="feature", dtype=str))
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    return pd.DataFrame({"p_value": planes[0].reshape(-1), "statistic": planes[1].reshape(-1), "fold_change": planes[2].reshape(-1)},
+                        index=index, copy=False)

@@ -65,9 +65,12 @@ def test_two_ranks_spawned_by_bench_itself_gloo_shared_device():
     assert sc["n1_reference"]["genes"] == 256 and sc["n1_reference"]["ms_single_call"] > 0
     assert sc["speedup_vs_n1"] == pytest.approx(sc["n1_reference"]["ms_single_call"] / sc["ms_single_call"], rel=1e-2)
     assert two["steady_state"]["ms_per_step"] == two["ms_per_step"]
+    # ... and the drop-in scope of the same call: every rank's planes into its own columns of one shared host result
+    assert sc["ms_to_host"] > 0 and sc["to_host"]["bytes_to_host_total"] == 24 * 50 * 256 and sc["to_host"]["bytes_to_host_per_rank"] == 24 * 50 * 128
     # (c): configs[4] in the same line
     c5 = two["c5_strong"]
     assert c5["single_call"]["blocks"] >= 4 and c5["single_call"]["speedup_vs_n1"] > 0 and c5["single_call"]["n1_reference"]["genes"] == 192
+    assert c5["single_call"]["ms_to_host"] > 0 and c5["single_call"]["to_host"]["bytes_to_host_total"] == 24 * 40 * 192
     assert c5["genes_total"] == 192 and c5["genes_per_gpu"] == 96 and c5["cells"] == 30000 and c5["groups"] == 40 and c5["scaling"] == "strong"
     assert c5["ms_pass"] > 0 and c5["ms_gather_alone"] > 0 and c5["ms_pass_plus_gather"] > 0 and c5["bytes_into_rank0"] == 24 * 40 * 96
     assert 0 < c5["roofline"]["frac"] < 1 and c5["parity"]["statistic_mismatches"] == 0
@@ -79,6 +82,7 @@ def test_two_ranks_spawned_by_bench_itself_gloo_shared_device():
     assert one["config"]["genes_total"] == 256 and "final_gather" not in one
     assert one["c5_strong"]["genes_per_gpu"] == 192 and one["c5_strong"]["bytes_into_rank0"] == 0 and one["c5_strong"]["ms_gather_alone"] == 0
     assert one["single_call"]["blocks"] == 1 and one["single_call"]["ms_single_call"] > 0 and "speedup_vs_n1" not in one["single_call"]
+    assert one["single_call"]["ms_to_host"] > 0 and one["c5_strong"]["single_call"]["ms_to_host"] > 0
     # the other single-GPU BASELINE configs and one continuous line ride in the same (N = 1) line, at the headline's shape
     assert all(k not in two for k in ("c3", "c3_csr", "c4", "c2_continuous_ovr"))
     for tag, fmt, test, values in (("c3", "csc", "ovo", "counts"), ("c3_csr", "csr", "ovo", "counts"), ("c4", "dense", "ovr", "counts"),

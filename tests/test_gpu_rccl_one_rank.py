@@ -33,9 +33,11 @@ fmt, test = {fmt!r}, {test!r}
 M = {{"dense": X, "csc": sparse.csc_matrix(X), "csr": sparse.csr_matrix(X)}}[fmt]
 adata = AnnDataLite(M, obs=pd.DataFrame({{"pert": labels}}))
 ref = "non-targeting" if test == "ovo" else None
-df = asymptotic_wilcoxon_sharded(adata, False, "pert", ref, n_blocks=3)
+df = asymptotic_wilcoxon_sharded(adata, False, "pert", ref, n_blocks=3, tail="device")   # planes gathered over RCCL, one D2H on rank 0
 one = asymptotic_wilcoxon(adata, is_log1p=False, group_keys="pert", reference=ref)
 pd.testing.assert_frame_equal(df, one, check_exact=True)
+dfh = asymptotic_wilcoxon_sharded(adata, False, "pert", ref, n_blocks=3)                 # default tail: the engine writes host planes of the shared result
+pd.testing.assert_frame_equal(dfh, one, check_exact=True)
 # the block gather on its own: device tensors in, device tensors out, asynchronous handle
 st = torch.arange(3 * 5 * 7, dtype=torch.float64, device="cuda").reshape(3, 5, 7)
 recv = [torch.empty_like(st)]
