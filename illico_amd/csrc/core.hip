@@ -176,6 +176,12 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "ovr_full_dump")) c->ovr_full_dump = value != 0;
     else if (!strcmp(key, "no_packed_dense")) c->no_packed_dense = value != 0;
     else if (!strcmp(key, "packed_eq_buckets")) c->packed_eq_buckets = (int)value;
+    else if (!strcmp(key, "no_ovo_parts")) c->no_ovo_parts = value != 0;
+    else if (!strcmp(key, "no_big_runs_global")) c->no_big_runs_global = value != 0;
+    else if (!strcmp(key, "packed_ref_cap")) c->packed_ref_cap = (int)value;
+    else if (!strcmp(key, "debug_routes")) c->debug_routes = value != 0;
+    else if (!strcmp(key, "no_sparse_packed_small")) c->no_sparse_packed_small = value != 0;
+    else if (!strcmp(key, "big_runs_cap")) c->big_runs_cap = (int)value;
     else if (!strcmp(key, "no_ovr_packed_partition")) c->no_ovr_packed_partition = value != 0;
     else if (!strcmp(key, "no_csc_counts_path")) c->no_csc_counts_path = value != 0;
     else if (!strcmp(key, "no_csc_counts_mixed")) c->no_csc_counts_mixed = value != 0;

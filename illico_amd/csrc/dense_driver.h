@@ -51,44 +51,75 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.gofs = gofs; Q.blk_cnt = nullptr; Q.out_sum = ssum; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum;
         if ((rc = launch_group_compact<InT, KeyT>(c, Q, nb, flags, true))) return rc;
     }
+    bool parts = false;
     BigRunFn<KeyT> *big_fn = nullptr;
+    void *big_tmp = nullptr; // groups with more cells than k_bucket_big_runs' LDS slots: a second key buffer, into which such runs are dealt
     if (c->pk_nbig > 0) { // runs of more than 256 non-zero keys are dealt into value buckets in place: the rank kernel walks them in pieces
         if ((rc = get_scratch(c, "packed_big_fn", (size_t)nb * c->pk_nbig * sizeof(BigRunFn<KeyT>), &v))) return rc;
         big_fn = (BigRunFn<KeyT> *)v;
         ProfScope ps(c, KID_GROUP_COMPACT);
-        auto kern = k_bucket_big_runs<KeyT>;
-        const int cap = (int)std::min<int64_t>(srt_cap<KeyT>(), (c->max_nonref + 63) & ~63ll); // (a run holds at most its group's cells)
-        const size_t lds = srt_lds_bytes(sizeof(KeyT), cap);
-        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(c->pk_nbig, nb), dim3(SRT_NT), lds, c->stream, (void *)Xt, (long long)stride, (const u16 *)nnz, (const u32 *)gofs,
-                           (const int *)c->d_pk_big, c->pk_nbig, G, cap, big_fn, route);
-        HIPCHK(c, hipGetLastError());
+        int cap = (int)std::min<int64_t>(srt_cap<KeyT>(), (c->max_nonref + 63) & ~63ll); // (a run holds at most its group's cells)
+        if (c->big_runs_cap > 0) cap = std::min(cap, std::max(c->big_runs_cap, 512) & ~63);
+        if (c->max_nonref > cap && !c->no_big_runs_global && get_scratch(c, "packed_big_tmp", (size_t)nb * (size_t)stride * sizeof(KeyT), &v) == ILLICO_OK) big_tmp = v;
+        if ((rc = launch_bucket_big_runs<KeyT>(c, (void *)Xt, big_tmp, (long long)stride, nnz, gofs, nb, G, cap, big_fn, route, c->max_nonref))) return rc;
     }
     {
         OvoCompactParams C;
         C.Xs = Xt; C.gene_stride = stride; C.counts = c->d_counts; C.nnz = nnz; C.gofs = gofs; C.ref_out = c->pk_ref_out; C.seg_nnz = seg_nnz; C.seg_sum = seg_sum;
         C.out_sum = ssum; C.G = G; C.ref = ref; C.n_genes = nb; C.nseg = nseg;
         packed_ref_sizing<KeyT>(n_ref, &C.ref_cap, &C.nbk_lg);
+        if (c->packed_ref_cap > 0) C.ref_cap = std::min(C.ref_cap, std::max(c->packed_ref_cap, 1024));
         C.out_2u = s2u; C.out_tie = stie; C.route = route; C.big_sorted = c->pk_nbig > 0 ? 1 : 0;
-        C.ref_by_gofs = 0; C.gene_flags = nullptr; C.big_fn = big_fn; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
+        C.ref_by_gofs = 0; C.gene_flags = nullptr; C.big_fn = big_fn; C.big_tmp = big_tmp; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
         const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
         // large references: the bucket function follows the reference's distribution (a crowded stretch of values would otherwise
         // fill buckets beyond three keys and send whole table words to key-by-key walks); "packed_eq_buckets" = 0 / 1 forces
         const bool eq = c->packed_eq_buckets >= 0 ? c->packed_eq_buckets != 0 : n_ref > 16384;
+        // a reference with more cells than the kernel has key slots: its genes may need value-range parts (kernels_ovo_compact.h: PARTS)
+        C.n_parts = packed_ref_parts<KeyT>(c, n_ref, C.ref_cap, C.nbk_lg);
+        parts = C.n_parts > 1;
+        C.needs_parts = nullptr;
+        if (parts) { // every part adds its share: the statistics start from zero (the plain kernel, first, stores those of the genes that need no parts)
+            if ((rc = get_scratch(c, "packed_needs_parts", (size_t)nb * 4, &v))) return rc;
+            C.needs_parts = (u32 *)v;
+            HIPCHK(c, hipMemsetAsync(C.needs_parts, 0, (size_t)nb * 4, c->stream));
+            HIPCHK(c, hipMemsetAsync(s2u, 0, (size_t)nb * G * sizeof(long long), c->stream));
+            HIPCHK(c, hipMemsetAsync(stie, 0, (size_t)nb * G * sizeof(u64), c->stream));
+        }
         auto kern = eq ? k_ovo_rank_compact<KeyT, true> : k_ovo_rank_compact<KeyT, false>;
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ProfScope ps(c, KID_OVO_RANK_COMPACT);
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(OCR_NT), lds, c->stream, C);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(OCR_NT), lds, c->stream, C);
         HIPCHK(c, hipGetLastError());
+        if (parts) {
+            auto kp = k_ovo_rank_compact<KeyT, true, true>;
+            HIPCHK(c, hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kp, dim3((unsigned)nb * (unsigned)C.n_parts), dim3(OCR_NT), lds, c->stream, C);
+            HIPCHK(c, hipGetLastError());
+        }
     }
-    if (!packed_leftovers_fit_sort_route<KeyT>(c)) { // what the packed kernel leaves cannot go to k_ovo_rank (groups of at most 1024 keys, a
-        // reference that fits its LDS): the caller sends those genes through the transposition + general sort route
+    // What the packed kernels left.  The plain kernel's genes (route word 1: a tie-heavy reference column, the reference's segments moved
+    // together) go to k_ovo_rank over the packed layout when its LDS holds the reference and the groups (<= 1024 keys); everything else --
+    // the PARTS kernel's genes (a reason in the word's high bits: their segments lie where they were), a run beyond every bucket kernel
+    // (route 2), or sizes k_ovo_rank does not take -- is handed back to the caller: transposition + the general sort route.
+    const bool sort_fits = packed_leftovers_fit_sort_route<KeyT>(c);
+    if (parts || !sort_fits || c->pk_nbig > 0) { // (runs above 256 keys: a gene with a value bucket above 256 keys leaves the rank kernel late, its segments unmoved)
         std::vector<u32> hr((size_t)nb);
         HIPCHK(c, hipMemcpyAsync(hr.data(), route, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int j = 0; j < nb; ++j)
-            if (hr[j]) redo->push_back(j);
-        return ILLICO_OK;
+        bool any_sort = false;
+        for (int j = 0; j < nb; ++j) {
+            if (hr[j] && (!sort_fits || hr[j] > 255u || (hr[j] & 255u) == 2u)) redo->push_back(j);
+            else if (hr[j]) any_sort = true;
+        }
+        if (c->debug_routes) { // why (PARTS: 1 = more parts than the launch has, 2 = a part beyond the slots, 3 = walks of overfull table words
+            // would dominate, 5 = a run above 256 keys not dealt)
+            int why[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r2 = 0;
+            for (int j = 0; j < nb; ++j) { if ((hr[j] & 255u) == 2u) ++r2; else if (hr[j]) ++why[(hr[j] >> 8) & 7u]; }
+            fprintf(stderr, "[illico] packed OVO: %d genes, parts %d, left %zu to the general route (route 2: %d; reasons 0..5: %d %d %d %d %d %d)\n", nb, parts ? 1 : 0,
+                    redo->size(), r2, why[0], why[1], why[2], why[3], why[4], why[5]);
+        }
+        if (!any_sort) return ILLICO_OK;
     }
     // the genes the packed kernel left (tie-heavy reference column, a group of more than 256 non-zeros): k_ovo_rank over the
     // packed layout; its workgroups return at once for every other gene
@@ -1010,7 +1041,36 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             if ((rc = launch_finalize(c, s2u, stie, ssum, gtot, nb, flags, alternative, o.p, o.u, o.fc, o.ld, cmap ? 0 : b0 - col_lb, cmap ? cmap + (b0 - col_lb) : nullptr))) return rc;
         }
     }
-    if (!redo_runs.empty()) // (tie-heavy columns of a matrix with groups above 1024 cells: transposition + the general sort route)
+    if (!redo_runs.empty()) { // (tie-heavy columns of a matrix with groups above 1024 cells: transposition + the general sort route)
+        // Few genes scattered over the window (each a run of its own: one transposition, one single-workgroup sort after the other --
+        // nine genes of a two-million-cell matrix: 480 ms): gathered into a narrow matrix and computed as ONE batch, side by side.
+        int64_t n = 0;
+        for (auto &r : redo_runs) n += r.second - r.first;
+        const int64_t n_pad = (n + 63) & ~63ll;
+        if (redo_runs.size() > 1 && !col_map && (flags & ILLICO_FLAG_INPUT_DEVICE) && !c->tap && !c->no_leftover_gather && n * 2 <= col_ub - col_lb &&
+            col_ub <= 0x7FFFFFFFll && (size_t)N * (size_t)n_pad * sizeof(InT) <= (size_t)c->scratch_bytes) {
+            std::vector<int> src, dst;
+            for (auto &r : redo_runs)
+                for (int64_t j = r.first; j < r.second; ++j) { src.push_back((int)j); dst.push_back((int)(j - col_lb)); }
+            void *v;
+            int rc;
+            if ((rc = get_scratch(c, "xredo", (size_t)N * (size_t)n_pad * sizeof(InT), &v))) return rc;
+            InT *xl = (InT *)v;
+            if ((rc = get_scratch(c, "xredo_cols", (size_t)n * 8, &v))) return rc;
+            int *d_src = (int *)v, *d_dst = d_src + n;
+            HIPCHK(c, hipMemcpyAsync(d_src, src.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_dst, dst.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            {
+                ProfScope ps(c, KID_GATHER_COLS);
+                hipLaunchKernelGGL((k_gather_columns<InT>), dim3((unsigned)((N + 63) / 64)), dim3(256), 0, c->stream, (const InT *)X, (long long)ld, (int)N,
+                                   (const int *)d_src, (int)n, (int)n_pad, xl, (long long)n_pad, 0ll);
+                HIPCHK(c, hipGetLastError());
+            }
+            HIPCHK(c, hipStreamSynchronize(c->stream)); // (the host lists go out of scope)
+            std::vector<std::pair<int64_t, int64_t>> all{{0, n}};
+            return run_dense_twopass<InT, KeyT>(c, xl, dtype, N, n_pad, 0, n, flags, alternative, o, all, d_dst, prefer_counts, false);
+        }
         return run_dense_twopass<InT, KeyT>(c, X, dtype, N, ld, col_lb, col_ub, flags, alternative, o, redo_runs, col_map, prefer_counts, false);
+    }
     return ILLICO_OK;
 }

@@ -140,6 +140,12 @@ struct illico_ctx {
     bool no_fused_path = false;
     bool no_ovr_packed_partition = false; // 1: dense OVR partitions the padded rows (every key) instead of the packed ones
     bool no_packed_dense = false;      // 1: dense OVO on continuous values takes the transpose + k_ovo_rank route (no group-wise packing)
+    bool no_sparse_packed_small = false; // sparse OVO, eight-byte keys: genes beyond k_csc_gene's LDS go to k_ovo_rank / the dense window (as before round 5), not to the packed rank kernel
+    bool debug_routes = false;         // stderr: what the packed OVO rank kernel left to the general routes, and why
+    int packed_ref_cap = 0;            // > 0: caps the packed rank kernel's key slots for the reference (tests: value-range parts at small sizes)
+    int big_runs_cap = 0;              // > 0: caps k_bucket_big_runs' LDS key slots (tests: the route through HBM at small sizes)
+    bool no_big_runs_global = false;   // packed routes: a (gene, group) run beyond k_bucket_big_runs' LDS slots sends its gene to the general route (as before round 5)
+    bool no_ovo_parts = false;         // packed rank kernel: never take a reference in value-range parts (genes beyond the LDS slots go to the general routes, as before round 5)
     int packed_eq_buckets = -1;        // packed rank kernel: distribution-following bucket function; -1 = for references above 16384 cells
     bool no_csc_counts_windows = false; // 1: count-valued CSC with more groups than LDS holds tables for never takes k_csc_counts (windows of groups)
     bool no_csc_counts_wide = false;   // 1: count-valued CSC with more than 8 groups above 255 cells never takes k_csc_counts (16-bit cells)

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(NT, ((KMAX <= 4 && !LG) ? 1024 : 512) / NT * (NT / 
 
     for (int gene = blockIdx.x; gene < P.n_genes; gene += gridDim.x) {
         if (gene_flags && gene_flags[gene] == 0) continue; // count-valued gene: handled by k_ovo_counts
-        if (P.only && P.only[gene] == 0u) continue;
+        if (P.only && (P.only[gene] == 0u || P.only[gene] > 255u)) continue; // (a word above 255: the packed PARTS kernel's gene, not laid out for this kernel)
         // ---- reference column -> LDS, sorted ----
         long long rstart;
         u32 nA;

@@ -313,8 +313,13 @@ struct OvoCompactParams {
                              // (seg_nnz: [n_genes] its length, nseg = 1; no seg_sum: value sums are formed elsewhere); gene_stride = 0
     const u32 *gene_flags;   // optional [n_genes]: a gene whose word is 0 is somebody else's (count-valued: the histogram kernel's)
     const void *big_fn;      // [n_genes][n_cand] BigRunFn<KeyT>: each such run's bucket function
+    const void *big_tmp;     // the second key buffer (laid out like Xs) that holds the runs k_bucket_big_runs_global dealt
     const int *cand_of;      // [G] a group's place among the n_cand groups of more than 256 cells, or -1
     int n_cand;
+    u32 *needs_parts;        // optional [n_genes], zeroed by the host.  The plain kernel sets the word of a gene whose reference has more non-zero keys
+                             // than slots and leaves the gene alone; the PARTS kernel, launched behind it, takes exactly those genes
+    int n_parts;             // PARTS kernels: value-range parts a gene's reference may be taken in (grid.x = n_genes * n_parts; out_2u / out_tie
+                             // zeroed by the host: every part ADDS its terms)
     u32 *route;              // [n_genes], zeroed by the host: set to 1 for the genes this kernel leaves to k_ovo_rank (packed
                              // mode): crowded value buckets (a tie-heavy column: it wants the sorted reference and the sort form
                              // of the group loop) or a group of more than 256 non-zeros.  For those the reference's segments are
@@ -395,13 +400,18 @@ template <typename KeyT, bool EQ> __device__ __forceinline__ void ocr_find_exact
 // ZEROK).  Straight-line per round: Bloom insert (one returning LDS atomic), one table word, 2 keys, 4 compares.
 // Per-lane partial results: less = sum of #A<q (non-zero reference keys), eqs = sum of #A==q, TT = sum t (t + 1); negs
 // (uniform) = keys below zero.  bloom[] is all-zero on entry and on exit.
-template <typename KeyT, int NR, bool EQ>
+// MASKED (the reference taken in value-range parts: a group's keys outside the part were replaced by ZEROK, which is no packed key):
+// a lane is valid where its key is not ZEROK, in every round; else the lanes past the last key (of the last round only) are the invalid ones.
+template <typename KeyT, int NR, bool EQ, bool MASKED = false>
 __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, const OcrRef<KeyT, EQ> &R, u32 *bloom, int lane, u64 lt_mask,
                                           u32 &less_out, u32 &eq_out, u64 &TT_out, u32 &negs_out) {
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     const int rem = nB - 64 * (NR - 1);               // keys of the last round, 1..64
     const u64 vlast = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
     const bool vl = (vlast >> lane) & 1ull;
+    bool val[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) val[r] = MASKED ? cur[r] != ZEROK : (r < NR - 1 || vl);
     u32 wofs[NR], lessr[NR];
     u64 fm[NR], eqr[NR], ovr_[NR], eqm = 0, ovm = 0;
 #pragma unroll
@@ -410,7 +420,7 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
         const u32 h = ocr_hash(q);
         wofs[r] = (h >> 5) & (OCR_BLOOM_WORDS - 1);
         bool flag = false;
-        if (r < NR - 1 || vl) {
+        if (val[r]) {
             const u32 old = atomicOr(&bloom[wofs[r]], 1u << (h & 31));
             flag = (old >> (h & 31)) & 1u;
         }
@@ -424,10 +434,11 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
         const u32 w = pw[0], h = pw[1];
         const u32 lo = min((h + ocr_below(w, sh)) & 0xFFFFu, R.nA); // meaningless in an overfull word (bit 31 of h): redone below
         const KeyT a0 = R.A[lo], a1 = R.A[lo + 1], a2 = R.A[lo + 2]; // a bucket holds at most 3; past it: later buckets / the pad: > q or == MAXK
-        if (r < NR - 1 || vl) bloom[wofs[r]] = 0u;       // wipe (LDS operations of one wavefront execute in order)
+        if (val[r]) bloom[wofs[r]] = 0u;       // wipe (LDS operations of one wavefront execute in order)
         u32 l = lo + (a0 < q ? 1u : 0u) + (a1 < q ? 1u : 0u) + (a2 < q ? 1u : 0u);
         u64 e4 = __ballot(a0 == q) | __ballot(a1 == q) | __ballot(a2 == q), o4 = __ballot((int)h < 0), n4 = __ballot(q < ZEROK);
-        if (r == NR - 1) { l = vl ? l : 0u; e4 &= vlast; o4 &= vlast; n4 &= vlast; }
+        if (MASKED) { const u64 vm = __ballot(val[r]); l = val[r] ? l : 0u; e4 &= vm; o4 &= vm; n4 &= vm; }
+        else if (r == NR - 1) { l = vl ? l : 0u; e4 &= vlast; o4 &= vlast; n4 &= vlast; }
         lessr[r] = l;
         eqr[r] = e4; ovr_[r] = o4;
         eqm |= e4; ovm |= o4;
@@ -446,7 +457,7 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
                 const u32 w = R.tab[2 * (b >> 4)], h = R.tab[2 * (b >> 4) + 1], c = (w >> sh) & 3u;
                 const u32 lo = min((h + ocr_below(w, sh)) & 0xFFFFu, R.nA);
                 const u32 e = ((c > 0u && R.A[lo] == q) ? 1u : 0u) + ((c > 1u && R.A[lo + 1] == q) ? 1u : 0u) + ((c > 2u && R.A[lo + 2] == q) ? 1u : 0u);
-                a[r] = (r < NR - 1 || vl) ? e : 0u;
+                a[r] = val[r] ? e : 0u;
             }
         }
     }
@@ -457,7 +468,7 @@ __device__ __forceinline__ void ocr_group(const KeyT (&cur)[OCR_KMAX], int nB, c
             const KeyT q = cur[r];
             const u32 W = ocr_bucket(R, q) >> 4;
             const u32 h = R.tab[2 * W + 1];
-            const bool ov = (r < NR - 1 || vl) && (int)h < 0;
+            const bool ov = val[r] && (int)h < 0;
             const u32 wlo = min(h & 0xFFFFu, R.nA), whi = ov ? (R.tab[2 * W + 3] & 0xFFFFu) : wlo;
             u32 l = wlo, e = 0;
 #pragma unroll
@@ -536,13 +547,93 @@ template <typename KeyT> __host__ __device__ constexpr int srt_cap() { return si
 // LDS for runs of at most `cap` keys (the host passes the largest candidate group's cell count, capped): keys + bucket counters
 static inline int srt_lg_of(int n) { int lg = 6; while (lg < SRT_LG_MAX && (4 << lg) < n) ++lg; return lg; }
 static inline size_t srt_lds_bytes(size_t key_size, int cap) { return (size_t)cap * key_size + ((size_t)4 << srt_lg_of(cap)) + 64; }
+#define BIG_RUN_IN_TMP (1 << 30) // in BigRunFn::shift: the dealt run lies in the second key buffer (k_bucket_big_runs_global), not in place
 template <typename KeyT> struct BigRunFn { KeyT kmin; int shift; };
 template <typename KeyT> __device__ __forceinline__ u32 big_bucket(const BigRunFn<KeyT> &f, KeyT k) { return (u32)((KeyT)(k - f.kmin) >> f.shift); }
+
+// A run longer than the LDS buffer (half of a 100 000-cell cluster non-zero: 50 000 keys) is dealt through HBM instead, by a kernel of
+// its own (k_bucket_big_runs leaves such runs alone when one follows): range and bucket counts from two reads of the run, the counters
+// -- up to 2^14 in LDS: 64 KB, two workgroups of 1024 threads per CU, four requests in flight per thread -- scanned, the keys
+// scattered into the run's place in a second key buffer `tmp` (laid out like Xs; the run's ~200 KB stay in L2), where the rank kernel
+// reads it (BIG_RUN_IN_TMP in the run's bucket function: no copy back).
+#define SRT_LG_MAX_G 14
+#define SRTG_NT 1024
+template <typename KeyT>
+__global__ __launch_bounds__(SRTG_NT) void k_bucket_big_runs_global(void *Xs, void *tmp, long long gene_stride, const u16 *__restrict__ nnz, const u32 *__restrict__ gofs,
+                                                                    const int *__restrict__ cand, int n_cand, int G, int cap /* runs up to here are k_bucket_big_runs' */,
+                                                                    int lg_max /* log2 of the counters the launch's LDS holds */, BigRunFn<KeyT> *__restrict__ big_fn,
+                                                                    u32 *__restrict__ route) {
+    extern __shared__ __align__(16) unsigned char srtg_smem[];
+    constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
+    constexpr int NT = SRTG_NT;
+    u32 *cnt = (u32 *)srtg_smem;
+    __shared__ KeyT g_min, g_max;
+    __shared__ u32 g_part[NT / 64];
+    const int gene = blockIdx.y, g = cand[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = (int)nnz[(size_t)gene * G + g];
+    if (n <= cap) return; // (uniform)
+    if (n >= 65535) { if (tid == 0) route[gene] = 2u; return; } // (the 16-bit run length saturated: the true length is not known here)
+    const size_t off = (size_t)((long long)gene * gene_stride) + gofs[(size_t)gene * G + g];
+    KeyT *run = (KeyT *)Xs + off, *out = (KeyT *)tmp + off;
+    if (tid == 0) { g_min = MAXK; g_max = (KeyT)0; }
+    __syncthreads();
+    // four keys per thread and step, requested together; lanes past the end read the run's last key (harmless for min / max) or skip
+    KeyT lo = MAXK, hi = (KeyT)0;
+    for (int i = tid; i < n; i += 4 * NT) {
+        KeyT k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = run[min(i + u * NT, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { lo = k[u] < lo ? k[u] : lo; hi = k[u] > hi ? k[u] : hi; }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const KeyT a = __shfl_xor(lo, d), b = __shfl_xor(hi, d); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if (lane == 0) { atomicMin(&g_min, lo); atomicMax(&g_max, hi); }
+    __syncthreads();
+    int lg = 6;
+    while (lg < lg_max && (4 << lg) < n) ++lg;
+    const int B = 1 << lg;
+    const KeyT range = (KeyT)(g_max - g_min);
+    const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
+    BigRunFn<KeyT> f;
+    f.kmin = g_min;
+    f.shift = bits > lg ? bits - lg : 0;
+    if (tid == 0) { BigRunFn<KeyT> fo = f; fo.shift |= BIG_RUN_IN_TMP; big_fn[(size_t)gene * n_cand + blockIdx.x] = fo; } // (the rank kernel reads this run from `tmp`)
+    for (int b = tid; b < B; b += NT) cnt[b] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += 4 * NT) {
+        KeyT k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = run[min(i + u * NT, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + u * NT < n) atomicAdd(&cnt[big_bucket(f, k[u])], 1u);
+    }
+    __syncthreads();
+    { // exclusive scan of the B counters: a thread owns B / 1024 consecutive ones
+        const int per = (B + NT - 1) / NT;
+        u32 sum = 0;
+        for (int e = 0; e < per; ++e) { const int b = tid * per + e; sum += b < B ? cnt[b] : 0u; }
+        const u32 inc = (u32)wave_incl_scan_add((int)sum);
+        if (lane == 63) g_part[wave] = inc;
+        __syncthreads();
+        u32 base = inc - sum;
+        for (int w = 0; w < wave; ++w) base += g_part[w];
+        for (int e = 0; e < per; ++e) { const int b = tid * per + e; if (b < B) { const u32 c = cnt[b]; cnt[b] = base; base += c; } }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 4 * NT) {
+        KeyT k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = run[min(i + u * NT, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + u * NT < n) out[atomicAdd(&cnt[big_bucket(f, k[u])], 1u)] = k[u];
+    }
+}
 
 template <typename KeyT>
 __global__ __launch_bounds__(SRT_NT) void k_bucket_big_runs(void *Xs, long long gene_stride, const u16 *__restrict__ nnz, const u32 *__restrict__ gofs,
                                                             const int *__restrict__ cand, int n_cand, int G, int cap /* LDS key slots */,
-                                                            BigRunFn<KeyT> *__restrict__ big_fn, u32 *__restrict__ route) {
+                                                            BigRunFn<KeyT> *__restrict__ big_fn, u32 *__restrict__ route, int global_follows /* k_bucket_big_runs_global takes the longer runs */) {
     extern __shared__ __align__(16) unsigned char srt_smem[];
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
     KeyT *K = (KeyT *)srt_smem;
@@ -552,8 +643,8 @@ __global__ __launch_bounds__(SRT_NT) void k_bucket_big_runs(void *Xs, long long 
     const int gene = blockIdx.y, g = cand[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = (int)nnz[(size_t)gene * G + g];
     if (n <= 64 * OCR_KMAX) return;
-    if (n > cap) { if (tid == 0) route[gene] = 2u; return; }
     KeyT *run = (KeyT *)Xs + (long long)gene * gene_stride + gofs[(size_t)gene * G + g];
+    if (n > cap) { if (tid == 0 && !global_follows) route[gene] = 2u; return; } // (uniform)
     if (tid == 0) { s_min = MAXK; s_max = (KeyT)0; }
     __syncthreads();
     KeyT lo = MAXK, hi = (KeyT)0;
@@ -609,7 +700,15 @@ static __global__ __launch_bounds__(256) void k_seg_to_packed(const u32 *__restr
     if (g == ref) ref_nnz[gene] = (u16)(n > 65535u ? 65535u : n);
 }
 
-template <typename KeyT, bool EQ>
+// PARTS: a reference whose non-zero keys outgrow the LDS slots is taken in VALUE-RANGE PARTS, one workgroup per (gene, part): 4096 cells
+// over the reference's key range are counted, cut where the running count passes j / P of the keys, and the workgroup of part j keeps the
+// keys of its cells only -- table, look-ups and tie search as before, a group's keys outside the part masked out (every part reads every
+// group's packed keys: P reads of the packed rows, from L2 / MALL when the parts of a gene run side by side).  Equal keys share a
+// cell, hence a part: S2 = sum over parts of [2 (keys of the reference below the part) + 2 #A_part<b + #A_part==b] over the part's b, and
+// the tie terms add up likewise.  Every part ADDS its share into out_2u / out_tie (zeroed by the host); part 0 adds the terms of
+// the zeros.  (Replaces, for references of any size, what rank_sum_and_ties_from_sorted does by merging: utils/ranking.py:52-158.)
+#define OCR_CELL_LG 12
+template <typename KeyT, bool EQ, bool PARTS = false>
 __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NT = OCR_NT, NW = NT / 64, KMAX = OCR_KMAX;
@@ -628,11 +727,15 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     KeyT *s_kr = (KeyT *)(s_red + NW); // [2] min, max
     u32 *s_cnt = (u32 *)(s_kr + 2);    // [0] negatives  [1] non-zero keys  [2] fullest overfull word  [3] largest group  [4] keys in overfull words
     u32 *s_scan = s_cnt + 8;           // [NW]
+    u32 *s_b = s_scan + NW;            // PARTS: [0] first cell of the part  [1] reference keys below it  [2] one past its last cell  [3] keys below that
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gene = blockIdx.x;
+    // (part-major: the workgroups of part 0 first.  Gene-major would put the parts a gene does NOT need -- workgroups that return at once --
+    //  on every n_parts-th workgroup slot, i.e. on fixed XCDs: with two parts, half of the chip idle whenever the genes need one.)
+    const int gene = PARTS ? (int)blockIdx.x % P.n_genes : (int)blockIdx.x;
+    const int part = PARTS ? (int)blockIdx.x / P.n_genes : 0;
     if (P.gene_flags && P.gene_flags[gene] == 0u) return; // (uniform)
-    if (P.big_sorted && P.route[gene] == 2u) return;      // (uniform) k_bucket_big_runs met a run beyond its slots: the general route's gene
+    if (P.big_sorted && (P.route[gene] & 255u) == 2u) return; // (uniform) k_bucket_big_runs met a run beyond its slots: the general route's gene
     const int G = P.G, ref = P.ref;
     const int n_ref = P.counts[ref];
     u16 *nnz = P.nnz + (size_t)gene * G;
@@ -655,8 +758,24 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         for (int i = tid; i < (NWD + 2) / 2; i += NT) t4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (EQ && tid < 256) ccnt[tid] = 0u;
-    if (tid == 0) { s_kr[0] = MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; s_cnt[3] = 0u; s_cnt[4] = 0u; }
+    if (tid == 0) { s_kr[0] = MAXK; s_kr[1] = (KeyT)0; s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0u; s_cnt[3] = 0u; s_cnt[4] = 0u; s_red[0] = 0ull; }
     __syncthreads();
+    for (int sg = tid; sg < P.nseg; sg += NT) atomicAdd(&s_cnt[1], (u32)seg_nnz[sg]); // (a reference of any size: nseg = n_ref / 512)
+    int n_parts_gene = 1;
+    if constexpr (!PARTS) {
+        if (P.needs_parts) { // (uniform) a PARTS launch follows: the genes beyond the slots are its own
+            __syncthreads();
+            if (s_cnt[1] > (u32)P.ref_cap) { if (tid == 0) P.needs_parts[gene] = 1u; return; }
+        }
+    }
+    if constexpr (PARTS) { // how many parts this gene's reference needs (an eighth of the slots is slack: the cuts fall on cell boundaries)
+        if (P.needs_parts[gene] == 0u) return; // (uniform) the plain kernel's gene
+        __syncthreads();
+        const u32 n_all = s_cnt[1], cap_s = (u32)P.ref_cap - (u32)P.ref_cap / 8u;
+        if (n_all > (u32)P.ref_cap) n_parts_gene = (int)((n_all + cap_s - 1u) / cap_s);
+        if (n_parts_gene > P.n_parts) { if (tid == 0 && part == 0) P.route[gene] = P.ref_by_gofs ? 1u : (1u | (1u << 8)); return; } // (uniform; the high bits say why: "debug_routes")
+        if (part >= n_parts_gene) return;                                                          // (uniform)
+    }
     {
         KeyT tmin = MAXK, tmax = (KeyT)0;
         u32 ng = 0;
@@ -677,27 +796,71 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
             atomicMax(&s_kr[1], tmax);
             if (ng) atomicAdd(&s_cnt[0], ng);
         }
-        for (int sg = tid; sg < P.nseg; sg += NT) atomicAdd(&s_cnt[1], (u32)seg_nnz[sg]); // (a reference of any size: nseg = n_ref / 512)
         u32 gmax = 0;
         for (int gq = tid; gq < G; gq += NT) gmax = max(gmax, gq == ref ? 0u : (u32)nnz[gq]);
         gmax = (u32)wave_incl_scan_max((int)gmax);
         if (lane == 63 && gmax) atomicMax(&s_cnt[3], gmax);
-        if (tid == NT - 1 && P.seg_sum) { // the reference's value sum: its segments' sums in order
+        if (tid == NT - 1 && P.seg_sum && part == 0) { // the reference's value sum: its segments' sums in order
             double t = 0.0;
             for (int sg = 0; sg < P.nseg; ++sg) t += P.seg_sum[(size_t)gene * P.nseg + sg];
             P.out_sum[(size_t)gene * G + ref] = t;
         }
     }
     __syncthreads();
-    const u32 nA = s_cnt[1];
-    const u32 aZ = (u32)n_ref - nA;
+    const u32 nA_all = s_cnt[1];
+    const u32 aZ = (u32)n_ref - nA_all;
+    u32 nA = nA_all, n_low = 0;               // the part's reference keys; the reference's non-zero keys below the part
+    KeyT p_lo = (KeyT)0, p_hi = MAXK;         // the part's key range, both ends included (part 0 starts at 0, the last part ends at MAXK)
+    KeyT kmin_p = s_kr[0], kmax_p = s_kr[1];  // the range its value buckets cover
+    if constexpr (PARTS) {
+        if (n_parts_gene > 1) { // (uniform) 4096 cells over the reference's key range, counted in the (still empty) table's space
+            u32 *cells = tab;
+            const KeyT kmin_all = s_kr[0], range_all = (KeyT)(s_kr[1] - s_kr[0]);
+            const int bits_all = range_all ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range_all) : __clz((int)range_all)) : 0;
+            const int cs0 = bits_all > OCR_CELL_LG ? bits_all - OCR_CELL_LG : 0;
+            for_ref([&](KeyT k) { atomicAdd(&cells[(u32)((KeyT)(k - kmin_all) >> cs0)], 1u); });
+            if (tid < 4) s_b[tid] = tid == 2 ? (1u << OCR_CELL_LG) : tid == 3 ? nA_all : 0u; // part 0 starts at cell 0, the last part ends behind the last cell
+            __syncthreads();
+            constexpr int CPT = (1 << OCR_CELL_LG) / NT;
+            u32 c4[CPT], sum = 0;
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) { c4[e] = cells[tid * CPT + e]; sum += c4[e]; }
+            const u32 inc = (u32)wave_incl_scan_add((int)sum);
+            if (lane == 63) s_scan[wave] = inc;
+            __syncthreads();
+            u32 ex = inc - sum;
+            for (int w = 0; w < wave; ++w) ex += s_scan[w];
+            // the cut in front of part j: the cell in which the running count passes j / P of the keys (the cell itself goes to part j)
+            const u32 t_lo = (u32)((u64)nA_all * (u64)part / (u64)n_parts_gene), t_hi = (u32)((u64)nA_all * (u64)(part + 1) / (u64)n_parts_gene);
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) {
+                if (c4[e]) {
+                    if (part > 0 && ex <= t_lo && t_lo < ex + c4[e]) { s_b[0] = (u32)(tid * CPT + e); s_b[1] = ex; }
+                    if (part + 1 < n_parts_gene && ex <= t_hi && t_hi < ex + c4[e]) { s_b[2] = (u32)(tid * CPT + e); s_b[3] = ex; }
+                }
+                ex += c4[e];
+            }
+            __syncthreads();
+            const u32 c_lo = s_b[0], c_hi = s_b[2];
+            n_low = s_b[1];
+            nA = s_b[3] - s_b[1];
+            if (part > 0) { p_lo = (KeyT)(kmin_all + ((KeyT)c_lo << cs0)); kmin_p = p_lo; }
+            if (part + 1 < n_parts_gene) { p_hi = (KeyT)(kmin_all + ((KeyT)c_hi << cs0) - (KeyT)1); kmax_p = p_hi; }
+            for (int i = tid; i < (1 << OCR_CELL_LG); i += NT) cells[i] = 0u; // the table's space is empty again
+            __syncthreads();
+        }
+    }
+    auto for_part = [&](auto f) { // the reference's keys of this part
+        if constexpr (PARTS) for_ref([&](KeyT k) { if (k >= p_lo && k <= p_hi) f(k); });
+        else for_ref(f);
+    };
     for (u32 i = tid; i < min(nA, (u32)P.ref_cap) + 4u; i += NT) A[i] = MAXK; // empty slots (the scatter claims them by compare-and-swap) and the pad
     OcrRef<KeyT, EQ> R;
     R.A = A; R.tab = tab; R.last = (1u << P.nbk_lg) - 1u;
-    R.kmin = nA ? s_kr[0] : (KeyT)0;
+    R.kmin = nA ? kmin_p : (KeyT)0;
     R.ctab = ctab;
     {
-        const KeyT range = nA ? (KeyT)(s_kr[1] - s_kr[0]) : (KeyT)0;
+        const KeyT range = nA ? (KeyT)(kmax_p - kmin_p) : (KeyT)0;
         const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
         R.shift = bits > P.nbk_lg ? bits - P.nbk_lg : 0;
         R.cshift = bits > 8 ? bits - 8 : 0;
@@ -705,7 +868,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     }
     R.nA = nA;
     if constexpr (EQ) { // key counts of the 256 coarse cells -> each cell's share of the fine buckets
-        for_ref([&](KeyT k) { atomicAdd(&ccnt[(u32)((KeyT)(k - R.kmin) >> R.cshift)], 1u); });
+        for_part([&](KeyT k) { atomicAdd(&ccnt[(u32)((KeyT)(k - R.kmin) >> R.cshift)], 1u); });
         __syncthreads();
         if (wave == 0) { // four cells per lane.  A cell of cnt keys asks for cnt (NB - 256) / (2 n) buckets, rounded up to a power of
             // two (less than twice that) and at least one: the shares add up to at most NB
@@ -732,7 +895,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     // counters: +1 on the bucket's two bits; a bucket already at 3 takes the increment back and marks its word overfull (the
     // carry it sent into the next field in between is removed by the subtraction; whatever the fields of such a word end up
     // holding is never used).  The word's key count is kept in the high half meanwhile.
-    for_ref([&](KeyT k) {
+    for_part([&](KeyT k) {
         const u32 b = ocr_bucket(R, k), sh = (b & 15u) << 1;
         u32 *pw = tab + 2 * (b >> 4);
         atomicAdd(&pw[1], 1u);
@@ -747,18 +910,34 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         const int per_wave = NWD / NW, iters = per_wave / 64; // NWD >= NW * 64
         u32 *slice = tab + 2 * (wave * per_wave);
         u32 tot = 0, fmax = 0, ftot = 0;
+        u64 fsq = 0;
         for (int it = 0; it < iters; ++it) {
             const u32 h = slice[2 * (it * 64 + lane) + 1], c = h & 0xFFFFu;
             tot += c;
-            if (h >> 31) { fmax = max(fmax, c); ftot += c; }
+            if (h >> 31) { fmax = max(fmax, c); ftot += c; fsq += (u64)c * c; }
         }
         tot = (u32)wave_sum((int)tot);
         ftot = (u32)wave_sum((int)ftot);
         fmax = (u32)wave_incl_scan_max((int)fmax);
-        if (lane == 0) { s_scan[wave] = tot; if (ftot) atomicAdd(&s_cnt[4], ftot); }
+        if constexpr (PARTS) fsq = wave_sum<u64>(fsq);
+        if (lane == 0) { s_scan[wave] = tot; if (ftot) atomicAdd(&s_cnt[4], ftot); if (PARTS && fsq) atomicAdd((unsigned long long *)&s_red[0], (unsigned long long)fsq); }
         if (lane == 63 && fmax) atomicMax(&s_cnt[2], fmax);
         __syncthreads();
-        if (nA > (u32)P.ref_cap || s_cnt[2] > OCR_MAX_WORD || s_cnt[4] * 2u > nA || (s_cnt[3] > 64u * OCR_KMAX && !P.big_sorted)) { // uniform: this gene goes to k_ovo_rank
+        // Crowded tables.  What such a gene falls back to is k_ovo_rank (30 us a gene) without parts -- the thresholds are tuned for that --
+        // but the general route with them (a per-gene radix sort in HBM: 50 ms for a column of two million cells): there the gene stays
+        // unless the key-by-key walks would cost more than that -- a look-up that meets an overfull word of c keys walks c keys, and
+        // meets it with probability ~ c / nA: the expected walk is sum c^2 / nA keys per look-up; 32 is where the walks double the kernel.
+        const bool crowded = PARTS ? s_red[0] > 32ull * (u64)nA : (s_cnt[2] > OCR_MAX_WORD || s_cnt[4] * 2u > nA);
+        if (nA > (u32)P.ref_cap || crowded || (s_cnt[3] > 64u * OCR_KMAX && !P.big_sorted)) { // uniform: this gene goes to k_ovo_rank
+            if constexpr (PARTS) { // (the other parts of the gene are reading the segments: nothing is moved; the gene takes the general route)
+                // (dense layout: a reason in the high bits keeps k_ovo_rank away; regrouped sparse input: the reference is one run, that kernel can take it)
+                if (tid == 0) P.route[gene] = P.ref_by_gofs ? 1u : (1u | ((nA > (u32)P.ref_cap ? 2u : crowded ? 3u : 5u) << 8));
+#ifdef OCR_DEBUG_PRINT
+                if (tid == 0) printf("left: gene %d part %d/%d nA %u of %u, fullest word %u, in overfull words %u, kmin %llx kmax %llx, part range %llx .. %llx, n_low %u\n", gene, part,
+                                     n_parts_gene, nA, nA_all, s_cnt[2], s_cnt[4], (unsigned long long)s_kr[0], (unsigned long long)s_kr[1], (unsigned long long)kmin_p, (unsigned long long)kmax_p, n_low);
+#endif
+                return;
+            }
             u32 dst = P.nseg ? (u32)seg_nnz[0] : 0u;
             for (int sg = 1; sg < P.nseg; ++sg) { // move the reference's segments together (a segment holds at most NT / 2 keys)
                 const u32 c = (u32)seg_nnz[sg];
@@ -783,7 +962,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     }
     __syncthreads();
     // scatter: a key's bucket owns the slots [lo, hi) (an overfull word: the word's slots); the first empty one is claimed
-    for_ref([&](KeyT k) {
+    for_part([&](KeyT k) {
         const u32 b = ocr_bucket(R, k), W = b >> 4, sh = (b & 15u) << 1;
         const u32 w = tab[2 * W], h = tab[2 * W + 1];
         u32 lo, hi;
@@ -819,6 +998,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         TrReduce<u32> rS2;
         u64 tt_out = 0;   // lane j: sum t (t + 1) over group g0 + j's keys (non-zero only where keys tie)
         u32 neg_out = 0;  // lane j: group g0 + j's keys below zero
+        u32 nv_out = 0;   // PARTS, lane j: group g0 + j's keys inside the part
         KeyT nxt[KMAX];
         int nB_n = 0;
         auto fetch = [&](int j) {
@@ -827,7 +1007,11 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
             const KeyT *seg = Xg + __builtin_amdgcn_readlane(my_pos, j & 63);
 #pragma unroll
             for (int r = 0; r < KMAX; ++r)
-                if (r * 64 < nB_n) nxt[r] = (r * 64 + lane < nB_n) ? seg[r * 64 + lane] : ZEROK;
+                if (r * 64 < nB_n) {
+                    KeyT k = (r * 64 + lane < nB_n) ? seg[r * 64 + lane] : ZEROK;
+                    if constexpr (PARTS) k = (k >= p_lo && k <= p_hi) ? k : ZEROK; // (keys of other parts: masked out)
+                    nxt[r] = k;
+                }
         };
         fetch(0);
         for (int j = 0; j < 64; ++j) { // always 64 pushes so that the transpose-reduce completes
@@ -837,13 +1021,22 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
             const int nB = nB_n;
             fetch(j + 1);
             u32 S2 = 0;
-            if (nB) { // uniform
+            u32 nv = 0;
+            if constexpr (PARTS) {
+                if (nB) {
+#pragma unroll
+                    for (int r = 0; r < KMAX; ++r)
+                        if (r * 64 < nB) nv += (u32)__popcll(__ballot(cur[r] != ZEROK));
+                    if (lane == j) nv_out = nv;
+                }
+            }
+            if (PARTS ? nv != 0u : nB != 0) { // uniform
                 u32 less = 0, eqs = 0, negs = 0;
                 u64 TT = 0;
-                if (nB <= 64) ocr_group<KeyT, 1>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
-                else if (nB <= 128) ocr_group<KeyT, 2>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
-                else if (nB <= 192) ocr_group<KeyT, 3>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
-                else ocr_group<KeyT, 4>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                if (nB <= 64) ocr_group<KeyT, 1, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else if (nB <= 128) ocr_group<KeyT, 2, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else if (nB <= 192) ocr_group<KeyT, 3, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else ocr_group<KeyT, 4, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
                 S2 = 2u * less + eqs;
                 const u64 tm = __ballot(TT != 0ull);
                 if (tm) { // ties are few: mostly one lane holds the whole term
@@ -865,8 +1058,20 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
         if (gl < G && my_n <= 64u * KMAX) { // lane j now holds the totals of group g0 + j
             const size_t o = (size_t)gene * G + gl;
             if (gl == ref) {
-                P.out_2u[o] = -2;
-                P.out_tie[o] = 0;
+                if (part == 0) { P.out_2u[o] = -2; P.out_tie[o] = 0; }
+            } else if constexpr (PARTS) { // this part's share, added: its keys against the reference's keys below the part, inside it, and the zeros
+                const long long n_g = P.counts[gl];
+                u64 S2 = (u64)rS2.result + 2ull * n_low * (u64)nv_out + 2ull * aZ * (u64)(nv_out - neg_out);
+                u64 tie = T_A + 3ull * tt_out;
+                long long two_u = 0;
+                if (part == 0) { // the group's zeros, the constant term
+                    const u64 zc = (u64)(n_g - (long long)my_n), t0 = (u64)aZ + zc;
+                    S2 += zc * (2ull * nneg + aZ);
+                    tie += t0 * t0 * t0 - t0;
+                    two_u = 2ll * (long long)n_ref * n_g;
+                }
+                atomicAdd((unsigned long long *)&P.out_2u[o], (unsigned long long)(two_u - (long long)S2));
+                atomicAdd((unsigned long long *)&P.out_tie[o], (unsigned long long)tie);
             } else {
                 const long long n_g = P.counts[gl];
                 const u64 zc = (u64)(n_g - (long long)my_n);       // the group's zeros: one run against aZ reference zeros
@@ -884,10 +1089,12 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
             if (gb == ref) continue;
             const int n = (int)nnz[gb];
             if (n <= 64 * KMAX) continue;
-            const KeyT *seg = Xg + P.gofs[(size_t)gene * G + gb];
-            const BigRunFn<KeyT> fn = ((const BigRunFn<KeyT> *)P.big_fn)[(size_t)gene * P.n_cand + P.cand_of[gb]];
+            BigRunFn<KeyT> fn = ((const BigRunFn<KeyT> *)P.big_fn)[(size_t)gene * P.n_cand + P.cand_of[gb]];
+            const KeyT *seg = ((fn.shift & BIG_RUN_IN_TMP) ? (const KeyT *)P.big_tmp + (long long)gene * P.gene_stride : (const KeyT *)Xg) + P.gofs[(size_t)gene * G + gb];
+            fn.shift &= ~BIG_RUN_IN_TMP;
             u64 s2_acc = 0, tt_acc = 0; // per-lane partial sums
             u32 neg_acc = 0;            // (uniform)
+            u32 nv_acc = 0;             // (uniform) PARTS: keys inside the part
             bool bad = false;
             for (int s0 = 0; s0 < n && !bad;) {
                 const int win = min(64 * KMAX, n - s0);
@@ -905,28 +1112,53 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
                 if (nB == 0) { bad = true; break; } // a bucket of more than 256 keys: a tie-heavy column, not for this kernel
 #pragma unroll
                 for (int r = 0; r < KMAX; ++r) cur[r] = (r * 64 + lane < nB) ? cur[r] : ZEROK;
+                if constexpr (PARTS) { // the run is in ascending bucket order: most pieces lie wholly inside or outside the part
+                    u32 nv = 0;
+#pragma unroll
+                    for (int r = 0; r < KMAX; ++r) {
+                        cur[r] = (cur[r] >= p_lo && cur[r] <= p_hi) ? cur[r] : ZEROK;
+                        nv += (u32)__popcll(__ballot(cur[r] != ZEROK));
+                    }
+                    nv_acc += nv;
+                    if (nv == 0u) { s0 += nB; continue; } // (uniform)
+                }
                 u32 less = 0, eqs = 0, negs = 0;
                 u64 TT = 0;
-                if (nB <= 64) ocr_group<KeyT, 1>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
-                else if (nB <= 128) ocr_group<KeyT, 2>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
-                else if (nB <= 192) ocr_group<KeyT, 3>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
-                else ocr_group<KeyT, 4>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                if (nB <= 64) ocr_group<KeyT, 1, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else if (nB <= 128) ocr_group<KeyT, 2, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else if (nB <= 192) ocr_group<KeyT, 3, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else ocr_group<KeyT, 4, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
                 s2_acc += 2ull * less + eqs;
                 tt_acc += TT;
                 neg_acc += negs;
                 s0 += nB;
             }
-            if (bad) { if (lane == 0) P.route[gene] = 2u; continue; }
+            // (dense layout: the reference's segments lie where they were -- not k_ovo_rank's gene: a word above 255 sends it to the general route)
+            if (bad) { if (lane == 0) P.route[gene] = P.ref_by_gofs ? 2u : (2u | (6u << 8)); continue; }
             s2_acc = wave_sum<u64>(s2_acc);
             tt_acc = wave_sum<u64>(tt_acc);
             if (lane == 0) {
                 const size_t o = (size_t)gene * G + gb;
                 const long long n_g = P.counts[gb];
-                const u64 zc = (u64)(n_g - (long long)n);
-                const u64 S2 = s2_acc + 2ull * aZ * (u64)((u32)n - neg_acc) + zc * (2ull * nneg + aZ);
-                const u64 t0 = (u64)aZ + zc;
-                P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
-                P.out_tie[o] = T_A + 3ull * tt_acc + (t0 * t0 * t0 - t0);
+                if constexpr (PARTS) {
+                    u64 S2 = s2_acc + 2ull * n_low * (u64)nv_acc + 2ull * aZ * (u64)(nv_acc - neg_acc);
+                    u64 tie = T_A + 3ull * tt_acc;
+                    long long two_u = 0;
+                    if (part == 0) {
+                        const u64 zc = (u64)(n_g - (long long)n), t0 = (u64)aZ + zc;
+                        S2 += zc * (2ull * nneg + aZ);
+                        tie += t0 * t0 * t0 - t0;
+                        two_u = 2ll * (long long)n_ref * n_g;
+                    }
+                    atomicAdd((unsigned long long *)&P.out_2u[o], (unsigned long long)(two_u - (long long)S2));
+                    atomicAdd((unsigned long long *)&P.out_tie[o], (unsigned long long)tie);
+                } else {
+                    const u64 zc = (u64)(n_g - (long long)n);
+                    const u64 S2 = s2_acc + 2ull * aZ * (u64)((u32)n - neg_acc) + zc * (2ull * nneg + aZ);
+                    const u64 t0 = (u64)aZ + zc;
+                    P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
+                    P.out_tie[o] = T_A + 3ull * tt_acc + (t0 * t0 * t0 - t0);
+                }
             }
         }
     }

@@ -39,6 +39,14 @@ template <typename KeyT> static void packed_ref_sizing(int64_t n_ref, int *cap, 
     const size_t fixed = ocr_lds_bytes(0, 16, sizeof(KeyT));
     *cap = (int)std::min<int64_t>(n_ref, (int64_t)((kMaxLds - fixed) / sizeof(KeyT)) - 8);
 }
+// Value-range parts (k_ovo_rank_compact<.., PARTS>): how many a gene of this reference may need -- every cell non-zero, an eighth of
+// the slots kept as slack for cuts that fall on cell boundaries -- or 1 when its cells fit the slots anyway (or the table is too small
+// to count the 4096 cells in, or "no_ovo_parts").  Genes that would need more than 32 parts are left to the general route by the kernel.
+template <typename KeyT> static int packed_ref_parts(const illico_ctx *c, int64_t n_ref, int cap, int lg) {
+    if (c->no_ovo_parts || n_ref <= cap || lg < 16 || cap < 1024) return 1;
+    const int64_t cap_s = cap - cap / 8;
+    return (int)std::min<int64_t>(32, (n_ref + cap_s - 1) / cap_s);
+}
 // Sizes the route holds.  The reference may be of any size: it
 // is packed in 512-row segments, the rank kernel keeps as many of its NON-ZERO keys as LDS holds (packed_ref_sizing) and leaves a gene
 // with more -- like the tie-heavy ones -- to k_ovo_rank, or, when that kernel's LDS does not hold the reference either (or groups exceed
@@ -54,6 +62,31 @@ template <typename KeyT> static bool packed_route_fits(const illico_ctx *c) {
 // ... and whether what the packed kernel leaves can go to k_ovo_rank over the same layout
 template <typename KeyT> static bool packed_leftovers_fit_sort_route(const illico_ctx *c) {
     return c->max_nonref <= 1024 && ovo_sort_route_fits<KeyT>(c->h_counts[c->ref], c->max_nonref);
+}
+
+
+// the two launches that deal the runs of more than 256 keys into value buckets (kernels_ovo_compact.h): through LDS up to `cap` keys, through
+// the second key buffer `tmp` beyond (tmp == nullptr: such a run sends its gene to the general route)
+template <typename KeyT>
+static int launch_bucket_big_runs(illico_ctx *c, void *Xs, void *tmp, long long stride, const u16 *nnz, const u32 *gofs, int nb, int G, int cap, BigRunFn<KeyT> *big_fn,
+                                  u32 *route, int64_t longest_run) {
+    auto kern = k_bucket_big_runs<KeyT>;
+    const size_t lds = srt_lds_bytes(sizeof(KeyT), cap);
+    const bool global = tmp != nullptr && longest_run > cap;
+    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(c->pk_nbig, nb), dim3(SRT_NT), lds, c->stream, Xs, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, big_fn, route, global ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    if (global) {
+        auto kg = k_bucket_big_runs_global<KeyT>;
+        int lg = 6;
+        while (lg < SRT_LG_MAX_G && (4ll << lg) < longest_run) ++lg;
+        if (c->big_runs_cap > 0) lg = std::min(lg, 11); // (tests: few counters as well)
+        const size_t ldsg = (size_t)4 << lg;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
+        hipLaunchKernelGGL(kg, dim3(c->pk_nbig, nb), dim3(SRTG_NT), ldsg, c->stream, Xs, tmp, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, lg, big_fn, route);
+        HIPCHK(c, hipGetLastError());
+    }
+    return ILLICO_OK;
 }
 
 constexpr int kOvrThreads = 256; // several small workgroups per CU overlap each other's barriers (1024 measured the same)

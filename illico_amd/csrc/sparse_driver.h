@@ -317,7 +317,17 @@ static int run_csc_counts_deferred(illico_ctx *c, const void *data, const void *
 // the two-kernel route): statistics + finalize per batch.
 template <typename InT, typename IdxT, typename KeyT>
 static int run_csc_gene_route(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, const int *d_codes,
-                              int dtype, int64_t col_lb, int flags, int alternative, const OutPlanes &o, std::vector<int64_t> &cols) {
+                              int dtype, int64_t col_lb, int flags, int alternative, const OutPlanes &o, std::vector<int64_t> &cols,
+                              const std::vector<int64_t> *gene_nnz = nullptr /* stored entries of gene col_lb + j */) {
+    if (gene_nnz) { // genes with more entries than the kernel's LDS key buffer would only be flagged by it: when that is most of them (eight-byte
+        // keys at C3's 30 000 entries per gene) the launch is skipped altogether
+        const int runend_cap0 = (int)std::max<int64_t>(1, std::min<int64_t>(c->h_counts[c->ref], 8192));
+        const size_t fixed0 = cscg_lds_bytes((int)c->n_groups, 0, runend_cap0, sizeof(KeyT), false);
+        const int64_t cap0 = fixed0 < kMaxLds ? (int64_t)((kMaxLds - fixed0) / sizeof(KeyT)) : 0;
+        int64_t fit = 0;
+        for (int64_t cc : cols) fit += (*gene_nnz)[cc - col_lb] <= cap0 ? 1 : 0;
+        if (fit * 4 < (int64_t)cols.size()) return ILLICO_OK; // every gene stays in `cols` for the two-kernel route
+    }
     const int64_t g0 = 0, g1 = (int64_t)cols.size();
     std::vector<int64_t> fallback_cols;
     const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
@@ -563,10 +573,21 @@ static int launch_csr_counts_route(illico_ctx *c, const InT *d_data, const IdxT 
 
 // Sparse OVO with groups whose (gene, group) runs outgrow what k_csc_gene / k_ovo_rank take quickly (clusters of hundreds or
 // thousands of cells): regroup, then the packed rank kernel of the dense route (kernels_ovo_compact.h) on the regrouped runs
-static bool sparse_packed_rank_fits(const illico_ctx *c) {
-    if (c->ref < 0 || c->no_packed_dense || c->max_nonref <= 256 || c->max_nonref > 65535) return false;
+// (small_groups: groups of at most 256 cells as well -- k_csc_gene takes those in one kernel when a gene's entries fit its LDS key buffer;
+//  genes that do not -- eight-byte keys: C3's 30 000 entries per gene -- are ranked by the packed kernel too, not by k_ovo_rank)
+static bool sparse_packed_rank_fits(const illico_ctx *c, bool small_groups = false) {
+    if (c->ref < 0 || c->no_packed_dense || (c->max_nonref <= 256 && !small_groups) || c->max_nonref > 65535) return false;
     const int64_t n_ref = c->h_counts[c->ref];
     return n_ref >= 1 && n_ref <= 65535;
+}
+
+// Average stored entries per column above which a sparse window is written out dense (the dense routes then rank it): what the per-gene
+// LDS kernels hold -- 32 768 four-byte keys, half as many eight-byte ones.  OVO with eight-byte keys keeps the four-byte bound: its columns
+// are regrouped in HBM and ranked by the packed kernel, whatever their length (C3 shape as CSR in float64: 14.3 ms through the dense
+// window -- 19 GB of it --, 24 through k_ovo_rank).
+template <typename KeyT> static double long_column(const illico_ctx *c) {
+    if (sizeof(KeyT) == 8 && c->ref >= 0 && !c->no_sparse_packed_small && sparse_packed_rank_fits(c, true)) return 32768.0;
+    return 32768.0 * 4.0 / (double)sizeof(KeyT);
 }
 
 // sizes the group-major CSR pass holds (kernels_csr_counts.h)
@@ -845,7 +866,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     // fraction d of cells stored: 6e-13 at |z| = 37 (p ~ 1e-300) for d = 0.04, the bound used here; below that the window stays with
     // the sparse routes (kernels_finalize.h: tie_f64_sparse).
     if (is_csr && allow_dense_window && allow_transpose && !c->no_csr_densify_any && !c->tap && !c->big_n && n_rows < (1ll << 31) &&
-        density * (double)n_rows > 32768.0 * 4.0 / (double)sizeof(KeyT) && (c->ref >= 0 || density >= 0.04) && (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
+        density * (double)n_rows > long_column<KeyT>(c) && (c->ref >= 0 || density >= 0.04) && (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
         int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * sizeof(InT))) & ~63ll;
         wmax = std::min<int64_t>(wmax, (1ll << 29));
         if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, (c->gene_batch + 63) & ~63ll);
@@ -1027,7 +1048,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     // ---- CSC, any values, columns longer than the per-gene LDS kernels hold: a dense window in the matrix's own type + the dense routes
     // (as for CSR above; the columns' row indices must ascend: asked on the device) ----
     if (!is_csr && !indices_are_codes && allow_dense_window && !c->no_csr_densify_any && !c->tap && !c->big_n && n_rows < (1ll << 31) &&
-        (int64_t)cols.size() == W && W > 0 && (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) / (double)W > 32768.0 * 4.0 / (double)sizeof(KeyT) &&
+        (int64_t)cols.size() == W && W > 0 && (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) / (double)W > long_column<KeyT>(c) &&
         (c->ref >= 0 || (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) >= 0.04 * (double)W * (double)n_rows) &&
         (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
         if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
@@ -1062,7 +1083,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
         }
     }
     if (!is_csr && !ovr && !c->no_csc_gene_path && !sparse_packed_rank_fits(c)) { // (runs of more than 128 keys leave k_csc_gene, runs of 32 .. 128 are slow in it)
-        if ((rc = run_csc_gene_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, d_codes, dtype, col_lb, flags, alternative, o, cols)))
+        if ((rc = run_csc_gene_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, d_codes, dtype, col_lb, flags, alternative, o, cols, &gene_nnz)))
             return rc;
         if (cols.empty()) return ILLICO_OK;
     }
@@ -1208,7 +1229,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
             // short runs of a sparse layout cheap for any key type); the histogram route is kept for the sizes it
             // alone can take without the global-sort fallback.
             const u32 *route_flags = need_glob ? gflags : nullptr;
-            if (sparse_packed_rank_fits(c) && ovo_sort_route_fits<KeyT>(std::min<int64_t>(c->h_counts[c->ref], b.max_gene), 1024)) {
+            if (sparse_packed_rank_fits(c, sizeof(KeyT) == 8 && !c->no_sparse_packed_small) && ovo_sort_route_fits<KeyT>(std::min<int64_t>(c->h_counts[c->ref], b.max_gene), 1024)) {
                 // groups of hundreds / thousands of cells: the regrouped runs in the packed layout's terms, runs above 256 keys dealt into
                 // value buckets, then k_ovo_rank_compact (look-ups in the bucketed reference, pieces of 256 keys); what it leaves -- tie-heavy
                 // reference runs -- and the count-valued genes (gflags == 0: k_ovo_counts) go on to launch_ovo
@@ -1225,12 +1246,11 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                     if (c->pk_nbig > 0) {
                         if ((rc = get_scratch(c, "packed_big_fn", (size_t)nb * c->pk_nbig * sizeof(BigRunFn<KeyT>), &v))) return rc;
                         big_fn = (BigRunFn<KeyT> *)v;
-                        auto kern = k_bucket_big_runs<KeyT>;
-                        const int cap = (int)std::min<int64_t>(srt_cap<KeyT>(), (std::min<int64_t>(c->max_nonref, b.max_gene) + 63) & ~63ll);
-                        const size_t lds = srt_lds_bytes(sizeof(KeyT), cap);
-                        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        hipLaunchKernelGGL(kern, dim3(c->pk_nbig, nb), dim3(SRT_NT), lds, c->stream, (void *)Xs, 0ll, (const u16 *)pk_nnz, (const u32 *)pk_gofs,
-                                           (const int *)c->d_pk_big, c->pk_nbig, G, cap, big_fn, route);
+                        const int64_t longest = std::min<int64_t>(c->max_nonref, b.max_gene);
+                        int cap = (int)std::min<int64_t>(srt_cap<KeyT>(), (longest + 63) & ~63ll);
+                        if (c->big_runs_cap > 0) cap = std::min(cap, std::max(c->big_runs_cap, 512) & ~63);
+                        // (runs beyond the LDS slots are dealt through the global sort's second key buffer)
+                        if ((rc = launch_bucket_big_runs<KeyT>(c, (void *)Xs, c->no_big_runs_global ? nullptr : kb, 0ll, pk_nnz, pk_gofs, nb, G, cap, big_fn, route, longest))) return rc;
                     }
                     HIPCHK(c, hipGetLastError());
                 }
@@ -1240,15 +1260,33 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                     C.Xs = Xs; C.gene_stride = 0; C.counts = c->d_counts; C.nnz = pk_nnz; C.gofs = pk_gofs; C.ref_out = 0; C.seg_nnz = ref_nnz; C.seg_sum = nullptr;
                     C.out_sum = nullptr; C.G = G; C.ref = (int)c->ref; C.n_genes = nb; C.nseg = 1;
                     packed_ref_sizing<KeyT>(std::min<int64_t>(c->h_counts[c->ref], std::max<int64_t>(b.max_gene, 1)), &C.ref_cap, &C.nbk_lg);
+                    if (c->packed_ref_cap > 0) C.ref_cap = std::min(C.ref_cap, std::max(c->packed_ref_cap, 1024));
                     C.out_2u = s2u; C.out_tie = stie; C.route = route; C.big_sorted = c->pk_nbig > 0 ? 1 : 0; C.ref_by_gofs = 1; C.gene_flags = route_flags;
-                    C.big_fn = big_fn; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
+                    C.big_fn = big_fn; C.big_tmp = kb; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
                     const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
                     const bool eq = c->packed_eq_buckets >= 0 ? c->packed_eq_buckets != 0 : c->h_counts[c->ref] > 16384;
+                    // a reference run longer than the kernel's key slots is taken in value-range parts (every part adds its share: the
+                    // statistics start from zero; k_ovo_counts writes the count-valued genes' afterwards)
+                    C.n_parts = packed_ref_parts<KeyT>(c, std::min<int64_t>(c->h_counts[c->ref], std::max<int64_t>(b.max_gene, 1)), C.ref_cap, C.nbk_lg);
+                    const bool parts = C.n_parts > 1;
+                    if (parts) {
+                        if ((rc = get_scratch(c, "packed_needs_parts", (size_t)nb * 4, &v))) return rc;
+                        C.needs_parts = (u32 *)v;
+                        HIPCHK(c, hipMemsetAsync(C.needs_parts, 0, (size_t)nb * 4, c->stream));
+                        HIPCHK(c, hipMemsetAsync(s2u, 0, (size_t)nb * G * sizeof(long long), c->stream));
+                        HIPCHK(c, hipMemsetAsync(stie, 0, (size_t)nb * G * sizeof(u64), c->stream));
+                    }
                     auto kern = eq ? k_ovo_rank_compact<KeyT, true> : k_ovo_rank_compact<KeyT, false>;
                     HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     ProfScope ps(c, KID_OVO_RANK_COMPACT);
-                    hipLaunchKernelGGL(kern, dim3(nb), dim3(OCR_NT), lds, c->stream, C);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(OCR_NT), lds, c->stream, C);
                     HIPCHK(c, hipGetLastError());
+                    if (parts) {
+                        auto kp = k_ovo_rank_compact<KeyT, true, true>;
+                        HIPCHK(c, hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        hipLaunchKernelGGL(kp, dim3((unsigned)nb * (unsigned)C.n_parts), dim3(OCR_NT), lds, c->stream, C);
+                        HIPCHK(c, hipGetLastError());
+                    }
                 }
                 if ((rc = launch_ovo<KeyT>(c, P, ref_cap_b, grp_cap_b, route_flags, &gb, true, route))) return rc;
             } else

@@ -89,7 +89,9 @@ int illico_ctx_set_stream(illico_ctx *ctx, void *hip_stream);
  * for OVO, the transposition with the group sums folded in for OVR; 1 = the plain transposition and the kernels behind it;
  * "no_ovr_packed_partition" = 1: dense OVR splits the padded key rows -- every key -- instead of the packed ones;
  * "packed_eq_buckets": the packed OVO kernel's value buckets follow the reference's distribution, 1 = always, 0 = never,
- * -1 = for references of more than 16384 cells, the default),
+ * -1 = for references of more than 16384 cells, the default; "no_ovo_parts" = 1: a reference whose non-zero keys outgrow the kernel's
+ * LDS slots is never taken in value-range parts -- such genes go to the general sort routes; "no_big_runs_global" = 1: a ranked
+ * group's run of more keys than LDS holds is not dealt into value buckets through HBM -- its gene goes to the general sort routes),
  * "no_ovo_ref_buckets" (OVO sort route: reference column in value buckets instead of sorted), "no_ovr_parts_path" (dense OVR, any values: value-range parts ranked in LDS; "ovr_parts_cap" > 0 caps the keys per part), "no_csc_gene_path" (CSC OVO single-kernel route), "no_csc_ovr_gene_path" (CSC OVR single-kernel route; "csc_ovr_sorted_form" = 1 makes it sort every
  * gene in LDS, the form tie-heavy columns take, instead of bucketing the keys), "no_csc_regroup_lds" (two-kernel CSC route: regroup with scattered
  * stores only),
