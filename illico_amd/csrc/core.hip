@@ -180,6 +180,8 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_big_runs_global")) c->no_big_runs_global = value != 0;
     else if (!strcmp(key, "packed_ref_cap")) c->packed_ref_cap = (int)value;
     else if (!strcmp(key, "debug_routes")) c->debug_routes = value != 0;
+    else if (!strcmp(key, "host_fill_threads")) c->host_fill_threads = (int)value;
+    else if (!strcmp(key, "no_host_numa")) c->no_host_numa = value != 0;
     else if (!strcmp(key, "no_sparse_packed_small")) c->no_sparse_packed_small = value != 0;
     else if (!strcmp(key, "big_runs_cap")) c->big_runs_cap = (int)value;
     else if (!strcmp(key, "no_ovr_packed_partition")) c->no_ovr_packed_partition = value != 0;
@@ -188,6 +190,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_csc_regroup_lds")) c->no_csc_regroup_lds = value != 0;
     else if (!strcmp(key, "no_csc_gene_path")) c->no_csc_gene_path = value != 0;
     else if (!strcmp(key, "ovr_parts_cap")) c->ovr_parts_cap = value;
+    else if (!strcmp(key, "ovr_rank_whole")) c->ovr_rank_whole = value != 0;
     else if (!strcmp(key, "no_ovo_ref_buckets")) c->no_ovo_ref_buckets = value != 0;
     else if (!strcmp(key, "no_ovr_parts_path")) c->no_ovr_parts_path = value != 0;
     else if (!strcmp(key, "no_csc_ovr_gene_path")) c->no_csc_ovr_gene_path = value != 0;

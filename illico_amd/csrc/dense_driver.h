@@ -477,9 +477,11 @@ static int host_windows_pipeline(illico_ctx *c, const InT *X, int64_t ld, int64_
     double t_fill = 0.0, t_wait = 0.0; // (ILLICO_HS_DEBUG=1 prints them: seconds the producer spent filling slots / the consumer waiting for one)
     const int device = c->device;
     hipStream_t compute = c->stream;
+    const int x_node = c->no_host_numa ? -1 : numa_node_of_buffer(X, (size_t)N * (size_t)ld * sizeof(InT));
     std::thread producer([&] {
         hipSetDevice(device);
-        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(HS_THREADS, N / 4096 + 1));
+        numa_confine_this_thread(x_node); // (the fill threads started below inherit the mask; this thread ends with the call)
+        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(c->host_fill_threads > 0 ? c->host_fill_threads : HS_THREADS, N / 4096 + 1));
         for (int64_t k = 0; k < n_win; ++k) {
             const int j = (int)(k % HS_SLOTS);
             const int64_t w0 = col_lb + k * wmax, wn = std::min<int64_t>(wmax, col_ub - w0);
@@ -613,9 +615,11 @@ static int host_windows_pipeline_narrow(illico_ctx *c, const InT *X, int64_t ld,
     double t_fill = 0.0, t_wait = 0.0;
     const int device = c->device;
     hipStream_t compute = c->stream;
+    const int x_node = c->no_host_numa ? -1 : numa_node_of_buffer(X, (size_t)N * (size_t)ld * sizeof(InT));
     std::thread producer([&] {
         hipSetDevice(device);
-        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(HS_THREADS_NARROW, N / 4096 + 1));
+        numa_confine_this_thread(x_node); // (the fill threads started below inherit the mask; this thread ends with the call)
+        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(c->host_fill_threads > 0 ? c->host_fill_threads : HS_THREADS_NARROW, N / 4096 + 1));
         for (int64_t k = 0; k < n_win; ++k) {
             const int j = (int)(k % HS_SLOTS);
             const int64_t w0 = col_lb + k * wmax, wn = std::min<int64_t>(wmax, col_ub - w0), pitch = (wn + 63) & ~63ll;
@@ -685,8 +689,8 @@ static int host_windows_pipeline_narrow(illico_ctx *c, const InT *X, int64_t ld,
     producer.join();
     hipStreamSynchronize(hs->copy);
     if (getenv("ILLICO_HS_DEBUG"))
-        fprintf(stderr, "[illico] host byte windows: %lld x %lld genes, slot fill %.1f ms, consumer waited %.1f ms for uploads\n", (long long)n_win,
-                (long long)wmax, t_fill * 1e3, t_wait * 1e3);
+        fprintf(stderr, "[illico] host byte windows: %lld x %lld genes, slot fill %.1f ms, consumer waited %.1f ms for uploads, matrix on NUMA node %d\n", (long long)n_win,
+                (long long)wmax, t_fill * 1e3, t_wait * 1e3, x_node);
     return rc;
 }
 

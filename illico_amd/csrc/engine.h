@@ -141,6 +141,8 @@ struct illico_ctx {
     bool no_ovr_packed_partition = false; // 1: dense OVR partitions the padded rows (every key) instead of the packed ones
     bool no_packed_dense = false;      // 1: dense OVO on continuous values takes the transpose + k_ovo_rank route (no group-wise packing)
     bool no_sparse_packed_small = false; // sparse OVO, eight-byte keys: genes beyond k_csc_gene's LDS go to k_ovo_rank / the dense window (as before round 5), not to the packed rank kernel
+    bool no_host_numa = false;         // host-window pipelines: do not confine the fill threads to the NUMA node the caller's matrix lives on
+    int host_fill_threads = 0;         // > 0: host threads that fill the pinned slots of the host-window pipelines (default: 12 float32 / 16 byte windows)
     bool debug_routes = false;         // stderr: what the packed OVO rank kernel left to the general routes, and why
     int packed_ref_cap = 0;            // > 0: caps the packed rank kernel's key slots for the reference (tests: value-range parts at small sizes)
     int big_runs_cap = 0;              // > 0: caps k_bucket_big_runs' LDS key slots (tests: the route through HBM at small sizes)
@@ -155,6 +157,7 @@ struct illico_ctx {
     bool no_fused_wide = false;        // 1: no second, 256-value pass of the fused OVO route (genes beyond 63 go to the two-pass routes)
     bool no_csc_regroup_lds = false;   // 1: the two-kernel CSC route regroups with k_csc_segment only
     bool no_csc_gene_path = false;
+    bool ovr_rank_whole = false;       // dense OVR rank kernel: one 1024-thread workgroup per CU with all of the LDS (as before round 5) instead of two of 512
     int64_t ovr_parts_cap = 0;         // > 0: keys per part at most in the value-range parts route (tests: many small parts)
     bool no_ovo_ref_buckets = false;   // 1: the OVO sort route always sorts the reference column (no value-bucket form)
     bool no_ovr_parts_path = false;    // 1: dense OVR (any values) never takes the value-range parts route (k_ovr_partition + k_csc_ovr_gene)

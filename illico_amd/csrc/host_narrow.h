@@ -4,7 +4,76 @@
 // staging slots (dense_driver.h: host_windows_pipeline_narrow); float32 rows go through AVX2 when the CPU has it (16 cells per step).
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#if defined(__linux__)
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#endif
+
+// ---- where the caller's matrix lives ---------------------------------------------------------------------------------------------
+// The threads that fill the pinned slots read the whole matrix once, in row pieces a few KB long.  On a two-socket host those reads
+// cost twice as much from the other socket (C2 shape, byte windows, 16 threads: 60 ms with the threads on the matrix's NUMA node,
+// 131 - 158 ms on the other one, 84 ms wherever the scheduler puts them; profiles/NOTES_r05.md).  The pages' node is asked of the kernel
+// (move_pages in query mode: sixteen pages spread over the buffer); when three quarters of them sit on one node, the producer thread --
+// and with it the fill threads it starts -- is confined to that node's CPUs (those of them the process may use at all).
+static inline int numa_node_of_buffer(const void *p, size_t bytes) {
+#if defined(__linux__) && defined(SYS_move_pages)
+    const long page = sysconf(_SC_PAGESIZE);
+    if (page <= 0 || bytes < (size_t)page * 64) return -1;
+    void *pages[16];
+    int status[16];
+    for (int i = 0; i < 16; ++i) {
+        const uintptr_t a = (uintptr_t)p + (uintptr_t)((double)bytes * ((double)i + 0.5) / 16.0);
+        pages[i] = (void *)(a & ~(uintptr_t)(page - 1));
+        status[i] = -1;
+    }
+    if (syscall(SYS_move_pages, 0, 16ul, pages, nullptr, status, 0) != 0) return -1;
+    int cnt[64] = {0}, best = 0;
+    for (int i = 0; i < 16; ++i)
+        if (status[i] >= 0 && status[i] < 64) ++cnt[status[i]];
+    for (int n = 1; n < 64; ++n)
+        if (cnt[n] > cnt[best]) best = n;
+    return cnt[best] * 4 >= 16 * 3 ? best : -1;
+#else
+    (void)p; (void)bytes;
+    return -1;
+#endif
+}
+// confines the CALLING thread (and the threads it starts afterwards) to the CPUs of `node` that its present mask allows; false: nothing changed
+static inline bool numa_confine_this_thread(int node) {
+#if defined(__linux__)
+    if (node < 0) return false;
+    char path[96], buf[4096];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    const size_t got = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[got] = 0;
+    cpu_set_t now, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof now, &now) != 0) return false;
+    int any = 0;
+    for (const char *q = buf; *q;) { // "0-63,128-191"
+        char *e;
+        const long lo = strtol(q, &e, 10);
+        if (e == q) break;
+        long hi = lo;
+        if (*e == '-') { q = e + 1; hi = strtol(q, &e, 10); }
+        for (long cpu = lo; cpu <= hi && cpu < CPU_SETSIZE; ++cpu)
+            if (cpu >= 0 && CPU_ISSET((int)cpu, &now)) { CPU_SET((int)cpu, &want); ++any; }
+        q = *e == ',' ? e + 1 : e;
+        if (*e != ',' ) break;
+    }
+    if (any < 4) return false; // (a handful of CPUs would starve the fill)
+    return sched_setaffinity(0, sizeof want, &want) == 0;
+#else
+    (void)node;
+    return false;
+#endif
+}
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif

@@ -38,9 +38,9 @@ struct OvrRankGeneParams {
     u64 *out_tie;             // [nb][G]
 };
 
-template <typename KeyT>
-__global__ __launch_bounds__(CSCO_NT) void k_ovr_rank_gene_parts(OvrRankGeneParams P) {
-    constexpr int NT = CSCO_NT, NW = NT / 64, CH = 64 * CSCO_K, UL = 8;
+template <typename KeyT, int NT_ = CSCO_NT>
+__global__ __launch_bounds__(NT_) void k_ovr_rank_gene_parts(OvrRankGeneParams P) {
+    constexpr int NT = NT_, NW = NT / 64, CH = 64 * CSCO_K, UL = 8;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
     constexpr u64 CNT1 = 1ull << CSCO_CNT_SHIFT, R2MASK = CNT1 - 1ull;

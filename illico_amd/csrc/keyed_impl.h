@@ -91,9 +91,15 @@ int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, 
     if (c->no_ovr_parts_path || G > 65535 || c->max_nonref >= (1ll << 23) ||
         (double)c->max_nonref * 2.0 * (double)N >= (double)(1ull << CSCO_CNT_SHIFT))
         return ILLICO_OK;
-    int lg = 14;
-    if (csco_key_cap(G, lg, sizeof(KeyT), kMaxLds, true) < 12288) lg = 13;
-    const int key_cap = csco_key_cap(G, lg, sizeof(KeyT), kMaxLds, true);
+    // Two workgroups of 512 threads per CU, each with half of the LDS (parts half as long, twice as many), while a part still holds 8192
+    // keys beside the groups' accumulators: one workgroup's barriers and first loads of a part run under the other's ranking -- the rank
+    // kernel 8.0 -> 6.0 ms at C2 shape, the partition (twice the parts to write) 4.8 -> 6.1: 17.5 -> 16.7 ms.  "ovr_rank_whole" = 1: one
+    // workgroup of 1024 threads, as before round 5.
+    const bool half = !c->ovr_rank_whole && csco_key_cap(G, 13, sizeof(KeyT), kMaxLds / 2, true) >= 8192;
+    const size_t lds_budget = half ? kMaxLds / 2 : kMaxLds;
+    int lg = half ? 13 : 14;
+    if (csco_key_cap(G, lg, sizeof(KeyT), lds_budget, true) < 12288 && !half) lg = 13;
+    const int key_cap = csco_key_cap(G, lg, sizeof(KeyT), lds_budget, true);
     int cap = key_cap & ~1023; // any part can also take the sorted form (1024-key chunks)
     if (cap < 4096) return ILLICO_OK;
     if (c->ovr_parts_cap > 0) cap = (int)std::min<int64_t>(cap, std::max<int64_t>(1024, c->ovr_parts_cap & ~1023ll)); // tests: many small parts
@@ -145,12 +151,19 @@ int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, 
         P.out_2u = s2u; P.out_tie = stie;
         const size_t lds = csco_fixed_lds_bytes(G, lg, true) + (size_t)(key_cap + 4) * sizeof(KeyT);
         ProfScope ps(c, KID_OVR_RANK_PARTS);
-        auto kern = k_ovr_rank_gene_parts<KeyT>;
-        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int n_cu = 256;
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-        const unsigned grid = (unsigned)std::min<long long>((long long)nb, std::max(n_cu, 1)); // one resident workgroup per CU (LDS)
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(CSCO_NT), lds, c->stream, P);
+        if (half) {
+            auto kern = k_ovr_rank_gene_parts<KeyT, 512>;
+            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const unsigned grid = (unsigned)std::min<long long>((long long)nb, 2ll * std::max(n_cu, 1)); // two resident workgroups per CU
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, P);
+        } else {
+            auto kern = k_ovr_rank_gene_parts<KeyT>;
+            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const unsigned grid = (unsigned)std::min<long long>((long long)nb, std::max(n_cu, 1)); // one resident workgroup per CU (LDS)
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(CSCO_NT), lds, c->stream, P);
+        }
         HIPCHK(c, hipGetLastError());
     }
     // genes that left the route (a coarse bucket too full, a part that fits neither form): the general route, over the

@@ -56,6 +56,7 @@ SETS: dict[str, list[tuple[str, str]]] = {
         ("cont_dense_g2000", "--workload c2 --values continuous"),
         ("cont_dense_g10000", "--workload c2 --values continuous --groups 10000"),
         ("cont_dense_ovr_g50", "--workload c2 --values continuous --test ovr --groups 50"),
+        ("cont_dense_ovr_g2000", "--workload c2 --values continuous --test ovr"),
         ("cont_dense_ovr_g10000", "--workload c2 --values continuous --test ovr --groups 10000"),
         ("cont_csc_g50", "--workload c3 --values continuous --groups 50"),
         ("cont_csc_g300", "--workload c3 --values continuous --groups 300"),
