@@ -182,6 +182,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "debug_routes")) c->debug_routes = value != 0;
     else if (!strcmp(key, "host_fill_threads")) c->host_fill_threads = (int)value;
     else if (!strcmp(key, "no_host_numa")) c->no_host_numa = value != 0;
+    else if (!strcmp(key, "no_sparse_byte_values")) c->no_sparse_byte_values = value != 0;
     else if (!strcmp(key, "no_sparse_packed_small")) c->no_sparse_packed_small = value != 0;
     else if (!strcmp(key, "big_runs_cap")) c->big_runs_cap = (int)value;
     else if (!strcmp(key, "no_ovr_packed_partition")) c->no_ovr_packed_partition = value != 0;
@@ -601,6 +602,10 @@ void free_host_stage(illico_ctx *c) {
     if (!hs) return;
     if (hs->copy) { hipStreamSynchronize(hs->copy); hipStreamDestroy(hs->copy); }
     if (hs->lists) hipHostFree(hs->lists);
+    for (int j = 0; j < 2; ++j) {
+        if (hs->sp_pin[j]) hipHostFree(hs->sp_pin[j]);
+        if (hs->sp_up[j]) hipEventDestroy(hs->sp_up[j]);
+    }
     for (int j = 0; j < HS_SLOTS; ++j) {
         if (hs->pin[j]) hipHostFree(hs->pin[j]);
         if (hs->up[j]) hipEventDestroy(hs->up[j]);

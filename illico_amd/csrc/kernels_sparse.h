@@ -652,6 +652,12 @@ static __global__ __launch_bounds__(256) void k_f64_to_f32(const double *__restr
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = (float)v[i];
 }
 
+// stored count values that travelled to the device as bytes (sparse_driver.h: upload_values_as_bytes) back in the matrix's own type
+template <typename InT>
+__global__ __launch_bounds__(256) void k_bytes_to_values(const uint8_t *__restrict__ b, long long n, InT *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = (InT)b[i];
+}
+
 // replaces check_indices_sorted_per_parcel (utils/ranking.py:245-273) for device-resident CSR
 template <typename IdxT>
 __global__ void k_csr_sorted_check(const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr, int n_rows, int *__restrict__ bad) {

@@ -2,6 +2,8 @@
 #pragma once
 
 #include "keyed_driver.h"
+#include "host_narrow.h"
+#include <thread>
 // ---- order-independent value sums (kernels_sums.h) ----
 template <typename InT, typename IdxT>
 static int launch_csc_value_sums(illico_ctx *c, const InT *d_data, const IdxT *d_indices, const IdxT *d_indptr, int64_t kshift, int64_t col0,
@@ -571,6 +573,77 @@ static int launch_csr_counts_route(illico_ctx *c, const InT *d_data, const IdxT 
     return ILLICO_OK;
 }
 
+// Host-resident sparse input whose stored values are counts below 255 (what a raw count matrix holds): the values travel as BYTES -- a
+// quarter of a float32 array's share of the link; C3's 0.96 GB of values become 0.24 -- narrowed by host threads (on the NUMA node the array
+// lives on) into two pinned 32-MB chunks, chunk k + 1 under the upload of chunk k, and widened again on the device (k_bytes_to_values) into
+// the buffer the kernels read: the same values, bit for bit.  A value that is no integer in [0, 255) stops the attempt (*done = false:
+// the caller uploads the array as it is).  `d_out` receives entries [k0, k1) of `data`.
+#define SPB_CHUNK (32ll << 20)
+// `meanwhile` runs on the calling thread while the values are narrowed and sent (the caller's upload of the index array: the link then
+// carries both, the narrowing costs nothing on the clock); it runs in every case, exactly once; its status is returned first.
+template <typename InT, typename Meanwhile>
+static int upload_values_as_bytes(illico_ctx *c, const InT *data, int64_t k0, int64_t k1, InT *d_out, bool *done, Meanwhile &&meanwhile) {
+    *done = false;
+    const int64_t n = k1 - k0;
+    bool look = !c->no_sparse_byte_values && n >= (4ll << 20);
+    for (int64_t i = 0; i < 4096 && look; ++i) { // a look first: 4096 evenly spaced values
+        uint8_t b;
+        narrow_cells<InT>(data + k0 + (n - 1) * i / 4095, &b, 1);
+        if (b == 255) look = false;
+    }
+    if (!look) return meanwhile();
+    HostStage *hs = host_stage_of(c);
+    for (int j = 0; j < 2; ++j) {
+        if (!hs->sp_pin[j]) HIPCHK(c, hipHostMalloc(&hs->sp_pin[j], (size_t)SPB_CHUNK, hipHostMallocDefault));
+        if (!hs->sp_up[j]) HIPCHK(c, hipEventCreateWithFlags(&hs->sp_up[j], hipEventDisableTiming));
+    }
+    void *v;
+    int rc;
+    if ((rc = get_scratch(c, "sp_bytes", (size_t)n, &v))) return rc;
+    uint8_t *d_bytes = (uint8_t *)v;
+    const int node = c->no_host_numa ? -1 : numa_node_of_buffer(data + k0, (size_t)n * sizeof(InT));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(c->host_fill_threads > 0 ? c->host_fill_threads : 16, 64));
+    bool bad = false;
+    int hip_err = 0;
+    std::thread producer([&] { // (a thread of its own: its CPU mask -- the array's NUMA node -- is inherited by the narrowing threads and ends with it)
+        hipSetDevice(c->device);
+        numa_confine_this_thread(node);
+        int64_t chunk_no = 0;
+        for (int64_t o = 0; o < n && !bad && !hip_err; o += SPB_CHUNK, ++chunk_no) {
+            const int j = (int)(chunk_no & 1);
+            const int64_t m = std::min<int64_t>(SPB_CHUNK, n - o);
+            if (chunk_no >= 2 && hipEventSynchronize(hs->sp_up[j]) != hipSuccess) { hip_err = 1; break; }
+            uint8_t *dst = (uint8_t *)hs->sp_pin[j];
+            std::vector<int> flags((size_t)T, 0);
+            auto piece = [&](int t) {
+                const int64_t a = m * t / T, b = m * (t + 1) / T;
+                narrow_cells<InT>(data + k0 + o + a, dst + a, b - a);
+                int f = 0;
+                for (int64_t i = a; i < b; ++i) f |= dst[i] == 255 ? 1 : 0;
+                flags[(size_t)t] = f;
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < T; ++t) pool.emplace_back(piece, t);
+            piece(0);
+            for (auto &th : pool) th.join();
+            for (int t = 0; t < T; ++t) bad = bad || flags[(size_t)t] != 0;
+            if (bad) break;
+            if (hipMemcpyAsync(d_bytes + o, dst, (size_t)m, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipEventRecord(hs->sp_up[j], c->stream) != hipSuccess) hip_err = 1;
+        }
+    });
+    const int rc_meanwhile = meanwhile();
+    producer.join();
+    if (rc_meanwhile) return rc_meanwhile;
+    if (hip_err) return fail(c, ILLICO_ERR_HIP, "upload of a sparse matrix's values as bytes failed");
+    if (bad) { HIPCHK(c, hipStreamSynchronize(c->stream)); return ILLICO_OK; } // (the pinned chunks are free again; the caller uploads the values as they are)
+    hipLaunchKernelGGL((k_bytes_to_values<InT>), dim3(4096), dim3(256), 0, c->stream, (const uint8_t *)d_bytes, (long long)n, d_out);
+    HIPCHK(c, hipGetLastError());
+    c->h2d_input_bytes += n;
+    *done = true;
+    return ILLICO_OK;
+}
+
 // Sparse OVO with groups whose (gene, group) runs outgrow what k_csc_gene / k_ovo_rank take quickly (clusters of hundreds or
 // thousands of cells): regroup, then the packed rank kernel of the dense route (kernels_ovo_compact.h) on the regrouped runs
 // (small_groups: groups of at most 256 cells as well -- k_csc_gene takes those in one kernel when a gene's entries fit its LDS key buffer;
@@ -722,13 +795,29 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
         const int64_t k1 = is_csr ? total_nnz : (int64_t)h_indptr[col_ub];
         const size_t cnt = (size_t)std::max<int64_t>(k1 - k0, 1);
         if ((rc = get_scratch(c, "sp_data", cnt * sizeof(InT), &v))) return rc;
-        HIPCHK(c, hipMemcpyAsync(v, (const InT *)data + k0, (size_t)(k1 - k0) * sizeof(InT), hipMemcpyHostToDevice, c->stream));
+        void *v_idx;
+        if ((rc = get_scratch(c, "sp_indices", cnt * sizeof(IdxT), &v_idx))) return rc;
+        // the index array goes up on the copy stream while host threads narrow the values (count values below 255 travel as bytes: a quarter
+        // of their bytes over the link); the context's stream waits for it
+        HostStage *hs = host_stage_of(c);
+        if (!hs->copy) HIPCHK(c, hipStreamCreateWithFlags(&hs->copy, hipStreamNonBlocking));
+        if (!hs->up[0]) HIPCHK(c, hipEventCreateWithFlags(&hs->up[0], hipEventDisableTiming));
+        auto upload_indices = [&]() -> int {
+            HIPCHK(c, hipMemcpyAsync(v_idx, (const IdxT *)indices + k0, (size_t)(k1 - k0) * sizeof(IdxT), hipMemcpyHostToDevice, hs->copy));
+            HIPCHK(c, hipEventRecord(hs->up[0], hs->copy));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, hs->up[0], 0));
+            return ILLICO_OK;
+        };
+        bool as_bytes = false;
+        if ((rc = upload_values_as_bytes<InT>(c, (const InT *)data, k0, k1, (InT *)v, &as_bytes, upload_indices))) return rc;
+        if (!as_bytes) {
+            HIPCHK(c, hipMemcpyAsync(v, (const InT *)data + k0, (size_t)(k1 - k0) * sizeof(InT), hipMemcpyHostToDevice, c->stream));
+            c->h2d_input_bytes += (int64_t)((size_t)(k1 - k0) * sizeof(InT));
+        }
         d_data = (const InT *)v;
         kshift = k0;
-        if ((rc = get_scratch(c, "sp_indices", cnt * sizeof(IdxT), &v))) return rc;
-        HIPCHK(c, hipMemcpyAsync(v, (const IdxT *)indices + k0, (size_t)(k1 - k0) * sizeof(IdxT), hipMemcpyHostToDevice, c->stream));
-        d_indices = (const IdxT *)v;
-        c->h2d_input_bytes += (int64_t)(n_ptr * sizeof(IdxT) + (size_t)(k1 - k0) * (sizeof(InT) + sizeof(IdxT)));
+        d_indices = (const IdxT *)v_idx;
+        c->h2d_input_bytes += (int64_t)(n_ptr * sizeof(IdxT) + (size_t)(k1 - k0) * sizeof(IdxT));
     }
 
     auto take_sample = [&]() -> int { // 64k evenly spaced stored values (device-resident arrays: taken with the indptr copy above)

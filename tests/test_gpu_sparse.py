@@ -1015,3 +1015,43 @@ def test_float64_sparse_values_with_is_log1p_keep_the_float64_kernels(engine, fm
         engine.set_option("no_f64_narrowing", 0)
     for a, b in zip(got, wide):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_host_sparse_count_values_travel_as_bytes(engine, fmt):
+    """Host-resident sparse input whose stored values are counts below 255: the values go up as bytes (a quarter of the float32 array's
+    share of the link) and are widened on the device -- the same planes, bit for bit, as with the array uploaded as it is, and the
+    oracle's; a single value of 300 somewhere behind the sampled look makes the attempt stop and the array go up in its own type."""
+    rng = np.random.RandomState(31)
+    n, m = 60_000, 700
+    X = (rng.poisson(rng.uniform(0.5, 12.0, size=m), size=(n, m)) * (rng.rand(n, m) < 0.11)).astype(np.float32)
+    labels = make_labels(rng, n, 25, n_ref=3000)
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting")
+    engine.set_groups(g)
+    M = (sparse.csr_matrix if fmt == "csr" else sparse.csc_matrix)(X)
+    assert M.nnz > 4 << 20
+    run = lambda Mx: engine.run_sparse(fmt, Mx.data, Mx.indices, Mx.indptr, Mx.shape, 0, m)
+    b0 = engine.input_bytes()
+    got = run(M)
+    as_bytes = engine.input_bytes() - b0
+    engine.set_option("no_sparse_byte_values", 1)
+    try:
+        b0 = engine.input_bytes()
+        plain = run(M)
+        as_values = engine.input_bytes() - b0
+    finally:
+        engine.set_option("no_sparse_byte_values", 0)
+    for a, b in zip(got, plain):
+        np.testing.assert_array_equal(a, b)
+    assert as_values - as_bytes == 3 * M.nnz, (as_values, as_bytes, M.nnz)       # one byte instead of four per stored value
+    cols = [0, 233, 466, 699]
+    want = oracle.run(np.ascontiguousarray(X[:, cols]), g)
+    assert_planes_match(tuple(a[:, cols] for a in got), want, ref_row=g.encoded_ref_group, what=f"host {fmt}, values as bytes")
+    M2 = M.copy()
+    M2.data[M2.nnz // 2 + 12345] = 300.0
+    X2 = M2.toarray()
+    b0 = engine.input_bytes()
+    got2 = run(M2)
+    assert engine.input_bytes() - b0 >= as_values                                # (whatever went up as bytes before the value was met, plus the array itself)
+    assert_planes_match(tuple(a[:, cols] for a in got2), oracle.run(np.ascontiguousarray(X2[:, cols]), g), ref_row=g.encoded_ref_group,
+                        what=f"host {fmt}, one value beyond a byte")
