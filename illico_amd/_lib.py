@@ -6,6 +6,7 @@ calls below raise -- nothing here imports the CPU oracle.
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 from pathlib import Path
 
@@ -488,5 +489,15 @@ def get_engine(device: int | None = None) -> Engine:
     if cache is None:
         cache = _engines.cache = {}
     if device not in cache:
-        cache[device] = Engine(device)
+        eng = cache[device] = Engine(device)
+        if os.environ.get("ILLICO_PREWARM", "1") != "0":
+            # The first call on a host-resident dense matrix pins three staging slots and allocates three device windows (~80 ms of a
+            # 190-ms first drop-in call at C2 shape): done here, on a thread of its own, while the caller is still encoding groups.  (The
+            # context's lock orders it before the first engine call if that comes sooner.)
+            def prewarm(e=eng):
+                try:
+                    e.set_option("prewarm_host_window_bytes", 256 << 20)
+                except Exception:
+                    pass
+            threading.Thread(target=prewarm, name="illico-prewarm", daemon=True).start()
     return cache[device]

@@ -181,6 +181,24 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "packed_ref_cap")) c->packed_ref_cap = (int)value;
     else if (!strcmp(key, "debug_routes")) c->debug_routes = value != 0;
     else if (!strcmp(key, "host_fill_threads")) c->host_fill_threads = (int)value;
+    else if (!strcmp(key, "prewarm_host_window_bytes")) { // what a context's FIRST call on a host-resident dense matrix otherwise pays for (~80 ms
+        // of a 190-ms first drop-in call at C2): the three pinned slots and the three device windows of the host-window pipelines
+        if (value > 0) {
+            if (hipSetDevice(c->device) != hipSuccess) return ILLICO_ERR_HIP;
+            HostStage *hs = host_stage_of(c);
+            const size_t want = (size_t)value;
+            if (hs->pin_bytes < want) {
+                for (int j = 0; j < HS_SLOTS; ++j) { if (hs->pin[j]) hipHostFree(hs->pin[j]); hs->pin[j] = nullptr; }
+                hs->pin_bytes = 0;
+                for (int j = 0; j < HS_SLOTS; ++j)
+                    if (hipHostMalloc(&hs->pin[j], want, hipHostMallocDefault) != hipSuccess) return fail(c, ILLICO_ERR_OOM, "pinning %zu bytes failed", want);
+                hs->pin_bytes = want;
+            }
+            static const char *names[HS_SLOTS] = {"xin0", "xin1", "xin2"};
+            void *v;
+            for (int j = 0; j < HS_SLOTS; ++j) { const int rc = get_scratch(c, names[j], want, &v); if (rc) return rc; }
+        }
+    }
     else if (!strcmp(key, "no_host_numa")) c->no_host_numa = value != 0;
     else if (!strcmp(key, "no_sparse_byte_values")) c->no_sparse_byte_values = value != 0;
     else if (!strcmp(key, "no_sparse_packed_small")) c->no_sparse_packed_small = value != 0;

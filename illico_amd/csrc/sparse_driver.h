@@ -687,7 +687,10 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     const bool in_dev = flags & ILLICO_FLAG_INPUT_DEVICE;
     const int64_t W = col_ub - col_lb;
     const int64_t n_ptr = (is_csr ? n_rows : n_cols) + 1;
-    if (seg_lds_bytes(G) > kMaxLds) return fail(c, ILLICO_ERR_UNSUPPORTED, "sparse input with %d groups exceeds the LDS histogram of this build", G);
+    // More groups than the regrouping kernels' LDS histogram holds (~40 000): what the count-valued routes below do not take is written out as
+    // a dense window in the matrix's own type and takes the dense routes, which know no such limit (the reference has none either:
+    // ovr/sparse_ovr.py:23-97, utils/groups.py:18-58).
+    const bool many_groups = seg_lds_bytes(G) > kMaxLds;
     int rc;
     void *v;
 
@@ -955,7 +958,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     // fraction d of cells stored: 6e-13 at |z| = 37 (p ~ 1e-300) for d = 0.04, the bound used here; below that the window stays with
     // the sparse routes (kernels_finalize.h: tie_f64_sparse).
     if (is_csr && allow_dense_window && allow_transpose && !c->no_csr_densify_any && !c->tap && !c->big_n && n_rows < (1ll << 31) &&
-        density * (double)n_rows > long_column<KeyT>(c) && (c->ref >= 0 || density >= 0.04) && (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
+        (many_groups || (density * (double)n_rows > long_column<KeyT>(c) && (c->ref >= 0 || density >= 0.04))) && (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
         int64_t wmax = (int64_t)((size_t)c->scratch_bytes / ((size_t)n_rows * sizeof(InT))) & ~63ll;
         wmax = std::min<int64_t>(wmax, (1ll << 29));
         if (c->gene_batch > 0) wmax = std::min<int64_t>(wmax, (c->gene_batch + 63) & ~63ll);
@@ -976,6 +979,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
         return ILLICO_OK;
     }
 
+    if (many_groups && is_csr) return fail(c, ILLICO_ERR_UNSUPPORTED, "CSR input with %d groups: beyond the regrouping kernels' LDS histogram, and the dense window was not available here", G);
     // ---- CSR, any values: transpose the column window into CSC on the device, then the CSC routes ----
     if (is_csr && allow_transpose && !c->no_csr_transpose_path && n_rows < (1ll << 31)) {
         // sorted column indices (the reference's contract) allow the gather form of pass 2
@@ -1137,8 +1141,8 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     // ---- CSC, any values, columns longer than the per-gene LDS kernels hold: a dense window in the matrix's own type + the dense routes
     // (as for CSR above; the columns' row indices must ascend: asked on the device) ----
     if (!is_csr && !indices_are_codes && allow_dense_window && !c->no_csr_densify_any && !c->tap && !c->big_n && n_rows < (1ll << 31) &&
-        (int64_t)cols.size() == W && W > 0 && (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) / (double)W > long_column<KeyT>(c) &&
-        (c->ref >= 0 || (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) >= 0.04 * (double)W * (double)n_rows) &&
+        W > 0 && (many_groups || ((int64_t)cols.size() == W && (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) / (double)W > long_column<KeyT>(c) &&
+        (c->ref >= 0 || (double)((int64_t)h_indptr[col_ub] - (int64_t)h_indptr[col_lb]) >= 0.04 * (double)W * (double)n_rows))) &&
         (size_t)n_rows * 64 * sizeof(InT) <= (size_t)c->scratch_bytes) {
         if ((rc = get_scratch(c, "flag", 16, &v))) return rc;
         int *d_bad = (int *)v;
@@ -1171,6 +1175,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
             return ILLICO_OK;
         }
     }
+    if (many_groups) return fail(c, ILLICO_ERR_UNSUPPORTED, "CSC input with %d groups: beyond the regrouping kernels' LDS histogram, and the dense window was not available here (row indices out of order?)", G);
     if (!is_csr && !ovr && !c->no_csc_gene_path && !sparse_packed_rank_fits(c)) { // (runs of more than 128 keys leave k_csc_gene, runs of 32 .. 128 are slow in it)
         if ((rc = run_csc_gene_route<InT, IdxT, KeyT>(c, d_data, d_indices, d_indptr, kshift, d_codes, dtype, col_lb, flags, alternative, o, cols, &gene_nnz)))
             return rc;

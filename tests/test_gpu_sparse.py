@@ -1055,3 +1055,33 @@ def test_host_sparse_count_values_travel_as_bytes(engine, fmt):
     assert engine.input_bytes() - b0 >= as_values                                # (whatever went up as bytes before the value was met, plus the array itself)
     assert_planes_match(tuple(a[:, cols] for a in got2), oracle.run(np.ascontiguousarray(X2[:, cols]), g), ref_row=g.encoded_ref_group,
                         what=f"host {fmt}, one value beyond a byte")
+
+
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+@pytest.mark.parametrize("test,values", [("ovo", "counts"), ("ovo", "continuous"), ("ovr", "continuous")])
+def test_sparse_input_with_more_groups_than_the_regrouping_kernels_hold(engine, fmt, test, values):
+    """45 000 groups (two or three cells each): beyond the LDS histogram of the sparse regrouping kernels (~40 000 groups), which round 4
+    refused (NotImplementedError).  The reference has no such limit (ovr/sparse_ovr.py:23-97, utils/groups.py:18-58): count-valued CSR
+    keeps its group-major pass, everything else is written out as a dense window in the matrix's own type and takes the dense routes."""
+    import torch
+    rng = np.random.RandomState(45)
+    G, n, m = 45_000, 110_000, 48
+    codes = np.concatenate([np.zeros(2_000, dtype=np.int64), 1 + rng.randint(0, G - 1, size=n - 2_000 - (G - 1)), np.arange(1, G)])
+    rng.shuffle(codes)
+    labels = np.where(codes == 0, "non-targeting", np.char.add("pert_", np.char.zfill(codes.astype(str), 6)))
+    X = rng.poisson(rng.uniform(0.5, 8.0, size=m), size=(n, m)).astype(np.float32)
+    if values == "continuous":
+        X = np.log1p(X * rng.uniform(0.5, 1.5, size=(n, m))).astype(np.float32)
+    X *= rng.rand(n, m) < 0.15
+    _, g = oracle.encode_and_count_groups(labels, "non-targeting" if test == "ovo" else None)
+    assert g.counts.size == G
+    engine.set_groups(g)
+    M = (sparse.csr_matrix if fmt == "csr" else sparse.csc_matrix)(X)
+    dev = torch.device("cuda", engine.device)
+    d, i, p = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (M.data, M.indices, M.indptr))
+    got = engine.run_sparse(fmt, d, i, p, M.shape, 0, m)
+    # (sparse OVR, a seventh of the cells stored: the dense routes' exact-integer tie sums against the reference's float64 ones -- 1e-12 of p)
+    assert_planes_match(got, oracle.run(X, g, n_threads=4), ref_row=g.encoded_ref_group, what=f"45 000 groups {fmt} {test} {values}")
+    got_h = engine.run_sparse(fmt, M.data, M.indices, M.indptr, M.shape, 8, 40)          # host arrays, a column window
+    for a, b in zip(got_h, got):
+        np.testing.assert_array_equal(a, b[:, 8:40])
