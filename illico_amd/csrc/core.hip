@@ -201,6 +201,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     }
     else if (!strcmp(key, "no_host_numa")) c->no_host_numa = value != 0;
     else if (!strcmp(key, "no_sparse_byte_values")) c->no_sparse_byte_values = value != 0;
+    else if (!strcmp(key, "csc_counts_max_windows")) c->csc_counts_max_windows = (int)value;
     else if (!strcmp(key, "no_sparse_packed_small")) c->no_sparse_packed_small = value != 0;
     else if (!strcmp(key, "big_runs_cap")) c->big_runs_cap = (int)value;
     else if (!strcmp(key, "no_ovr_packed_partition")) c->no_ovr_packed_partition = value != 0;

@@ -141,6 +141,7 @@ struct illico_ctx {
     bool no_ovr_packed_partition = false; // 1: dense OVR partitions the padded rows (every key) instead of the packed ones
     bool no_packed_dense = false;      // 1: dense OVO on continuous values takes the transpose + k_ovo_rank route (no group-wise packing)
     bool no_sparse_packed_small = false; // sparse OVO, eight-byte keys: genes beyond k_csc_gene's LDS go to k_ovo_rank / the dense window (as before round 5), not to the packed rank kernel
+    int csc_counts_max_windows = 0;    // > 0: count-valued CSC with more windows of groups than this leaves the histogram route (8: as before round 5)
     bool no_sparse_byte_values = false; // host-resident sparse input: the stored values always go up in their own type (count values: as bytes otherwise)
     bool no_host_numa = false;         // host-window pipelines: do not confine the fill threads to the NUMA node the caller's matrix lives on
     int host_fill_threads = 0;         // > 0: host threads that fill the pinned slots of the host-window pipelines (default: 12 float32 / 16 byte windows)

@@ -701,10 +701,11 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
     for (int g = 0; g < G; ++g)
         if (g != c->ref) { n_big_groups += c->h_counts[g] > 255 ? 1 : 0; max_ranked = std::max<int64_t>(max_ranked, c->h_counts[g]); }
     // (more than CSCC_MAX_BIG groups above 255 cells: 16-bit cells for every group, while those fit LDS)
-    // ... and more groups than LDS holds tables for: windows of groups, at most 8 launches over the same entries)
+    // ... and more groups than LDS holds tables for: windows of groups, one launch each over the same entries -- up to 33 of them (65 535 groups:
+    // the 16-bit code table's limit); 30 000 groups of ten cells at C3 shape: 52.7 ms through the per-gene sort routes when eight was the limit)
     const bool w16_needed = n_big_groups > CSCC_MAX_BIG || (!ovr && c->h_counts[c->ref] >= 30000); // (64-bit sweep terms for a large reference)
     const int n_windows = (G + cscc_group_window(G, w16_needed) - 1) / std::max(1, cscc_group_window(G, w16_needed));
-    const bool cells_fit = (!w16_needed || (max_ranked <= 65535 && !c->no_csc_counts_wide)) && n_windows <= 8 &&
+    const bool cells_fit = (!w16_needed || (max_ranked <= 65535 && !c->no_csc_counts_wide)) && n_windows <= (c->csc_counts_max_windows > 0 ? c->csc_counts_max_windows : 33) &&
                            (n_windows == 1 || (!c->no_csc_counts_windows && c->d_codes16 && !indices_are_codes));
     // (big_n -- OVR over more than 2^21 - 1 cells --: the table kernels' t^3 terms could wrap; the sort-based routes hold)
     const bool counts_route = !is_csr && !c->big_n && !c->no_csc_counts_path && !(flags & ILLICO_FLAG_LOG1P) && cells_fit && n_rows < (1ll << 30) &&

@@ -94,6 +94,8 @@ SHAPES = [
     ("counts", 0.9, "csc", 300, "ovo"),           # groups above 255 cells: 16-bit cells
     ("counts", 0.9, "csc", 5000, "ovr"),          # windows of groups over the LDS histograms
     ("counts", 0.9, "csc", 10000, "ovo"),
+    ("counts", 0.9, "csc", 30000, "ovo"),         # 15 windows of groups over the LDS histograms (eight were the limit: 52.7 ms at full size in round 4)
+    ("counts", 0.9, "csc", 30000, "ovr"),
     ("counts", 0.5, "csc", 2000, "ovo"),          # half of the entries stored: 4-bit cells overflow
     ("continuous", 0.9, "csc", 50, "ovo"),        # clusters of thousands of cells on sparse input: 21 ms at the start of round 4
     ("continuous", 0.9, "csc", 300, "ovo"),
