@@ -71,7 +71,11 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         if (c->packed_ref_cap > 0) C.ref_cap = std::min(C.ref_cap, std::max(c->packed_ref_cap, 1024));
         C.out_2u = s2u; C.out_tie = stie; C.route = route; C.big_sorted = c->pk_nbig > 0 ? 1 : 0;
         C.ref_by_gofs = 0; C.gene_flags = nullptr; C.big_fn = big_fn; C.big_tmp = big_tmp; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
-        const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
+        // small problems per gene (a reference of at most 2048 cells, fewer than 128 groups, none above 256 cells): workgroups of 256 threads,
+        // several per CU
+        const bool eq0 = c->packed_eq_buckets >= 0 ? c->packed_eq_buckets != 0 : n_ref > 16384;
+        const bool small_wg = n_ref <= 2048 && G < 128 && c->pk_nbig == 0 && !c->no_packed_small_wg && C.nbk_lg <= 16 && !eq0; // (such a reference never needs parts)
+        const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT), small_wg ? 256 : OCR_NT);
         // large references: the bucket function follows the reference's distribution (a crowded stretch of values would otherwise
         // fill buckets beyond three keys and send whole table words to key-by-key walks); "packed_eq_buckets" = 0 / 1 forces
         const bool eq = c->packed_eq_buckets >= 0 ? c->packed_eq_buckets != 0 : n_ref > 16384;
@@ -86,10 +90,10 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
             HIPCHK(c, hipMemsetAsync(s2u, 0, (size_t)nb * G * sizeof(long long), c->stream));
             HIPCHK(c, hipMemsetAsync(stie, 0, (size_t)nb * G * sizeof(u64), c->stream));
         }
-        auto kern = eq ? k_ovo_rank_compact<KeyT, true> : k_ovo_rank_compact<KeyT, false>;
+        auto kern = small_wg ? k_ovo_rank_compact<KeyT, false, false, 256> : eq ? k_ovo_rank_compact<KeyT, true> : k_ovo_rank_compact<KeyT, false>;
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ProfScope ps(c, KID_OVO_RANK_COMPACT);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(OCR_NT), lds, c->stream, C);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(small_wg ? 256 : OCR_NT), lds, c->stream, C);
         HIPCHK(c, hipGetLastError());
         if (parts) {
             auto kp = k_ovo_rank_compact<KeyT, true, true>;

@@ -336,10 +336,10 @@ struct OvoCompactParams {
 // so a bucket's first key is at  prefix + (sum of the counters below it)  = two popcounts, and with ~30 buckets per key nearly
 // every bucket holds 0 or 1 keys: a look-up reads one table word and two keys.  Overfull words (and a bucket of exactly 3, and
 // keys that tie with the reference) take an exact per-lane walk over the word's / bucket's keys.
-__host__ __device__ static inline size_t ocr_lds_bytes(int ref_cap, int nbk_lg, size_t key_size) {
+__host__ __device__ static inline size_t ocr_lds_bytes(int ref_cap, int nbk_lg, size_t key_size, int nt = OCR_NT) {
     size_t b = (((size_t)ref_cap + 4) * key_size + 15) & ~(size_t)15;
     b += (((size_t)1 << nbk_lg) / 16 + 2) * 8;
-    b += (size_t)(OCR_NT / 64) * OCR_BLOOM_WORDS * 4;
+    b += (size_t)(nt / 64) * OCR_BLOOM_WORDS * 4;
     b += 2048; // coarse cells of the distribution-following bucket function: table + counters
     b += 256; // reduction words
     return b;
@@ -708,10 +708,12 @@ static __global__ __launch_bounds__(256) void k_seg_to_packed(const u32 *__restr
 // the tie terms add up likewise.  Every part ADDS its share into out_2u / out_tie (zeroed by the host); part 0 adds the terms of
 // the zeros.  (Replaces, for references of any size, what rank_sum_and_ties_from_sorted does by merging: utils/ranking.py:52-158.)
 #define OCR_CELL_LG 12
-template <typename KeyT, bool EQ, bool PARTS = false>
-__global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P) {
+// NT_ = 256: small references and few groups (a wide matrix: 120 000 genes x 20 000 cells): a gene is a few microseconds of work behind a
+// dozen barriers -- several small workgroups per CU overlap them (one of 1024 threads per CU: 11.4 ms at that shape).
+template <typename KeyT, bool EQ, bool PARTS = false, int NT_ = OCR_NT>
+__global__ __launch_bounds__(NT_) void k_ovo_rank_compact(OvoCompactParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int NT = OCR_NT, NW = NT / 64, KMAX = OCR_KMAX;
+    constexpr int NT = NT_, NW = NT / 64, KMAX = OCR_KMAX;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK, MAXK = KeyInfo<KeyT>::MAXK;
     const int NWD = (1 << P.nbk_lg) >> 4; // table words
     KeyT *A = (KeyT *)smem;
@@ -821,6 +823,7 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
             for_ref([&](KeyT k) { atomicAdd(&cells[(u32)((KeyT)(k - kmin_all) >> cs0)], 1u); });
             if (tid < 4) s_b[tid] = tid == 2 ? (1u << OCR_CELL_LG) : tid == 3 ? nA_all : 0u; // part 0 starts at cell 0, the last part ends behind the last cell
             __syncthreads();
+            static_assert(!PARTS || (1 << OCR_CELL_LG) % NT == 0, "cells per thread");
             constexpr int CPT = (1 << OCR_CELL_LG) / NT;
             u32 c4[CPT], sum = 0;
 #pragma unroll
@@ -939,12 +942,15 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
                 return;
             }
             u32 dst = P.nseg ? (u32)seg_nnz[0] : 0u;
-            for (int sg = 1; sg < P.nseg; ++sg) { // move the reference's segments together (a segment holds at most NT / 2 keys)
+            for (int sg = 1; sg < P.nseg; ++sg) { // move the reference's segments together (a segment holds at most GCMP_SEG_ROWS keys: NT keys a step)
                 const u32 c = (u32)seg_nnz[sg];
-                KeyT k = (KeyT)0;
-                if ((u32)tid < c) k = src[(size_t)sg * GCMP_SEG_ROWS + tid];
-                __syncthreads();
-                if ((u32)tid < c) src[dst + tid] = k;
+                for (u32 o = 0; o < c; o += (u32)NT) { // (the destination ends below the source's start: a step's reads come before its writes, steps in order)
+                    KeyT k = (KeyT)0;
+                    if (o + (u32)tid < c) k = src[(size_t)sg * GCMP_SEG_ROWS + o + tid];
+                    __syncthreads();
+                    if (o + (u32)tid < c) src[dst + o + tid] = k;
+                    __syncthreads();
+                }
                 dst += c;
             }
             if (tid == 0) { nnz[ref] = (u16)nA; if (!P.ref_by_gofs) P.gofs[(size_t)gene * G + ref] = (u32)P.ref_out; P.route[gene] = 1u; }
@@ -990,7 +996,55 @@ __global__ __launch_bounds__(OCR_NT) void k_ovo_rank_compact(OvoCompactParams P)
     // ---- every other group: one wavefront each, 64 groups per output block ----
     u32 *bloom = bloom_all + wave * OCR_BLOOM_WORDS;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int g0 = wave * 64; g0 < G; g0 += NW * 64) {
+    // Few groups (a cluster-level comparison, a small screen: fewer than 32 groups per wavefront): the blocks of 64 groups below would leave all
+    // but G / 64 wavefronts idle, each walking its 64 groups one after the other (20 000 cells x 120 000 genes x 100 groups: 31 ms, 66 us a gene,
+    // of which the two working wavefronts' 64 look-ups in a row are nearly all).  Here the groups are dealt round robin, one wavefront-sum each.
+    const bool few_groups = G < NW * 32;
+    if (few_groups) {
+        for (int g = wave; g < G; g += NW) {
+            const size_t o = (size_t)gene * G + g;
+            if (g == ref) { if (part == 0 && lane == 0) { P.out_2u[o] = -2; P.out_tie[o] = 0; } continue; }
+            const int nB = (int)nnz[g];
+            if (nB > 64 * KMAX) continue; // (big_sorted: walked piece by piece below)
+            const KeyT *seg = Xg + P.gofs[o];
+            KeyT cur[KMAX];
+            u32 nv = 0;
+#pragma unroll
+            for (int r = 0; r < KMAX; ++r) {
+                KeyT k = (r * 64 + lane < nB) ? seg[r * 64 + lane] : ZEROK;
+                if constexpr (PARTS) k = (k >= p_lo && k <= p_hi) ? k : ZEROK;
+                cur[r] = k;
+                if constexpr (PARTS) nv += (u32)__popcll(__ballot(k != ZEROK));
+            }
+            u32 less = 0, eqs = 0, negs = 0;
+            u64 TT = 0;
+            if (PARTS ? nv != 0u : nB != 0) {
+                if (nB <= 64) ocr_group<KeyT, 1, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else if (nB <= 128) ocr_group<KeyT, 2, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else if (nB <= 192) ocr_group<KeyT, 3, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                else ocr_group<KeyT, 4, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+            }
+            const u64 s2_sum = wave_sum<u64>((u64)(2u * less + eqs));
+            const u64 tt_sum = __ballot(TT != 0ull) ? wave_sum<u64>(TT) : 0ull;
+            if (lane == 0) {
+                const long long n_g = P.counts[g];
+                const u64 zc = (u64)(n_g - (long long)nB), t0 = (u64)aZ + zc;
+                if constexpr (PARTS) {
+                    u64 S2 = s2_sum + 2ull * n_low * (u64)nv + 2ull * aZ * (u64)(nv - negs);
+                    u64 tie = T_A + 3ull * tt_sum;
+                    long long two_u = 0;
+                    if (part == 0) { S2 += zc * (2ull * nneg + aZ); tie += t0 * t0 * t0 - t0; two_u = 2ll * (long long)n_ref * n_g; }
+                    atomicAdd((unsigned long long *)&P.out_2u[o], (unsigned long long)(two_u - (long long)S2));
+                    atomicAdd((unsigned long long *)&P.out_tie[o], (unsigned long long)tie);
+                } else {
+                    const u64 S2 = s2_sum + 2ull * aZ * (u64)((u32)nB - negs) + zc * (2ull * nneg + aZ);
+                    P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
+                    P.out_tie[o] = T_A + 3ull * tt_sum + (t0 * t0 * t0 - t0);
+                }
+            }
+        }
+    }
+    for (int g0 = wave * 64; g0 < G && !few_groups; g0 += NW * 64) {
         const int gl = g0 + lane;
         const bool has = gl < G && gl != ref;
         const u32 my_n = has ? (u32)nnz[gl] : 0u;

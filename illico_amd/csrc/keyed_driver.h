@@ -30,7 +30,14 @@ struct OvoGlobalBufs { // scratch of the global-sort fallback (same element coun
 // buckets -- an expression matrix is mostly zeros, so the non-zeros of a 33 000-cell reference still fit -- and a gene whose
 // non-zeros exceed the slots is left to k_ovo_rank by the kernel (as the tie-heavy ones are).
 template <typename KeyT> static void packed_ref_sizing(int64_t n_ref, int *cap, int *lg) {
-    if (ocr_lds_bytes((int)n_ref, 17, sizeof(KeyT)) <= kMaxLds) { *cap = (int)n_ref; *lg = 17; return; }
+    if (ocr_lds_bytes((int)n_ref, 17, sizeof(KeyT)) <= kMaxLds) {
+        // (a small reference: ~32 buckets per key are as good as 2^17 of them, and a table of 2^14 .. 2^16 buckets is zeroed and scanned in a
+        //  quarter of the time -- what a gene of a wide matrix, 120 000 genes x 20 000 cells, mostly costs)
+        int l = 14;
+        while (l < 17 && (32ll << 0) * n_ref > (1ll << l)) ++l;
+        *cap = (int)n_ref; *lg = l;
+        return;
+    }
     // 2^17 buckets while 55 % of the reference's cells would still fit the slots left beside them, else 2^16 and more slots
     const size_t fixed17 = ocr_lds_bytes(0, 17, sizeof(KeyT));
     const int64_t cap17 = fixed17 < kMaxLds ? (int64_t)((kMaxLds - fixed17) / sizeof(KeyT)) - 8 : 0;

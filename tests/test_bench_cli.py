@@ -89,7 +89,7 @@ def test_two_ranks_spawned_by_bench_itself_gloo_shared_device():
                                    ("c2_continuous_ovr", "dense", "ovr", "continuous")):
         x = one[tag]
         assert (x["format"], x["test"], x["values"]) == (fmt, test, values), x
-        assert x["ms_per_step"] > 0 and x["tests_per_s"] == pytest.approx(50 * 256 / (x["ms_per_step"] * 1e-3), rel=1e-3)
+        assert x["ms_per_step"] > 0 and x["tests_per_s"] == pytest.approx(50 * 256 / (x["ms_per_step"] * 1e-3), rel=2e-2)   # (ms_per_step is rounded to 0.1 us)
         rf = x["roofline"]
         assert rf["bound"] == "hbm" and rf["kernel"] and 0 < rf["frac"] < 1 and 0 < rf["pipeline_frac"] < 1 and "traffic" in rf and rf["avg_launch_ms"] > 0
         assert x["parity"]["statistic_mismatches"] == 0 and x["parity"]["p_value_max_rel_err"] <= 1e-12 and x["parity"]["fold_change_max_rel_err"] <= 1e-12
