@@ -44,11 +44,18 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
     u32 *gofs = route + nb;
     HIPCHK(c, hipMemsetAsync(route, 0, (size_t)nb * 4, c->stream));
     const int is_log1p = (flags & ILLICO_FLAG_LOG1P) ? 1 : 0;
+    u32 *run_n = nullptr;
     {
         GroupCompactParams Q;
         Q.X = X; Q.ld = ld; Q.col0 = col0; Q.ncols = nb; Q.perm = c->d_perm; Q.pos_ptr = c->d_posptr; Q.G = G; Q.ref = ref; Q.nseg = nseg;
         Q.blk_g0 = c->d_pk_blk; Q.blk_g1 = c->d_pk_blk + c->pk_nblk; Q.blk_out = c->d_pk_blk + 2 * c->pk_nblk; Q.nblk = c->pk_nblk; Q.ref_out = c->pk_ref_out;
         Q.Xt = Xt; Q.xt_stride = stride; Q.nnz = nnz; Q.gofs = gofs; Q.blk_cnt = nullptr; Q.out_sum = ssum; Q.seg_nnz = seg_nnz; Q.seg_sum = seg_sum;
+        Q.cand_of = nullptr; Q.run_n = nullptr; Q.n_cand = c->pk_nbig;
+        if (c->pk_nbig > 0 && c->max_nonref >= 65535) { // a (gene, group) run can outgrow the 16-bit lengths: exact ones beside them
+            if ((rc = get_scratch(c, "packed_run_n", (size_t)nb * c->pk_nbig * 4, &v))) return rc;
+            run_n = (u32 *)v;
+            Q.cand_of = c->d_pk_big + c->pk_nbig; Q.run_n = run_n;
+        }
         if ((rc = launch_group_compact<InT, KeyT>(c, Q, nb, flags, true))) return rc;
     }
     bool parts = false;
@@ -61,7 +68,7 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         int cap = (int)std::min<int64_t>(srt_cap<KeyT>(), (c->max_nonref + 63) & ~63ll); // (a run holds at most its group's cells)
         if (c->big_runs_cap > 0) cap = std::min(cap, std::max(c->big_runs_cap, 512) & ~63);
         if (c->max_nonref > cap && !c->no_big_runs_global && get_scratch(c, "packed_big_tmp", (size_t)nb * (size_t)stride * sizeof(KeyT), &v) == ILLICO_OK) big_tmp = v;
-        if ((rc = launch_bucket_big_runs<KeyT>(c, (void *)Xt, big_tmp, (long long)stride, nnz, gofs, nb, G, cap, big_fn, route, c->max_nonref))) return rc;
+        if ((rc = launch_bucket_big_runs<KeyT>(c, (void *)Xt, big_tmp, (long long)stride, nnz, gofs, nb, G, cap, big_fn, route, c->max_nonref, run_n))) return rc;
     }
     {
         OvoCompactParams C;
@@ -70,7 +77,7 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         packed_ref_sizing<KeyT>(n_ref, &C.ref_cap, &C.nbk_lg);
         if (c->packed_ref_cap > 0) C.ref_cap = std::min(C.ref_cap, std::max(c->packed_ref_cap, 1024));
         C.out_2u = s2u; C.out_tie = stie; C.route = route; C.big_sorted = c->pk_nbig > 0 ? 1 : 0;
-        C.ref_by_gofs = 0; C.gene_flags = nullptr; C.big_fn = big_fn; C.big_tmp = big_tmp; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
+        C.ref_by_gofs = 0; C.gene_flags = nullptr; C.big_fn = big_fn; C.big_tmp = big_tmp; C.run_n = run_n; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
         // small problems per gene (a reference of at most 2048 cells, fewer than 128 groups, none above 256 cells): workgroups of 256 threads,
         // several per CU
         const bool eq0 = c->packed_eq_buckets >= 0 ? c->packed_eq_buckets != 0 : n_ref > 16384;

@@ -67,6 +67,9 @@ struct GroupCompactParams {
     double *out_sum;        // [ncols][G] value sums (expm1'd if LOG1P); the reference's entry is not written
     u16 *seg_nnz;           // [ncols][nseg] non-zero keys per segment of the reference
     double *seg_sum;        // [ncols][nseg]
+    const int *cand_of;     // optional [G]: a group's place among the n_cand groups of more than 256 cells, or -1 ...
+    u32 *run_n;             // ... and [ncols][n_cand]: the exact length of each such (gene, group) run (nnz saturates at 65535)
+    int n_cand;
 };
 
 template <typename InT> __device__ __forceinline__ double gcmp_value(InT v, int is_log1p);
@@ -252,8 +255,12 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
             if (PACK && lane < GPW && geneW < P.ncols) {
                 if (seg >= 0) P.seg_nnz[(size_t)geneW * P.nseg + seg] = (u16)cntv;
                 else {
-                    P.nnz[(size_t)geneW * P.G + cg] = (u16)min(cntv - gstartv, 65535); // (saturating: a run of 65535 keys or more is beyond k_bucket_big_runs' slots, which sends the gene to the general route)
+                    P.nnz[(size_t)geneW * P.G + cg] = (u16)min(cntv - gstartv, 65535); // (saturating: the exact length of a long run is in run_n)
                     P.gofs[(size_t)geneW * P.G + cg] = (u32)(out0 + gstartv);
+                    if (P.run_n) { // (uniform: cg is the workgroup's current group)
+                        const int cd = P.cand_of[cg];
+                        if (cd >= 0) P.run_n[(size_t)geneW * P.n_cand + cd] = (u32)(cntv - gstartv);
+                    }
                 }
             }
             gstartv = cntv;
@@ -313,6 +320,7 @@ struct OvoCompactParams {
                              // (seg_nnz: [n_genes] its length, nseg = 1; no seg_sum: value sums are formed elsewhere); gene_stride = 0
     const u32 *gene_flags;   // optional [n_genes]: a gene whose word is 0 is somebody else's (count-valued: the histogram kernel's)
     const void *big_fn;      // [n_genes][n_cand] BigRunFn<KeyT>: each such run's bucket function
+    const u32 *run_n;        // optional [n_genes][n_cand]: exact lengths of the runs of the groups above 256 cells (nnz saturates at 65535)
     const void *big_tmp;     // the second key buffer (laid out like Xs) that holds the runs k_bucket_big_runs_global dealt
     const int *cand_of;      // [G] a group's place among the n_cand groups of more than 256 cells, or -1
     int n_cand;
@@ -562,7 +570,7 @@ template <typename KeyT>
 __global__ __launch_bounds__(SRTG_NT) void k_bucket_big_runs_global(void *Xs, void *tmp, long long gene_stride, const u16 *__restrict__ nnz, const u32 *__restrict__ gofs,
                                                                     const int *__restrict__ cand, int n_cand, int G, int cap /* runs up to here are k_bucket_big_runs' */,
                                                                     int lg_max /* log2 of the counters the launch's LDS holds */, BigRunFn<KeyT> *__restrict__ big_fn,
-                                                                    u32 *__restrict__ route) {
+                                                                    u32 *__restrict__ route, const u32 *__restrict__ run_n /* exact run lengths, or null */) {
     extern __shared__ __align__(16) unsigned char srtg_smem[];
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
     constexpr int NT = SRTG_NT;
@@ -570,9 +578,12 @@ __global__ __launch_bounds__(SRTG_NT) void k_bucket_big_runs_global(void *Xs, vo
     __shared__ KeyT g_min, g_max;
     __shared__ u32 g_part[NT / 64];
     const int gene = blockIdx.y, g = cand[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = (int)nnz[(size_t)gene * G + g];
+    int n = (int)nnz[(size_t)gene * G + g];
     if (n <= cap) return; // (uniform)
-    if (n >= 65535) { if (tid == 0) route[gene] = 2u; return; } // (the 16-bit run length saturated: the true length is not known here)
+    if (n >= 65535) { // the 16-bit run length saturated
+        if (!run_n) { if (tid == 0) route[gene] = 2u; return; }
+        n = (int)run_n[(size_t)gene * n_cand + blockIdx.x];
+    }
     const size_t off = (size_t)((long long)gene * gene_stride) + gofs[(size_t)gene * G + g];
     KeyT *run = (KeyT *)Xs + off, *out = (KeyT *)tmp + off;
     if (tid == 0) { g_min = MAXK; g_max = (KeyT)0; }
@@ -689,12 +700,15 @@ __global__ __launch_bounds__(SRT_NT) void k_bucket_big_runs(void *Xs, long long 
 
 // sparse input regrouped into Xs + seg ([n_genes][G + 1] offsets of the (gene, group) runs): the same runs in the packed layout's terms
 static __global__ __launch_bounds__(256) void k_seg_to_packed(const u32 *__restrict__ seg, int G, int nb, int ref, u16 *__restrict__ nnz, u32 *__restrict__ gofs,
-                                                             u16 *__restrict__ ref_nnz, u32 *__restrict__ route) {
+                                                             u16 *__restrict__ ref_nnz, u32 *__restrict__ route, const int *__restrict__ cand_of, u32 *__restrict__ run_n,
+                                                             int n_cand) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)nb * G) return;
     const int gene = (int)(i / G), g = (int)(i - (long long)gene * G);
     const u32 a = seg[(size_t)gene * (G + 1) + g], n = seg[(size_t)gene * (G + 1) + g + 1] - a;
-    if (n > 65535u) route[gene] = 2u; // (16-bit run lengths: the gene takes the general sort route)
+    const int cd = (run_n && g != ref) ? cand_of[g] : -1;
+    if (cd >= 0) run_n[(size_t)gene * n_cand + cd] = n;
+    if (n > 65535u && (cd < 0 || g == ref)) route[gene] = 2u; // (16-bit run lengths; a ranked group's long run has its exact length in run_n)
     nnz[i] = (u16)(n > 65535u ? 65535u : n);
     gofs[i] = a;
     if (g == ref) ref_nnz[gene] = (u16)(n > 65535u ? 65535u : n);
@@ -1141,8 +1155,9 @@ __global__ __launch_bounds__(NT_) void k_ovo_rank_compact(OvoCompactParams P) {
     if (P.big_sorted && s_cnt[3] > 64u * KMAX) {
         for (int gb = wave; gb < G; gb += NW) { // (uniform per wavefront; few groups are big)
             if (gb == ref) continue;
-            const int n = (int)nnz[gb];
+            int n = (int)nnz[gb];
             if (n <= 64 * KMAX) continue;
+            if (n >= 65535 && P.run_n) n = (int)P.run_n[(size_t)gene * P.n_cand + P.cand_of[gb]]; // (the 16-bit length saturated)
             BigRunFn<KeyT> fn = ((const BigRunFn<KeyT> *)P.big_fn)[(size_t)gene * P.n_cand + P.cand_of[gb]];
             const KeyT *seg = ((fn.shift & BIG_RUN_IN_TMP) ? (const KeyT *)P.big_tmp + (long long)gene * P.gene_stride : (const KeyT *)Xg) + P.gofs[(size_t)gene * G + gb];
             fn.shift &= ~BIG_RUN_IN_TMP;

@@ -76,7 +76,7 @@ template <typename KeyT> static bool packed_leftovers_fit_sort_route(const illic
 // the second key buffer `tmp` beyond (tmp == nullptr: such a run sends its gene to the general route)
 template <typename KeyT>
 static int launch_bucket_big_runs(illico_ctx *c, void *Xs, void *tmp, long long stride, const u16 *nnz, const u32 *gofs, int nb, int G, int cap, BigRunFn<KeyT> *big_fn,
-                                  u32 *route, int64_t longest_run) {
+                                  u32 *route, int64_t longest_run, const u32 *run_n) {
     auto kern = k_bucket_big_runs<KeyT>;
     const size_t lds = srt_lds_bytes(sizeof(KeyT), cap);
     const bool global = tmp != nullptr && longest_run > cap;
@@ -90,7 +90,7 @@ static int launch_bucket_big_runs(illico_ctx *c, void *Xs, void *tmp, long long 
         if (c->big_runs_cap > 0) lg = std::min(lg, 11); // (tests: few counters as well)
         const size_t ldsg = (size_t)4 << lg;
         HIPCHK(c, hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
-        hipLaunchKernelGGL(kg, dim3(c->pk_nbig, nb), dim3(SRTG_NT), ldsg, c->stream, Xs, tmp, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, lg, big_fn, route);
+        hipLaunchKernelGGL(kg, dim3(c->pk_nbig, nb), dim3(SRTG_NT), ldsg, c->stream, Xs, tmp, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, lg, big_fn, route, run_n);
         HIPCHK(c, hipGetLastError());
     }
     return ILLICO_OK;

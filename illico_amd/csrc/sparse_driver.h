@@ -1337,7 +1337,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                 {
                     ProfScope ps(c, KID_GROUP_COMPACT);
                     hipLaunchKernelGGL(k_seg_to_packed, dim3((unsigned)(((size_t)nb * G + 255) / 256)), dim3(256), 0, c->stream, (const u32 *)seg, G, nb, (int)c->ref,
-                                       pk_nnz, pk_gofs, ref_nnz, route);
+                                       pk_nnz, pk_gofs, ref_nnz, route, (const int *)nullptr, (u32 *)nullptr, 0); // (groups of at most 65535 cells here: 16-bit run lengths hold)
                     if (c->pk_nbig > 0) {
                         if ((rc = get_scratch(c, "packed_big_fn", (size_t)nb * c->pk_nbig * sizeof(BigRunFn<KeyT>), &v))) return rc;
                         big_fn = (BigRunFn<KeyT> *)v;
@@ -1345,7 +1345,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                         int cap = (int)std::min<int64_t>(srt_cap<KeyT>(), (longest + 63) & ~63ll);
                         if (c->big_runs_cap > 0) cap = std::min(cap, std::max(c->big_runs_cap, 512) & ~63);
                         // (runs beyond the LDS slots are dealt through the global sort's second key buffer)
-                        if ((rc = launch_bucket_big_runs<KeyT>(c, (void *)Xs, c->no_big_runs_global ? nullptr : kb, 0ll, pk_nnz, pk_gofs, nb, G, cap, big_fn, route, longest))) return rc;
+                        if ((rc = launch_bucket_big_runs<KeyT>(c, (void *)Xs, c->no_big_runs_global ? nullptr : kb, 0ll, pk_nnz, pk_gofs, nb, G, cap, big_fn, route, longest, nullptr))) return rc;
                     }
                     HIPCHK(c, hipGetLastError());
                 }

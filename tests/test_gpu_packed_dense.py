@@ -319,7 +319,8 @@ def test_dense_ovo_continuous_with_a_reference_of_more_than_65535_cells(engine, 
 def test_dense_ovo_continuous_with_a_ranked_group_of_more_than_65535_cells(engine):
     """Cluster against cluster on continuous values: a ranked group of 70 000 cells.  A tenth of the values stored: the group's run of 7000
     keys per gene is dealt into value buckets and ranked piece by piece (packed rank kernel); a gene stored in full -- a run of 70 000 keys,
-    beyond the 16-bit run length and the bucket kernel's slots -- is flagged there and redone by the general route."""
+    beyond the 16-bit run length (its exact length travels beside it) and the bucket kernel's LDS slots -- is dealt through HBM and ranked by
+    the same kernel; the column with ties (value buckets above 256 keys) is redone by the general route."""
     import torch
     rng = np.random.RandomState(654)
     n, m = 88_000, 66

@@ -144,6 +144,7 @@ SETS: dict[str, list[tuple[str, str]]] = {
         ("clus_dense_cont_ovo", f"{CLUS} --workload c2 --values continuous --sparsity 0.9"),
         ("clus_dense_cont_ovo_s50", f"{CLUS} --workload c2 --values continuous"),
         ("clus_dense_cont_ovr_s50", f"{CLUS} --workload c2 --values continuous --test ovr"),
+        ("clus_dense_cont_ovo_s20", f"{CLUS} --workload c2 --values continuous --sparsity 0.2"),   # runs of 80 000 keys: beyond the 16-bit run lengths
         ("clus_csr_ovr", f"{CLUS} --workload c3 --format csr --test ovr"),
         ("clus_csr_ovo", f"{CLUS} --workload c3 --format csr"),
         ("clus_csc_ovo", f"{CLUS} --workload c3"),
