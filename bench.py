@@ -398,7 +398,7 @@ class Job:
         with np.errstate(divide="ignore", invalid="ignore"):
             perr = np.abs(got[0][mask] - want[0][mask]) / np.abs(want[0][mask])
             ferr = np.abs(got[2] - want[2]) / np.abs(want[2])
-        perr = np.where(got[0][mask] == want[0][mask], 0.0, perr)
+        perr = np.where((got[0][mask] == want[0][mask]) | (np.isnan(got[0][mask]) & np.isnan(want[0][mask])), 0.0, perr)  # (a group without cells: NaN on both sides)
         ferr = np.where((got[2] == want[2]) | (np.isnan(got[2]) & np.isnan(want[2])), 0.0, ferr)
         return {"genes_checked": cols, "tests_checked": int(mask.sum() * len(cols)),
                 "statistic_mismatches": int((got[1][mask] != want[1][mask]).sum()),
@@ -497,7 +497,7 @@ def single_call_of(torch, dist, eng, args, job, job_kw, n_blocks, tests, steady_
     try:
         from illico_amd.distributed import SharedHostPlanes, shard_bounds
         shared = SharedHostPlanes(job.G, job.M_total, group=None)
-        nb = max(1, n_blocks)
+        nb = max(1, n_blocks) if world > 1 else 1   # (one GPU: the call is one pass over every column, as above)
 
         def to_host_once():
             job.sync()
