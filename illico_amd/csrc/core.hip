@@ -178,6 +178,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "packed_eq_buckets")) c->packed_eq_buckets = (int)value;
     else if (!strcmp(key, "no_ovo_parts")) c->no_ovo_parts = value != 0;
     else if (!strcmp(key, "no_packed_small_wg")) c->no_packed_small_wg = value != 0;
+    else if (!strcmp(key, "no_deal_runs")) c->no_deal_runs = value != 0;
     else if (!strcmp(key, "no_big_runs_global")) c->no_big_runs_global = value != 0;
     else if (!strcmp(key, "packed_ref_cap")) c->packed_ref_cap = (int)value;
     else if (!strcmp(key, "debug_routes")) c->debug_routes = value != 0;

@@ -102,12 +102,7 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         ProfScope ps(c, KID_OVO_RANK_COMPACT);
         hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(small_wg ? 256 : OCR_NT), lds, c->stream, C);
         HIPCHK(c, hipGetLastError());
-        if (parts) {
-            auto kp = k_ovo_rank_compact<KeyT, true, true>;
-            HIPCHK(c, hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kp, dim3((unsigned)nb * (unsigned)C.n_parts), dim3(OCR_NT), lds, c->stream, C);
-            HIPCHK(c, hipGetLastError());
-        }
+        if (parts && (rc = launch_rank_parts<KeyT>(c, C, nb, lds))) return rc;
     }
     // What the packed kernels left.  The plain kernel's genes (route word 1: a tie-heavy reference column, the reference's segments moved
     // together) go to k_ovo_rank over the packed layout when its LDS holds the reference and the groups (<= 1024 keys); everything else --

@@ -149,6 +149,7 @@ struct illico_ctx {
     int packed_ref_cap = 0;            // > 0: caps the packed rank kernel's key slots for the reference (tests: value-range parts at small sizes)
     int big_runs_cap = 0;              // > 0: caps k_bucket_big_runs' LDS key slots (tests: the route through HBM at small sizes)
     bool no_big_runs_global = false;   // packed routes: a (gene, group) run beyond k_bucket_big_runs' LDS slots sends its gene to the general route (as before round 5)
+    bool no_deal_runs = false;         // packed rank kernel in parts: never deal the short runs by part first (every part then looks every key up, masked)
     bool no_packed_small_wg = false;   // packed rank kernel: never the 256-thread form for small references with few groups
     bool no_ovo_parts = false;         // packed rank kernel: never take a reference in value-range parts (genes beyond the LDS slots go to the general routes, as before round 5)
     int packed_eq_buckets = -1;        // packed rank kernel: distribution-following bucket function; -1 = for references above 16384 cells

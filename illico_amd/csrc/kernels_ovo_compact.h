@@ -34,6 +34,10 @@
 #define OCR_NT 1024
 #endif
 #define OCR_KMAX 4          // 64-key rounds per group: groups of up to 256 non-zero keys
+#ifndef OCR_PAIR
+#define OCR_PAIR 1          // groups whose keys are requested ahead of their look-ups.  2 (requests two look-up rounds ahead) measured the same at C2 / C5
+                            // shapes and 20 % slower in the 256-thread form: what the wavefronts wait on is the chain table word -> keys in LDS, not HBM
+#endif
 #ifndef OCR_BLOOM_WORDS
 #define OCR_BLOOM_WORDS 256 // per wavefront: 8192 bits
 #endif
@@ -326,6 +330,8 @@ struct OvoCompactParams {
     int n_cand;
     u32 *needs_parts;        // optional [n_genes], zeroed by the host.  The plain kernel sets the word of a gene whose reference has more non-zero keys
                              // than slots and leaves the gene alone; the PARTS kernel, launched behind it, takes exactly those genes
+    const void *cuts;        // PARTS: [n_genes] PartCuts<KeyT> (k_ref_cuts): the parts of each gene that needs them
+    const u16 *pofs;         // PARTS, optional: [n_genes][G][4] where parts 1 .. 3 of a dealt (gene, group) run begin (k_deal_runs; genes of at most 4 parts)
     int n_parts;             // PARTS kernels: value-range parts a gene's reference may be taken in (grid.x = n_genes * n_parts; out_2u / out_tie
                              // zeroed by the host: every part ADDS its terms)
     u32 *route;              // [n_genes], zeroed by the host: set to 1 for the genes this kernel leaves to k_ovo_rank (packed
@@ -714,6 +720,155 @@ static __global__ __launch_bounds__(256) void k_seg_to_packed(const u32 *__restr
     if (g == ref) ref_nnz[gene] = (u16)(n > 65535u ? 65535u : n);
 }
 
+// ---- value-range parts of a reference that outgrows the rank kernel's key slots ---------------------------------------------------
+#define OCR_CELL_LG 12
+#define OCR_PMAX 32
+template <typename KeyT> struct PartCuts {
+    u32 n_parts;             // 0: the gene needs more parts than OCR_PMAX / the launch has (flagged for the general route)
+    u32 n_all;               // the reference's non-zero keys
+    KeyT kmin, kmax;         // their range
+    KeyT lo[OCR_PMAX];       // lo[j]: the smallest key of part j (j >= 1; part 0 starts at 0, the last part ends at the largest key)
+    u32 n_low[OCR_PMAX + 1]; // n_low[j]: reference keys below part j; n_low[n_parts] = n_all
+};
+
+// One workgroup per gene that the plain rank kernel handed over (needs_parts): 4096 cells over the reference's key range are counted
+// and cut where the running count passes j / P of the keys (P = ceil(keys / (7/8 of the slots)): the cuts fall on cell boundaries, an
+// eighth of the slots is slack; a part that still outgrows the slots -- a cell that holds a crowd -- is caught by the rank kernel).
+template <typename KeyT>
+__global__ __launch_bounds__(1024) void k_ref_cuts(OvoCompactParams P, PartCuts<KeyT> *__restrict__ cuts) {
+    constexpr int NT = 1024, NW = NT / 64, NC = 1 << OCR_CELL_LG, CPT = NC / NT;
+    constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
+    __shared__ u32 cells[NC];
+    __shared__ KeyT s_kr[2];
+    __shared__ u32 s_n, s_scan[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gene = blockIdx.x, G = P.G;
+    if (P.needs_parts[gene] == 0u) return; // (uniform)
+    const KeyT *Xg = (const KeyT *)P.Xs + (long long)gene * P.gene_stride;
+    const KeyT *src = P.ref_by_gofs ? Xg + P.gofs[(size_t)gene * G + P.ref] : Xg + P.ref_out;
+    const u16 *seg_nnz = P.seg_nnz + (size_t)gene * P.nseg;
+    auto for_ref = [&](auto f) {
+        for (int sg = wave; sg < P.nseg; sg += NW) {
+            const int c = (int)seg_nnz[sg];
+            const KeyT *sp = src + (size_t)sg * GCMP_SEG_ROWS;
+            for (int i = lane; i < c; i += 64) f(sp[i]);
+        }
+    };
+    for (int i = tid; i < NC; i += NT) cells[i] = 0u;
+    if (tid == 0) { s_kr[0] = MAXK; s_kr[1] = (KeyT)0; s_n = 0u; }
+    __syncthreads();
+    for (int sg = tid; sg < P.nseg; sg += NT) atomicAdd(&s_n, (u32)seg_nnz[sg]);
+    {
+        KeyT tmin = MAXK, tmax = (KeyT)0;
+        for_ref([&](KeyT k) { tmin = k < tmin ? k : tmin; tmax = k > tmax ? k : tmax; });
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const KeyT o1 = __shfl_xor(tmin, d), o2 = __shfl_xor(tmax, d);
+            tmin = o1 < tmin ? o1 : tmin;
+            tmax = o2 > tmax ? o2 : tmax;
+        }
+        if (lane == 0) { atomicMin(&s_kr[0], tmin); atomicMax(&s_kr[1], tmax); }
+    }
+    __syncthreads();
+    const u32 n_all = s_n, cap_s = (u32)P.ref_cap - (u32)P.ref_cap / 8u;
+    const int n_parts = (int)((n_all + cap_s - 1u) / cap_s);
+    PartCuts<KeyT> &C = cuts[gene];
+    if (n_parts > P.n_parts || n_parts > OCR_PMAX) { // (uniform) the general route's gene (dense layout: a reason in the word's high bits keeps k_ovo_rank away)
+        if (tid == 0) { C.n_parts = 0u; P.route[gene] = P.ref_by_gofs ? 1u : (1u | (1u << 8)); }
+        return;
+    }
+    const KeyT kmin = s_kr[0], range = (KeyT)(s_kr[1] - s_kr[0]);
+    const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
+    const int cs0 = bits > OCR_CELL_LG ? bits - OCR_CELL_LG : 0;
+    for_ref([&](KeyT k) { atomicAdd(&cells[(u32)((KeyT)(k - kmin) >> cs0)], 1u); });
+    __syncthreads();
+    u32 c4[CPT], sum = 0;
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) { c4[e] = cells[tid * CPT + e]; sum += c4[e]; }
+    const u32 inc = (u32)wave_incl_scan_add((int)sum);
+    if (lane == 63) s_scan[wave] = inc;
+    __syncthreads();
+    u32 ex = inc - sum;
+    for (int w = 0; w < wave; ++w) ex += s_scan[w];
+    if (tid == 0) { C.n_parts = (u32)n_parts; C.n_all = n_all; C.kmin = kmin; C.kmax = s_kr[1]; C.lo[0] = (KeyT)0; C.n_low[0] = 0u; C.n_low[n_parts] = n_all; }
+    // the cut in front of part j: the cell in which the running count passes j / P of the keys (the cell itself goes to part j)
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+        if (c4[e]) {
+            for (int j = 1; j < n_parts; ++j) {
+                const u32 t = (u32)((u64)n_all * (u64)j / (u64)n_parts);
+                if (ex <= t && t < ex + c4[e]) { C.lo[j] = (KeyT)(kmin + ((KeyT)(u32)(tid * CPT + e) << cs0)); C.n_low[j] = ex; }
+            }
+        }
+        ex += c4[e];
+    }
+}
+
+// The runs of at most 256 keys of a gene that is taken in 2 .. 4 parts, DEALT by part in place: one wavefront loads a (gene, group) run,
+// finds each key's part (at most three compares against the cuts) and writes the keys back part after part; pofs[gene][group][j] = where
+// part j begins (j = 1 .. 3; part 0 begins at 0, the last part ends with the run).  The parts kernel then reads, for its part, that
+// stretch only: a look-up per key instead of one per key and part (masked), and 1 / P of the bytes.  Longer runs are left alone: they
+// lie in value-bucket order (k_bucket_big_runs), the parts kernel skips their pieces outside its range.
+#define DEAL_NT 256
+template <typename KeyT>
+__global__ __launch_bounds__(DEAL_NT) void k_deal_runs(OvoCompactParams P, const PartCuts<KeyT> *__restrict__ cuts, u16 *__restrict__ pofs) {
+    constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
+    constexpr int KMAX = OCR_KMAX, NW = DEAL_NT / 64;
+    const int gene = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, G = P.G;
+    if (P.needs_parts[gene] == 0u) return; // (uniform)
+    const PartCuts<KeyT> &C = cuts[gene];
+    const int np = (int)C.n_parts;
+    if (np < 2 || np > 4) return;          // (uniform)
+    const KeyT c1 = C.lo[1], c2 = np > 2 ? C.lo[2] : KeyInfo<KeyT>::MAXK, c3 = np > 3 ? C.lo[3] : KeyInfo<KeyT>::MAXK;
+    const bool two = np > 2, three = np > 3;
+    KeyT *Xg = (KeyT *)P.Xs + (long long)gene * P.gene_stride;
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // a run is a kilobyte: the next group's keys are requested before this group's are dealt (the pass would otherwise run on latency)
+    const int step = (int)gridDim.x * NW;
+    auto meta = [&](int g, int &n, long long &off) {
+        n = 0; off = 0;
+        if (g < G && g != P.ref) { const size_t o = (size_t)gene * G + g; n = (int)P.nnz[o]; off = (long long)P.gofs[o]; }
+    };
+    auto load = [&](int n, long long off, KeyT (&k)[KMAX]) {
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r) k[r] = (n <= 64 * KMAX && r * 64 + lane < n) ? Xg[off + r * 64 + lane] : ZEROK;
+    };
+    int g = (int)blockIdx.x * NW + wave, n, n2;
+    long long off, off2;
+    KeyT cur[KMAX], nxt[KMAX];
+    meta(g, n, off);
+    load(n, off, cur);
+    for (; g < G; g += step) {
+        meta(g + step, n2, off2);
+        load(n2, off2, nxt);
+        if (g != P.ref) {
+            u16 *po = pofs + ((size_t)gene * G + g) * 4;
+            if (n == 0 || n > 64 * KMAX) { if (lane < 4) po[lane] = 0; } // (not dealt: the parts kernel reads pofs only of runs of 1 .. 256 keys)
+            else {
+                KeyT *seg = Xg + off;
+                int pt[KMAX];
+#pragma unroll
+                for (int r = 0; r < KMAX; ++r)
+                    pt[r] = (r * 64 + lane < n) ? (int)(cur[r] >= c1) + (int)(two && cur[r] >= c2) + (int)(three && cur[r] >= c3) : 7;
+                int base = 0;
+                for (int q = 0; q < np; ++q) { // (uniform) part q's keys behind the keys of the parts before it
+                    if (q > 0 && lane == 0) po[q] = (u16)base;
+#pragma unroll
+                    for (int r = 0; r < KMAX; ++r) {
+                        if (r * 64 >= n) break; // (uniform)
+                        const u64 m = __ballot(pt[r] == q);
+                        if (pt[r] == q) seg[base + (int)__popcll(m & lt_mask)] = cur[r];
+                        base += (int)__popcll(m);
+                    }
+                }
+                if (lane == 0) { po[0] = 1; for (int q = np; q < 4; ++q) po[q] = (u16)n; } // po[0] = 1: dealt
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r) cur[r] = nxt[r];
+        n = n2; off = off2;
+    }
+}
+
 // PARTS: a reference whose non-zero keys outgrow the LDS slots is taken in VALUE-RANGE PARTS, one workgroup per (gene, part): 4096 cells
 // over the reference's key range are counted, cut where the running count passes j / P of the keys, and the workgroup of part j keeps the
 // keys of its cells only -- table, look-ups and tie search as before, a group's keys outside the part masked out (every part reads every
@@ -721,7 +876,6 @@ static __global__ __launch_bounds__(256) void k_seg_to_packed(const u32 *__restr
 // cell, hence a part: S2 = sum over parts of [2 (keys of the reference below the part) + 2 #A_part<b + #A_part==b] over the part's b, and
 // the tie terms add up likewise.  Every part ADDS its share into out_2u / out_tie (zeroed by the host); part 0 adds the terms of
 // the zeros.  (Replaces, for references of any size, what rank_sum_and_ties_from_sorted does by merging: utils/ranking.py:52-158.)
-#define OCR_CELL_LG 12
 // NT_ = 256: small references and few groups (a wide matrix: 120 000 genes x 20 000 cells): a gene is a few microseconds of work behind a
 // dozen barriers -- several small workgroups per CU overlap them (one of 1024 threads per CU: 11.4 ms at that shape).
 template <typename KeyT, bool EQ, bool PARTS = false, int NT_ = OCR_NT>
@@ -786,11 +940,8 @@ __global__ __launch_bounds__(NT_) void k_ovo_rank_compact(OvoCompactParams P) {
     }
     if constexpr (PARTS) { // how many parts this gene's reference needs (an eighth of the slots is slack: the cuts fall on cell boundaries)
         if (P.needs_parts[gene] == 0u) return; // (uniform) the plain kernel's gene
-        __syncthreads();
-        const u32 n_all = s_cnt[1], cap_s = (u32)P.ref_cap - (u32)P.ref_cap / 8u;
-        if (n_all > (u32)P.ref_cap) n_parts_gene = (int)((n_all + cap_s - 1u) / cap_s);
-        if (n_parts_gene > P.n_parts) { if (tid == 0 && part == 0) P.route[gene] = P.ref_by_gofs ? 1u : (1u | (1u << 8)); return; } // (uniform; the high bits say why: "debug_routes")
-        if (part >= n_parts_gene) return;                                                          // (uniform)
+        n_parts_gene = (int)((const PartCuts<KeyT> *)P.cuts)[gene].n_parts; // (0: more parts than the launch has -- k_ref_cuts flagged the gene)
+        if (part >= n_parts_gene) return;       // (uniform)
     }
     {
         KeyT tmin = MAXK, tmax = (KeyT)0;
@@ -828,44 +979,12 @@ __global__ __launch_bounds__(NT_) void k_ovo_rank_compact(OvoCompactParams P) {
     u32 nA = nA_all, n_low = 0;               // the part's reference keys; the reference's non-zero keys below the part
     KeyT p_lo = (KeyT)0, p_hi = MAXK;         // the part's key range, both ends included (part 0 starts at 0, the last part ends at MAXK)
     KeyT kmin_p = s_kr[0], kmax_p = s_kr[1];  // the range its value buckets cover
-    if constexpr (PARTS) {
-        if (n_parts_gene > 1) { // (uniform) 4096 cells over the reference's key range, counted in the (still empty) table's space
-            u32 *cells = tab;
-            const KeyT kmin_all = s_kr[0], range_all = (KeyT)(s_kr[1] - s_kr[0]);
-            const int bits_all = range_all ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range_all) : __clz((int)range_all)) : 0;
-            const int cs0 = bits_all > OCR_CELL_LG ? bits_all - OCR_CELL_LG : 0;
-            for_ref([&](KeyT k) { atomicAdd(&cells[(u32)((KeyT)(k - kmin_all) >> cs0)], 1u); });
-            if (tid < 4) s_b[tid] = tid == 2 ? (1u << OCR_CELL_LG) : tid == 3 ? nA_all : 0u; // part 0 starts at cell 0, the last part ends behind the last cell
-            __syncthreads();
-            static_assert(!PARTS || (1 << OCR_CELL_LG) % NT == 0, "cells per thread");
-            constexpr int CPT = (1 << OCR_CELL_LG) / NT;
-            u32 c4[CPT], sum = 0;
-#pragma unroll
-            for (int e = 0; e < CPT; ++e) { c4[e] = cells[tid * CPT + e]; sum += c4[e]; }
-            const u32 inc = (u32)wave_incl_scan_add((int)sum);
-            if (lane == 63) s_scan[wave] = inc;
-            __syncthreads();
-            u32 ex = inc - sum;
-            for (int w = 0; w < wave; ++w) ex += s_scan[w];
-            // the cut in front of part j: the cell in which the running count passes j / P of the keys (the cell itself goes to part j)
-            const u32 t_lo = (u32)((u64)nA_all * (u64)part / (u64)n_parts_gene), t_hi = (u32)((u64)nA_all * (u64)(part + 1) / (u64)n_parts_gene);
-#pragma unroll
-            for (int e = 0; e < CPT; ++e) {
-                if (c4[e]) {
-                    if (part > 0 && ex <= t_lo && t_lo < ex + c4[e]) { s_b[0] = (u32)(tid * CPT + e); s_b[1] = ex; }
-                    if (part + 1 < n_parts_gene && ex <= t_hi && t_hi < ex + c4[e]) { s_b[2] = (u32)(tid * CPT + e); s_b[3] = ex; }
-                }
-                ex += c4[e];
-            }
-            __syncthreads();
-            const u32 c_lo = s_b[0], c_hi = s_b[2];
-            n_low = s_b[1];
-            nA = s_b[3] - s_b[1];
-            if (part > 0) { p_lo = (KeyT)(kmin_all + ((KeyT)c_lo << cs0)); kmin_p = p_lo; }
-            if (part + 1 < n_parts_gene) { p_hi = (KeyT)(kmin_all + ((KeyT)c_hi << cs0) - (KeyT)1); kmax_p = p_hi; }
-            for (int i = tid; i < (1 << OCR_CELL_LG); i += NT) cells[i] = 0u; // the table's space is empty again
-            __syncthreads();
-        }
+    if constexpr (PARTS) { // this part's key range, the reference's keys below it and inside it: k_ref_cuts has them
+        const PartCuts<KeyT> &C = ((const PartCuts<KeyT> *)P.cuts)[gene];
+        n_low = C.n_low[part];
+        nA = C.n_low[part + 1] - n_low;
+        if (part > 0) { p_lo = C.lo[part]; kmin_p = p_lo; }
+        if (part + 1 < n_parts_gene) { p_hi = (KeyT)(C.lo[part + 1] - (KeyT)1); kmax_p = p_hi; }
     }
     auto for_part = [&](auto f) { // the reference's keys of this part
         if constexpr (PARTS) for_ref([&](KeyT k) { if (k >= p_lo && k <= p_hi) f(k); });
@@ -1018,9 +1137,20 @@ __global__ __launch_bounds__(NT_) void k_ovo_rank_compact(OvoCompactParams P) {
         for (int g = wave; g < G; g += NW) {
             const size_t o = (size_t)gene * G + g;
             if (g == ref) { if (part == 0 && lane == 0) { P.out_2u[o] = -2; P.out_tie[o] = 0; } continue; }
-            const int nB = (int)nnz[g];
-            if (nB > 64 * KMAX) continue; // (big_sorted: walked piece by piece below)
+            const int n_run = (int)nnz[g];   // the group's non-zero keys (all parts)
+            if (n_run > 64 * KMAX) continue; // (big_sorted: walked piece by piece below)
             const KeyT *seg = Xg + P.gofs[o];
+            int nB = n_run;
+            if constexpr (PARTS) { // a dealt run (k_deal_runs): this part's stretch of it
+                if (P.pofs && n_run) {
+                    const u16 *po = P.pofs + o * 4;
+                    if (po[0] == 1) {
+                        const int beg = part ? (int)po[part] : 0, end = part + 1 < n_parts_gene ? (int)po[part + 1] : n_run;
+                        seg += beg;
+                        nB = end - beg;
+                    }
+                }
+            }
             KeyT cur[KMAX];
             u32 nv = 0;
 #pragma unroll
@@ -1042,7 +1172,7 @@ __global__ __launch_bounds__(NT_) void k_ovo_rank_compact(OvoCompactParams P) {
             const u64 tt_sum = __ballot(TT != 0ull) ? wave_sum<u64>(TT) : 0ull;
             if (lane == 0) {
                 const long long n_g = P.counts[g];
-                const u64 zc = (u64)(n_g - (long long)nB), t0 = (u64)aZ + zc;
+                const u64 zc = (u64)(n_g - (long long)n_run), t0 = (u64)aZ + zc;
                 if constexpr (PARTS) {
                     u64 S2 = s2_sum + 2ull * n_low * (u64)nv + 2ull * aZ * (u64)(nv - negs);
                     u64 tie = T_A + 3ull * tt_sum;
@@ -1051,7 +1181,7 @@ __global__ __launch_bounds__(NT_) void k_ovo_rank_compact(OvoCompactParams P) {
                     atomicAdd((unsigned long long *)&P.out_2u[o], (unsigned long long)(two_u - (long long)S2));
                     atomicAdd((unsigned long long *)&P.out_tie[o], (unsigned long long)tie);
                 } else {
-                    const u64 S2 = s2_sum + 2ull * aZ * (u64)((u32)nB - negs) + zc * (2ull * nneg + aZ);
+                    const u64 S2 = s2_sum + 2ull * aZ * (u64)((u32)n_run - negs) + zc * (2ull * nneg + aZ);
                     P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
                     P.out_tie[o] = T_A + 3ull * tt_sum + (t0 * t0 * t0 - t0);
                 }
@@ -1062,32 +1192,57 @@ __global__ __launch_bounds__(NT_) void k_ovo_rank_compact(OvoCompactParams P) {
         const int gl = g0 + lane;
         const bool has = gl < G && gl != ref;
         const u32 my_n = has ? (u32)nnz[gl] : 0u;
-        const int my_pos = has ? (int)P.gofs[(size_t)gene * G + gl] : 0;
+        int my_pos = has ? (int)P.gofs[(size_t)gene * G + gl] : 0;
+        u32 my_len = my_n; // keys to look up: the whole run, or -- a dealt run (k_deal_runs) -- this part's stretch of it
+        if constexpr (PARTS) {
+            if (P.pofs && my_n && my_n <= 64u * KMAX) {
+                const u16 *po = P.pofs + ((size_t)gene * G + gl) * 4;
+                if (po[0] == 1) {
+                    const u32 beg = part ? (u32)po[part] : 0u, end = part + 1 < n_parts_gene ? (u32)po[part + 1] : my_n;
+                    my_pos += (int)beg;
+                    my_len = end - beg;
+                }
+            }
+        }
         TrReduce<u32> rS2;
         u64 tt_out = 0;   // lane j: sum t (t + 1) over group g0 + j's keys (non-zero only where keys tie)
         u32 neg_out = 0;  // lane j: group g0 + j's keys below zero
         u32 nv_out = 0;   // PARTS, lane j: group g0 + j's keys inside the part
-        KeyT nxt[KMAX];
-        int nB_n = 0;
-        auto fetch = [&](int j) {
-            nB_n = j < 64 ? (int)__builtin_amdgcn_readlane((int)my_n, j) : 0;
-            if (nB_n > 64 * KMAX) nB_n = 0; // (big_sorted: such a group is walked piece by piece below)
+        // OCR_PAIR groups' keys are requested ahead and looked up back to back
+        constexpr int PF = OCR_PAIR;
+        KeyT nxt[PF][KMAX];
+        int nB_n[PF];
+        auto fetch = [&](int j, int h) {
+            int nb = j < 64 ? (int)__builtin_amdgcn_readlane((int)my_len, j & 63) : 0;
+            if (nb > 64 * KMAX) nb = 0; // (big_sorted: such a group is walked piece by piece below)
+            nB_n[h] = nb;
             const KeyT *seg = Xg + __builtin_amdgcn_readlane(my_pos, j & 63);
 #pragma unroll
             for (int r = 0; r < KMAX; ++r)
-                if (r * 64 < nB_n) {
-                    KeyT k = (r * 64 + lane < nB_n) ? seg[r * 64 + lane] : ZEROK;
+                if (r * 64 < nb) {
+                    KeyT k = (r * 64 + lane < nb) ? seg[r * 64 + lane] : ZEROK;
                     if constexpr (PARTS) k = (k >= p_lo && k <= p_hi) ? k : ZEROK; // (keys of other parts: masked out)
-                    nxt[r] = k;
+                    nxt[h][r] = k;
                 }
         };
-        fetch(0);
-        for (int j = 0; j < 64; ++j) { // always 64 pushes so that the transpose-reduce completes
-            KeyT cur[KMAX];
 #pragma unroll
-            for (int r = 0; r < KMAX; ++r) cur[r] = nxt[r];
-            const int nB = nB_n;
-            fetch(j + 1);
+        for (int h = 0; h < PF; ++h) fetch(h, h);
+        for (int j0 = 0; j0 < 64; j0 += PF) { // always 64 pushes so that the transpose-reduce completes
+            KeyT cur2[PF][KMAX];
+            int nB2[PF];
+#pragma unroll
+            for (int h = 0; h < PF; ++h) {
+#pragma unroll
+                for (int r = 0; r < KMAX; ++r) cur2[h][r] = nxt[h][r];
+                nB2[h] = nB_n[h];
+            }
+#pragma unroll
+            for (int h = 0; h < PF; ++h) fetch(j0 + PF + h, h);
+#pragma unroll
+            for (int h = 0; h < PF; ++h) {
+            const int j = j0 + h;
+            const KeyT (&cur)[KMAX] = cur2[h];
+            const int nB = nB2[h];
             u32 S2 = 0;
             u32 nv = 0;
             if constexpr (PARTS) {
@@ -1122,6 +1277,7 @@ __global__ __launch_bounds__(NT_) void k_ovo_rank_compact(OvoCompactParams P) {
                 if (negs && lane == j) neg_out = negs;
             }
             rS2.push(S2, j, lane);
+            }
         }
         if (gl < G && my_n <= 64u * KMAX) { // lane j now holds the totals of group g0 + j
             const size_t o = (size_t)gene * G + gl;

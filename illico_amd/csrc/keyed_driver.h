@@ -96,6 +96,33 @@ static int launch_bucket_big_runs(illico_ctx *c, void *Xs, void *tmp, long long 
     return ILLICO_OK;
 }
 
+
+// The PARTS launch of the packed rank kernel with what it needs in front of it (kernels_ovo_compact.h): the cuts of every gene the plain
+// kernel handed over (k_ref_cuts), and -- for genes of at most four parts -- their short runs dealt by part (k_deal_runs).
+template <typename KeyT>
+static int launch_rank_parts(illico_ctx *c, OvoCompactParams C, int nb, size_t lds) {
+    void *v;
+    int rc;
+    if ((rc = get_scratch(c, "packed_cuts", (size_t)nb * sizeof(PartCuts<KeyT>), &v))) return rc;
+    PartCuts<KeyT> *cuts = (PartCuts<KeyT> *)v;
+    C.cuts = cuts; C.pofs = nullptr;
+    hipLaunchKernelGGL((k_ref_cuts<KeyT>), dim3((unsigned)nb), dim3(1024), 0, c->stream, C, cuts);
+    HIPCHK(c, hipGetLastError());
+    if (!c->no_deal_runs && C.n_parts <= 4) { // (more parts: the masked look-ups of the parts kernel)
+        if ((rc = get_scratch(c, "packed_pofs", (size_t)nb * (size_t)C.G * 8, &v))) return rc;
+        u16 *pofs = (u16 *)v;
+        const unsigned gx = (unsigned)std::max(1, std::min((C.G + DEAL_NT / 64 - 1) / (DEAL_NT / 64), 64));
+        hipLaunchKernelGGL((k_deal_runs<KeyT>), dim3(gx, (unsigned)nb), dim3(DEAL_NT), 0, c->stream, C, (const PartCuts<KeyT> *)cuts, pofs);
+        HIPCHK(c, hipGetLastError());
+        C.pofs = pofs;
+    }
+    auto kp = k_ovo_rank_compact<KeyT, true, true>;
+    HIPCHK(c, hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kp, dim3((unsigned)nb * (unsigned)C.n_parts), dim3(OCR_NT), lds, c->stream, C);
+    HIPCHK(c, hipGetLastError());
+    return ILLICO_OK;
+}
+
 constexpr int kOvrThreads = 256; // several small workgroups per CU overlap each other's barriers (1024 measured the same)
 
 struct OvrPackedInput {

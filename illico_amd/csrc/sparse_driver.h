@@ -1376,12 +1376,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                     ProfScope ps(c, KID_OVO_RANK_COMPACT);
                     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(OCR_NT), lds, c->stream, C);
                     HIPCHK(c, hipGetLastError());
-                    if (parts) {
-                        auto kp = k_ovo_rank_compact<KeyT, true, true>;
-                        HIPCHK(c, hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        hipLaunchKernelGGL(kp, dim3((unsigned)nb * (unsigned)C.n_parts), dim3(OCR_NT), lds, c->stream, C);
-                        HIPCHK(c, hipGetLastError());
-                    }
+                    if (parts && (rc = launch_rank_parts<KeyT>(c, C, nb, lds))) return rc;
                 }
                 if ((rc = launch_ovo<KeyT>(c, P, ref_cap_b, grp_cap_b, route_flags, &gb, true, route))) return rc;
             } else

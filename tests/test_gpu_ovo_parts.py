@@ -24,7 +24,7 @@ def engine():
     eng = get_engine()
     eng.set_option("no_fused_path", 1)
     yield eng
-    for k in ("no_fused_path", "packed_ref_cap", "big_runs_cap", "no_ovo_parts", "no_big_runs_global", "profile"):
+    for k in ("no_fused_path", "packed_ref_cap", "big_runs_cap", "no_ovo_parts", "no_big_runs_global", "no_deal_runs", "profile"):
         eng.set_option(k, 0)
 
 
@@ -54,9 +54,10 @@ def _profiled(engine, run):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("zero_frac", [0.0, 0.4])
-def test_reference_in_value_range_parts(engine, dtype, zero_frac):
-    """A reference of 6000 cells against key slots capped at 1024: up to seven parts per gene.  Columns: continuous, mixed sign without
+@pytest.mark.parametrize("zero_frac,cap", [(0.0, 1024), (0.4, 1024), (0.0, 2048), (0.4, 3072)])
+def test_reference_in_value_range_parts(engine, dtype, zero_frac, cap):
+    """A reference of 6000 cells against key slots capped at 1024 / 2048 / 3072: seven parts per gene (every part looks every key up,
+    the other parts' lanes masked), four, or two (the groups' runs dealt by part first: k_deal_runs).  Columns: continuous, mixed sign without
     zeros (scaled data), ties between the reference and the groups and inside groups (values rounded to a grid), a column whose
     reference is one value (a cell of the cut holds everything: the gene leaves the route, the general route computes it), a constant
     column, one outlier stretching the key range."""
@@ -75,9 +76,14 @@ def test_reference_in_value_range_parts(engine, dtype, zero_frac):
     _, g = oracle.encode_and_count_groups(labels, "non-targeting")
     engine.set_groups(g)
     want = oracle.run(np.ascontiguousarray(X, dtype=np.float64) if dtype == np.float64 else X, g)
-    engine.set_option("packed_ref_cap", 1024)
+    engine.set_option("packed_ref_cap", cap)
     got, prof = _profiled(engine, lambda: engine.run_dense(X, 0, m))
-    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"reference in parts {dtype.__name__} zeros {zero_frac}")
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"reference in parts {dtype.__name__} zeros {zero_frac} slots {cap}")
+    engine.set_option("no_deal_runs", 1)
+    try:
+        _same(got, engine.run_dense(X, 0, m))                  # (dealt runs or masked look-ups: the same integers)
+    finally:
+        engine.set_option("no_deal_runs", 0)
     assert "k_ovo_rank_compact" in prof and "k_group_compact" in prof, prof
     stats = engine.rank_statistics(X, 0, m)
     engine.set_option("no_ovo_parts", 1)                      # (with the slots still capped: every gene leaves the kernel)
