@@ -179,6 +179,10 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_ovo_parts")) c->no_ovo_parts = value != 0;
     else if (!strcmp(key, "no_packed_small_wg")) c->no_packed_small_wg = value != 0;
     else if (!strcmp(key, "no_deal_runs")) c->no_deal_runs = value != 0;
+    else if (!strcmp(key, "big_runs_slice_bytes")) c->big_runs_slice_bytes = (int)value;
+    else if (!strcmp(key, "no_big_runs_wide")) c->no_big_runs_wide = value != 0;
+    else if (!strcmp(key, "no_compact_narrow")) c->no_compact_narrow = value != 0;
+    else if (!strcmp(key, "compact_narrow_rows")) c->compact_narrow_rows = value > 0 ? value : 8192;
     else if (!strcmp(key, "no_big_runs_global")) c->no_big_runs_global = value != 0;
     else if (!strcmp(key, "packed_ref_cap")) c->packed_ref_cap = (int)value;
     else if (!strcmp(key, "debug_routes")) c->debug_routes = value != 0;
@@ -351,7 +355,8 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
         std::vector<int> g0, g1, out;
         int64_t pos = 0, rows = 0;
         bool open = false;
-        auto close = [&](int64_t end) { g1.push_back((int)end); pos += (rows + 63) & ~63ll; open = false; };
+        c->pk_max_block_rows = 0;
+        auto close = [&](int64_t end) { g1.push_back((int)end); pos += (rows + 63) & ~63ll; open = false; c->pk_max_block_rows = std::max(c->pk_max_block_rows, rows); };
         for (int64_t g = 0; g < n_groups; ++g) {
             if (g == ref) { if (open) close(g); continue; }
             if (!open) { g0.push_back((int)g); out.push_back((int)pos); rows = 0; open = true; }

@@ -12,9 +12,14 @@ static int launch_group_compact(illico_ctx *c, GroupCompactParams Q, int nb, int
     constexpr int VEC = 16 / (int)sizeof(InT);
     const bool aligned = ((uintptr_t)Q.X % 16 == 0) && (Q.ld % VEC == 0) && (Q.col0 % VEC == 0);
     const bool lg = flags & ILLICO_FLAG_LOG1P;
-    const dim3 grid(((Q.nseg + 7) & ~7) + Q.nblk, (nb + 63) / 64);
+    // few, long blocks (cluster-sized groups): a workgroup's chain of 64-row chunks is what the launch waits for -- tiles of 32 genes
+    // (128-byte row pieces) put twice the workgroups on the same rows
+    const bool narrow = !c->no_compact_narrow && c->pk_max_block_rows >= c->compact_narrow_rows && (long long)Q.nblk * ((nb + 63) / 64) < 2048; // (8 per compute unit)
+    const int tw = narrow ? 32 : 64;
+    const dim3 grid(((Q.nseg + 7) & ~7) + Q.nblk, (nb + tw - 1) / tw);
     ProfScope ps(c, KID_GROUP_COMPACT);
-#define GC_LAUNCH(V, L, K) hipLaunchKernelGGL((k_group_compact<InT, KeyT, V, L, K>), grid, dim3(GCMP_NT), 0, c->stream, Q)
+#define GC_LAUNCH(V, L, K) do { if (narrow) hipLaunchKernelGGL((k_group_compact<InT, KeyT, V, L, K, 32>), grid, dim3(GCMP_NT), 0, c->stream, Q); \
+                                else hipLaunchKernelGGL((k_group_compact<InT, KeyT, V, L, K, 64>), grid, dim3(GCMP_NT), 0, c->stream, Q); } while (0)
     if (pack) {
         if (aligned && !lg) GC_LAUNCH(true, false, true); else if (aligned) GC_LAUNCH(true, true, true);
         else if (!lg) GC_LAUNCH(false, false, true); else GC_LAUNCH(false, true, true);

@@ -118,6 +118,7 @@ struct illico_ctx {
     int *d_pk_big = nullptr;      // [pk_nbig] the groups (never the reference) of more than 256 cells: their packed runs may need k_bucket_big_runs;
                                   // then [G]: a group's place in that list, or -1
     int pk_nbig = 0;
+    int64_t pk_max_block_rows = 0; // rows of the longest block
     int64_t pk_len = 0;           // ... of which the blocks take the first pk_len (the padded dense layout's row length)
     int *d_counts = nullptr;      // [G]
     GroupConst *d_gconst = nullptr; // [G] per-group constants of the p-value / fold change for this ref (kernels_finalize.h)
@@ -148,7 +149,11 @@ struct illico_ctx {
     bool debug_routes = false;         // stderr: what the packed OVO rank kernel left to the general routes, and why
     int packed_ref_cap = 0;            // > 0: caps the packed rank kernel's key slots for the reference (tests: value-range parts at small sizes)
     int big_runs_cap = 0;              // > 0: caps k_bucket_big_runs' LDS key slots (tests: the route through HBM at small sizes)
+    int big_runs_slice_bytes = 0;      // > 0: the LDS bytes of k_bucket_big_runs_global's slice buffer (default: what the CU's LDS leaves beside the counters)
+    bool no_big_runs_wide = false;     // k_bucket_big_runs: 256 threads whatever the runs' length
     bool no_big_runs_global = false;   // packed routes: a (gene, group) run beyond k_bucket_big_runs' LDS slots sends its gene to the general route (as before round 5)
+    bool no_compact_narrow = false;    // k_group_compact: never the 32-gene tiles for few, long blocks
+    int64_t compact_narrow_rows = 8192; // ... from this many rows in the longest block
     bool no_deal_runs = false;         // packed rank kernel in parts: never deal the short runs by part first (every part then looks every key up, masked)
     bool no_packed_small_wg = false;   // packed rank kernel: never the 256-thread form for small references with few groups
     bool no_ovo_parts = false;         // packed rank kernel: never take a reference in value-range parts (genes beyond the LDS slots go to the general routes, as before round 5)

@@ -91,16 +91,17 @@ template <> __device__ __forceinline__ double gcmp_value<int64_t>(int64_t v, int
 // PACK = false (dense OVR): every key of the block's rows is kept, zeros included -- the "padded dense" layout: the key rows of
 // kernels_ovo.h with each block starting at a multiple of 64 keys (holes hold the zero key) -- and only the sums are written
 // beside the keys: the transposition with the group sums folded in.
-template <typename InT, typename KeyT, bool VECLOAD, bool LOG1P, bool PACK = true>
+template <typename InT, typename KeyT, bool VECLOAD, bool LOG1P, bool PACK = true, int TW = 64>
 __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P) {
     constexpr int VEC = 16 / (int)sizeof(InT);
-    constexpr int LPR = 64 / VEC;      // lanes per 64-gene row segment
+    constexpr int LPR = TW / VEC;      // lanes per TW-gene row segment
     constexpr int RPI = GCMP_NT / LPR; // rows per load iteration
     constexpr int NLD = 64 / RPI;      // loads per thread per 64-row chunk
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
     typedef InT __attribute__((ext_vector_type(VEC))) InV;
-    __shared__ KeyT tile[64][65];
-    static_assert(sizeof(tile) >= sizeof(double) * RPI * 64, "the tile doubles as the sum scratch");
+    constexpr int TILE_KEYS = (TW * 65 * (int)sizeof(KeyT) >= (int)sizeof(double) * RPI * TW) ? TW * 65 : (int)(sizeof(double) * RPI * TW / sizeof(KeyT));
+    __shared__ KeyT tile_mem[TILE_KEYS]; // [TW][65] keys; doubles as the sum scratch ([RPI][TW] doubles)
+    KeyT (*tile)[65] = reinterpret_cast<KeyT (*)[65]>(tile_mem);
 
     const int nseg_pad = (P.nseg + 7) & ~7;
     int gA, gB, out0, seg = -1, seg_row0 = 0, seg_n = 0, blk = 0;
@@ -118,13 +119,13 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
         blk = b;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c0 = blockIdx.y * 64;
+    const int c0 = blockIdx.y * TW;
     const int q = tid % LPR, r0 = tid / LPR;
     const InT *X = (const InT *)P.X;
     KeyT *Xt = (KeyT *)P.Xt;
     const int cq = c0 + q * VEC;
     const bool colv = cq + VEC <= P.ncols;
-    const int geneW = c0 + wave * (64 / (GCMP_NT / 64)) + lane; // lanes 0..GPW-1: the gene whose counts this lane keeps
+    const int geneW = c0 + wave * (TW / (GCMP_NT / 64)) + lane; // lanes 0..GPW-1: the gene whose counts this lane keeps
 
     // chunk cursors (uniform scalars): group, chunk inside it, the group's rows and first position -- one for the loads being
     // issued (i*), one for the chunk being packed (c*)
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
 #define GCMP_CUR_NEXT(g, c, n, row0) { ++c; if (c * 64 >= n) { ++g; c = 0; grp_rows(g, n, row0); GCMP_CUR_SKIP(g, c, n, row0) } }
     if (seg < 0) { // groups without cells have no chunk: their outputs here
         for (int g = gA; g < gB; ++g)
-            if (P.pos_ptr[g + 1] == P.pos_ptr[g] && tid < 64 && c0 + tid < P.ncols) {
+            if (P.pos_ptr[g + 1] == P.pos_ptr[g] && tid < TW && c0 + tid < P.ncols) {
                 if (PACK) {
                     P.nnz[(size_t)(c0 + tid) * P.G + g] = 0;
                     P.gofs[(size_t)(c0 + tid) * P.G + g] = (u32)out0;
@@ -158,12 +159,13 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
     // staging of packed keys (4-byte keys): per gene a 128-key ring piece in LDS; whenever 64 keys are there, one 256-byte
     // aligned store of full lines goes out.  (Pieces of a line written one store at a time make the L2 fetch the line first.)
     constexpr bool STAGE = sizeof(KeyT) == 4;
-    constexpr int NWV = GCMP_NT / 64, GPW = 64 / NWV; // wavefronts, genes packed by each
+    constexpr int NWV = GCMP_NT / 64, GPW = TW / NWV; // wavefronts, genes packed by each
     __shared__ KeyT stage[STAGE ? NWV * GPW * 128 : 1];
     KeyT *st = stage + (STAGE ? wave * GPW * 128 : 0);
 
     int rows[NLD]; // row indices of the next chunk to load
-    InV bufA[NLD], bufB[NLD];
+    constexpr int DEPTH = 2; // chunks of rows in flight (4 with the 32-gene tiles: 6.1 -> 8.8 ms on ten clusters of 100 000 cells -- a step's own chain of waits, not the gather, is what a chunk takes)
+    InV bufs[DEPTH][NLD];
     auto load_rows = [&](int c, int n, int row0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -200,9 +202,10 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
     GCMP_CUR_SKIP(ig, ic, in_, irow0)
     int cg = ig, cc = 0, cn = in_, crow0 = irow0;
     bool rows_ready = false;
-    // two chunks of rows in flight (bufA: the chunk packed next, bufB: the one after), row indices of a third
-    if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) load_chunk(bufA); }
-    if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) load_chunk(bufB); }
+    // DEPTH chunks of rows in flight (bufs[0]: the chunk packed next, bufs[1]: the one after, ...), row indices of one more
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) load_chunk(bufs[d]); }
     if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) rows_ready = true; }
     auto step = [&](InV (&buf)[NLD]) { // pack the chunk in buf, then refill buf with the chunk rows[] describes
 #pragma unroll
@@ -245,14 +248,14 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
         }
         __syncthreads();
         if ((cc + 1) * 64 >= cn) { // the group's last chunk: its sums ([RPI row slots][64 genes] partials, added in row-slot order), counts, start
-            double *part = (double *)&tile[0][0];
+            double *part = (double *)tile_mem;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) { part[r0 * 64 + q * VEC + e] = sum[e]; sum[e] = 0.0; }
+            for (int e = 0; e < VEC; ++e) { part[r0 * TW + q * VEC + e] = sum[e]; sum[e] = 0.0; }
             __syncthreads();
-            if (tid < 64 && c0 + tid < P.ncols) {
+            if (tid < TW && c0 + tid < P.ncols) {
                 double tot = 0.0;
 #pragma unroll 4
-                for (int r = 0; r < RPI; ++r) tot += part[r * 64 + tid];
+                for (int r = 0; r < RPI; ++r) tot += part[r * TW + tid];
                 if (seg >= 0) P.seg_sum[(size_t)(c0 + tid) * P.nseg + seg] = tot;
                 else P.out_sum[(size_t)(c0 + tid) * P.G + cg] = tot;
             }
@@ -273,8 +276,9 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
         GCMP_CUR_NEXT(cg, cc, cn, crow0)
     };
     while (cg < gB) {
-        step(bufA);
-        if (cg < gB) step(bufB);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (cg < gB) step(bufs[d]);
     }
     if (PACK && seg < 0 && P.blk_cnt && lane < GPW && geneW < P.ncols) P.blk_cnt[(size_t)geneW * P.nblk + blk] = (u32)cntv;
     if constexpr (STAGE) { // what is left in the staging pieces: one partial store per gene
@@ -565,142 +569,208 @@ static inline size_t srt_lds_bytes(size_t key_size, int cap) { return (size_t)ca
 template <typename KeyT> struct BigRunFn { KeyT kmin; int shift; };
 template <typename KeyT> __device__ __forceinline__ u32 big_bucket(const BigRunFn<KeyT> &f, KeyT k) { return (u32)((KeyT)(k - f.kmin) >> f.shift); }
 
+// every key of a run (and its index) to f, NT threads: 16-byte loads (the run starts anywhere: up to three keys in front of the first whole piece and
+// behind the last go one by one), four of them in flight per thread
+template <typename KeyT, int NT, typename F> __device__ __forceinline__ void run_for_keys(const KeyT *__restrict__ run, int n, int tid, F f) {
+    constexpr int V = 16 / (int)sizeof(KeyT);
+    typedef KeyT __attribute__((ext_vector_type(V))) KV;
+    const int head = min(n, (int)(((16u - (unsigned)((uintptr_t)run & 15u)) & 15u) / (unsigned)sizeof(KeyT)));
+    if (tid < head) f(run[tid], tid);
+    const KV *rv = reinterpret_cast<const KV *>(run + head);
+    const int nv = (n - head) / V;
+    for (int i = tid; i < nv; i += 4 * NT) {
+        KV k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = rv[min(i + u * NT, nv - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * NT < nv) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) f(k[u][e], head + (i + u * NT) * V + e);
+            }
+    }
+    const int t0 = head + nv * V;
+    if (tid < n - t0) f(run[t0 + tid], t0 + tid);
+}
+
 // A run longer than the LDS buffer (half of a 100 000-cell cluster non-zero: 50 000 keys) is dealt through HBM instead, by a kernel of
 // its own (k_bucket_big_runs leaves such runs alone when one follows): range and bucket counts from two reads of the run, the counters
-// -- up to 2^14 in LDS: 64 KB, two workgroups of 1024 threads per CU, four requests in flight per thread -- scanned, the keys
-// scattered into the run's place in a second key buffer `tmp` (laid out like Xs; the run's ~200 KB stay in L2), where the rank kernel
-// reads it (BIG_RUN_IN_TMP in the run's bucket function: no copy back).
-#define SRT_LG_MAX_G 14
+// -- up to 2^13 in LDS, ~6 keys per bucket at 50 000 -- scanned, the keys dealt slice by slice of the output through LDS key slots behind
+// the counters (all of a CU's LDS: one workgroup of 1024 threads) into the run's place in a second key buffer `tmp` (laid out like
+// Xs), where the rank kernel reads it (BIG_RUN_IN_TMP in the run's bucket function: no copy back).
+#define SRT_LG_MAX_G 13
 #define SRTG_NT 1024
 template <typename KeyT>
 __global__ __launch_bounds__(SRTG_NT) void k_bucket_big_runs_global(void *Xs, void *tmp, long long gene_stride, const u16 *__restrict__ nnz, const u32 *__restrict__ gofs,
                                                                     const int *__restrict__ cand, int n_cand, int G, int cap /* runs up to here are k_bucket_big_runs' */,
                                                                     int lg_max /* log2 of the counters the launch's LDS holds */, BigRunFn<KeyT> *__restrict__ big_fn,
-                                                                    u32 *__restrict__ route, const u32 *__restrict__ run_n /* exact run lengths, or null */) {
+                                                                    u32 *__restrict__ route, const u32 *__restrict__ run_n /* exact run lengths, or null */, int slice_keys /* LDS key slots behind the counters */) {
     extern __shared__ __align__(16) unsigned char srtg_smem[];
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
     constexpr int NT = SRTG_NT;
     u32 *cnt = (u32 *)srtg_smem;
     __shared__ KeyT g_min, g_max;
     __shared__ u32 g_part[NT / 64];
-    const int gene = blockIdx.y, g = cand[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int n = (int)nnz[(size_t)gene * G + g];
-    if (n <= cap) return; // (uniform)
-    if (n >= 65535) { // the 16-bit run length saturated
-        if (!run_n) { if (tid == 0) route[gene] = 2u; return; }
-        n = (int)run_n[(size_t)gene * n_cand + blockIdx.x];
-    }
-    const size_t off = (size_t)((long long)gene * gene_stride) + gofs[(size_t)gene * G + g];
-    KeyT *run = (KeyT *)Xs + off, *out = (KeyT *)tmp + off;
-    if (tid == 0) { g_min = MAXK; g_max = (KeyT)0; }
-    __syncthreads();
-    // four keys per thread and step, requested together; lanes past the end read the run's last key (harmless for min / max) or skip
-    KeyT lo = MAXK, hi = (KeyT)0;
-    for (int i = tid; i < n; i += 4 * NT) {
-        KeyT k[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) k[u] = run[min(i + u * NT, n - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { lo = k[u] < lo ? k[u] : lo; hi = k[u] > hi ? k[u] : hi; }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { const KeyT a = __shfl_xor(lo, d), b = __shfl_xor(hi, d); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
-    if (lane == 0) { atomicMin(&g_min, lo); atomicMax(&g_max, hi); }
-    __syncthreads();
-    int lg = 6;
-    while (lg < lg_max && (4 << lg) < n) ++lg;
-    const int B = 1 << lg;
-    const KeyT range = (KeyT)(g_max - g_min);
-    const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
-    BigRunFn<KeyT> f;
-    f.kmin = g_min;
-    f.shift = bits > lg ? bits - lg : 0;
-    if (tid == 0) { BigRunFn<KeyT> fo = f; fo.shift |= BIG_RUN_IN_TMP; big_fn[(size_t)gene * n_cand + blockIdx.x] = fo; } // (the rank kernel reads this run from `tmp`)
-    for (int b = tid; b < B; b += NT) cnt[b] = 0u;
-    __syncthreads();
-    for (int i = tid; i < n; i += 4 * NT) {
-        KeyT k[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) k[u] = run[min(i + u * NT, n - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (i + u * NT < n) atomicAdd(&cnt[big_bucket(f, k[u])], 1u);
-    }
-    __syncthreads();
-    { // exclusive scan of the B counters: a thread owns B / 1024 consecutive ones
-        const int per = (B + NT - 1) / NT;
-        u32 sum = 0;
-        for (int e = 0; e < per; ++e) { const int b = tid * per + e; sum += b < B ? cnt[b] : 0u; }
-        const u32 inc = (u32)wave_incl_scan_add((int)sum);
-        if (lane == 63) g_part[wave] = inc;
+    __shared__ int s_list[NT], s_nl;
+    const int gene = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n_cand + (int)gridDim.x - 1) / (int)gridDim.x, c_end = min(n_cand, ((int)blockIdx.x + 1) * per);
+    for (int c0 = (int)blockIdx.x * per; c0 < c_end; c0 += NT) { // (the workgroup's stretch of the gene's candidates, as in k_bucket_big_runs)
+      if (tid == 0) s_nl = 0;
+      __syncthreads();
+      if (c0 + tid < c_end && (int)nnz[(size_t)gene * G + cand[c0 + tid]] > cap) s_list[atomicAdd(&s_nl, 1)] = c0 + tid;
+      __syncthreads();
+      const int nl = s_nl;
+      for (int li = 0; li < nl; ++li) {
+        const int cd = s_list[li], g = cand[cd];
+        int n = (int)nnz[(size_t)gene * G + g];
+        if (n >= 65535) { // the 16-bit run length saturated
+            if (!run_n) { if (tid == 0) route[gene] = 2u; continue; }
+            n = (int)run_n[(size_t)gene * n_cand + cd];
+        }
+        const size_t off = (size_t)((long long)gene * gene_stride) + gofs[(size_t)gene * G + g];
+        KeyT *run = (KeyT *)Xs + off, *out = (KeyT *)tmp + off;
+        if (tid == 0) { g_min = MAXK; g_max = (KeyT)0; }
         __syncthreads();
-        u32 base = inc - sum;
-        for (int w = 0; w < wave; ++w) base += g_part[w];
-        for (int e = 0; e < per; ++e) { const int b = tid * per + e; if (b < B) { const u32 c = cnt[b]; cnt[b] = base; base += c; } }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += 4 * NT) {
-        KeyT k[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) k[u] = run[min(i + u * NT, n - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (i + u * NT < n) out[atomicAdd(&cnt[big_bucket(f, k[u])], 1u)] = k[u];
+        KeyT lo = MAXK, hi = (KeyT)0;
+        run_for_keys<KeyT, NT>(run, n, tid, [&](KeyT k, int) { lo = k < lo ? k : lo; hi = k > hi ? k : hi; });
+    #pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const KeyT a = __shfl_xor(lo, d), b = __shfl_xor(hi, d); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+        if (lane == 0) { atomicMin(&g_min, lo); atomicMax(&g_max, hi); }
+        __syncthreads();
+        int lg = 6;
+        while (lg < lg_max && (4 << lg) < n) ++lg;
+        const int B = 1 << lg;
+        const KeyT range = (KeyT)(g_max - g_min);
+        const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
+        BigRunFn<KeyT> f;
+        f.kmin = g_min;
+        f.shift = bits > lg ? bits - lg : 0;
+        if (tid == 0) { BigRunFn<KeyT> fo = f; fo.shift |= BIG_RUN_IN_TMP; big_fn[(size_t)gene * n_cand + cd] = fo; } // (the rank kernel reads this run from `tmp`)
+        for (int b = tid; b < B; b += NT) cnt[b] = 0u;
+        __syncthreads();
+        run_for_keys<KeyT, NT>(run, n, tid, [&](KeyT k, int) { atomicAdd(&cnt[big_bucket(f, k)], 1u); });
+        __syncthreads();
+        { // exclusive scan of the B counters: a thread owns B / 1024 consecutive ones
+            const int per = (B + NT - 1) / NT;
+            u32 sum = 0;
+            for (int e = 0; e < per; ++e) { const int b = tid * per + e; sum += b < B ? cnt[b] : 0u; }
+            const u32 inc = (u32)wave_incl_scan_add((int)sum);
+            if (lane == 63) g_part[wave] = inc;
+            __syncthreads();
+            u32 base = inc - sum;
+            for (int w = 0; w < wave; ++w) base += g_part[w];
+            for (int e = 0; e < per; ++e) { const int b = tid * per + e; if (b < B) { const u32 c = cnt[b]; cnt[b] = base; base += c; } }
+        }
+        // the scatter, in SLICES of the output through LDS: a slice = the buckets that start inside [s T, (s + 1) T) of the output, T = the slice
+        // buffer less 256 keys (a bucket of more than 256 keys -- its gene leaves the rank kernel anyway -- may overhang: those keys go straight
+        // out); the run is read once per slice (16-byte loads, from L2), its keys of the slice take their places in the buffer, the buffer goes
+        // out in whole lines.  (Scattered from here, every 4-byte store was an L2 request of its own: 1.2 G of them for ten clusters of 100 000
+        // cells half non-zero, 13 of the kernel's 16 ms.)
+        KeyT *buf = (KeyT *)(srtg_smem + ((size_t)4 << lg_max));
+        const int T = max(slice_keys - 256, 64);
+        __syncthreads();
+        for (int b_lo = 0, b_hi; b_lo < B; b_lo = b_hi) { // (uniform)
+            const u32 base = cnt[b_lo]; // (buckets from b_lo on: their starts, untouched so far)
+            if (base >= (u32)n) break;
+            { // the first bucket behind b_lo that starts at or after base + T
+                int lo_b = b_lo + 1, hi_b = B;
+                const u32 t = base + (u32)T;
+                while (lo_b < hi_b) { const int mid = (lo_b + hi_b) >> 1; if (cnt[mid] >= t) hi_b = mid; else lo_b = mid + 1; }
+                b_hi = lo_b;
+            }
+            const u32 end = b_hi < B ? cnt[b_hi] : (u32)n;
+            __syncthreads(); // (every thread has read the starts before the first atomic moves one)
+            run_for_keys<KeyT, NT>(run, n, tid, [&](KeyT k, int) {
+                const u32 b = big_bucket(f, k);
+                if (b >= (u32)b_lo && b < (u32)b_hi) {
+                    const u32 pos = atomicAdd(&cnt[b], 1u), loc = pos - base;
+                    if (loc < (u32)slice_keys) buf[loc] = k; else out[pos] = k;
+                }
+            });
+            __syncthreads();
+            const u32 m = min(end - base, (u32)slice_keys);
+            for (u32 i = tid; i < m; i += NT) out[base + i] = buf[i];
+            __syncthreads();
+        }
+        __syncthreads(); // (the next run reuses the counters and the range)
+      }
+      __syncthreads(); // (the list is rebuilt)
     }
 }
 
-template <typename KeyT>
-__global__ __launch_bounds__(SRT_NT) void k_bucket_big_runs(void *Xs, long long gene_stride, const u16 *__restrict__ nnz, const u32 *__restrict__ gofs,
+template <typename KeyT, int NT_ = SRT_NT>
+__global__ __launch_bounds__(NT_) void k_bucket_big_runs(void *Xs, long long gene_stride, const u16 *__restrict__ nnz, const u32 *__restrict__ gofs,
                                                             const int *__restrict__ cand, int n_cand, int G, int cap /* LDS key slots */,
-                                                            BigRunFn<KeyT> *__restrict__ big_fn, u32 *__restrict__ route, int global_follows /* k_bucket_big_runs_global takes the longer runs */) {
+                                                            BigRunFn<KeyT> *__restrict__ big_fn, u32 *__restrict__ route, int global_follows /* another launch takes the longer runs */,
+                                                            int n_min /* runs up to here are left alone (64 * OCR_KMAX, or another launch's) */) {
     extern __shared__ __align__(16) unsigned char srt_smem[];
+    constexpr int NTK = NT_; // (256 threads; 1024 in a launch of its own for runs above 8192 keys: the LDS they take leaves room for two workgroups per CU)
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
     KeyT *K = (KeyT *)srt_smem;
-    u32 *cnt = (u32 *)(srt_smem + (size_t)cap * sizeof(KeyT)); // [buckets]
     __shared__ KeyT s_min, s_max;
-    __shared__ u32 s_part[SRT_NT / 64];
-    const int gene = blockIdx.y, g = cand[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = (int)nnz[(size_t)gene * G + g];
-    if (n <= 64 * OCR_KMAX) return;
-    KeyT *run = (KeyT *)Xs + (long long)gene * gene_stride + gofs[(size_t)gene * G + g];
-    if (n > cap) { if (tid == 0 && !global_follows) route[gene] = 2u; return; } // (uniform)
-    if (tid == 0) { s_min = MAXK; s_max = (KeyT)0; }
-    __syncthreads();
-    KeyT lo = MAXK, hi = (KeyT)0;
-    for (int i = tid; i < n; i += SRT_NT) { const KeyT k = run[i]; K[i] = k; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { const KeyT a = __shfl_xor(lo, d), b = __shfl_xor(hi, d); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
-    if (lane == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
-    __syncthreads();
-    // about four keys per bucket
-    int lg = 6;
-    while (lg < SRT_LG_MAX && (4 << lg) < n) ++lg;
-    const int B = 1 << lg;
-    const KeyT range = (KeyT)(s_max - s_min);
-    const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
-    BigRunFn<KeyT> f;
-    f.kmin = s_min;
-    f.shift = bits > lg ? bits - lg : 0;
-    if (tid == 0) big_fn[(size_t)gene * n_cand + blockIdx.x] = f;
-    for (int b = tid; b < B; b += SRT_NT) cnt[b] = 0u;
-    __syncthreads();
-    for (int i = tid; i < n; i += SRT_NT) atomicAdd(&cnt[big_bucket(f, K[i])], 1u);
-    __syncthreads();
-    { // exclusive scan of the B counters (B <= 4096 = 8 per thread)
-        const int per = (B + SRT_NT - 1) / SRT_NT;
-        u32 loc[(1 << SRT_LG_MAX) / SRT_NT], sum = 0;
-#pragma unroll
-        for (int e = 0; e < (1 << SRT_LG_MAX) / SRT_NT; ++e) { const int b = tid * per + e; loc[e] = (e < per && b < B) ? cnt[b] : 0u; sum += loc[e]; }
-        const u32 inc = (u32)wave_incl_scan_add((int)sum);
-        if (lane == 63) s_part[wave] = inc;
+    __shared__ u32 s_part[NTK / 64];
+    __shared__ int s_list[NTK], s_nl;
+    const int gene = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 *cnt = (u32 *)(srt_smem + (size_t)cap * sizeof(KeyT)); // [buckets]
+    // the workgroup's stretch of the gene's candidate groups: their run lengths are looked at NTK at a time, the runs above 256 keys
+    // listed, the list walked (300 groups of 333 cells half non-zero are 1.5 M candidates none of which holds 256 keys)
+    const int per = (n_cand + (int)gridDim.x - 1) / (int)gridDim.x, c_end = min(n_cand, ((int)blockIdx.x + 1) * per);
+    for (int c0 = (int)blockIdx.x * per; c0 < c_end; c0 += NTK) {
+      if (tid == 0) s_nl = 0;
+      __syncthreads();
+      if (c0 + tid < c_end && (int)nnz[(size_t)gene * G + cand[c0 + tid]] > n_min) s_list[atomicAdd(&s_nl, 1)] = c0 + tid;
+      __syncthreads();
+      const int nl = s_nl;
+      for (int li = 0; li < nl; ++li) {
+        const int cd = s_list[li], g = cand[cd];
+        const int n = (int)nnz[(size_t)gene * G + g];
+        KeyT *run = (KeyT *)Xs + (long long)gene * gene_stride + gofs[(size_t)gene * G + g];
+        if (n > cap) { if (tid == 0 && !global_follows) route[gene] = 2u; continue; } // (uniform)
+        if (tid == 0) { s_min = MAXK; s_max = (KeyT)0; }
         __syncthreads();
-        u32 base = inc - sum;
-        for (int w = 0; w < wave; ++w) base += s_part[w];
+        KeyT lo = MAXK, hi = (KeyT)0;
+        run_for_keys<KeyT, NTK>(run, n, tid, [&](KeyT k, int i) { K[i] = k; lo = k < lo ? k : lo; hi = k > hi ? k : hi; });
 #pragma unroll
-        for (int e = 0; e < (1 << SRT_LG_MAX) / SRT_NT; ++e) { const int b = tid * per + e; if (e < per && b < B) { cnt[b] = base; base += loc[e]; } }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += SRT_NT) {
-        const KeyT k = K[i];
-        run[atomicAdd(&cnt[big_bucket(f, k)], 1u)] = k;
+        for (int d = 32; d > 0; d >>= 1) { const KeyT a = __shfl_xor(lo, d), b = __shfl_xor(hi, d); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+        if (lane == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+        __syncthreads();
+        // about four keys per bucket
+        int lg = 6;
+        while (lg < SRT_LG_MAX && (4 << lg) < n) ++lg;
+        const int B = 1 << lg;
+        const KeyT range = (KeyT)(s_max - s_min);
+        const int bits = range ? (int)(sizeof(KeyT) * 8) - (sizeof(KeyT) == 8 ? __clzll((long long)range) : __clz((int)range)) : 0;
+        BigRunFn<KeyT> f;
+        f.kmin = s_min;
+        f.shift = bits > lg ? bits - lg : 0;
+        if (tid == 0) big_fn[(size_t)gene * n_cand + cd] = f;
+        for (int b = tid; b < B; b += NTK) cnt[b] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n; i += NTK) atomicAdd(&cnt[big_bucket(f, K[i])], 1u);
+        __syncthreads();
+        { // exclusive scan of the B counters (B <= 4096 = 16 per thread)
+            const int per = (B + NTK - 1) / NTK;
+            u32 loc[(1 << SRT_LG_MAX) / NTK], sum = 0;
+#pragma unroll
+            for (int e = 0; e < (1 << SRT_LG_MAX) / NTK; ++e) { const int b = tid * per + e; loc[e] = (e < per && b < B) ? cnt[b] : 0u; sum += loc[e]; }
+            const u32 inc = (u32)wave_incl_scan_add((int)sum);
+            if (lane == 63) s_part[wave] = inc;
+            __syncthreads();
+            u32 base = inc - sum;
+            for (int w = 0; w < wave; ++w) base += s_part[w];
+#pragma unroll
+            for (int e = 0; e < (1 << SRT_LG_MAX) / NTK; ++e) { const int b = tid * per + e; if (e < per && b < B) { cnt[b] = base; base += loc[e]; } }
+        }
+        __syncthreads();
+        // (dealt into a second LDS buffer first and written back in whole lines: no faster on dense input -- 11.05 vs 11.06 ms, 10 groups of
+        //  30 000 cells -- and the LDS it takes halves the workgroups per CU: 1.43 -> 2.59 ms on CSC input with 50 groups)
+        for (int i = tid; i < n; i += NTK) {
+            const KeyT k = K[i];
+            run[atomicAdd(&cnt[big_bucket(f, k)], 1u)] = k;
+        }
+        __syncthreads(); // (the next run reuses K, the counters and the range)
+      }
+      __syncthreads(); // (the list is rebuilt)
     }
 }
 

@@ -77,20 +77,42 @@ template <typename KeyT> static bool packed_leftovers_fit_sort_route(const illic
 template <typename KeyT>
 static int launch_bucket_big_runs(illico_ctx *c, void *Xs, void *tmp, long long stride, const u16 *nnz, const u32 *gofs, int nb, int G, int cap, BigRunFn<KeyT> *big_fn,
                                   u32 *route, int64_t longest_run, const u32 *run_n) {
-    auto kern = k_bucket_big_runs<KeyT>;
-    const size_t lds = srt_lds_bytes(sizeof(KeyT), cap);
     const bool global = tmp != nullptr && longest_run > cap;
-    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(c->pk_nbig, nb), dim3(SRT_NT), lds, c->stream, Xs, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, big_fn, route, global ? 1 : 0);
-    HIPCHK(c, hipGetLastError());
+    // a workgroup takes a stretch of a gene's candidates when there are many (most hold no run above 256 keys)
+    const unsigned gx = (long long)c->pk_nbig * nb <= 32768 ? (unsigned)c->pk_nbig : (unsigned)std::max(1, std::min(c->pk_nbig, (32768 + nb - 1) / nb));
+    // runs up to 8192 keys: 256 threads each; longer ones (they take the LDS of half a CU and more): 1024 threads, a launch of their own
+    // (10 groups of 30 000 cells half non-zero: 6.9 -> 5.6 ms; at 1024 threads, runs of 3000 keys took 9.1 instead of 8.2)
+    const int cap_a = c->no_big_runs_wide ? cap : std::min(cap, 8192);
+    {
+        auto kern = k_bucket_big_runs<KeyT, SRT_NT>;
+        const size_t lds = srt_lds_bytes(sizeof(KeyT), cap_a);
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(gx, nb), dim3(SRT_NT), lds, c->stream, Xs, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap_a, big_fn, route,
+                           (global || cap > cap_a) ? 1 : 0, 64 * OCR_KMAX);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (cap > cap_a) {
+        auto kern = k_bucket_big_runs<KeyT, 1024>;
+        const size_t lds = srt_lds_bytes(sizeof(KeyT), cap);
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(gx, nb), dim3(1024), lds, c->stream, Xs, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, big_fn, route, global ? 1 : 0, cap_a);
+        HIPCHK(c, hipGetLastError());
+    }
     if (global) {
         auto kg = k_bucket_big_runs_global<KeyT>;
         int lg = 6;
         while (lg < SRT_LG_MAX_G && (4ll << lg) < longest_run) ++lg;
         if (c->big_runs_cap > 0) lg = std::min(lg, 11); // (tests: few counters as well)
-        const size_t ldsg = (size_t)4 << lg;
+        // LDS: the counters, and behind them the key slots of one slice of the output -- everything a CU has (one workgroup of 1024 threads
+        // each): a slice costs a read of the run, and ten clusters of 100 000 cells half non-zero took 6.2 ms with 48 KB of slots (two
+        // workgroups per CU), 4.9 with 96 KB, 4.1 with 126 KB
+        const size_t cnt_bytes = (size_t)4 << lg;
+        size_t slice_bytes = c->big_runs_slice_bytes > 0 ? (size_t)c->big_runs_slice_bytes : (size_t)kMaxLds - cnt_bytes - 8192; // (8 KB: the kernel's own static LDS)
+        slice_bytes = std::min(std::max(slice_bytes, (size_t)512 * sizeof(KeyT)), (size_t)kMaxLds - cnt_bytes - 8192);
+        const int slice_keys = (int)(slice_bytes / sizeof(KeyT));
+        const size_t ldsg = cnt_bytes + (size_t)slice_keys * sizeof(KeyT);
         HIPCHK(c, hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
-        hipLaunchKernelGGL(kg, dim3(c->pk_nbig, nb), dim3(SRTG_NT), ldsg, c->stream, Xs, tmp, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, lg, big_fn, route, run_n);
+        hipLaunchKernelGGL(kg, dim3(gx, nb), dim3(SRTG_NT), ldsg, c->stream, Xs, tmp, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, lg, big_fn, route, run_n, slice_keys);
         HIPCHK(c, hipGetLastError());
     }
     return ILLICO_OK;

@@ -13,15 +13,18 @@ from conftest import assert_planes_match, make_labels
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "eq-buckets"])
+@pytest.fixture(scope="module", params=["auto", "eq-buckets", "narrow-tiles"])
 def engine(request):
     """"eq-buckets": the packed rank kernel's distribution-following bucket function (on its own only for references above
-    16384 cells) forced on every case."""
+    16384 cells) forced on every case.  "narrow-tiles": k_group_compact's 32-gene tiles (on their own only with blocks of 8192 rows
+    and more: cluster-sized groups) on every case."""
     from illico_amd._lib import get_engine
     eng = get_engine()
     eng.set_option("no_fused_path", 1)  # every gene through the two-pass routes
     eng.set_option("packed_eq_buckets", 1 if request.param == "eq-buckets" else -1)
+    eng.set_option("compact_narrow_rows", 1 if request.param == "narrow-tiles" else 0)
     yield eng
+    eng.set_option("compact_narrow_rows", 0)
     eng.set_option("no_fused_path", 0)
     eng.set_option("no_packed_dense", 0)
     eng.set_option("packed_eq_buckets", -1)
