@@ -179,6 +179,8 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_ovo_parts")) c->no_ovo_parts = value != 0;
     else if (!strcmp(key, "no_packed_small_wg")) c->no_packed_small_wg = value != 0;
     else if (!strcmp(key, "no_deal_runs")) c->no_deal_runs = value != 0;
+    else if (!strcmp(key, "no_ovr_part_coop")) c->no_ovr_part_coop = value != 0;
+    else if (!strcmp(key, "no_ovr_packed_big")) c->no_ovr_packed_big = value != 0;
     else if (!strcmp(key, "big_runs_slice_bytes")) c->big_runs_slice_bytes = (int)value;
     else if (!strcmp(key, "no_big_runs_wide")) c->no_big_runs_wide = value != 0;
     else if (!strcmp(key, "no_compact_narrow")) c->no_compact_narrow = value != 0;

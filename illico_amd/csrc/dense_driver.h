@@ -224,7 +224,7 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
     if (probe && !wide_only) { // OVR on device-resident input: which genes are count-valued at all is found on the device (the OVO pass has
         // k_fused_ref, which reads every reference row first)
         ProfScope ps(c, KID_FUSED_REF);
-        hipLaunchKernelGGL((k_fused_probe<InT, RT>), dim3(tiles), dim3(256), 0, c->stream, P);
+        hipLaunchKernelGGL((k_fused_probe<InT, RT>), dim3(tiles), dim3(FUSED_PROBE_NT), 0, c->stream, P);
         HIPCHK(c, hipGetLastError());
     }
     const dim3 main_grid(tiles, ((int)c->n_groups + P.groups_per_wg - 1) / P.groups_per_wg);
@@ -967,7 +967,8 @@ static int run_dense_twopass(illico_ctx *c, const void *X, int dtype, int64_t N,
             continue;
         }
         OvrPackedInput pki;
-        const bool ovr_packed = padded && !c->no_ovr_packed_partition && !c->no_ovr_parts_path && G <= 65535 && c->max_nonref <= 65535;
+        // (groups of any size: a group of 65535 cells and more is the last of its block, whose 16-bit length the partition never looks at)
+        const bool ovr_packed = padded && !c->no_ovr_packed_partition && !c->no_ovr_parts_path && G <= 65535 && (c->max_nonref <= 65535 || !c->no_ovr_packed_big);
         if (padded) {
             GroupCompactParams Q;
             memset(&Q, 0, sizeof Q);

@@ -154,6 +154,8 @@ struct illico_ctx {
     bool no_big_runs_global = false;   // packed routes: a (gene, group) run beyond k_bucket_big_runs' LDS slots sends its gene to the general route (as before round 5)
     bool no_compact_narrow = false;    // k_group_compact: never the 32-gene tiles for few, long blocks
     int64_t compact_narrow_rows = 8192; // ... from this many rows in the longest block
+    bool no_ovr_part_coop = false;     // k_ovr_partition_packed: one wavefront per block whatever the blocks' lengths
+    bool no_ovr_packed_big = false;    // dense OVR: groups above 65535 cells take the padded rows (every key, zeros included), as before
     bool no_deal_runs = false;         // packed rank kernel in parts: never deal the short runs by part first (every part then looks every key up, masked)
     bool no_packed_small_wg = false;   // packed rank kernel: never the 256-thread form for small references with few groups
     bool no_ovo_parts = false;         // packed rank kernel: never take a reference in value-range parts (genes beyond the LDS slots go to the general routes, as before round 5)

@@ -550,6 +550,8 @@ struct OvrPartPackedParams {
     void *out_keys;
     u16 *out_codes;
     u32 *part_start, *gene_info; // as OvrPartParams
+    int coop;                  // 1: some block is long (a cluster of thousands of cells): every block's 512-key units are dealt over ALL the
+                               // wavefronts (unit u of block b: wavefront (u + b) % NW) instead of one wavefront walking a block alone
 };
 
 template <typename KeyT>
@@ -578,6 +580,13 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
     __syncthreads();
     { // key range for the bucket function, from every 8th block
         KeyT tmin = MAXK, tmax = (KeyT)0;
+        if (P.coop) { // every 8th 64-key piece of every block
+            for (int b = wave; b < P.nblk; b += NW) {
+                const int n_b = (int)bcnt[b];
+                const KeyT *src = row + P.blk_out[b];
+                for (int i = lane; i < n_b; i += 64 * 8) { const KeyT k = src[i]; tmin = k < tmin ? k : tmin; tmax = k > tmax ? k : tmax; }
+            }
+        } else
         for (int b = wave * 8; b < P.nblk; b += NW * 8) {
             const int n_b = (int)bcnt[b];
             const KeyT *src = row + P.blk_out[b];
@@ -597,10 +606,11 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
     };
     {
         u32 neg = 0;
-        for (int b = wave; b < P.nblk; b += NW) {
+        for (int b = P.coop ? 0 : wave; b < P.nblk; b += P.coop ? 1 : NW) {
             const int n_b = (int)bcnt[b];
             const KeyT *src = row + P.blk_out[b];
-            for (int o = 0; o < n_b; o += 64 * UL) {
+            const int o_first = P.coop ? ((wave - b) & (NW - 1)) * (64 * UL) : 0, o_step = P.coop ? NW * 64 * UL : 64 * UL;
+            for (int o = o_first; o < n_b; o += o_step) {
                 KeyT k[UL];
 #pragma unroll
                 for (int u = 0; u < UL; ++u) { const int i = o + u * 64 + lane; k[u] = i < n_b ? src[i] : ZEROK; }
@@ -642,11 +652,17 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
     if (tid == 0) pstart[n_parts] = n;
     const int p_bits = 32 - __clz(n_parts);
     __syncthreads();
-    for (int b = wave; b < P.nblk; b += NW) {
+    static_assert((NW & (NW - 1)) == 0, "units are dealt by (u + b) % NW");
+    for (int b = P.coop ? 0 : wave; b < P.nblk; b += P.coop ? 1 : NW) {
         const int n_b = (int)bcnt[b];
         const KeyT *src = row + P.blk_out[b];
         int gcur = P.blk_g0[b];
         const int glast = P.blk_g1[b];
+        // coop: the block's units over all the wavefronts when its group ends sit in a register (else one wavefront walks it, as without coop)
+        const bool split = P.coop && glast - gcur <= 64;
+        if (P.coop && !split && (b & (NW - 1)) != wave) continue;
+        const int o_first = split ? ((wave - b) & (NW - 1)) * (64 * UL) : 0, o_step = split ? NW * 64 * UL : 64 * UL;
+        if (o_first >= n_b) continue;
         int gend = gcur < glast ? (int)nnz[gcur] : 0; // offset (inside the block) where group gcur's keys end
         // A block of at most 64 groups (the usual case: ~7 groups of ~150 cells per 1024 rows) keeps its group ends in ONE register,
         // lane l = the offset where group g0 + l ends: the walks below then read a lane instead of loading nnz[g] from memory -- a
@@ -654,8 +670,11 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
         const int g0 = gcur, ng = glast - g0;
         const bool ends_in_lanes = ng <= 64;
         int endv = 0, gi = 0; // gi: gcur - g0
+        // (a group of 65535 cells and more is the LAST of its block -- a block closes at 1024 rows -- and a block's last end is never looked
+        //  at: the 16-bit lengths may saturate there)
         if (ends_in_lanes) endv = wave_incl_scan_add(lane < ng ? (int)nnz[g0 + lane] : 0);
-        for (int o = 0; o < n_b; o += 64 * UL) {
+        for (int o = o_first; o < n_b; o += o_step) {
+            if (split) gi = min(ng - 1, (int)__popcll(__ballot(lane < ng && endv <= o))); // the groups that end at or before this unit's first key
             KeyT k[UL];
 #pragma unroll
             for (int u = 0; u < UL; ++u) { const int i = o + u * 64 + lane; k[u] = i < n_b ? src[i] : ZEROK; }

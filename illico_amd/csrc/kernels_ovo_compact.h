@@ -164,8 +164,7 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
     KeyT *st = stage + (STAGE ? wave * GPW * 128 : 0);
 
     int rows[NLD]; // row indices of the next chunk to load
-    constexpr int DEPTH = 2; // chunks of rows in flight (4 with the 32-gene tiles: 6.1 -> 8.8 ms on ten clusters of 100 000 cells -- a step's own chain of waits, not the gather, is what a chunk takes)
-    InV bufs[DEPTH][NLD];
+    InV bufA[NLD], bufB[NLD];
     auto load_rows = [&](int c, int n, int row0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -202,10 +201,10 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
     GCMP_CUR_SKIP(ig, ic, in_, irow0)
     int cg = ig, cc = 0, cn = in_, crow0 = irow0;
     bool rows_ready = false;
-    // DEPTH chunks of rows in flight (bufs[0]: the chunk packed next, bufs[1]: the one after, ...), row indices of one more
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) load_chunk(bufs[d]); }
+    // two chunks of rows in flight (bufA: the chunk packed next, bufB: the one after), row indices of a third.  (Four in flight with the
+    // 32-gene tiles: 6.1 -> 8.8 ms on ten clusters of 100 000 cells -- a step's own chain of waits, not the gather, is what a chunk takes.)
+    if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) load_chunk(bufA); }
+    if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) load_chunk(bufB); }
     if (ig < gB) { load_rows(ic, in_, irow0); GCMP_CUR_NEXT(ig, ic, in_, irow0) rows_ready = true; }
     auto step = [&](InV (&buf)[NLD]) { // pack the chunk in buf, then refill buf with the chunk rows[] describes
 #pragma unroll
@@ -276,9 +275,8 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
         GCMP_CUR_NEXT(cg, cc, cn, crow0)
     };
     while (cg < gB) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
-            if (cg < gB) step(bufs[d]);
+        step(bufA);
+        if (cg < gB) step(bufB);
     }
     if (PACK && seg < 0 && P.blk_cnt && lane < GPW && geneW < P.ncols) P.blk_cnt[(size_t)geneW * P.nblk + blk] = (u32)cntv;
     if constexpr (STAGE) { // what is left in the staging pieces: one partial store per gene

@@ -205,15 +205,18 @@ __global__ void k_sample_noncount_dense(const InT *__restrict__ X, long long ld,
 // a value outside the table is flagged here, before the main pass, whose workgroups leave at once when every gene of their
 // tile is flagged.  On normalised (continuous) data that is every gene, so the pass over X costs nothing and no host round
 // trip is needed to choose the route; a gene this probe misses is flagged by the main pass itself.
-#define FUSED_PROBE_ROWS 256
+// (1024 rows, 16 wavefronts: with 256 a gene stored in 1 % of its cells -- a lowly expressed gene of a normalised matrix -- showed the probe
+//  nothing but zeros one time in ten, and its whole tile was then read by the passes behind: 1.2 ms of 8.9 on ten clusters of 100 000 cells)
+#define FUSED_PROBE_ROWS 1024
+#define FUSED_PROBE_NT 1024
 template <typename InT, int RT>
-__global__ __launch_bounds__(256) void k_fused_probe(FusedParams P) {
+__global__ __launch_bounds__(FUSED_PROBE_NT) void k_fused_probe(FusedParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gene = blockIdx.x * 64 + lane;
     if (gene >= P.ncols) return;
     const InT *Xg = (const InT *)P.X + P.col0 + gene;
     bool bad = false, hopeless = false; // hopeless: not a count below 256 either: the wider second stage need not look at this gene
-    constexpr int PER = FUSED_PROBE_ROWS / 4;
+    constexpr int PER = FUSED_PROBE_ROWS / (FUSED_PROBE_NT / 64);
     InT v[8];
     for (int i0 = 0; i0 < PER; i0 += 8) {
 #pragma unroll
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void k_fused_probe(FusedParams P) {
             hopeless |= !exact_wide;
         }
     }
-    if (bad) P.gene_flags[gene] = hopeless ? 3u : 1u; // 3: as 1 (the host's two-pass routes), and skipped by the 256-value stage
+    if (bad) atomicMax(&P.gene_flags[gene], hopeless ? 3u : 1u); // 3: as 1 (the host's two-pass routes), and skipped by the 256-value stage
 }
 
 // After the 64-value pass: is the 256-value stage worth running over the window as it lies?  It reads every row of every tile that holds

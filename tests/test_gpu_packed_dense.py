@@ -364,3 +364,44 @@ def test_dense_ovo_continuous_with_a_reference_of_600000_cells(engine):
     engine.profile(False)
     assert "k_ovo_rank_compact" in prof, prof
     assert_planes_match(got, want, ref_row=g.encoded_ref_group, what="ovo continuous, reference of 600 000 cells")
+
+
+@pytest.mark.parametrize("density", [0.1, 0.85])
+def test_dense_ovr_continuous_with_clusters_of_more_than_65535_cells(engine, density):
+    """rank_genes_groups on an atlas, one-versus-rest: clusters of 70 000 and 9 000 cells beside small groups, continuous values.  The
+    partition walks the PACKED rows (non-zero keys only) whatever the group sizes: a group of 65535 cells and more is the last of its block,
+    whose saturated 16-bit length is never looked at (its end is the block's key count); long blocks are dealt over all the wavefronts
+    in 512-key units (k_ovr_partition_packed, `coop`), and the units' group codes start from a ballot over the group ends.  At 85 % density
+    the big group's run per gene is 59 500 keys.  Against the oracle and, bit for bit, against the padded-rows form."""
+    import torch
+    rng = np.random.RandomState(77)
+    n, m = 92_000, 40
+    labels = np.array(["big"] * 70_000 + ["mid"] * 9_000 + [f"p{i % 40:02d}" for i in range(n - 79_000)])
+    rng.shuffle(labels)
+    X = (np.exp(rng.normal(0.0, 1.0, size=(n, m))) * (rng.rand(n, m) < density)).astype(np.float32)
+    X[:, 5] = np.round(X[:, 5], 1)                                          # ties
+    X[:, 6] = 0
+    X[:, 7] = rng.randn(n)                                                  # no zeros, both signs
+    _, g = oracle.encode_and_count_groups(labels, None)
+    want = oracle.run(X.astype(np.float64), g)
+    engine.set_groups(g)
+    Xd = torch.from_numpy(X).to(torch.device("cuda", engine.device))
+    engine.profile(True)
+    engine.profile_reset()
+    got = engine.run_dense(Xd, 0, m)
+    prof = engine.profile_get()
+    engine.profile(False)
+    assert "k_group_compact" in prof and "k_ovr_partition" in prof, prof
+    assert_planes_match(got, want, what=f"ovr continuous, clusters of 70 000 cells, density {density}")
+    stats = engine.rank_statistics(Xd, 0, m)
+    for opt in ("no_ovr_packed_big", "no_ovr_part_coop"):
+        engine.set_option(opt, 1)
+        try:
+            old = engine.run_dense(Xd, 0, m)
+            stats_old = engine.rank_statistics(Xd, 0, m)
+        finally:
+            engine.set_option(opt, 0)
+        np.testing.assert_array_equal(got[0], old[0], err_msg=opt)
+        np.testing.assert_array_equal(got[1], old[1], err_msg=opt)
+        np.testing.assert_array_equal(stats[0], stats_old[0], err_msg=opt)
+        np.testing.assert_array_equal(stats[1], stats_old[1], err_msg=opt)
