@@ -16,9 +16,9 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 SO = HERE / "libillico_hip.so"
 OBJ = HERE / "_build"
-UNITS = ["core", "keyed_u32", "keyed_u64", "dense_f32", "dense_f64", "dense_i32", "dense_i64", "dense_u8",
+UNITS = ["core", "keyed_u32", "keyed_u64", "keyed_coop", "dense_f32", "dense_f64", "dense_i32", "dense_i64", "dense_u8",
          "sparse_f32", "sparse_f64", "sparse_i32", "sparse_i64"]
-DEV_UNITS = ["core", "keyed_u32", "dense_f32", "dense_u8", "sparse_f32"]  # ILLICO_DEV_F32_ONLY=1: float32 values, int32 indices
+DEV_UNITS = ["core", "keyed_u32", "keyed_coop", "dense_f32", "dense_u8", "sparse_f32"]  # ILLICO_DEV_F32_ONLY=1: float32 values, int32 indices
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared", "-Wl,-z,defs", f"-Wl,--version-script={HERE / 'exports.map'}"]
 

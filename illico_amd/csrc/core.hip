@@ -101,12 +101,15 @@ int illico_ctx_create(int device_id, illico_ctx **out_ctx) {
 }
 
 static void free_groups(illico_ctx *c) {
-    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos, &c->d_pk_blk, &c->d_pk_code, &c->d_pk_big}) {
+    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos, &c->d_pk_blk, &c->d_pk_code, &c->d_pk_big, &c->d_pk_long}) {
         if (*p) hipFree(*p);
         *p = nullptr;
     }
     if (c->d_codes16) hipFree(c->d_codes16);
     c->d_codes16 = nullptr;
+    if (c->d_pk_islong) hipFree(c->d_pk_islong);
+    c->d_pk_islong = nullptr;
+    c->pk_nlong = 0;
     if (c->d_hist_off) hipFree(c->d_hist_off);
     c->d_hist_off = nullptr;
     if (c->d_gconst) hipFree(c->d_gconst);
@@ -372,6 +375,21 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
         packed.insert(packed.end(), out.begin(), out.end());
         if (packed.empty()) packed.push_back(0);
         c->pk_nblk = (int)g0.size();
+        { // long blocks (a cluster of thousands of cells, the control group of a screen): see k_ovr_partition_packed<COOP>
+            std::vector<int> lng;
+            std::vector<unsigned char> is_long(g0.size() + 1, 0);
+            for (size_t b = 0; b < g0.size(); ++b) {
+                int64_t rows_b = 0;
+                for (int g = g0[b]; g < g1[b]; ++g) rows_b += counts[g];
+                if (rows_b > 4096 /* OVRP_LONG_ROWS */ && g1[b] - g0[b] <= 64) { lng.push_back((int)b); is_long[b] = 1; }
+            }
+            c->pk_nlong = (int)lng.size();
+            if (lng.empty()) lng.push_back(0);
+            HIPCHK(c, hipMalloc((void **)&c->d_pk_long, lng.size() * sizeof(int)));
+            HIPCHK(c, hipMemcpy(c->d_pk_long, lng.data(), lng.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMalloc((void **)&c->d_pk_islong, is_long.size()));
+            HIPCHK(c, hipMemcpy(c->d_pk_islong, is_long.data(), is_long.size(), hipMemcpyHostToDevice));
+        }
         c->pk_ref_out = (int)pos;
         c->pk_len = pos;
         c->pk_stride = pos + (ref >= 0 ? ((counts[ref] + 63) & ~63ll) : 0) + 64;

@@ -119,6 +119,9 @@ struct illico_ctx {
                                   // then [G]: a group's place in that list, or -1
     int pk_nbig = 0;
     int64_t pk_max_block_rows = 0; // rows of the longest block
+    int pk_nlong = 0;             // blocks of more than OVRP_LONG_ROWS rows and at most 64 groups (k_ovr_partition_packed deals their units over all wavefronts)
+    int *d_pk_long = nullptr;     // [pk_nlong] those blocks
+    unsigned char *d_pk_islong = nullptr; // [pk_nblk]
     int64_t pk_len = 0;           // ... of which the blocks take the first pk_len (the padded dense layout's row length)
     int *d_counts = nullptr;      // [G]
     GroupConst *d_gconst = nullptr; // [G] per-group constants of the p-value / fold change for this ref (kernels_finalize.h)

@@ -550,11 +550,16 @@ struct OvrPartPackedParams {
     void *out_keys;
     u16 *out_codes;
     u32 *part_start, *gene_info; // as OvrPartParams
-    int coop;                  // 1: some block is long (a cluster of thousands of cells): every block's 512-key units are dealt over ALL the
-                               // wavefronts (unit u of block b: wavefront (u + b) % NW) instead of one wavefront walking a block alone
+    // the kernel's COOP form: some blocks are LONG (more than OVRP_LONG_ROWS rows and at most 64 groups: a cluster of thousands of cells, the
+    // control group of a screen): their 512-key units are dealt over ALL the wavefronts (unit u of the i-th long block: wavefront (u + i) % NW)
+    // instead of one wavefront walking the block alone; the other blocks stay with their wavefront
+    int n_long;
+    const int *long_blk;            // [n_long] the long blocks
+    const unsigned char *blk_is_long; // [nblk]
 };
+#define OVRP_LONG_ROWS 4096
 
-template <typename KeyT>
+template <typename KeyT, bool COOP = false>
 __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedParams P) {
     constexpr int NT = OVRP_NT, NW = NT / 64, NB = 1 << OVRP_LG;
     constexpr KeyT ZEROK = KeyInfo<KeyT>::ZEROK;
@@ -580,14 +585,15 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
     __syncthreads();
     { // key range for the bucket function, from every 8th block
         KeyT tmin = MAXK, tmax = (KeyT)0;
-        if (P.coop) { // every 8th 64-key piece of every block
-            for (int b = wave; b < P.nblk; b += NW) {
-                const int n_b = (int)bcnt[b];
+        if (COOP) { // (and every 8th 64-key piece of the long blocks)
+            for (int i8 = wave; i8 < P.n_long; i8 += NW) {
+                const int b = P.long_blk[i8], n_b = (int)bcnt[b];
                 const KeyT *src = row + P.blk_out[b];
                 for (int i = lane; i < n_b; i += 64 * 8) { const KeyT k = src[i]; tmin = k < tmin ? k : tmin; tmax = k > tmax ? k : tmax; }
             }
-        } else
+        }
         for (int b = wave * 8; b < P.nblk; b += NW * 8) {
+            if (COOP && P.blk_is_long[b]) continue;
             const int n_b = (int)bcnt[b];
             const KeyT *src = row + P.blk_out[b];
             for (int i = lane; i < n_b; i += 64) { const KeyT k = src[i]; tmin = k < tmin ? k : tmin; tmax = k > tmax ? k : tmax; }
@@ -606,10 +612,15 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
     };
     {
         u32 neg = 0;
-        for (int b = P.coop ? 0 : wave; b < P.nblk; b += P.coop ? 1 : NW) {
+        // (COOP: the wavefront's own blocks, the long ones left out, then its units of the long blocks)
+        const int n_own = (P.nblk - wave + NW - 1) / NW;
+        for (int it = 0; it < n_own + (COOP ? P.n_long : 0); ++it) {
+            const bool lng = COOP && it >= n_own;
+            const int b = lng ? P.long_blk[it - n_own] : wave + it * NW;
+            if (COOP && !lng && P.blk_is_long[b]) continue;
             const int n_b = (int)bcnt[b];
             const KeyT *src = row + P.blk_out[b];
-            const int o_first = P.coop ? ((wave - b) & (NW - 1)) * (64 * UL) : 0, o_step = P.coop ? NW * 64 * UL : 64 * UL;
+            const int o_first = lng ? ((wave - (it - n_own)) & (NW - 1)) * (64 * UL) : 0, o_step = lng ? NW * 64 * UL : 64 * UL;
             for (int o = o_first; o < n_b; o += o_step) {
                 KeyT k[UL];
 #pragma unroll
@@ -653,16 +664,17 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
     const int p_bits = 32 - __clz(n_parts);
     __syncthreads();
     static_assert((NW & (NW - 1)) == 0, "units are dealt by (u + b) % NW");
-    for (int b = P.coop ? 0 : wave; b < P.nblk; b += P.coop ? 1 : NW) {
+    const int n_own_c = (P.nblk - wave + NW - 1) / NW;
+    for (int it = 0; it < n_own_c + (COOP ? P.n_long : 0); ++it) {
+        const bool split = COOP && it >= n_own_c; // a long block (at most 64 groups: its group ends sit in a register): this wavefront's units of it
+        const int b = split ? P.long_blk[it - n_own_c] : wave + it * NW;
+        if (COOP && !split && P.blk_is_long[b]) continue;
         const int n_b = (int)bcnt[b];
         const KeyT *src = row + P.blk_out[b];
         int gcur = P.blk_g0[b];
         const int glast = P.blk_g1[b];
-        // coop: the block's units over all the wavefronts when its group ends sit in a register (else one wavefront walks it, as without coop)
-        const bool split = P.coop && glast - gcur <= 64;
-        if (P.coop && !split && (b & (NW - 1)) != wave) continue;
-        const int o_first = split ? ((wave - b) & (NW - 1)) * (64 * UL) : 0, o_step = split ? NW * 64 * UL : 64 * UL;
-        if (o_first >= n_b) continue;
+        const int o_first = split ? ((wave - (it - n_own_c)) & (NW - 1)) * (64 * UL) : 0, o_step = split ? NW * 64 * UL : 64 * UL;
+        if (COOP && o_first >= n_b) continue;
         int gend = gcur < glast ? (int)nnz[gcur] : 0; // offset (inside the block) where group gcur's keys end
         // A block of at most 64 groups (the usual case: ~7 groups of ~150 cells per 1024 rows) keeps its group ends in ONE register,
         // lane l = the offset where group g0 + l ends: the walks below then read a lane instead of loading nnz[g] from memory -- a

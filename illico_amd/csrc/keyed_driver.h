@@ -154,6 +154,7 @@ struct OvrPackedInput {
 };
 
 // ---- the launchers (keyed_impl.h; instantiated in keyed_u32.hip / keyed_u64.hip) ----
+template <typename KeyT> int launch_ovr_partition_packed_coop(illico_ctx *c, const OvrPartPackedParams &Q, int nb); // (keyed_coop.hip)
 template <typename KeyT> int launch_seg_value_sums(illico_ctx *c, const KeyT *Xs, const u32 *seg, int nb, int dtype, int flags, double *ssum);
 template <typename KeyT> int launch_group_sums_rows(illico_ctx *c, const KeyT *Xt, int64_t stride, int nb, int dtype, int flags, double *ssum);
 // Per-group accumulators in LDS when they fit, else in HBM (one [3*G] u64 block per gene of the batch).

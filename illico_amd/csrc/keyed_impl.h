@@ -126,12 +126,16 @@ int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, 
         Q.Xt = Xt; Q.stride = stride; Q.n_genes = nb; Q.G = G; Q.nblk = c->pk_nblk; Q.nnz = packed->nnz; Q.blk_cnt = packed->blk_cnt;
         Q.blk_g0 = c->d_pk_blk; Q.blk_g1 = c->d_pk_blk + c->pk_nblk; Q.blk_out = c->d_pk_blk + 2 * c->pk_nblk; Q.cap = cap;
         Q.out_keys = pkeys; Q.out_codes = pcodes; Q.part_start = part_start; Q.gene_info = gene_info;
-        Q.coop = (c->pk_max_block_rows > 4096 && !c->no_ovr_part_coop) ? 1 : 0;
+        Q.n_long = c->no_ovr_part_coop ? 0 : c->pk_nlong; Q.long_blk = c->d_pk_long; Q.blk_is_long = c->d_pk_islong;
         ProfScope ps(c, KID_OVR_PART);
-        auto kern = k_ovr_partition_packed<KeyT>;
-        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovrp_lds_bytes()));
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(OVRP_NT), ovrp_lds_bytes(), c->stream, Q);
-        HIPCHK(c, hipGetLastError());
+        if (Q.n_long > 0) { // (the COOP form lives in keyed_coop.hip)
+            if ((rc = launch_ovr_partition_packed_coop<KeyT>(c, Q, nb))) return rc;
+        } else {
+            auto kern = k_ovr_partition_packed<KeyT, false>;
+            HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ovrp_lds_bytes()));
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(OVRP_NT), ovrp_lds_bytes(), c->stream, Q);
+            HIPCHK(c, hipGetLastError());
+        }
     } else {
         OvrPartParams Q;
         Q.Xt = Xt; Q.stride = stride; Q.n_genes = nb; Q.n_cells = padded ? (int)c->pk_len : N; Q.code_by_pos = padded ? c->d_pk_code : c->d_code_by_pos; Q.cap = cap;
