@@ -1,6 +1,6 @@
 """Build libillico_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-The library is a dozen translation units -- the context / C-ABI (core.hip), the launchers that depend on the key type only
+The library is thirteen translation units -- the context / C-ABI (core.hip), the launchers that depend on the key type only
 (keyed_u32 / keyed_u64), and one unit per value type for the dense and for the sparse drivers -- compiled in parallel into
 _build/*.o and linked.  A unit is recompiled when it, or a header its last compile read (the -MD dependency file), changed:
 an edit to one kernel family rebuilds the units that include it, side by side, in about a minute instead of five.
