@@ -221,7 +221,11 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
     HIPCHK(c, hipMemsetAsync(skipw, 0, 4, c->stream));
     if (wide_only) HIPCHK(c, hipMemcpyAsync(P.gene_flags, init_flags, (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
     else HIPCHK(c, hipMemsetAsync(P.gene_flags, 0, (size_t)nb * 4, c->stream));
-    if (probe && !wide_only) { // OVR on device-resident input: which genes are count-valued at all is found on the device (the OVO pass has
+    // few, large groups (clusters of an atlas): the (group, gene) value histograms first, rows split over as many wavefronts as the launch
+    // needs, then the same integers from the histograms (kernels_group_hists.h) -- the fused kernels give a wavefront one GROUP at a time
+    const bool hist_route = !wide_only && !c->no_group_hist_route && (int64_t)((nb + 63) / 64) * ((c->n_groups + 3) / 4) < 1024 && c->n_cells >= c->group_hist_min_cells &&
+                            c->n_cells < (1ll << 21) && (size_t)c->n_groups * (size_t)((nb + 63) / 64) * RT * 64 * 4 <= ((size_t)256 << 20);
+    if ((probe || hist_route) && !wide_only) { // OVR on device-resident input: which genes are count-valued at all is found on the device (the OVO pass has
         // k_fused_ref, which reads every reference row first)
         ProfScope ps(c, KID_FUSED_REF);
         hipLaunchKernelGGL((k_fused_probe<InT, RT>), dim3(tiles), dim3(FUSED_PROBE_NT), 0, c->stream, P);
@@ -238,7 +242,29 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
         HIPCHK(c, hipGetLastError());
         return ILLICO_OK;
     };
-    if (!ovr) {
+    if (hist_route) {
+        const size_t h_bytes = (size_t)c->n_groups * tiles * RT * 64 * 4;
+        if ((rc = get_scratch(c, "group_value_hists", h_bytes, &v))) return rc;
+        u32 *H = (u32 *)v;
+        HIPCHK(c, hipMemsetAsync(H, 0, h_bytes, c->stream));
+        constexpr int NWH = GH_NT / 64;
+        // positions per wavefront: ~2048 workgroups, at most 4096 positions (16-bit cells)
+        int wave_rows = (int)std::min<int64_t>(4096, std::max<int64_t>(256, (c->n_cells * tiles / (2048 * NWH) + 31) & ~31ll));
+        const int chunks = (int)((c->n_cells + (int64_t)NWH * wave_rows - 1) / ((int64_t)NWH * wave_rows));
+        {
+            ProfScope ps(c, ovr ? KID_OVR_FUSED : KID_OVO_FUSED);
+            hipLaunchKernelGGL((k_group_value_hists<InT, RT>), dim3(tiles, chunks), dim3(GH_NT), 0, c->stream, P, H, wave_rows);
+            HIPCHK(c, hipGetLastError());
+        }
+        ProfScope ps(c, KID_FUSED_REF);
+        if (ovr) hipLaunchKernelGGL((k_group_hists_to_column<RT, true>), dim3(tiles), dim3(256), 0, c->stream, P, (const u32 *)H);
+        else hipLaunchKernelGGL((k_group_hists_to_column<RT, false>), dim3(tiles), dim3(256), 0, c->stream, P, (const u32 *)H);
+        hipLaunchKernelGGL((k_fused_tables_all<RT>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, P);
+        const dim3 ge(tiles, ((int)c->n_groups + 3) / 4);
+        if (ovr) hipLaunchKernelGGL((k_emit_from_group_hists<RT, true>), ge, dim3(256), 0, c->stream, P, (const u32 *)H);
+        else hipLaunchKernelGGL((k_emit_from_group_hists<RT, false>), ge, dim3(256), 0, c->stream, P, (const u32 *)H);
+        HIPCHK(c, hipGetLastError());
+    } else if (!ovr) {
         if (wide_only) {
         } else if (tiles >= 100) { // one 1024-thread workgroup per tile builds the tables (C2: 125 tiles, 0.074 ms)
             ProfScope ps(c, KID_FUSED_REF);

@@ -533,3 +533,54 @@ def test_dense_ovo_counts_with_a_ranked_group_of_more_than_65535_cells(engine, w
     engine.profile(False)
     assert "k_ovo_fused" in prof, prof
     assert_planes_match(got, want, ref_row=g.encoded_ref_group, what=f"ovo, a ranked group of 70 000 cells, {where}")
+
+
+@pytest.mark.parametrize("test", ["ovo", "ovr"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32])
+def test_few_large_groups_take_the_group_histogram_route(engine, test, dtype):
+    """Count-valued dense input with few, large groups (clusters): the rows of a group are split over many wavefronts that count
+    (group, gene) value histograms (k_group_value_hists), the statistics come from the histograms (k_emit_from_group_hists:
+    kernels_group_hists.h).  Against the oracle and, bit for bit (planes and integer statistics), against the fused kernels the route
+    replaces -- ragged groups (1 .. 9000 cells, an empty stretch boundary in the middle of a wavefront's positions), a one-valued column
+    (a tie block of the whole column), an all-zero column, columns beyond the 64-value table and a non-integer column (they leave
+    the route), a column window."""
+    import torch
+    rng = np.random.RandomState(5150)
+    sizes = [9000, 7000, 4000, 2500, 1300, 700, 64, 33, 2, 1]
+    labels = np.concatenate([[f"c{i:02d}"] * sz for i, sz in enumerate(sizes)])
+    rng.shuffle(labels)
+    n, m = labels.size, 150
+    X = rng.poisson(rng.uniform(0.2, 14.0, size=m), size=(n, m)).astype(np.float64)
+    X[rng.rand(n, m) < 0.5] = 0
+    X[:, 3] = 5
+    X[:, 4] = 0
+    X[:, 9] = rng.poisson(80.0, size=n)        # beyond the 64-value table
+    X[:, 10] = rng.poisson(500.0, size=n)      # beyond the 256-value table
+    X[:, 11] = rng.rand(n)                     # no counts at all
+    X[:, 12] = 63 * (rng.rand(n) < 0.3)        # the table's last value
+    X = X.astype(dtype)
+    _, g = oracle.encode_and_count_groups(labels, "c02" if test == "ovo" else None)
+    want = oracle.run(np.ascontiguousarray(X, dtype=np.float64) if dtype != np.float32 else X, g, col_lb=3, col_ub=m)
+    engine.set_groups(g)
+    Xd = torch.from_numpy(X).to(torch.device("cuda", engine.device))
+    engine.set_option("group_hist_min_cells", 1)
+    try:
+        engine.profile(True)
+        engine.profile_reset()
+        got = engine.run_dense(Xd, 3, m)
+        prof = engine.profile_get()
+        engine.profile(False)
+        stats = engine.rank_statistics(Xd, 3, m)
+        engine.set_option("no_group_hist_route", 1)
+        old = engine.run_dense(Xd, 3, m)
+        stats_old = engine.rank_statistics(Xd, 3, m)
+    finally:
+        engine.set_option("no_group_hist_route", 0)
+        engine.set_option("group_hist_min_cells", 0)
+        engine.profile(False)
+    assert ("k_ovr_fused" if test == "ovr" else "k_ovo_fused") in prof, prof
+    assert_planes_match(got, want, ref_row=g.encoded_ref_group if test == "ovo" else None, what=f"group histograms {test} {np.dtype(dtype).name}")
+    for a, b in zip(got, old):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(stats[0], stats_old[0])
+    np.testing.assert_array_equal(stats[1], stats_old[1])
