@@ -35,7 +35,7 @@
 #define CSCO_CNT_SHIFT 40   // acc word: doubled rank sum below, stored non-zeros of the group above
 #define OVRP_NT 512         // k_ovr_partition
 #define OVRP_LG 13          // its coarse buckets: (key - kmin) >> shift, 8192 of them over the gene's own key range
-#define OVRP_PMAX 128       // parts per gene at most (8-bit part ids)
+#define OVRP_PMAX 255       // parts per gene at most (8-bit part ids; 128 until late in round 5: a column of more cells than 128 parts hold left the route)
 
 struct CscOvrParams {
     // CSC source

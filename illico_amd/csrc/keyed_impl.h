@@ -95,7 +95,10 @@ int run_ovr_dense_parts(illico_ctx *c, KeyT *Xt, int64_t stride, int nb, int N, 
     // keys beside the groups' accumulators: one workgroup's barriers and first loads of a part run under the other's ranking -- the rank
     // kernel 8.0 -> 6.0 ms at C2 shape, the partition (twice the parts to write) 4.8 -> 6.1: 17.5 -> 16.7 ms.  "ovr_rank_whole" = 1: one
     // workgroup of 1024 threads, as before round 5.
-    const bool half = !c->ovr_rank_whole && csco_key_cap(G, 13, sizeof(KeyT), kMaxLds / 2, true) >= 8192;
+    // (columns too long for 128 half-size parts -- two million cells -- take whole-size parts, up to OVRP_PMAX = 255 of them: the general
+    //  route instead was 151 ms at 2 000 000 x 1200 continuous, where the parts are 17)
+    const bool half = !c->ovr_rank_whole && csco_key_cap(G, 13, sizeof(KeyT), kMaxLds / 2, true) >= 8192 &&
+                      (int64_t)(csco_key_cap(G, 13, sizeof(KeyT), kMaxLds / 2, true) & ~1023) * 128 >= N;
     const size_t lds_budget = half ? kMaxLds / 2 : kMaxLds;
     int lg = half ? 13 : 14;
     if (csco_key_cap(G, lg, sizeof(KeyT), lds_budget, true) < 12288 && !half) lg = 13;

@@ -139,6 +139,26 @@ BEYOND_LDS = [
 def test_continuous_ovo_beyond_the_lds_resident_lookups(base_rate, name, cells, genes, G, sparsity, budget_ms):
     """Exact on four genes against the oracle, within 4x of the bytes at the yardstick rate (what the packed routes do when neither the
     reference's keys nor a group's run fit LDS)."""
+    _atlas_case(base_rate, name, cells, genes, G, sparsity, "continuous", False, budget_ms)
+
+
+# ---- atlas shapes (round 5, second half): clusters of 100 000 cells and columns of two million cells, every test and value kind ----
+ATLAS = [
+    # name,                                   cells,     genes, groups, sparsity, values,       test
+    ("clusters, counts, ovo",                 1_000_000, 1200, 10, 0.5, "counts", "ovo"),       # 9.1 ms at full size (2400 genes) -> 1.8: group histograms, rows split over the wavefronts
+    ("clusters, counts, ovr",                 1_000_000, 1200, 10, 0.5, "counts", "ovr"),       # 8.6 -> 1.9
+    ("clusters, a tenth stored, ovr",         1_000_000, 1200, 10, 0.9, "continuous", "ovr"),   # 20.4 -> 7.7: packed rows for the partition, long blocks dealt over the wavefronts
+    ("clusters, half non-zero, ovr",          1_000_000, 1200, 10, 0.5, "continuous", "ovr"),   # 33 -> 23
+    ("tall, half non-zero, ovr",              2_000_000, 256, 2000, 0.5, "continuous", "ovr"),  # 166 ms at 1200 genes (the general route: columns longer than 128 half-size parts) -> 27
+]
+
+
+@pytest.mark.parametrize("name,cells,genes,G,sparsity,values,test", ATLAS)
+def test_atlas_shapes(base_rate, name, cells, genes, G, sparsity, values, test):
+    _atlas_case(base_rate, name, cells, genes, G, sparsity, values, test == "ovr", None)
+
+
+def _atlas_case(base_rate, name, cells, genes, G, sparsity, values, ovr, budget_ms):
     import torch
     from bench import group_container, make_labels, make_matrix
     from illico_amd._lib import Engine
@@ -147,8 +167,8 @@ def test_continuous_ovo_beyond_the_lds_resident_lookups(base_rate, name, cells, 
     eng = Engine(0)
     try:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        X = make_matrix(torch, cells, genes, sparsity, 0, dev, values="continuous")
-        grpc = group_container(make_labels(cells, G, 0), G, False)
+        X = make_matrix(torch, cells, genes, sparsity, 0, dev, values=values)
+        grpc = group_container(make_labels(cells, G, 0), G, ovr)
         eng.set_groups(grpc)
         out = tuple(torch.empty((G, genes), dtype=torch.float64, device=dev) for _ in range(3))
 
@@ -166,7 +186,7 @@ def test_continuous_ovo_beyond_the_lds_resident_lookups(base_rate, name, cells, 
         cols = list(range(0, genes, genes // 4))[:4]
         got = tuple(t[:, cols].cpu().numpy() for t in out)
         want = oracle.run(X[:, cols].contiguous().cpu().numpy(), grpc, batch_size=1, n_threads=4)
-        assert_planes_match(got, want, ref_row=grpc.encoded_ref_group, what=name)
+        assert_planes_match(got, want, ref_row=None if ovr else grpc.encoded_ref_group, what=name)
         alg = cells * genes * 4 + 4 * cells + 24 * G * genes
         budget = (4.0 * alg / base_rate if budget_ms is None else budget_ms) + 0.3
         print(f"{name}: {best:.2f} ms, budget {budget:.2f} ms")
