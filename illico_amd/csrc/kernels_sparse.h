@@ -271,15 +271,22 @@ __global__ void k_sample_noncount_cols(const InT *__restrict__ data, const IdxT 
 // Device counterpart of csr_get_contig_cols_into_csc (utils/sparse/csr.py:19-100).
 #define TR_NT 256
 #define TRC_NT 1024 // the counting pass: a row block is one workgroup, and there are only n_rows / 512 of them -- 16 wavefronts each
+// (16-bit counters, two columns per LDS word -- a (block, column) pair holds at most RB <= 512 entries: 65 536 columns in 128 KB, so a
+//  matrix of 33 000 - 65 000 genes is ONE window, not two sequential passes over every stored entry)
 template <typename IdxT>
 __global__ __launch_bounds__(TRC_NT) void k_csr_block_count(const IdxT *__restrict__ indices, const IdxT *__restrict__ indptr, int n_rows,
                                                           int RB, long long c0, int W, u32 *__restrict__ counts) {
-    extern __shared__ u32 tr_cnt[];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < W; i += TRC_NT) tr_cnt[i] = 0;
+    extern __shared__ u32 tr_cnt[]; // [(W + 1) / 2]: column 2 i in the low half of word i, 2 i + 1 in the high half
+    const int tid = threadIdx.x, W2 = (W + 1) >> 1;
+    for (int i = tid; i < W2; i += TRC_NT) tr_cnt[i] = 0;
     __syncthreads();
     const int r0 = blockIdx.x * RB, r1 = min(r0 + RB, n_rows);
-    const long long k0 = (long long)indptr[r0], k1 = (long long)indptr[r1];
+    long long k0 = (long long)indptr[r0], k1 = (long long)indptr[r1];
+    if (gridDim.y > 1) { // few row blocks (a matrix of few cells and many genes): the block's entries in gridDim.y slices, the counts added up in `counts` (zeroed by the host)
+        const long long per = (k1 - k0 + gridDim.y - 1) / gridDim.y;
+        k0 += per * blockIdx.y;
+        k1 = min(k1, k0 + per);
+    }
     // eight requests in flight per thread (one at a time, this pass ran at 1.2 TB/s: 0.77 ms at C3 shape for 0.9 GB of column indices)
     for (long long kb = k0; kb < k1; kb += TRC_NT * 8) {
         long long col[8];
@@ -290,11 +297,15 @@ __global__ __launch_bounds__(TRC_NT) void k_csr_block_count(const IdxT *__restri
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (col[u] >= 0 && col[u] < W) atomicAdd(&tr_cnt[col[u]], 1u);
+            if (col[u] >= 0 && col[u] < W) atomicAdd(&tr_cnt[col[u] >> 1], (col[u] & 1) ? 0x10000u : 1u);
     }
     __syncthreads();
     u32 *dst = counts + (size_t)blockIdx.x * W;
-    for (int i = tid; i < W; i += TRC_NT) dst[i] = tr_cnt[i];
+    if (gridDim.y > 1) {
+        for (int i = tid; i < W; i += TRC_NT) { const u32 n = (tr_cnt[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu; if (n) atomicAdd(&dst[i], n); }
+    } else {
+        for (int i = tid; i < W; i += TRC_NT) dst[i] = (tr_cnt[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+    }
 }
 // per column: exclusive scan of the block counts (in place) and the column's total
 static __global__ void k_col_block_scan(u32 *__restrict__ counts, int n_blocks, int W, u32 *__restrict__ col_total) {
@@ -372,6 +383,9 @@ __global__ __launch_bounds__(TRG_NT) void k_csr_tile_gather(const InT *__restric
     // loads when it runs dry.  A thread walks ITS row, so its loads are uncoalesced across lanes (64 cache lines per
     // instruction): fetching 8 entries with 2 + 2 wide loads instead of 16 narrow ones is what keeps the texture
     // addresser from being the limiter (it was: 7 of 8 ms).
+    // gridDim.y > 1 (few row blocks): the window's 64-column tiles in gridDim.y stretches, one workgroup each
+    const int tiles_all = (W + TRG_COLS - 1) / TRG_COLS, tiles_per = (tiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int cb_lo = (int)blockIdx.y * tiles_per * TRG_COLS, cb_hi = min(W, cb_lo + tiles_per * TRG_COLS);
     long long knext[RPT], kend[RPT];
     int wcol[RPT][WN], wp[RPT], wn[RPT], tag[RPT]; // tag: what is stored for the row -- its group code, or the row index
     InT wval[RPT][WN];
@@ -405,7 +419,8 @@ __global__ __launch_bounds__(TRG_NT) void k_csr_tile_gather(const InT *__restric
         if (r < r1) {
             if (row_codes) tag[j] = row_codes[r];
             long long a = (long long)indptr[r], e = (long long)indptr[r + 1], b = e;
-            while (a < b) { const long long m = (a + b) >> 1; if ((long long)indices[m] < c0) a = m + 1; else b = m; } // window start
+            const long long first = c0 + cb_lo; // (the first column of this workgroup's stretch of the window)
+            while (a < b) { const long long m = (a + b) >> 1; if ((long long)indices[m] < first) a = m + 1; else b = m; } // window start
             knext[j] = a;
             kend[j] = e;
         }
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(TRG_NT) void k_csr_tile_gather(const InT *__restric
     // next block's (the column total for the last block)
     const u32 *off = offsets + (size_t)blockIdx.x * W;
     const u32 *off_next = (blockIdx.x + 1 < gridDim.x) ? off + W : col_total;
-    for (int cb = 0; cb < W; cb += TRG_COLS) {
+    for (int cb = cb_lo; cb < cb_hi; cb += TRG_COLS) {
         const int ncols = min(TRG_COLS, W - cb);
         const int chi = cb + ncols; // columns are kept relative to c0
         if (tid < 64) {

@@ -1005,7 +1005,11 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
             while (RB > 64 && RB * per_row > cap / 2) RB >>= 1;
         }
         const int n_blocks = (int)((n_rows + RB - 1) / RB);
-        int64_t wmax = std::min<int64_t>(W, 32768); // the per-block column tables live in LDS (4 bytes per column)
+        // few row blocks (20 000 cells: 40): the counting pass takes a block's entries in slices, the gather form a window's tiles in stretches
+        const int ny = (n_blocks >= 2048 || c->no_csr_transpose_split) ? 1 : std::min(16, (2048 + n_blocks - 1) / n_blocks);
+        // the per-block column tables live in LDS: 16-bit counters in the counting pass (RB <= 512 entries per (block, column)), 32-bit
+        // cursors in the scatter form of pass 2 (unsorted rows, or a (block, tile) piece beyond the gather form's staging)
+        int64_t wmax = std::min<int64_t>(W, (sorted && RB <= 512) ? 65536 : 32768);
         for (int64_t w0 = col_lb; w0 < col_ub;) {
             const int64_t wn = std::min<int64_t>(wmax, col_ub - w0);
             if ((rc = get_scratch(c, "tr_counts", (size_t)n_blocks * wn * 4, &v))) return rc;
@@ -1017,8 +1021,9 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                 ProfScope ps(c, KID_SPARSE_SEG);
                 HIPCHK(c, hipMemsetAsync(col_total + wn, 0, 4, c->stream));
                 HIPCHK(c, hipMemsetAsync(d_over, 0, 4, c->stream));
-                HIPCHK(c, hipFuncSetAttribute((const void *)k_csr_block_count<IdxT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wn * 4)));
-                hipLaunchKernelGGL((k_csr_block_count<IdxT>), dim3(n_blocks), dim3(TRC_NT), (size_t)wn * 4, c->stream, d_indices, d_indptr,
+                HIPCHK(c, hipFuncSetAttribute((const void *)k_csr_block_count<IdxT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((wn + 1) / 2) * 4)));
+                if (ny > 1) HIPCHK(c, hipMemsetAsync(counts, 0, (size_t)n_blocks * wn * 4, c->stream));
+                hipLaunchKernelGGL((k_csr_block_count<IdxT>), dim3(n_blocks, ny), dim3(TRC_NT), (size_t)((wn + 1) / 2) * 4, c->stream, d_indices, d_indptr,
                                    (int)n_rows, RB, (long long)w0, (int)wn, counts);
                 hipLaunchKernelGGL(k_col_block_scan, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, c->stream, counts, n_blocks, (int)wn, col_total);
                 hipLaunchKernelGGL(k_gene_base_scan, dim3(1), dim3(1024), 0, c->stream, (const u32 *)col_total, (int)wn + 1, col_ptr);
@@ -1042,7 +1047,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                 ProfScope ps(c, KID_SPARSE_SEG);
                 const size_t lds = (size_t)cap * (sizeof(InT) + 4 + 1);
                 HIPCHK(c, hipFuncSetAttribute((const void *)k_csr_tile_gather<InT, IdxT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((k_csr_tile_gather<InT, IdxT>), dim3(n_blocks), dim3(TRG_NT), lds, c->stream,
+                hipLaunchKernelGGL((k_csr_tile_gather<InT, IdxT>), dim3(n_blocks, ny), dim3(TRG_NT), lds, c->stream,
                                    d_data, d_indices, d_indptr, (int)n_rows, RB, (long long)w0, (int)wn, (const u32 *)counts, (const u32 *)col_total,
                                    (const u32 *)col_ptr, cap, (const int *)c->d_codes, t_data, t_rows, d_over);
                 HIPCHK(c, hipGetLastError());
@@ -1050,6 +1055,10 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                 HIPCHK(c, hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 done = over == 0; // a (block, tile) piece larger than the LDS staging: redo the window with the scatter form
+            }
+            if (!done && wn > 32768) { // (the scatter form keeps 32-bit cursors per column in LDS: narrower windows)
+                wmax = 32768;
+                continue;
             }
             if (!done) {
                 ProfScope ps(c, KID_SPARSE_SEG);
