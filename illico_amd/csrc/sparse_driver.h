@@ -416,6 +416,14 @@ static int run_csc_ovr_route(illico_ctx *c, const InT *d_data, const IdxT *d_ind
         }
     }
     if (key_cap <= 0) return ILLICO_OK;
+    // short columns (a matrix of few cells: 2000 stored entries per gene): no more key slots and buckets than the longest column needs --
+    // two workgroups per CU then run side by side (one's barriers under the other's passes)
+    if (!accg && !c->no_csc_ovr_small_lds && max_nnz + 64 < key_cap) {
+        int lg_s = lg;
+        while (lg_s > 11 && (1ll << (lg_s - 1)) >= 2 * max_nnz) --lg_s;
+        const int cap_s = (int)std::min<int64_t>(csco_key_cap(G, lg_s, sizeof(KeyT), kMaxLds), std::max<int64_t>((max_nnz + 64 + 1023) & ~1023ll, 2048));
+        if (cap_s >= max_nnz) { lg = lg_s; key_cap = cap_s; }
+    }
     int rc;
     void *v;
     const bool contiguous = cols.back() - cols.front() + 1 == (int64_t)cols.size();
