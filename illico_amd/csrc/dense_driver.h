@@ -223,8 +223,12 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
     else HIPCHK(c, hipMemsetAsync(P.gene_flags, 0, (size_t)nb * 4, c->stream));
     // few, large groups (clusters of an atlas): the (group, gene) value histograms first, rows split over as many wavefronts as the launch
     // needs, then the same integers from the histograms (kernels_group_hists.h) -- the fused kernels give a wavefront one GROUP at a time
-    const bool hist_route = !wide_only && !c->no_group_hist_route && (int64_t)((nb + 63) / 64) * ((c->n_groups + 3) / 4) < 1024 && c->n_cells >= c->group_hist_min_cells &&
-                            c->n_cells < (1ll << 21) && (size_t)c->n_groups * (size_t)((nb + 63) / 64) * RT * 64 * 4 <= ((size_t)256 << 20);
+    // ... and OVR with a group beyond the 16-bit cells of the one-pass form (an atlas whose control group has 66 667 cells): the histograms
+    // here are 32 bits wide, one read of X instead of the two-pass form's two (2 000 000 x 1200 x 2000 groups: 6.9 ms)
+    const size_t gh_bytes = (size_t)c->n_groups * (size_t)((nb + 63) / 64) * RT * 64 * 4;
+    const bool gh_few = (int64_t)((nb + 63) / 64) * ((c->n_groups + 3) / 4) < 1024 && gh_bytes <= ((size_t)256 << 20);
+    const bool gh_ovr_big = ovr && c->max_nonref > 65535 && gh_bytes <= ((size_t)1 << 30);
+    const bool hist_route = !wide_only && !c->no_group_hist_route && (gh_few || gh_ovr_big) && c->n_cells >= c->group_hist_min_cells && c->n_cells <= (1ll << 21);
     if ((probe || hist_route) && !wide_only) { // OVR on device-resident input: which genes are count-valued at all is found on the device (the OVO pass has
         // k_fused_ref, which reads every reference row first)
         ProfScope ps(c, KID_FUSED_REF);
@@ -257,8 +261,10 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
             HIPCHK(c, hipGetLastError());
         }
         ProfScope ps(c, KID_FUSED_REF);
-        if (ovr) hipLaunchKernelGGL((k_group_hists_to_column<RT, true>), dim3(tiles), dim3(256), 0, c->stream, P, (const u32 *)H);
-        else hipLaunchKernelGGL((k_group_hists_to_column<RT, false>), dim3(tiles), dim3(256), 0, c->stream, P, (const u32 *)H);
+        if (ovr) {
+            HIPCHK(c, hipMemsetAsync(P.hist_all, 0, (size_t)nb * RT * 4, c->stream));
+            hipLaunchKernelGGL((k_group_hists_to_column<RT, true>), dim3(tiles, ((int)c->n_groups + 63) / 64), dim3(256), 0, c->stream, P, (const u32 *)H);
+        } else hipLaunchKernelGGL((k_group_hists_to_column<RT, false>), dim3(tiles), dim3(256), 0, c->stream, P, (const u32 *)H);
         hipLaunchKernelGGL((k_fused_tables_all<RT>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, P);
         const dim3 ge(tiles, ((int)c->n_groups + 3) / 4);
         if (ovr) hipLaunchKernelGGL((k_emit_from_group_hists<RT, true>), ge, dim3(256), 0, c->stream, P, (const u32 *)H);

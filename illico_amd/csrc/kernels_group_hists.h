@@ -81,17 +81,19 @@ __global__ __launch_bounds__(GH_NT) void k_group_value_hists(FusedParams P, u32 
     if (act && bad && P.gene_flags[gene] != 3u) P.gene_flags[gene] = 1u;
 }
 
-// hist_all[gene][c] (what k_fused_tables_all reads): OVR: the column's histogram = the sum over groups; OVO: the reference group's
+// hist_all[gene][c] (what k_fused_tables_all reads): OVR: the column's histogram = the sum over groups (grid.y stretches of 64 groups,
+// added with atomics: hist_all zeroed by the host); OVO: the reference group's (grid.y = 1)
 template <int RT, bool OVR>
 __global__ __launch_bounds__(256) void k_group_hists_to_column(FusedParams P, const u32 *__restrict__ H) {
     const int tile = blockIdx.x, tiles = gridDim.x;
+    const int g0 = OVR ? (int)blockIdx.y * 64 : P.ref, g1 = OVR ? min(P.G, g0 + 64) : P.ref + 1;
     for (int i = threadIdx.x; i < RT * 64; i += 256) {
         const int c = i >> 6, l = i & 63, gene = tile * 64 + l;
         if (gene >= P.ncols) continue;
         u32 s = 0;
-        if (OVR) { for (int g = 0; g < P.G; ++g) s += H[((size_t)g * tiles + tile) * (RT * 64) + i]; }
-        else s = H[((size_t)P.ref * tiles + tile) * (RT * 64) + i];
-        P.hist_all[(size_t)gene * RT + c] = s;
+        for (int g = g0; g < g1; ++g) s += H[((size_t)g * tiles + tile) * (RT * 64) + i];
+        if (OVR) { if (s) atomicAdd(&P.hist_all[(size_t)gene * RT + c], s); }
+        else P.hist_all[(size_t)gene * RT + c] = s;
     }
 }
 
