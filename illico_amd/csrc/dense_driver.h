@@ -227,7 +227,8 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
     // here are 32 bits wide, one read of X instead of the two-pass form's two (2 000 000 x 1200 x 2000 groups: 6.9 ms)
     const size_t gh_bytes = (size_t)c->n_groups * (size_t)((nb + 63) / 64) * RT * 64 * 4;
     const bool gh_few = (int64_t)((nb + 63) / 64) * ((c->n_groups + 3) / 4) < 1024 && gh_bytes <= ((size_t)256 << 20);
-    const bool gh_ovr_big = ovr && c->max_nonref > 65535 && gh_bytes <= ((size_t)1 << 30);
+    // (OVO with a ranked group beyond 65535 cells: the fused kernel's 32-bit multiplicities take 82 KB of LDS -- one workgroup, four wavefronts, per CU)
+    const bool gh_ovr_big = c->max_nonref > 65535 && gh_bytes <= ((size_t)1 << 30);
     const bool hist_route = !wide_only && !c->no_group_hist_route && (gh_few || gh_ovr_big) && c->n_cells >= c->group_hist_min_cells && c->n_cells <= (1ll << 21);
     if ((probe || hist_route) && !wide_only) { // OVR on device-resident input: which genes are count-valued at all is found on the device (the OVO pass has
         // k_fused_ref, which reads every reference row first)
