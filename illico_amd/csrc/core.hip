@@ -4,7 +4,7 @@
 #include "engine.h"
 
 const char *const kKernelNames[KID_COUNT] = {"k_transpose_permute", "k_ovo_rank", "k_ovo_counts", "k_ovo_fused", "k_ovr_fused",
-                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums", "k_ovo_fused_wide", "k_group_compact", "k_ovo_rank_compact", "k_ovr_counts", "k_gather_columns", "k_csr_counts", "k_densify"};
+                                              "k_fused_tables", "k_finalize", "k_ovr_gene", "k_sparse_seg", "k_csc_gene", "k_gene_totals", "k_csc_counts", "k_csc_ovr_gene", "k_ovr_partition", "k_ovr_rank_parts", "k_value_sums", "k_ovo_fused_wide", "k_group_compact", "k_ovo_rank_compact", "k_ovr_counts", "k_gather_columns", "k_csr_counts", "k_densify", "k_group_value_hists"};
 
 // The message of a failed call is kept per calling thread (and in the context, for single-threaded callers): a second
 // thread's failure must not replace the text the first is about to read through illico_last_error.

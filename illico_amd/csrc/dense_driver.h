@@ -257,7 +257,7 @@ int run_fused_ovo(illico_ctx *c, const void *X, int64_t ld, int64_t b0, int nb, 
         int wave_rows = (int)std::min<int64_t>(4096, std::max<int64_t>(256, (c->n_cells * tiles / (2048 * NWH) + 31) & ~31ll));
         const int chunks = (int)((c->n_cells + (int64_t)NWH * wave_rows - 1) / ((int64_t)NWH * wave_rows));
         {
-            ProfScope ps(c, ovr ? KID_OVR_FUSED : KID_OVO_FUSED);
+            ProfScope ps(c, KID_GROUP_HISTS);
             hipLaunchKernelGGL((k_group_value_hists<InT, RT>), dim3(tiles, chunks), dim3(GH_NT), 0, c->stream, P, H, wave_rows);
             HIPCHK(c, hipGetLastError());
         }

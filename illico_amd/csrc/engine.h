@@ -60,6 +60,7 @@ enum {
     KID_GATHER_COLS,
     KID_CSR_COUNTS,
     KID_DENSIFY,
+    KID_GROUP_HISTS,
     KID_COUNT
 };
 extern const char *const kKernelNames[KID_COUNT];

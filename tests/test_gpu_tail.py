@@ -89,5 +89,5 @@ def test_dense_count_ovr_far_tail_matches_the_reference_arithmetic(engine):
         prof = engine.profile_get()
     finally:
         engine.set_option("profile", 0)
-    assert "k_ovr_fused" in prof and "k_ovr_counts" not in prof, prof
+    assert ("k_ovr_fused" in prof or "k_group_value_hists" in prof) and "k_ovr_counts" not in prof, prof   # (39 groups of ~50 000 cells: the group-histogram form of the fused route)
     assert_planes_match(got, want, what="far tail dense counts")
