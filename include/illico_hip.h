@@ -92,6 +92,14 @@ int illico_ctx_set_stream(illico_ctx *ctx, void *hip_stream);
  * -1 = for references of more than 16384 cells, the default; "no_ovo_parts" = 1: a reference whose non-zero keys outgrow the kernel's
  * LDS slots is never taken in value-range parts -- such genes go to the general sort routes; "no_big_runs_global" = 1: a ranked
  * group's run of more keys than LDS holds is not dealt into value buckets through HBM -- its gene goes to the general sort routes),
+ * "no_compact_narrow" (k_group_compact never takes its 32-gene tiles for few, long blocks; "compact_narrow_rows": rows of the longest
+ * block from which it does, default 8192), "no_big_runs_wide" (runs above 8192 keys get no 1024-thread launch of their own),
+ * "big_runs_slice_bytes" (> 0: LDS bytes of k_bucket_big_runs_global's slice buffer), "no_ovr_packed_big" (dense OVR with a group above
+ * 65535 cells partitions the padded rows, as before), "no_ovr_part_coop" (the packed partition walks every block with one wavefront),
+ * "no_group_hist_route" (count-valued dense input with few large groups, or OVR / OVO with a group above 65535 cells: the fused kernels
+ * instead of the (group, gene) value histograms of kernels_group_hists.h; "group_hist_min_cells": cells from which the route is
+ * taken, default 32768), "no_csr_transpose_split" (CSR -> CSC on the device: one workgroup per row block whatever their number),
+ * "no_csc_ovr_small_lds" (k_csc_ovr_gene takes a CU's whole LDS per workgroup whatever the columns' lengths),
  * "no_ovo_ref_buckets" (OVO sort route: reference column in value buckets instead of sorted), "no_ovr_parts_path" (dense OVR, any values: value-range parts ranked in LDS; "ovr_parts_cap" > 0 caps the keys per part), "no_csc_gene_path" (CSC OVO single-kernel route), "no_csc_ovr_gene_path" (CSC OVR single-kernel route; "csc_ovr_sorted_form" = 1 makes it sort every
  * gene in LDS, the form tie-heavy columns take, instead of bucketing the keys), "no_csc_regroup_lds" (two-kernel CSC route: regroup with scattered
  * stores only),
