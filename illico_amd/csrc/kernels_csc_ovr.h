@@ -384,6 +384,56 @@ __global__ __launch_bounds__(CSCO_NT) void k_csc_ovr_gene(CscOvrParams P) {
     }
 }
 
+// Parts of a gene whose coarse buckets are SKEWED (one holds more than a quarter of `cap`: heavy ties -- log1p of raw counts, counts times a
+// constant -- or a crowd of values in a sliver of the range).  A bucket above cap / 2 ("big") gets a part of its own; the small buckets
+// are split evenly by their own running count S (the big ones left out) with a quota of cap / 2, so a part of small buckets holds at most
+// cap keys:    part(b) = S(b) / (cap / 2) + 2 B(b) + [b is big],   B(b) = big buckets before b
+// -- monotone in b, ids with gaps (an unused id is an empty part: its start is the next part's).  A big bucket's part may exceed `cap`: the
+// rank kernel takes it in its streaming form when all its keys are equal (one value: nothing to rank, the records are only counted per
+// group) and hands the gene to the general route when they are not.  hist: exclusive bucket offsets; big_list: 2 x 128 words of scratch;
+// *np_out: the parts, or 0xFFFFFFFF (more than OVRP_PMAX ids, more than 128 big buckets).  Every thread of the workgroup calls it.
+// (Until late in round 5 a skewed gene left the route at once: dense OVR on log1p of raw counts ran the per-gene radix sort in HBM, 24 ms
+// for 2048 genes against 5 for tie-free values.)
+template <int NT>
+__device__ __forceinline__ void ovrp_assign_parts_skewed(const u32 *hist, int NB, u32 n, u32 cap, unsigned char *part_of, u32 *pstart, u32 *big_list,
+                                                         u32 *np_out, int tid) {
+    u32 *bigb = big_list, *bigc = big_list + 128;
+    const u32 half = cap / 2u;
+    if (tid == 0) *np_out = 0u; // (first: the number of big buckets; then: the largest part id)
+    for (int p = tid; p <= OVRP_PMAX; p += NT) pstart[p] = n;
+    __syncthreads();
+    for (int b = tid; b < NB; b += NT) {
+        const u32 c = (b + 1 < NB ? hist[b + 1] : n) - hist[b];
+        if (c > half) { const u32 i = atomicAdd(np_out, 1u); if (i < 128u) { bigb[i] = (u32)b; bigc[i] = c; } }
+    }
+    __syncthreads();
+    const u32 nbig = *np_out;
+    __syncthreads();
+    if (nbig > 128u) { if (tid == 0) *np_out = 0xFFFFFFFFu; __syncthreads(); return; }
+    if (tid == 0) *np_out = 0u;
+    __syncthreads();
+    u32 pmax = 0;
+    for (int b = tid; b < NB; b += NT) {
+        const u32 lo = hist[b], c = (b + 1 < NB ? hist[b + 1] : n) - lo;
+        u32 B = 0, BS = 0;
+        for (u32 i = 0; i < nbig; ++i) { const bool before = bigb[i] < (u32)b; B += before ? 1u : 0u; BS += before ? bigc[i] : 0u; }
+        const u32 pid = (lo - BS) / half + 2u * B + (c > half ? 1u : 0u);
+        part_of[b] = (unsigned char)min(pid, (u32)OVRP_PMAX - 1);
+        if (c) { pmax = max(pmax, pid); if (pid < (u32)OVRP_PMAX) atomicMin(&pstart[pid], lo); }
+    }
+    atomicMax(np_out, pmax);
+    __syncthreads();
+    const u32 top = *np_out;
+    __syncthreads();
+    if (top >= (u32)OVRP_PMAX) { if (tid == 0) *np_out = 0xFFFFFFFFu; __syncthreads(); return; }
+    if (tid == 0) { // an unused id starts where the next part does
+        for (int p = (int)top - 1; p >= 0; --p) pstart[p] = min(pstart[p], pstart[p + 1]);
+        pstart[top + 1] = n;
+        *np_out = n ? top + 1u : 0u;
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Dense (gene-major key rows, group-contiguous positions: what k_transpose_permute writes): split a gene's non-zero keys
 // by value into parts of at most `cap` keys.
@@ -473,8 +523,12 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition(OvrPartParams P) {
         // boundary and holds fewer than quota + mx = cap keys
         const bool skew = (unsigned long long)mx * 4ull > (unsigned long long)P.cap;
         const u32 quota = skew ? 1u : (u32)P.cap - mx;
-        const u32 n_parts = n ? (n - 1) / quota + 1 : 0u;
-        const bool bad = skew || n_parts > (u32)OVRP_PMAX;
+        u32 n_parts = n ? (n - 1) / quota + 1 : 0u;
+        if (skew) { // (uniform) crowded buckets get parts of their own: ovrp_assign_parts_skewed
+            ovrp_assign_parts_skewed<NT>(hist, NB, n, (u32)P.cap, part_of, pstart, tmp, &s_mx[0], tid);
+            n_parts = s_mx[0];
+        }
+        const bool bad = n_parts > (u32)OVRP_PMAX;
         u32 *gi = P.gene_info + (size_t)gene * 4;
         u32 *ps_out = P.part_start + (size_t)gene * (OVRP_PMAX + 1);
         if (bad) { // uniform: this gene goes to the general route
@@ -482,12 +536,14 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition(OvrPartParams P) {
             __syncthreads();
             continue;
         }
-        for (int b = tid; b < NB; b += NT) {
-            const u32 p = hist[b] / quota;
-            part_of[b] = (unsigned char)min(p, (u32)OVRP_PMAX - 1); // (empty buckets past the last key may overshoot)
-            if (p < n_parts && (b == 0 || hist[b - 1] / quota != p)) pstart[p] = hist[b];
+        if (!skew) {
+            for (int b = tid; b < NB; b += NT) {
+                const u32 p = hist[b] / quota;
+                part_of[b] = (unsigned char)min(p, (u32)OVRP_PMAX - 1); // (empty buckets past the last key may overshoot)
+                if (p < n_parts && (b == 0 || hist[b - 1] / quota != p)) pstart[p] = hist[b];
+            }
+            if (tid == 0) pstart[n_parts] = n;
         }
-        if (tid == 0) pstart[n_parts] = n;
         const int p_bits = 32 - __clz(n_parts); // bits of the values 0 .. n_parts
         __syncthreads();
         for (int i0 = 0; i0 < N; i0 += NT * UL) {
@@ -647,20 +703,26 @@ __global__ __launch_bounds__(OVRP_NT) void k_ovr_partition_packed(OvrPartPackedP
     const u32 nneg = s_mx[1];
     const bool skew = (unsigned long long)mx * 4ull > (unsigned long long)P.cap;
     const u32 quota = skew ? 1u : (u32)P.cap - mx;
-    const u32 n_parts = n ? (n - 1) / quota + 1 : 0u;
-    const bool bad = skew || n_parts > (u32)OVRP_PMAX;
+    u32 n_parts = n ? (n - 1) / quota + 1 : 0u;
+    if (skew) { // (uniform) crowded buckets get parts of their own: ovrp_assign_parts_skewed
+        ovrp_assign_parts_skewed<NT>(hist, NB, n, (u32)P.cap, part_of, pstart, tmp, &s_mx[0], tid);
+        n_parts = s_mx[0];
+    }
+    const bool bad = n_parts > (u32)OVRP_PMAX;
     u32 *gi = P.gene_info + (size_t)gene * 4;
     u32 *ps_out = P.part_start + (size_t)gene * (OVRP_PMAX + 1);
     if (bad) { // uniform: this gene goes to the general route
         if (tid == 0) { gi[0] = n; gi[1] = nneg; gi[2] = 0u; gi[3] = 1u; }
         return;
     }
-    for (int b = tid; b < NB; b += NT) {
-        const u32 p = hist[b] / quota;
-        part_of[b] = (unsigned char)min(p, (u32)OVRP_PMAX - 1);
-        if (p < n_parts && (b == 0 || hist[b - 1] / quota != p)) pstart[p] = hist[b];
+    if (!skew) {
+        for (int b = tid; b < NB; b += NT) {
+            const u32 p = hist[b] / quota;
+            part_of[b] = (unsigned char)min(p, (u32)OVRP_PMAX - 1);
+            if (p < n_parts && (b == 0 || hist[b - 1] / quota != p)) pstart[p] = hist[b];
+        }
+        if (tid == 0) pstart[n_parts] = n;
     }
-    if (tid == 0) pstart[n_parts] = n;
     const int p_bits = 32 - __clz(n_parts);
     __syncthreads();
     static_assert((NW & (NW - 1)) == 0, "units are dealt by (u + b) % NW");

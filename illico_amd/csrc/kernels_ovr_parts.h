@@ -77,7 +77,32 @@ __global__ __launch_bounds__(NT_) void k_ovr_rank_gene_parts(OvrRankGeneParams P
             const u32 base = ps[part];
             const int n = (int)(ps[part + 1] - base);
             if (n == 0) continue;
-            if (n > P.key_cap) { bad = true; break; } // uniform
+            if (n > (P.key_cap & ~1023)) { // (uniform; the sorted form below rounds a part up to 1024 keys) a part beyond the key slots: a crowded coarse bucket that the partition gave a part of its own
+                // (ovrp_assign_parts_skewed).  ONE value -- the ties of log1p'd or scaled counts -- needs no ranking: every record stands
+                // at base .. base + n - 1 with n equals; the records are only counted per group.  Different values: the general route's gene.
+                if (tid == 0) { s_k[0] = MAXK; s_k[1] = (KeyT)0; }
+                __syncthreads();
+                const long long k0 = (long long)gene * P.pstride + base, k1 = k0 + n;
+                KeyT tmin = MAXK, tmax = (KeyT)0;
+                for (long long k = k0 + tid; k < k1; k += NT) {
+                    const KeyT key = src.pkeys[k];
+                    tmin = key < tmin ? key : tmin;
+                    tmax = key > tmax ? key : tmax;
+                }
+                tmin = wave_min_key(tmin);
+                tmax = wave_max_key(tmax);
+                if (lane == 0) { atomicMin(&s_k[0], tmin); atomicMax(&s_k[1], tmax); }
+                __syncthreads();
+                const KeyT q = s_k[0];
+                const bool one_value = s_k[1] == q;
+                __syncthreads();
+                if (!one_value) { bad = true; break; }
+                const u64 add = 2ull * (u64)base + 1ull + CNT1 + ((q > ZEROK) ? 2ull * (u64)n0 : 0ull) + (u64)n;
+                for (long long k = k0 + tid; k < k1; k += NT) atomicAdd(&acc[src.pcodes[k]], add);
+                if (tid == 0) tie += (u64)n * ((u64)n * (u64)n - 1ull);
+                __syncthreads();
+                continue;
+            }
             const long long k0 = (long long)gene * P.pstride + base, k1 = k0 + n;
             for (int b = tid; b < NBKT / 2; b += NT) tab[b] = 0u;
             if (tid == 0) { s_k[0] = MAXK; s_k[1] = (KeyT)0; s_misc[2] = 0u; }

@@ -203,11 +203,12 @@ def test_ovr_dense_value_range_parts_route(engine, dtype, sorted_form, parts_cap
     """Dense OVR, any values: each gene's non-zero keys are split by value into parts that fit LDS and ranked part by
     part (k_ovr_partition + k_csc_ovr_gene<PARTS>; bucket form, and the sorted form when forced).  70 000 cells: fully
     dense columns need 3+ parts (5+ for float64 keys); half-empty and nearly empty columns, negatives, exact repeats
-    among continuous values, a tie-heavy column and a constant column (one coarse bucket holds everything: those genes
-    leave the route and the general route recomputes the gene range covering them), an all-zero column.  parts_cap =
+    among continuous values, a tie-heavy column and a constant column (crowded coarse buckets: parts of their own, counted per
+    group when they hold one value; two values in one crowded bucket: that gene leaves the route and the general route recomputes
+    it), an all-zero column.  parts_cap =
     1024 makes ~90 parts per dense column (more than 64: all 8 bits of the part id in play)."""
     rng = np.random.RandomState(509)
-    n, m = 70000, 12
+    n, m = 70000, 14
     sizes = [30000, 20000, 9000, 700, 300, 255, 40, 3, 1]
     sizes.append(n - sum(sizes))
     labels = np.concatenate([[f"s{i:02d}"] * sz for i, sz in enumerate(sizes)])
@@ -217,7 +218,7 @@ def test_ovr_dense_value_range_parts_route(engine, dtype, sorted_form, parts_cap
     X[:, 1] = rng.randn(n)                                                            # fully dense, negatives
     X[:, 2] = np.where(rng.rand(n) < 0.5, 0.0, rng.lognormal(0.0, 1.0, size=n))       # half empty
     X[:, 3] = np.where(rng.rand(n) < 0.999, 0.0, rng.rand(n))                         # nearly empty
-    X[:, 4] = rng.poisson(2.0, size=n)                                                # tie-heavy -> general route
+    X[:, 4] = rng.poisson(2.0, size=n)                                                # tie-heavy: crowded buckets, one value each
     X[:, 5] = rng.rand(n) * 1e-3 + 5.0                                                # narrow range: one coarse bucket
     X[:, 6] = 0.0                                                                     # all zero
     X[:, 7] = np.round(rng.lognormal(0.0, 1.0, size=n), 2)                            # many exact repeats, wide range
@@ -225,6 +226,12 @@ def test_ovr_dense_value_range_parts_route(engine, dtype, sorted_form, parts_cap
     X[:, 9] = 3.25                                                                    # constant
     X[:, 10] = rng.standard_cauchy(size=n)                                            # heavy tails both ways
     X[:, 11] = np.where(rng.rand(n) < 0.3, -rng.rand(n), rng.rand(n) * 100)
+    # crowded coarse buckets (each gets a part of its own, beyond the key slots: the streaming form when it is ONE value, else the
+    # general route): log1p of raw counts -- 64 distinct values, none an integer -- and two neighbouring values with an outlier that
+    # stretches the key range so that both fall into one bucket
+    X[:, 12] = np.log1p(rng.poisson(6.0, size=n) * (rng.rand(n) < 0.8))
+    X[:, 13] = np.where(rng.rand(n) < 0.5, 1.0, np.nextafter(dtype(1.0), dtype(2.0)))
+    X[7, 13] = 1.0e6
     X = X.astype(dtype)
     _, g = oracle.encode_and_count_groups(labels, None)
     want = oracle.run(X.astype(np.float64), g)
