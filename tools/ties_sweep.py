@@ -33,4 +33,19 @@ for test in ("ovo", "ovr"):
         pr = eng.profile_get(); eng.profile(False)
         top = sorted(((k, round(v["ms"] / 2, 2)) for k, v in pr.items()), key=lambda kv: -kv[1])[:4]
         print(f"{test} dense {name:30s} {dt:9.2f} ms  {top}", flush=True)
+    for name in ("counts", "log1p(counts)", "continuous (no ties)"):   # the same values 90 % sparse, as CSC and CSR
+        Xs = kinds[name] * (torch.rand((N, M), device=dev, generator=gen) < 0.2)
+        for fmt in ("csc", "csr"):
+            d, i, p = bench.compress(torch, Xs, fmt)
+            f = lambda: eng.run_sparse(fmt, d, i, p, (N, M), 0, M, out=out)
+            f(); eng.synchronize()
+            eng.profile(True); eng.profile_reset()
+            t0 = time.perf_counter()
+            for _ in range(2): f()
+            eng.synchronize()
+            dt = (time.perf_counter() - t0) / 2 * 1e3
+            pr = eng.profile_get(); eng.profile(False)
+            top = sorted(((k, round(v["ms"] / 2, 2)) for k, v in pr.items()), key=lambda kv: -kv[1])[:4]
+            print(f"{test} {fmt:5s} {name:30s} {dt:9.2f} ms  {top}", flush=True)
+        del Xs
     eng.close()
