@@ -185,12 +185,14 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_csc_ovr_small_lds")) c->no_csc_ovr_small_lds = value != 0;
     else if (!strcmp(key, "no_csr_transpose_split")) c->no_csr_transpose_split = value != 0;
     else if (!strcmp(key, "no_group_hist_route")) c->no_group_hist_route = value != 0;
+    else if (!strcmp(key, "group_hist_max_wgs")) c->group_hist_max_wgs = value > 0 ? value : 1024;
     else if (!strcmp(key, "group_hist_min_cells")) c->group_hist_min_cells = value > 0 ? value : 32768;
     else if (!strcmp(key, "no_ovr_part_coop")) c->no_ovr_part_coop = value != 0;
     else if (!strcmp(key, "no_ovr_packed_big")) c->no_ovr_packed_big = value != 0;
     else if (!strcmp(key, "big_runs_slice_bytes")) c->big_runs_slice_bytes = (int)value;
     else if (!strcmp(key, "no_big_runs_wide")) c->no_big_runs_wide = value != 0;
     else if (!strcmp(key, "no_compact_narrow")) c->no_compact_narrow = value != 0;
+    else if (!strcmp(key, "compact_narrow_wgs")) c->compact_narrow_wgs = value > 0 ? value : 2048;
     else if (!strcmp(key, "compact_narrow_rows")) c->compact_narrow_rows = value > 0 ? value : 8192;
     else if (!strcmp(key, "no_big_runs_global")) c->no_big_runs_global = value != 0;
     else if (!strcmp(key, "packed_ref_cap")) c->packed_ref_cap = (int)value;

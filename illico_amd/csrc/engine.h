@@ -158,10 +158,12 @@ struct illico_ctx {
     bool no_big_runs_wide = false;     // k_bucket_big_runs: 256 threads whatever the runs' length
     bool no_big_runs_global = false;   // packed routes: a (gene, group) run beyond k_bucket_big_runs' LDS slots sends its gene to the general route (as before round 5)
     bool no_compact_narrow = false;    // k_group_compact: never the 32-gene tiles for few, long blocks
+    int64_t compact_narrow_wgs = 2048;  // ... and the launch would have fewer 64-gene workgroups than this (8 per compute unit)
     int64_t compact_narrow_rows = 8192; // ... from this many rows in the longest block
     bool no_ovr_part_coop = false;     // k_ovr_partition_packed: one wavefront per block whatever the blocks' lengths
     bool no_ovr_packed_big = false;    // dense OVR: groups above 65535 cells take the padded rows (every key, zeros included), as before
     bool no_group_hist_route = false;  // count-valued dense input with few, large groups: the fused kernels (a wavefront per group), as before
+    int64_t group_hist_max_wgs = 1024;  // ... while the fused launch would have fewer workgroups than this
     int64_t group_hist_min_cells = 32768; // ... from this many cells (tests lower it)
     bool no_csr_transpose_split = false; // CSR -> CSC on the device: one workgroup per row block whatever their number
     bool no_csc_ovr_small_lds = false; // k_csc_ovr_gene: a CU's whole LDS per workgroup whatever the columns' lengths
