@@ -101,7 +101,7 @@ int illico_ctx_create(int device_id, illico_ctx **out_ctx) {
 }
 
 static void free_groups(illico_ctx *c) {
-    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos, &c->d_pk_blk, &c->d_pk_code, &c->d_pk_big, &c->d_pk_long}) {
+    for (int **p : {&c->d_codes, &c->d_perm, &c->d_posptr, &c->d_counts, &c->d_code_by_pos, &c->d_pk_blk, &c->d_pk_code, &c->d_pk_big, &c->d_pk_long, &c->d_pk_order}) {
         if (*p) hipFree(*p);
         *p = nullptr;
     }
@@ -191,6 +191,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_ovr_packed_big")) c->no_ovr_packed_big = value != 0;
     else if (!strcmp(key, "big_runs_slice_bytes")) c->big_runs_slice_bytes = (int)value;
     else if (!strcmp(key, "no_big_runs_wide")) c->no_big_runs_wide = value != 0;
+    else if (!strcmp(key, "no_compact_order")) c->no_compact_order = value != 0;
     else if (!strcmp(key, "no_compact_narrow")) c->no_compact_narrow = value != 0;
     else if (!strcmp(key, "compact_narrow_wgs")) c->compact_narrow_wgs = value > 0 ? value : 2048;
     else if (!strcmp(key, "compact_narrow_rows")) c->compact_narrow_rows = value > 0 ? value : 8192;
@@ -381,6 +382,22 @@ int illico_set_groups(illico_ctx *c, const int64_t *encoded_groups, const int64_
         packed.insert(packed.end(), out.begin(), out.end());
         if (packed.empty()) packed.push_back(0);
         c->pk_nblk = (int)g0.size();
+        { // blocks of very different lengths (clusters from fifty to tens of thousands of cells): k_group_compact numbers its workgroups
+            // block-major, longest block first, so that a long block's chain of chunks starts with the launch instead of ending it
+            std::vector<int64_t> rows_b(g0.size(), 0);
+            int64_t tot = 0, mx = 0;
+            for (size_t b = 0; b < g0.size(); ++b) {
+                for (int g = g0[b]; g < g1[b]; ++g) rows_b[b] += counts[g];
+                tot += rows_b[b]; mx = std::max(mx, rows_b[b]);
+            }
+            if (g0.size() >= 2 && mx * (int64_t)g0.size() >= 4 * tot) {
+                std::vector<int> ord(g0.size());
+                for (size_t b = 0; b < ord.size(); ++b) ord[b] = (int)b;
+                std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return rows_b[a] > rows_b[b]; });
+                HIPCHK(c, hipMalloc((void **)&c->d_pk_order, ord.size() * sizeof(int)));
+                HIPCHK(c, hipMemcpy(c->d_pk_order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice));
+            }
+        }
         { // long blocks (a cluster of thousands of cells, the control group of a screen): see k_ovr_partition_packed<COOP>
             std::vector<int> lng;
             std::vector<unsigned char> is_long(g0.size() + 1, 0);

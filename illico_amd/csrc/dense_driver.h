@@ -14,6 +14,7 @@ static int launch_group_compact(illico_ctx *c, GroupCompactParams Q, int nb, int
     const bool lg = flags & ILLICO_FLAG_LOG1P;
     // few, long blocks (cluster-sized groups): a workgroup's chain of 64-row chunks is what the launch waits for -- tiles of 32 genes
     // (128-byte row pieces) put twice the workgroups on the same rows
+    Q.blk_order = (c->no_compact_order || Q.nblk != c->pk_nblk) ? nullptr : c->d_pk_order; // (null unless the blocks' lengths differ much: set_groups)
     const bool narrow = !c->no_compact_narrow && c->pk_max_block_rows >= c->compact_narrow_rows && (long long)Q.nblk * ((nb + 63) / 64) < c->compact_narrow_wgs;
     const int tw = narrow ? 32 : 64;
     const dim3 grid(((Q.nseg + 7) & ~7) + Q.nblk, (nb + tw - 1) / tw);

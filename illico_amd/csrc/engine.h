@@ -121,6 +121,7 @@ struct illico_ctx {
                                   // then [G]: a group's place in that list, or -1
     int pk_nbig = 0;
     int64_t pk_max_block_rows = 0; // rows of the longest block
+    int *d_pk_order = nullptr;    // [pk_nblk] the blocks by falling row count, or null when their lengths are alike (k_group_compact starts the longest first)
     int pk_nlong = 0;             // blocks of more than OVRP_LONG_ROWS rows and at most 64 groups (k_ovr_partition_packed deals their units over all wavefronts)
     int *d_pk_long = nullptr;     // [pk_nlong] those blocks
     unsigned char *d_pk_islong = nullptr; // [pk_nblk]
@@ -157,6 +158,7 @@ struct illico_ctx {
     int big_runs_slice_bytes = 0;      // > 0: the LDS bytes of k_bucket_big_runs_global's slice buffer (default: what the CU's LDS leaves beside the counters)
     bool no_big_runs_wide = false;     // k_bucket_big_runs: 256 threads whatever the runs' length
     bool no_big_runs_global = false;   // packed routes: a (gene, group) run beyond k_bucket_big_runs' LDS slots sends its gene to the general route (as before round 5)
+    bool no_compact_order = false;     // k_group_compact: workgroups in grid order whatever the blocks' lengths
     bool no_compact_narrow = false;    // k_group_compact: never the 32-gene tiles for few, long blocks
     int64_t compact_narrow_wgs = 2048;  // ... and the launch would have fewer 64-gene workgroups than this (8 per compute unit)
     int64_t compact_narrow_rows = 8192; // ... from this many rows in the longest block

@@ -74,6 +74,8 @@ struct GroupCompactParams {
     const int *cand_of;     // optional [G]: a group's place among the n_cand groups of more than 256 cells, or -1 ...
     u32 *run_n;             // ... and [ncols][n_cand]: the exact length of each such (gene, group) run (nnz saturates at 65535)
     int n_cand;
+    const int *blk_order;   // optional [nblk]: the blocks by falling row count -- the launch then starts every tile of the longest blocks first (a long
+                            // block's chain of chunks is what a launch with blocks of very different lengths waits for)
 };
 
 template <typename InT> __device__ __forceinline__ double gcmp_value(InT v, int is_log1p);
@@ -105,21 +107,28 @@ __global__ __launch_bounds__(GCMP_NT) void k_group_compact(GroupCompactParams P)
 
     const int nseg_pad = (P.nseg + 7) & ~7;
     int gA, gB, out0, seg = -1, seg_row0 = 0, seg_n = 0, blk = 0;
-    if ((int)blockIdx.x < nseg_pad) {
-        seg = blockIdx.x;
+    // (virtual) grid position: x = segment / block, y = gene tile.  With blk_order the workgroups are numbered block-major, longest block first
+    int vx = (int)blockIdx.x, vy = (int)blockIdx.y;
+    if (P.blk_order) {
+        const int tiles = (int)gridDim.y, L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, nbt = P.nblk * tiles;
+        if (L < nbt) { vx = nseg_pad + P.blk_order[L / tiles]; vy = L - (L / tiles) * tiles; }
+        else { vx = (L - nbt) / tiles; vy = (L - nbt) - vx * tiles; }
+    }
+    if (vx < nseg_pad) {
+        seg = vx;
         if (seg >= P.nseg) return;
         gA = P.ref; gB = P.ref + 1;
         seg_row0 = P.pos_ptr[P.ref] + seg * GCMP_SEG_ROWS;
         seg_n = min(GCMP_SEG_ROWS, P.pos_ptr[P.ref + 1] - seg_row0);
         out0 = P.ref_out + seg * GCMP_SEG_ROWS;
     } else {
-        const int b = (int)blockIdx.x - nseg_pad;
+        const int b = vx - nseg_pad;
         gA = P.blk_g0[b]; gB = P.blk_g1[b];
         out0 = P.blk_out[b];
         blk = b;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c0 = blockIdx.y * TW;
+    const int c0 = vy * TW;
     const int q = tid % LPR, r0 = tid / LPR;
     const InT *X = (const InT *)P.X;
     KeyT *Xt = (KeyT *)P.Xt;

@@ -14,6 +14,11 @@ equal = bench.make_labels(N, G, 0)
 print("ragged sizes:", sorted(sizes.tolist())[:3], "...", sorted(sizes.tolist())[-3:])
 mats = {"counts": bench.make_matrix(torch, N, M, 0.5, 0, dev), "continuous": bench.make_matrix(torch, N, M, 0.9, 0, dev, values="continuous")}
 csr = bench.compress(torch, mats["continuous"], "csr")
+sp_counts = bench.make_matrix(torch, N, M, 0.9, 0, dev)
+csr_c = bench.compress(torch, sp_counts, "csr")
+csc_c = bench.compress(torch, sp_counts, "csc")
+csc = bench.compress(torch, mats["continuous"], "csc")
+del sp_counts
 for test in ("ovo", "ovr"):
     for lname, codes in (("equal", equal), ("ragged", ragged)):
         eng = Engine(0)
@@ -22,7 +27,10 @@ for test in ("ovo", "ovr"):
         eng.set_groups(bench.group_container(codes.astype(np.int64), G, test == "ovr"))
         out = tuple(torch.empty((G, M), dtype=torch.float64, device=dev) for _ in range(3))
         runs = {"dense counts": lambda: eng.run_dense(mats["counts"], 0, M, out=out), "dense continuous": lambda: eng.run_dense(mats["continuous"], 0, M, out=out),
-                "csr continuous": lambda: eng.run_sparse("csr", csr[0], csr[1], csr[2], (N, M), 0, M, out=out)}
+                "csr continuous": lambda: eng.run_sparse("csr", csr[0], csr[1], csr[2], (N, M), 0, M, out=out),
+                "csc continuous": lambda: eng.run_sparse("csc", csc[0], csc[1], csc[2], (N, M), 0, M, out=out),
+                "csr counts": lambda: eng.run_sparse("csr", csr_c[0], csr_c[1], csr_c[2], (N, M), 0, M, out=out),
+                "csc counts": lambda: eng.run_sparse("csc", csc_c[0], csc_c[1], csc_c[2], (N, M), 0, M, out=out)}
         for name, f in runs.items():
             f(); eng.synchronize()
             eng.profile(True); eng.profile_reset()
