@@ -182,6 +182,7 @@ int illico_ctx_set_option(illico_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "no_ovo_parts")) c->no_ovo_parts = value != 0;
     else if (!strcmp(key, "no_packed_small_wg")) c->no_packed_small_wg = value != 0;
     else if (!strcmp(key, "no_deal_runs")) c->no_deal_runs = value != 0;
+    else if (!strcmp(key, "no_coop_runs")) c->no_coop_runs = value != 0;
     else if (!strcmp(key, "no_csc_ovr_small_lds")) c->no_csc_ovr_small_lds = value != 0;
     else if (!strcmp(key, "no_csr_transpose_split")) c->no_csr_transpose_split = value != 0;
     else if (!strcmp(key, "no_group_hist_route")) c->no_group_hist_route = value != 0;

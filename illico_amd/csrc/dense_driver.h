@@ -66,6 +66,7 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
     }
     bool parts = false;
     BigRunFn<KeyT> *big_fn = nullptr;
+    u32 *run_cuts = nullptr;
     void *big_tmp = nullptr; // groups with more cells than k_bucket_big_runs' LDS slots: a second key buffer, into which such runs are dealt
     if (c->pk_nbig > 0) { // runs of more than 256 non-zero keys are dealt into value buckets in place: the rank kernel walks them in pieces
         if ((rc = get_scratch(c, "packed_big_fn", (size_t)nb * c->pk_nbig * sizeof(BigRunFn<KeyT>), &v))) return rc;
@@ -74,7 +75,11 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         int cap = (int)std::min<int64_t>(srt_cap<KeyT>(), (c->max_nonref + 63) & ~63ll); // (a run holds at most its group's cells)
         if (c->big_runs_cap > 0) cap = std::min(cap, std::max(c->big_runs_cap, 512) & ~63);
         if (c->max_nonref > cap && !c->no_big_runs_global && get_scratch(c, "packed_big_tmp", (size_t)nb * (size_t)stride * sizeof(KeyT), &v) == ILLICO_OK) big_tmp = v;
-        if ((rc = launch_bucket_big_runs<KeyT>(c, (void *)Xt, big_tmp, (long long)stride, nnz, gofs, nb, G, cap, big_fn, route, c->max_nonref, run_n))) return rc;
+        if (c->max_nonref > OCR_COOP_MIN && !c->no_coop_runs) { // runs long enough for the rank kernel to walk them with all its wavefronts: the bucket kernels leave cuts
+            if ((rc = get_scratch(c, "packed_run_cuts", (size_t)nb * c->pk_nbig * OCR_CUTS * 4, &v))) return rc;
+            run_cuts = (u32 *)v;
+        }
+        if ((rc = launch_bucket_big_runs<KeyT>(c, (void *)Xt, big_tmp, (long long)stride, nnz, gofs, nb, G, cap, big_fn, route, c->max_nonref, run_n, run_cuts))) return rc;
     }
     {
         OvoCompactParams C;
@@ -83,7 +88,7 @@ static int run_ovo_packed(illico_ctx *c, const void *X, int64_t ld, int64_t col0
         packed_ref_sizing<KeyT>(n_ref, &C.ref_cap, &C.nbk_lg);
         if (c->packed_ref_cap > 0) C.ref_cap = std::min(C.ref_cap, std::max(c->packed_ref_cap, 1024));
         C.out_2u = s2u; C.out_tie = stie; C.route = route; C.big_sorted = c->pk_nbig > 0 ? 1 : 0;
-        C.ref_by_gofs = 0; C.gene_flags = nullptr; C.big_fn = big_fn; C.big_tmp = big_tmp; C.run_n = run_n; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
+        C.ref_by_gofs = 0; C.gene_flags = nullptr; C.big_fn = big_fn; C.big_tmp = big_tmp; C.run_cuts = run_cuts; C.run_n = run_n; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
         // small problems per gene (a reference of at most 2048 cells, fewer than 128 groups, none above 256 cells): workgroups of 256 threads,
         // several per CU
         const bool eq0 = c->packed_eq_buckets >= 0 ? c->packed_eq_buckets != 0 : n_ref > 16384;

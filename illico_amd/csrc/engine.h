@@ -169,6 +169,7 @@ struct illico_ctx {
     int64_t group_hist_min_cells = 32768; // ... from this many cells (tests lower it)
     bool no_csr_transpose_split = false; // CSR -> CSC on the device: one workgroup per row block whatever their number
     bool no_csc_ovr_small_lds = false; // k_csc_ovr_gene: a CU's whole LDS per workgroup whatever the columns' lengths
+    bool no_coop_runs = false;         // packed rank kernel: a long run is walked by one wavefront (as before) instead of all of the workgroup's
     bool no_deal_runs = false;         // packed rank kernel in parts: never deal the short runs by part first (every part then looks every key up, masked)
     bool no_packed_small_wg = false;   // packed rank kernel: never the 256-thread form for small references with few groups
     bool no_ovo_parts = false;         // packed rank kernel: never take a reference in value-range parts (genes beyond the LDS slots go to the general routes, as before round 5)

@@ -42,6 +42,8 @@
 #define OCR_BLOOM_WORDS 256 // per wavefront: 8192 bits
 #endif
 
+#define OCR_COOP_MIN 8192   // k_ovo_rank_compact: a ranked group's run of more keys than this is walked by all the wavefronts of the gene's workgroup
+#define OCR_CUTS 15         // ... between the cuts the bucket kernels leave for such a run (sixteen stretches)
 #define GCMP_SEG_ROWS 512    // the reference group is packed in independent segments of this many rows (one workgroup each)
 #ifndef GCMP_BLOCK_ROWS
 #define GCMP_BLOCK_ROWS 1024
@@ -336,6 +338,7 @@ struct OvoCompactParams {
     const u32 *gene_flags;   // optional [n_genes]: a gene whose word is 0 is somebody else's (count-valued: the histogram kernel's)
     const void *big_fn;      // [n_genes][n_cand] BigRunFn<KeyT>: each such run's bucket function
     const u32 *run_n;        // optional [n_genes][n_cand]: exact lengths of the runs of the groups above 256 cells (nnz saturates at 65535)
+    const u32 *run_cuts;     // optional [n_genes][n_cand][OCR_CUTS]: for runs above OCR_COOP_MIN keys, bucket boundaries at or behind w / 16 of the run (the bucket kernels)
     const void *big_tmp;     // the second key buffer (laid out like Xs) that holds the runs k_bucket_big_runs_global dealt
     const int *cand_of;      // [G] a group's place among the n_cand groups of more than 256 cells, or -1
     int n_cand;
@@ -611,7 +614,8 @@ template <typename KeyT>
 __global__ __launch_bounds__(SRTG_NT) void k_bucket_big_runs_global(void *Xs, void *tmp, long long gene_stride, const u16 *__restrict__ nnz, const u32 *__restrict__ gofs,
                                                                     const int *__restrict__ cand, int n_cand, int G, int cap /* runs up to here are k_bucket_big_runs' */,
                                                                     int lg_max /* log2 of the counters the launch's LDS holds */, BigRunFn<KeyT> *__restrict__ big_fn,
-                                                                    u32 *__restrict__ route, const u32 *__restrict__ run_n /* exact run lengths, or null */, int slice_keys /* LDS key slots behind the counters */) {
+                                                                    u32 *__restrict__ route, const u32 *__restrict__ run_n /* exact run lengths, or null */, int slice_keys /* LDS key slots behind the counters */,
+                                                                    u32 *__restrict__ run_cuts /* optional: OCR_CUTS bucket boundaries per run for the rank kernel */) {
     extern __shared__ __align__(16) unsigned char srtg_smem[];
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
     constexpr int NT = SRTG_NT;
@@ -668,7 +672,16 @@ __global__ __launch_bounds__(SRTG_NT) void k_bucket_big_runs_global(void *Xs, vo
             for (int w = 0; w < wave; ++w) base += g_part[w];
             for (int e = 0; e < per; ++e) { const int b = tid * per + e; if (b < B) { const u32 c = cnt[b]; cnt[b] = base; base += c; } }
         }
-        // the scatter, in SLICES of the output through LDS: a slice = the buckets that start inside [s T, (s + 1) T) of the output, T = the slice
+        if (run_cuts) { // the rank kernel walks a long run with all its wavefronts: where stretch w of 16 begins (the first bucket that starts at or behind w n / 16)
+            __syncthreads();
+            if (tid >= 1 && tid <= OCR_CUTS) {
+                const u32 t = (u32)((long long)n * tid / (OCR_CUTS + 1));
+                int lo_b = 0, hi_b = B;
+                while (lo_b < hi_b) { const int mid = (lo_b + hi_b) >> 1; if (cnt[mid] >= t) hi_b = mid; else lo_b = mid + 1; }
+                run_cuts[((size_t)gene * n_cand + cd) * OCR_CUTS + (tid - 1)] = lo_b < B ? cnt[lo_b] : (u32)n;
+            }
+        }
+    // the scatter, in SLICES of the output through LDS: a slice = the buckets that start inside [s T, (s + 1) T) of the output, T = the slice
         // buffer less 256 keys (a bucket of more than 256 keys -- its gene leaves the rank kernel anyway -- may overhang: those keys go straight
         // out); the run is read once per slice (16-byte loads, from L2), its keys of the slice take their places in the buffer, the buffer goes
         // out in whole lines.  (Scattered from here, every 4-byte store was an L2 request of its own: 1.2 G of them for ten clusters of 100 000
@@ -709,7 +722,8 @@ template <typename KeyT, int NT_ = SRT_NT>
 __global__ __launch_bounds__(NT_) void k_bucket_big_runs(void *Xs, long long gene_stride, const u16 *__restrict__ nnz, const u32 *__restrict__ gofs,
                                                             const int *__restrict__ cand, int n_cand, int G, int cap /* LDS key slots */,
                                                             BigRunFn<KeyT> *__restrict__ big_fn, u32 *__restrict__ route, int global_follows /* another launch takes the longer runs */,
-                                                            int n_min /* runs up to here are left alone (64 * OCR_KMAX, or another launch's) */) {
+                                                            int n_min /* runs up to here are left alone (64 * OCR_KMAX, or another launch's) */,
+                                                            u32 *__restrict__ run_cuts /* optional: OCR_CUTS bucket boundaries per run above OCR_COOP_MIN keys */) {
     extern __shared__ __align__(16) unsigned char srt_smem[];
     constexpr int NTK = NT_; // (256 threads; 1024 in a launch of its own for runs above 8192 keys: the LDS they take leaves room for two workgroups per CU)
     constexpr KeyT MAXK = KeyInfo<KeyT>::MAXK;
@@ -767,6 +781,13 @@ __global__ __launch_bounds__(NT_) void k_bucket_big_runs(void *Xs, long long gen
             for (int w = 0; w < wave; ++w) base += s_part[w];
 #pragma unroll
             for (int e = 0; e < (1 << SRT_LG_MAX) / NTK; ++e) { const int b = tid * per + e; if (e < per && b < B) { cnt[b] = base; base += loc[e]; } }
+        }
+        __syncthreads();
+        if (run_cuts && n > OCR_COOP_MIN && tid >= 1 && tid <= OCR_CUTS) { // (as k_bucket_big_runs_global: the starts are still untouched)
+            const u32 t = (u32)((long long)n * tid / (OCR_CUTS + 1));
+            int lo_b = 0, hi_b = B;
+            while (lo_b < hi_b) { const int mid = (lo_b + hi_b) >> 1; if (cnt[mid] >= t) hi_b = mid; else lo_b = mid + 1; }
+            run_cuts[((size_t)gene * n_cand + cd) * OCR_CUTS + (tid - 1)] = lo_b < B ? cnt[lo_b] : (u32)n;
         }
         __syncthreads();
         // (dealt into a second LDS buffer first and written back in whole lines: no faster on dense input -- 11.05 vs 11.06 ms, 10 groups of
@@ -1385,83 +1406,142 @@ __global__ __launch_bounds__(NT_) void k_ovo_rank_compact(OvoCompactParams P) {
     }
     // ---- groups of more than 256 non-zero keys (dealt into value buckets by k_bucket_big_runs): one wavefront each, in pieces of at most
     // 256 keys cut at bucket boundaries -- every piece is a group of its own to ocr_group, and S2, the tie term and the negatives add up ----
+    // A LONG run (a cluster of tens of thousands of cells: more than OCR_COOP_MIN keys) is walked by ALL the wavefronts together: the bucket
+    // kernels left NW - 1 cuts per such run (bucket boundaries at or behind w / NW of the run: run_cuts), wavefront w walks the pieces between
+    // cut w and cut w + 1, the stretches' sums meet in LDS.  (One wavefront per run left seven of sixteen idle on ten clusters, fifteen on a
+    // single cluster against the reference.)
     if (P.big_sorted && s_cnt[3] > 64u * KMAX) {
+        u32 *lr_list = ccnt;                 // (the coarse cells' counters are done with) [0] long runs listed, [1 ..] their groups
+        u64 *lr_acc = (u64 *)(ccnt + 64);    // [0] S2 part  [1] tie part  [2] negatives  [3] keys inside the part  [4] a bucket above 256 keys
+        if (tid == 0) lr_list[0] = 0u;
+        __syncthreads();
+        // the pieces of seg[i_begin, i_end) (both bucket boundaries): sums into the accumulators; false: a bucket of more than 256 keys
+        auto walk = [&](const KeyT *seg, const BigRunFn<KeyT> &fn, int i_begin, int i_end, u64 &s2_acc, u64 &tt_acc, u32 &neg_acc, u32 &nv_acc) -> bool {
+            const int n = i_end;
+            bool bad = false;
+            for (int s0 = i_begin; s0 < n && !bad;) {
+                    const int win = min(64 * KMAX, n - s0);
+                    KeyT cur[KMAX];
+#pragma unroll
+                    for (int r = 0; r < KMAX; ++r) cur[r] = (r * 64 + lane < win) ? seg[s0 + r * 64 + lane] : ZEROK;
+                    int nB = win;
+                    if (s0 + win < n) { // does the window's last bucket go on beyond it?  then the piece ends where that bucket starts
+                        const u32 bn = big_bucket(fn, seg[s0 + win]); // (uniform address)
+                        int same = 0;
+#pragma unroll
+                        for (int r = 0; r < KMAX; ++r) same += (int)__popcll(__ballot(r * 64 + lane < win && big_bucket(fn, cur[r]) == bn));
+                        nB = win - same;
+                    }
+                    if (nB == 0) { bad = true; break; } // a bucket of more than 256 keys: a tie-heavy column, not for this kernel
+#pragma unroll
+                    for (int r = 0; r < KMAX; ++r) cur[r] = (r * 64 + lane < nB) ? cur[r] : ZEROK;
+                    if constexpr (PARTS) { // the run is in ascending bucket order: most pieces lie wholly inside or outside the part
+                        u32 nv = 0;
+#pragma unroll
+                        for (int r = 0; r < KMAX; ++r) {
+                            cur[r] = (cur[r] >= p_lo && cur[r] <= p_hi) ? cur[r] : ZEROK;
+                            nv += (u32)__popcll(__ballot(cur[r] != ZEROK));
+                        }
+                        nv_acc += nv;
+                        if (nv == 0u) { s0 += nB; continue; } // (uniform)
+                    }
+                    u32 less = 0, eqs = 0, negs = 0;
+                    u64 TT = 0;
+                    if (nB <= 64) ocr_group<KeyT, 1, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                    else if (nB <= 128) ocr_group<KeyT, 2, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                    else if (nB <= 192) ocr_group<KeyT, 3, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                    else ocr_group<KeyT, 4, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
+                    s2_acc += 2ull * less + eqs;
+                    tt_acc += TT;
+                    neg_acc += negs;
+                    s0 += nB;
+            }
+            return !bad;
+        };
+        // a big group's statistics from its run's sums (one lane)
+        auto emit_big = [&](int gb, int n, u64 s2_acc, u64 tt_acc, u32 neg_acc, u32 nv_acc) {
+            const size_t o = (size_t)gene * G + gb;
+            const long long n_g = P.counts[gb];
+            if constexpr (PARTS) {
+                u64 S2 = s2_acc + 2ull * n_low * (u64)nv_acc + 2ull * aZ * (u64)(nv_acc - neg_acc);
+                u64 tie = T_A + 3ull * tt_acc;
+                long long two_u = 0;
+                if (part == 0) {
+                    const u64 zc = (u64)(n_g - (long long)n), t0 = (u64)aZ + zc;
+                    S2 += zc * (2ull * nneg + aZ);
+                    tie += t0 * t0 * t0 - t0;
+                    two_u = 2ll * (long long)n_ref * n_g;
+                }
+                atomicAdd((unsigned long long *)&P.out_2u[o], (unsigned long long)(two_u - (long long)S2));
+                atomicAdd((unsigned long long *)&P.out_tie[o], (unsigned long long)tie);
+            } else {
+                const u64 zc = (u64)(n_g - (long long)n);
+                const u64 S2 = s2_acc + 2ull * aZ * (u64)((u32)n - neg_acc) + zc * (2ull * nneg + aZ);
+                const u64 t0 = (u64)aZ + zc;
+                P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
+                P.out_tie[o] = T_A + 3ull * tt_acc + (t0 * t0 * t0 - t0);
+            }
+        };
         for (int gb = wave; gb < G; gb += NW) { // (uniform per wavefront; few groups are big)
             if (gb == ref) continue;
             int n = (int)nnz[gb];
             if (n <= 64 * KMAX) continue;
             if (n >= 65535 && P.run_n) n = (int)P.run_n[(size_t)gene * P.n_cand + P.cand_of[gb]]; // (the 16-bit length saturated)
+            if (n > OCR_COOP_MIN && P.run_cuts) { // (at most 63 listed: the others are walked by their wavefront alone, below)
+                u32 slot = 0;
+                if (lane == 0) slot = atomicAdd(&lr_list[0], 1u);
+                slot = (u32)__builtin_amdgcn_readfirstlane((int)slot);
+                if (slot < 63u) { if (lane == 0) lr_list[1 + slot] = (u32)gb; continue; }
+            }
             BigRunFn<KeyT> fn = ((const BigRunFn<KeyT> *)P.big_fn)[(size_t)gene * P.n_cand + P.cand_of[gb]];
             const KeyT *seg = ((fn.shift & BIG_RUN_IN_TMP) ? (const KeyT *)P.big_tmp + (long long)gene * P.gene_stride : (const KeyT *)Xg) + P.gofs[(size_t)gene * G + gb];
             fn.shift &= ~BIG_RUN_IN_TMP;
             u64 s2_acc = 0, tt_acc = 0; // per-lane partial sums
             u32 neg_acc = 0;            // (uniform)
             u32 nv_acc = 0;             // (uniform) PARTS: keys inside the part
-            bool bad = false;
-            for (int s0 = 0; s0 < n && !bad;) {
-                const int win = min(64 * KMAX, n - s0);
-                KeyT cur[KMAX];
-#pragma unroll
-                for (int r = 0; r < KMAX; ++r) cur[r] = (r * 64 + lane < win) ? seg[s0 + r * 64 + lane] : ZEROK;
-                int nB = win;
-                if (s0 + win < n) { // does the window's last bucket go on beyond it?  then the piece ends where that bucket starts
-                    const u32 bn = big_bucket(fn, seg[s0 + win]); // (uniform address)
-                    int same = 0;
-#pragma unroll
-                    for (int r = 0; r < KMAX; ++r) same += (int)__popcll(__ballot(r * 64 + lane < win && big_bucket(fn, cur[r]) == bn));
-                    nB = win - same;
-                }
-                if (nB == 0) { bad = true; break; } // a bucket of more than 256 keys: a tie-heavy column, not for this kernel
-#pragma unroll
-                for (int r = 0; r < KMAX; ++r) cur[r] = (r * 64 + lane < nB) ? cur[r] : ZEROK;
-                if constexpr (PARTS) { // the run is in ascending bucket order: most pieces lie wholly inside or outside the part
-                    u32 nv = 0;
-#pragma unroll
-                    for (int r = 0; r < KMAX; ++r) {
-                        cur[r] = (cur[r] >= p_lo && cur[r] <= p_hi) ? cur[r] : ZEROK;
-                        nv += (u32)__popcll(__ballot(cur[r] != ZEROK));
-                    }
-                    nv_acc += nv;
-                    if (nv == 0u) { s0 += nB; continue; } // (uniform)
-                }
-                u32 less = 0, eqs = 0, negs = 0;
-                u64 TT = 0;
-                if (nB <= 64) ocr_group<KeyT, 1, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
-                else if (nB <= 128) ocr_group<KeyT, 2, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
-                else if (nB <= 192) ocr_group<KeyT, 3, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
-                else ocr_group<KeyT, 4, EQ, PARTS>(cur, nB, R, bloom, lane, lt_mask, less, eqs, TT, negs);
-                s2_acc += 2ull * less + eqs;
-                tt_acc += TT;
-                neg_acc += negs;
-                s0 += nB;
-            }
+            const bool bad = !walk(seg, fn, 0, n, s2_acc, tt_acc, neg_acc, nv_acc);
             // (dense layout: the reference's segments lie where they were -- not k_ovo_rank's gene: a word above 255 sends it to the general route)
             if (bad) { if (lane == 0) P.route[gene] = P.ref_by_gofs ? 2u : (2u | (6u << 8)); continue; }
             s2_acc = wave_sum<u64>(s2_acc);
             tt_acc = wave_sum<u64>(tt_acc);
+            if (lane == 0) emit_big(gb, n, s2_acc, tt_acc, neg_acc, nv_acc);
+        }
+        // ---- the long runs, every wavefront on each ----
+        __syncthreads();
+        const int n_long = (int)min(lr_list[0], 63u);
+        for (int li = 0; li < n_long; ++li) { // (uniform)
+            const int gb = (int)lr_list[1 + li];
+            if (tid < 5) lr_acc[tid] = 0ull;
+            __syncthreads();
+            int n = (int)nnz[gb];
+            if (n >= 65535 && P.run_n) n = (int)P.run_n[(size_t)gene * P.n_cand + P.cand_of[gb]];
+            const size_t ci = (size_t)gene * P.n_cand + P.cand_of[gb];
+            BigRunFn<KeyT> fn = ((const BigRunFn<KeyT> *)P.big_fn)[ci];
+            const KeyT *seg = ((fn.shift & BIG_RUN_IN_TMP) ? (const KeyT *)P.big_tmp + (long long)gene * P.gene_stride : (const KeyT *)Xg) + P.gofs[(size_t)gene * G + gb];
+            fn.shift &= ~BIG_RUN_IN_TMP;
+            const u32 *cuts = P.run_cuts + ci * OCR_CUTS; // cut w (w = 1 .. OCR_CUTS): the bucket boundary at or behind w / (OCR_CUTS + 1) of the run
+            // NW wavefronts over OCR_CUTS + 1 = 16 stretches: wavefront w takes stretches w * 16 / NW ... (NW = 16: one each; NW = 4: four each)
+            const int st0 = wave * (OCR_CUTS + 1) / NW, st1 = (wave + 1) * (OCR_CUTS + 1) / NW;
+            const int i0 = st0 == 0 ? 0 : min((int)cuts[st0 - 1], n), i1 = st1 > OCR_CUTS ? n : min((int)cuts[st1 - 1], n);
+            u64 s2_acc = 0, tt_acc = 0;
+            u32 neg_acc = 0, nv_acc = 0;
+            bool ok = true;
+            if (i0 < i1) ok = walk(seg, fn, i0, i1, s2_acc, tt_acc, neg_acc, nv_acc);
+            s2_acc = wave_sum<u64>(s2_acc);
+            tt_acc = wave_sum<u64>(tt_acc);
             if (lane == 0) {
-                const size_t o = (size_t)gene * G + gb;
-                const long long n_g = P.counts[gb];
-                if constexpr (PARTS) {
-                    u64 S2 = s2_acc + 2ull * n_low * (u64)nv_acc + 2ull * aZ * (u64)(nv_acc - neg_acc);
-                    u64 tie = T_A + 3ull * tt_acc;
-                    long long two_u = 0;
-                    if (part == 0) {
-                        const u64 zc = (u64)(n_g - (long long)n), t0 = (u64)aZ + zc;
-                        S2 += zc * (2ull * nneg + aZ);
-                        tie += t0 * t0 * t0 - t0;
-                        two_u = 2ll * (long long)n_ref * n_g;
-                    }
-                    atomicAdd((unsigned long long *)&P.out_2u[o], (unsigned long long)(two_u - (long long)S2));
-                    atomicAdd((unsigned long long *)&P.out_tie[o], (unsigned long long)tie);
-                } else {
-                    const u64 zc = (u64)(n_g - (long long)n);
-                    const u64 S2 = s2_acc + 2ull * aZ * (u64)((u32)n - neg_acc) + zc * (2ull * nneg + aZ);
-                    const u64 t0 = (u64)aZ + zc;
-                    P.out_2u[o] = 2ll * (long long)n_ref * n_g - (long long)S2;
-                    P.out_tie[o] = T_A + 3ull * tt_acc + (t0 * t0 * t0 - t0);
-                }
+                if (s2_acc) atomicAdd((unsigned long long *)&lr_acc[0], (unsigned long long)s2_acc);
+                if (tt_acc) atomicAdd((unsigned long long *)&lr_acc[1], (unsigned long long)tt_acc);
+                if (neg_acc) atomicAdd((unsigned long long *)&lr_acc[2], (unsigned long long)neg_acc);
+                if (nv_acc) atomicAdd((unsigned long long *)&lr_acc[3], (unsigned long long)nv_acc);
+                if (!ok) lr_acc[4] = 1ull;
             }
+            __syncthreads();
+            if (tid == 0) {
+                if (lr_acc[4]) P.route[gene] = P.ref_by_gofs ? 2u : (2u | (6u << 8));
+                else emit_big(gb, n, lr_acc[0], lr_acc[1], (u32)lr_acc[2], (u32)lr_acc[3]);
+            }
+            __syncthreads();
         }
     }
 }

@@ -76,7 +76,7 @@ template <typename KeyT> static bool packed_leftovers_fit_sort_route(const illic
 // the second key buffer `tmp` beyond (tmp == nullptr: such a run sends its gene to the general route)
 template <typename KeyT>
 static int launch_bucket_big_runs(illico_ctx *c, void *Xs, void *tmp, long long stride, const u16 *nnz, const u32 *gofs, int nb, int G, int cap, BigRunFn<KeyT> *big_fn,
-                                  u32 *route, int64_t longest_run, const u32 *run_n) {
+                                  u32 *route, int64_t longest_run, const u32 *run_n, u32 *run_cuts /* optional [nb][pk_nbig][OCR_CUTS] */) {
     const bool global = tmp != nullptr && longest_run > cap;
     // a workgroup takes a stretch of a gene's candidates when there are many (most hold no run above 256 keys)
     const unsigned gx = (long long)c->pk_nbig * nb <= 32768 ? (unsigned)c->pk_nbig : (unsigned)std::max(1, std::min(c->pk_nbig, (32768 + nb - 1) / nb));
@@ -88,14 +88,14 @@ static int launch_bucket_big_runs(illico_ctx *c, void *Xs, void *tmp, long long 
         const size_t lds = srt_lds_bytes(sizeof(KeyT), cap_a);
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(gx, nb), dim3(SRT_NT), lds, c->stream, Xs, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap_a, big_fn, route,
-                           (global || cap > cap_a) ? 1 : 0, 64 * OCR_KMAX);
+                           (global || cap > cap_a) ? 1 : 0, 64 * OCR_KMAX, run_cuts);
         HIPCHK(c, hipGetLastError());
     }
     if (cap > cap_a) {
         auto kern = k_bucket_big_runs<KeyT, 1024>;
         const size_t lds = srt_lds_bytes(sizeof(KeyT), cap);
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(gx, nb), dim3(1024), lds, c->stream, Xs, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, big_fn, route, global ? 1 : 0, cap_a);
+        hipLaunchKernelGGL(kern, dim3(gx, nb), dim3(1024), lds, c->stream, Xs, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, big_fn, route, global ? 1 : 0, cap_a, run_cuts);
         HIPCHK(c, hipGetLastError());
     }
     if (global) {
@@ -112,7 +112,7 @@ static int launch_bucket_big_runs(illico_ctx *c, void *Xs, void *tmp, long long 
         const int slice_keys = (int)(slice_bytes / sizeof(KeyT));
         const size_t ldsg = cnt_bytes + (size_t)slice_keys * sizeof(KeyT);
         HIPCHK(c, hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
-        hipLaunchKernelGGL(kg, dim3(gx, nb), dim3(SRTG_NT), ldsg, c->stream, Xs, tmp, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, lg, big_fn, route, run_n, slice_keys);
+        hipLaunchKernelGGL(kg, dim3(gx, nb), dim3(SRTG_NT), ldsg, c->stream, Xs, tmp, stride, nnz, gofs, (const int *)c->d_pk_big, c->pk_nbig, G, cap, lg, big_fn, route, run_n, slice_keys, run_cuts);
         HIPCHK(c, hipGetLastError());
     }
     return ILLICO_OK;

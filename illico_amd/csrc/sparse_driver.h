@@ -1362,7 +1362,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                         int cap = (int)std::min<int64_t>(srt_cap<KeyT>(), (longest + 63) & ~63ll);
                         if (c->big_runs_cap > 0) cap = std::min(cap, std::max(c->big_runs_cap, 512) & ~63);
                         // (runs beyond the LDS slots are dealt through the global sort's second key buffer)
-                        if ((rc = launch_bucket_big_runs<KeyT>(c, (void *)Xs, c->no_big_runs_global ? nullptr : kb, 0ll, pk_nnz, pk_gofs, nb, G, cap, big_fn, route, longest, nullptr))) return rc;
+                        if ((rc = launch_bucket_big_runs<KeyT>(c, (void *)Xs, c->no_big_runs_global ? nullptr : kb, 0ll, pk_nnz, pk_gofs, nb, G, cap, big_fn, route, longest, nullptr, nullptr))) return rc;
                     }
                     HIPCHK(c, hipGetLastError());
                 }
@@ -1374,7 +1374,7 @@ int run_sparse_t(illico_ctx *c, bool is_csr, const void *data, const void *indic
                     packed_ref_sizing<KeyT>(std::min<int64_t>(c->h_counts[c->ref], std::max<int64_t>(b.max_gene, 1)), &C.ref_cap, &C.nbk_lg);
                     if (c->packed_ref_cap > 0) C.ref_cap = std::min(C.ref_cap, std::max(c->packed_ref_cap, 1024));
                     C.out_2u = s2u; C.out_tie = stie; C.route = route; C.big_sorted = c->pk_nbig > 0 ? 1 : 0; C.ref_by_gofs = 1; C.gene_flags = route_flags;
-                    C.big_fn = big_fn; C.big_tmp = kb; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
+                    C.big_fn = big_fn; C.big_tmp = kb; C.run_cuts = nullptr; C.cand_of = c->pk_nbig > 0 ? c->d_pk_big + c->pk_nbig : nullptr; C.n_cand = c->pk_nbig;
                     const size_t lds = ocr_lds_bytes(C.ref_cap, C.nbk_lg, sizeof(KeyT));
                     const bool eq = c->packed_eq_buckets >= 0 ? c->packed_eq_buckets != 0 : c->h_counts[c->ref] > 16384;
                     // a reference run longer than the kernel's key slots is taken in value-range parts (every part adds its share: the
